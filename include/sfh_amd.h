@@ -1,0 +1,160 @@
+/*
+ * sfh_amd.h - C ABI of libsfh_amd.so: the MI355X (gfx950) hot path of
+ * darkAlert/sports-field-homography.
+ *
+ * The reference has no FFI layer: its operator boundary is the Python class
+ * models.Reconstructor (models/reconstructor.py:30-247), which delegates every
+ * device operation to ATen/cuDNN and Kornia.  Each entry point below replaces the
+ * ATen/Kornia call(s) named in its comment (paths relative to the reference root).
+ * The Python mirror of the class (sports-field-homography_amd/reconstructor.py)
+ * binds these symbols with ctypes; INTEGRATION.md shows the stub a maintainer of the
+ * reference would add.
+ *
+ * Conventions
+ *  - all pointers are DEVICE pointers (hipMalloc'd / torch CUDA tensors) unless named
+ *    host_*; activations are fp32 NHWC ("channels last"), checkpoint tensors keep the
+ *    reference layouts (OIHW conv weights, IOHW transposed-conv weights);
+ *  - every call is asynchronous on `stream` (a hipStream_t passed as void*), allocates
+ *    nothing, keeps no pointer and no global mutable state;
+ *  - return value: 0 = success, negative = SFH_E_* (message via sfh_last_error()).
+ */
+#ifndef SFH_AMD_H
+#define SFH_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SFH_OK 0
+#define SFH_E_ARG (-1)     /* invalid argument / unsupported shape */
+#define SFH_E_LAUNCH (-2)  /* HIP launch error */
+
+/* Tile shapes of the implicit-GEMM conv kernel (output pixels per workgroup). */
+#define SFH_TILE_8x32 0   /* 8 rows x 32 cols, MFMA pixel groups of 1x16 */
+#define SFH_TILE_16x16 1  /* 16 rows x 16 cols, 1x16 groups              */
+#define SFH_TILE_32x8 2   /* 32 rows x 8 cols, 2x8 groups (narrow maps)  */
+
+/* Output modes of sfh_conv_fwd. */
+#define SFH_OUT_NHWC 0        /* dst[b][y][x][co]                                        */
+#define SFH_OUT_UPSCATTER2 1  /* transposed conv k2 s2: virtual cout = (dy*2+dx)*Cout+co  */
+
+typedef struct sfh_conv_desc {
+  /* source 0: channels [0, c0) of the conv input; physical NHWC tensor (B, h0, w0, cs0). */
+  const float* src0;
+  int32_t c0, cs0, h0, w0;
+  int32_t pool0;  /* 1: 2x2/stride-2 max-pool applied on load (h0 >= 2*H, w0 >= 2*W) */
+  /* source 1 (optional, NULL if absent): channels [c0, c0+c1); physical (B, h1, w1, cs1),
+   * placed at (pad_top1, pad_left1) inside the H x W input frame, zero elsewhere.       */
+  const float* src1;
+  int32_t c1, cs1, h1, w1, pad_top1, pad_left1;
+  /* geometry */
+  int32_t batch, H, W;  /* conv input frame */
+  int32_t ksize;        /* 3 (pad 1), 1 (pad 0) or 4 (pad 2 before, 1 after; stem) */
+  int32_t stride;       /* 1 or 2 */
+  int32_t tile;         /* SFH_TILE_* */
+  /* weights packed by sfh_pack_conv_weights for this (ksize, c0, c1); per-channel epilogue */
+  const float* wpacked;
+  const float* scale;  /* [cout_virtual] */
+  const float* shift;  /* [cout_virtual] */
+  int32_t cout;        /* virtual output channels, multiple of 64 */
+  int32_t relu;
+  /* optional residual added before ReLU: NHWC tensor with the geometry of dst */
+  const float* residual;
+  /* destination */
+  float* dst;
+  int32_t dst_cs;   /* channel stride (floats per pixel) of dst */
+  int32_t out_mode; /* SFH_OUT_* */
+} sfh_conv_desc;
+
+const char* sfh_last_error(void);
+int sfh_version(void);
+
+/* conv3x3+BN+ReLU, 1x1 conv, ConvTranspose2d k2 s2 - fp32 MFMA implicit GEMM.
+ * Replaces nn.Conv2d/BatchNorm2d/ReLU of DoubleConv (unet/unet_parts.py:14-21), the
+ * MaxPool2d of Down (unet/unet_parts.py:33, via pool0), F.pad + torch.cat of Up
+ * (unet/unet_parts.py:59-67, via src1), nn.ConvTranspose2d of Up (unet/unet_parts.py:52),
+ * and the conv/BN/ReLU/residual of BasicBlock (models/resnet.py:64-82).                  */
+int sfh_conv_fwd(const sfh_conv_desc* d, void* stream);
+
+/* Number of floats of the packed weight buffer for a conv with the given geometry. */
+int64_t sfh_packed_weight_floats(int ksize, int c0, int c1, int cout_virtual);
+
+/* Re-layout checkpoint weights into MFMA fragment order.
+ * mode = 0: w is OIHW (cout, c0+c1, k, k)  (nn.Conv2d), ksize 1 or 3
+ * mode = 1: w is IOHW (cin, cout, 2, 2)    (nn.ConvTranspose2d), ksize must be 1 and
+ *           cout_virtual = 4*cout.
+ * mode = 2: w is OIHW (cout, aux, 7, 7), the stride-2 pad-3 stem of ResNetSTN
+ *           (models/resnet.py:172), re-expressed as a 4x4 conv (pad 2 before / 1 after) over
+ *           the 2x2 space-to-depth input produced by sfh_space_to_depth2; ksize = 4,
+ *           c0 = 4 * (padded channels of the un-shuffled tensor), aux = real cin.            */
+int sfh_pack_conv_weights(const float* w, float* packed, int ksize, int c0, int c1,
+                          int cout_virtual, int mode, int aux, void* stream);
+
+/* (B,H,W,cs) -> (B,ceil(H/2),ceil(W/2),4*cs): out[Y][X][(py*2+px)*cs + c] = in[2Y+py][2X+px][c]
+ * (zero where 2Y+py >= H or 2X+px >= W). */
+int sfh_space_to_depth2(const float* src, float* dst, int batch, int H, int W, int cs, void* stream);
+
+/* scale = gamma / sqrt(var + eps); shift = (conv_bias - mean) * scale + beta
+ * (eval-mode BatchNorm2d folded behind the conv; conv_bias may be NULL).
+ * With gamma == NULL: scale = 1, shift = conv_bias (plain bias epilogue).
+ * `repeat` replicates the n-vector (transposed conv: 4 sub-positions).                    */
+int sfh_fold_bn(const float* conv_bias, const float* gamma, const float* beta,
+                const float* mean, const float* var, float eps, int n, int repeat,
+                float* scale, float* shift, void* stream);
+
+/* (B, C, H, W) fp32 -> (B, H, W, cs) fp32, channels >= C zero-filled. */
+int sfh_nchw_to_nhwc(const float* src, float* dst, int batch, int C, int H, int W, int cs,
+                     void* stream);
+/* (B, H, W, cs) -> (B, C, H, W) */
+int sfh_nhwc_to_nchw(const float* src, float* dst, int batch, int C, int H, int W, int cs,
+                     void* stream);
+
+/* OutConv (unet/unet_parts.py:74-77): 1x1 conv cin -> nc (nc <= 8) + bias.
+ * x: NHWC (B,H,W,cin), w: (nc,cin,1,1), logits_nchw: (B,nc,H,W) or NULL.
+ * Optional fused consumers:
+ *   argmax_u8 (B,H,W): argmax over classes == preds_to_masks (utils/postprocess.py:7-18);
+ *   stn_in  (B,H,W,stn_cs): [logits(nc), frame channels (3, read from frame_nhwc with
+ *   stride frame_cs), zero padding] == torch.cat((logits, x), 1) of
+ *   models/reconstructor.py:179,214 in NHWC.                                               */
+int sfh_outconv_fwd(const float* x, int cin, const float* w, const float* bias, int nc,
+                    int batch, int H, int W, float* logits_nchw, uint8_t* argmax_u8,
+                    float* stn_in, int stn_cs, const float* frame_nhwc, int frame_cs,
+                    void* stream);
+
+/* Homography warp of the court template == kornia HomographyWarper(h, w, mode,
+ * normalized_coordinates=True)(template, theta) as called by Reconstructor.warp
+ * (models/reconstructor.py:109-118), fused with the predict-mode epilogue
+ * `* mask_classes` and `.type(int32)` (models/reconstructor.py:223,240).
+ * theta: (B,3,3); tmpl: (.,1,ht,wt) with batch stride tmpl_bstride floats (0 = one shared
+ * image); out_f32 (B,h,w) and/or out_i32 (B,h,w) = trunc(value * out_scale).
+ * mode: 0 nearest, 1 bilinear.                                                            */
+int sfh_homography_warp_fwd(const float* theta, const float* tmpl, int64_t tmpl_bstride,
+                            int ht, int wt, int batch, int h, int w, int mode,
+                            float out_scale, float* out_f32, int32_t* out_i32, void* stream);
+
+/* transform_poi (models/reconstructor.py:120-130): inverse(theta) applied to the court
+ * points, then p/2 + 0.5 if normalize.  theta (B,3,3), poi (B,N,2) -> out (B,N,2).        */
+int sfh_poi_project_fwd(const float* theta, const float* poi, int batch, int npts,
+                        int normalize, float* out, void* stream);
+
+/* Consistency score (models/reconstructor.py:226-238): mean over pixels of
+ * cross_entropy(logits[:, :, y, x], mask[y, x]).  logits NCHW (B,nc,H,W), mask int32
+ * (B,hm,wm) (nearest-resized to HxW when sizes differ), partial: workspace of
+ * sfh_ce_workspace_floats(batch, H, W) floats, score: (B).                                */
+int64_t sfh_ce_workspace_floats(int batch, int H, int W);
+int sfh_consistency_ce_fwd(const float* logits, const int32_t* mask, int batch, int nc, int H,
+                           int W, int hm, int wm, float* partial, float* score, void* stream);
+
+/* ResNetSTN pieces (models/resnet.py:235-254). */
+/* MaxPool2d(kernel 3, stride 2, padding 1) on NHWC (B,H,W,C) -> (B,Ho,Wo,C). */
+int sfh_maxpool3x3s2_fwd(const float* x, float* y, int batch, int H, int W, int C, void* stream);
+/* AdaptiveAvgPool2d(1) + flatten + Linear(C -> nout): x NHWC (B,H,W,C), w (nout,C), out (B,nout). */
+int sfh_avgpool_linear_fwd(const float* x, const float* w, const float* bias, int batch, int H,
+                           int W, int C, int nout, float* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SFH_AMD_H */

@@ -1,0 +1,211 @@
+"""Generates the committed fixtures.  Runs ONLY in the build container (it reads
+/root/reference); nothing under tests/, bench.py or the package imports this file.
+
+Two kinds of output:
+
+1. ``sports-field-homography_amd/data/*.npy`` - input DATA derived from the reference's
+   asset files (court class-id templates resized NEAREST like utils/dataset.py:51-53, the
+   RGBA pitch mask converted to ids with the colour table of
+   dataset_utils/preparation.py:216-239, POI coordinates normalised like
+   utils/dataset.py:78-79).
+2. ``tests/golden/*.npz`` - golden input/output vectors produced by the reference's OWN
+   classes (``unet/unet_parts.py``, ``models/resnet.py``; imported by file path because
+   the package ``__init__`` files pull in Kornia, which is not installed) on the
+   deterministic synthetic weights of ``sfh_amd.synth``.  These pin ``oracle/torch_ref.py``.
+
+Usage:  python oracle/make_fixtures.py [--full]     (--full adds the 640x360 end-to-end vector)
+"""
+import argparse
+import importlib.util
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+REF = "/root/reference"
+GOLD = os.path.join(ROOT, "tests", "golden")
+DATA = os.path.join(ROOT, "sports-field-homography_amd", "data")
+
+from sfh_amd import synth  # noqa: E402
+from oracle import torch_ref  # noqa: E402
+
+
+def _load(name, rel):
+    spec = importlib.util.spec_from_file_location(name, os.path.join(REF, rel))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def make_data():
+    from PIL import Image
+    os.makedirs(DATA, exist_ok=True)
+    im = Image.open(os.path.join(REF, "assets/mask_ncaa_v4_nc4_m_onehot.png"))
+    for (w, h) in [(640, 360), (1280, 720)]:
+        ids = np.array(im.resize((w, h), resample=Image.NEAREST)).astype(np.uint8)
+        np.save(os.path.join(DATA, f"court_ids_ncaa_nc4_{w}x{h}.npy"), ids)
+    rgba = np.array(Image.open(os.path.join(REF, "assets/pitch_mask_v3_nc4_hd.png")))
+    rgb = rgba[..., :3]
+    ids = np.zeros(rgb.shape[:2], np.uint8)
+    # dataset_utils/preparation.py:218-221 (colours given there in BGR order)
+    ids[(rgb == (0, 255, 0)).all(-1)] = 1
+    ids[(rgb == (0, 0, 255)).all(-1)] = 2   # BGR (255,0,0)
+    ids[(rgb == (255, 0, 0)).all(-1)] = 3   # BGR (0,0,255)
+    np.save(os.path.join(DATA, "court_ids_pitch_v3_nc4_1280x720.npy"), ids)
+    small = np.array(Image.fromarray(ids).resize((640, 360), resample=Image.NEAREST))
+    np.save(os.path.join(DATA, "court_ids_pitch_v3_nc4_640x360.npy"), small)
+    for tag, fn in [("pitch", "template_pitch_points.json"), ("ncaa", "template_ncaa_v4_points.json")]:
+        d = json.load(open(os.path.join(REF, "assets", fn)))
+        assert d["ranges"][0] == 1.0 and d["ranges"][1] == 1.0
+        pts = np.array([[(p["coords"][0] - 0.5) * 2, (p["coords"][1] - 0.5) * 2] for p in d["points"]])
+        np.save(os.path.join(DATA, f"court_poi_{tag}.npy"), pts.astype(np.float32))
+        print(tag, "poi", pts.shape)
+
+
+class _RefNet(nn.Module):
+    """The reference's UNet + ResNetSTN sub-modules under the attribute names of
+    models/reconstructor.py:66-97 (Reconstructor itself cannot be imported: Kornia)."""
+
+    def __init__(self, up_mod, rn_mod, mask_classes=4, bilinear=False, uv=False, resnet="resnet34"):
+        super().__init__()
+        f = 2 if bilinear else 1
+        self.inc = up_mod.DoubleConv(3, 64)
+        self.down1 = up_mod.Down(64, 128)
+        self.down2 = up_mod.Down(128, 256)
+        self.down3 = up_mod.Down(256, 512)
+        self.down4 = up_mod.Down(512, 1024 // f)
+        self.up1 = up_mod.Up(1024, 512 // f, bilinear)
+        self.up2 = up_mod.Up(512, 256 // f, bilinear)
+        self.up3 = up_mod.Up(256, 128 // f, bilinear)
+        self.up4 = up_mod.Up(128, 64, bilinear)
+        self.outc = up_mod.OutConv(64, mask_classes)
+        if uv:
+            self.outuv = up_mod.OutConv(64, 2)
+        self.resnet_reg = rn_mod.resnet_stn(resnet, None, mask_classes + 3 + (2 if uv else 0))
+
+    def unet(self, x):  # wiring of models/reconstructor.py:138-148
+        x1 = self.inc(x)
+        x2 = self.down1(x1)
+        x3 = self.down2(x2)
+        x4 = self.down3(x3)
+        xt = self.down4(x4)
+        y = self.up1(xt, x4)
+        y = self.up2(y, x3)
+        y = self.up3(y, x2)
+        y = self.up4(y, x1)
+        return self.outc(y), xt, y
+
+
+def _rand(shape, seed, name, lo=0.0, hi=1.0):
+    g = synth._rng(seed, name)
+    return torch.from_numpy(g.uniform(lo, hi, shape).astype(np.float32))
+
+
+def _loaded(mod, seed):
+    sd = synth.synth_state_dict(mod.state_dict(), seed)
+    mod.load_state_dict(sd, strict=True)
+    return mod.eval()
+
+
+def make_block_goldens(up_mod, rn_mod):
+    out = {}
+    with torch.no_grad():
+        # key layouts of the three UNet variants + resnet18/34
+        layouts = {}
+        for tag, kw in [("default", {}), ("bilinear", {"bilinear": True}), ("uv", {"uv": True}),
+                        ("resnet18", {"resnet": "resnet18"})]:
+            net = _RefNet(up_mod, rn_mod, **kw)
+            layouts[tag] = [[k, list(v.shape), str(v.dtype)] for k, v in net.state_dict().items()]
+        json.dump(layouts, open(os.path.join(GOLD, "state_dict_layouts.json"), "w"))
+        print("default layout keys:", len(layouts["default"]))
+
+        # channel counts are multiples of 64 so the same vectors also drive the MFMA kernels
+        m = _loaded(up_mod.DoubleConv(3, 64), 11)
+        x = _rand((2, 3, 20, 24), 11, "x")
+        out["dc_3_64.x"], out["dc_3_64.y"] = x.numpy(), m(x).numpy()
+
+        m = _loaded(up_mod.DoubleConv(64, 128, 64), 12)
+        x = _rand((1, 64, 17, 23), 12, "x", -1, 1)
+        out["dc_64_128_m64.x"], out["dc_64_128_m64.y"] = x.numpy(), m(x).numpy()
+
+        m = _loaded(up_mod.Down(64, 128), 13)
+        x = _rand((1, 64, 21, 18), 13, "x", -1, 1)
+        out["down_64_128.x"], out["down_64_128.y"] = x.numpy(), m(x).numpy()
+
+        m = _loaded(up_mod.Up(128, 64, False), 14)
+        x1 = _rand((1, 128, 10, 9), 14, "x1", -1, 1)
+        x2 = _rand((1, 64, 21, 19), 14, "x2", -1, 1)
+        out["up_128_64.x1"], out["up_128_64.x2"], out["up_128_64.y"] = x1.numpy(), x2.numpy(), m(x1, x2).numpy()
+
+        m = _loaded(up_mod.Up(128, 64, True), 15)
+        x1 = _rand((1, 64, 10, 9), 15, "x1", -1, 1)
+        x2 = _rand((1, 64, 21, 19), 15, "x2", -1, 1)
+        out["upbl_128_64.x1"], out["upbl_128_64.x2"], out["upbl_128_64.y"] = x1.numpy(), x2.numpy(), m(x1, x2).numpy()
+
+        m = _loaded(up_mod.OutConv(64, 4), 16)
+        x = _rand((1, 64, 9, 13), 16, "x", -1, 1)
+        out["outc_64_4.x"], out["outc_64_4.y"] = x.numpy(), m(x).numpy()
+
+        m = _loaded(rn_mod.resnet_stn("resnet34", None, 7), 17)
+        x = _rand((2, 7, 72, 128), 17, "x", -1, 1)
+        out["resnet34_7.x"], out["resnet34_7.theta"] = x.numpy(), m(x).numpy()
+        m = _loaded(rn_mod.resnet_stn("resnet18", None, 7), 18)
+        out["resnet18_7.theta"] = m(x).numpy()
+
+        # whole UNet + STN with the real channel plan on a small odd-sized frame
+        net = _loaded(_RefNet(up_mod, rn_mod), 19)
+        x = synth.smooth_frames(2, 90, 112, seed=19)
+        logits, xt, y = net.unet(x)
+        theta = net.resnet_reg(torch.cat((logits, x), 1))
+        out["net_90x112.logits"] = logits.numpy()
+        out["net_90x112.xtop_mean"] = xt.mean(dim=(2, 3)).numpy()
+        out["net_90x112.theta"] = theta.numpy()
+    np.savez_compressed(os.path.join(GOLD, "blocks.npz"), **out)
+    print("blocks.npz:", {k: v.shape for k, v in out.items()})
+
+
+def make_full_golden(up_mod, rn_mod):
+    """640x360 end-to-end vector: reference classes for UNet/ResNet + oracle warp/CE/POI."""
+    torch.set_num_threads(os.cpu_count())
+    B = 2
+    with torch.no_grad():
+        net = _loaded(_RefNet(up_mod, rn_mod), 0)
+        x = synth.frames_to_float(synth.synth_frames_u8(B, 360, 640, seed=0))
+        logits, _, _ = net.unet(x)
+        theta = net.resnet_reg(torch.cat((logits, x), 1))
+        court = synth.load_court_template("ncaa_nc4_640x360", 4, B)
+        poi = synth.load_court_poi("pitch", B)
+        wm = torch_ref.warp(theta, court, (640, 360), nearest=True) * 4
+        ce = torch.nn.functional.cross_entropy(logits, wm.long(), reduction="none").mean(dim=(1, 2))
+        p = torch_ref.transform_poi(theta, poi)
+        am = torch.argmax(logits, 1).to(torch.uint8).numpy()
+        top2 = torch.topk(logits, 2, dim=1).values
+        margin = (top2[:, 0] - top2[:, 1]).numpy()
+    packed = np.packbits(np.unpackbits(am[..., None], axis=-1)[..., 6:].reshape(B, -1), axis=-1)
+    np.savez_compressed(
+        os.path.join(GOLD, "full_640x360.npz"),
+        theta=theta.numpy(), consist=ce.numpy(), poi=p.numpy(),
+        argmax_2bit=packed, margin_f16=margin.astype(np.float16),
+        logits_sub=logits[:, :, ::8, ::8].numpy(), warp_mask=wm.numpy().astype(np.uint8),
+    )
+    print("full golden: theta", theta.numpy().reshape(B, 9), "consist", ce.numpy())
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--full", action="store_true")
+    ap.add_argument("--data-only", action="store_true")
+    a = ap.parse_args()
+    os.makedirs(GOLD, exist_ok=True)
+    make_data()
+    if not a.data_only:
+        up_mod = _load("ref_unet_parts", "unet/unet_parts.py")
+        rn_mod = _load("ref_resnet", "models/resnet.py")
+        make_block_goldens(up_mod, rn_mod)
+        if a.full:
+            make_full_golden(up_mod, rn_mod)

@@ -1,0 +1,86 @@
+"""ctypes binding of libsfh_amd.so (C ABI: include/sfh_amd.h).
+
+There is deliberately no fallback: if the library is missing or a symbol cannot be
+resolved, importing the hot path fails with an explicit error.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsfh_amd.so")
+
+TILE_8x32, TILE_16x16, TILE_32x8 = 0, 1, 2
+OUT_NHWC, OUT_UPSCATTER2 = 0, 1
+
+_p = C.c_void_p
+_i = C.c_int32
+
+
+class ConvDesc(C.Structure):
+    """Mirror of ``struct sfh_conv_desc`` (include/sfh_amd.h)."""
+    _fields_ = [
+        ("src0", _p), ("c0", _i), ("cs0", _i), ("h0", _i), ("w0", _i), ("pool0", _i),
+        ("src1", _p), ("c1", _i), ("cs1", _i), ("h1", _i), ("w1", _i), ("pad_top1", _i), ("pad_left1", _i),
+        ("batch", _i), ("H", _i), ("W", _i), ("ksize", _i), ("stride", _i), ("tile", _i),
+        ("wpacked", _p), ("scale", _p), ("shift", _p), ("cout", _i), ("relu", _i),
+        ("residual", _p),
+        ("dst", _p), ("dst_cs", _i), ("out_mode", _i),
+    ]
+
+
+# name -> (restype, argtypes); every symbol declared in include/sfh_amd.h
+SIGNATURES = {
+    "sfh_last_error": (C.c_char_p, []),
+    "sfh_version": (C.c_int, []),
+    "sfh_conv_fwd": (C.c_int, [C.POINTER(ConvDesc), _p]),
+    "sfh_packed_weight_floats": (C.c_int64, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    "sfh_pack_conv_weights": (C.c_int, [_p, _p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _p]),
+    "sfh_space_to_depth2": (C.c_int, [_p, _p, C.c_int, C.c_int, C.c_int, C.c_int, _p]),
+    "sfh_fold_bn": (C.c_int, [_p, _p, _p, _p, _p, C.c_float, C.c_int, C.c_int, _p, _p, _p]),
+    "sfh_nchw_to_nhwc": (C.c_int, [_p, _p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _p]),
+    "sfh_nhwc_to_nchw": (C.c_int, [_p, _p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _p]),
+    "sfh_outconv_fwd": (C.c_int, [_p, C.c_int, _p, _p, C.c_int, C.c_int, C.c_int, C.c_int, _p, _p,
+                                  _p, C.c_int, _p, C.c_int, _p]),
+    "sfh_homography_warp_fwd": (C.c_int, [_p, _p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int,
+                                          C.c_int, C.c_int, C.c_float, _p, _p, _p]),
+    "sfh_poi_project_fwd": (C.c_int, [_p, _p, C.c_int, C.c_int, C.c_int, _p, _p]),
+    "sfh_ce_workspace_floats": (C.c_int64, [C.c_int, C.c_int, C.c_int]),
+    "sfh_consistency_ce_fwd": (C.c_int, [_p, _p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                         _p, _p, _p]),
+    "sfh_maxpool3x3s2_fwd": (C.c_int, [_p, _p, C.c_int, C.c_int, C.c_int, C.c_int, _p]),
+    "sfh_avgpool_linear_fwd": (C.c_int, [_p, _p, _p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _p, _p]),
+}
+
+_lib = None
+
+
+class SfhError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libsfh_amd.so and bind every symbol; raises if anything is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise SfhError(
+            f"{LIB_PATH} not found: the HIP extension has not been built. Run "
+            "`python -c 'import __graft_entry__ as g; g.build()'` (needs hipcc). "
+            "There is no CPU/PyTorch fallback for this path."
+        )
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = load().sfh_last_error().decode(errors="replace")
+        if rc == -1:
+            raise ValueError(f"{what}: {msg}")
+        raise SfhError(f"{what}: error {rc}: {msg}")

@@ -1,0 +1,473 @@
+// conv_mfma.hip - fp32 implicit-GEMM convolution on the gfx950 matrix cores.
+//
+// One kernel family covers the conv-shaped work of the hot path:
+//   * conv3x3 pad1 + bias + BatchNorm(eval) + ReLU   (DoubleConv, unet/unet_parts.py:14-21)
+//   * MaxPool2d(2) fused into the consumer's loads    (Down, unet/unet_parts.py:33)
+//   * F.pad + torch.cat([skip, up]) as a 2-source load (Up, unet/unet_parts.py:59-67)
+//   * ConvTranspose2d k2 s2 as a 1x1 GEMM with a scatter epilogue (Up, unet/unet_parts.py:52)
+//   * stride-2 / residual variants of BasicBlock      (models/resnet.py:64-82)
+//
+// Arithmetic: v_mfma_f32_16x16x4_f32 (fp32 in, fp32 accumulate) - bit-for-bit an fp32
+// fmaf chain, which is what the 1e-4 / exact-argmax parity target of the path needs
+// (bf16 inputs would not hold it through ~45 layers).  Roofline: fp32 matrix peak
+// 157.3 TFLOP/s (MI355X_MICROARCH.md).
+//
+// GEMM view: D[cout][pixel] = sum_k W[cout][k] * X[k][pixel], k = (tap, cin).
+//   A operand = weights  (row = cout within a 16-group, k = lane>>4)
+//   B operand = pixels   (col = pixel within a 16-group, k = lane>>4)
+//   D: lane holds pixel (lane&15) and couts 4*(lane>>4)..+3  -> one 16-byte NHWC store.
+// One ds_read_b128 of a pixel's 4 consecutive channels (or of 4 consecutive cin of one
+// cout) feeds 4 MFMAs: register j of lane-group g is channel 4g+j of the 16-channel stage.
+//
+// Workgroup = 256 threads = 4 waves; block tile = NSUBT pixel-groups x 64 couts; wave w
+// owns pixel-groups [w*MT_M, (w+1)*MT_M) x all 4 cout-groups (MT_M*4 accumulators).
+// LDS per stage (16*NSUB input channels):
+//   halo  [4*NSUB planes][HPIXP pixels][4 ch]   (plane stride multiple of 256 B ->
+//                                                conflict-free ds_read_b128 for 1x16 groups)
+//   wts   [taps][4 cout-groups][64 lanes][4]    (fragment order, linear copy of the
+//                                                pre-packed global image)
+// Stages are register-prefetched: the global loads of stage s+1 are issued before the
+// MFMA block of stage s and written to LDS after it.  Two workgroups per CU (<= 60 KB
+// LDS, <= 256 VGPRs) overlap each other's staging with MFMA issue.
+//
+// Row space: for stride 1 the output rows of all frames are flattened with ONE shared
+// zero row between consecutive frames (row index r = b*(H+1) + y, y == H is the zero
+// row), so row tiles may straddle frames and only the last tile is partial.
+#include "common.h"
+
+namespace {
+
+template <int KS_, int STRIDE_, int NSUB_, int SH_, int SW_, int TH_, int TW_>
+struct ConvCfg {
+  static constexpr int KS = KS_, STRIDE = STRIDE_, NSUB = NSUB_;
+  static constexpr int SH = SH_, SW = SW_, TH = TH_, TW = TW_;
+  // padding before / after: 3x3 -> 1/1, 1x1 -> 0/0, 4x4 (space-to-depth stem) -> 2/1
+  static constexpr int PAD = KS / 2;
+  static constexpr int PADA = (KS - 1) / 2;
+  static constexpr int NTAP = KS * KS * NSUB;
+  // taps per LDS stage: the 16-tap 4x4 stem stages its weights in two halves
+  static constexpr int TPS = NTAP > 9 ? NTAP / 2 : NTAP;
+  static constexpr int TG = NTAP / TPS;
+  static constexpr int PLANES = 4 * NSUB;
+  static constexpr int CKS = 16 * NSUB;
+  static constexpr int HH = (TH - 1) * STRIDE + KS;
+  static constexpr int HW = (TW - 1) * STRIDE + KS;
+  static constexpr int HPIX = HH * HW;
+  static constexpr int HPIXP = (HPIX + 15) / 16 * 16;
+  static constexpr int HSLOTS = PLANES * HPIXP;
+  static constexpr int NSL = (HSLOTS + 255) / 256;
+  static constexpr int SUBX = TW / SW;
+  static constexpr int NSUBT = (TH / SH) * SUBX;
+  static constexpr int MT_M = NSUBT / 4;
+  static constexpr int LDS_BYTES = (HSLOTS + TPS * 256) * 16;
+  static constexpr bool FLATROWS = (STRIDE == 1);
+  static_assert(SH * SW == 16, "pixel group must hold 16 pixels");
+  static_assert(NSUBT % 4 == 0, "tile must split over 4 waves");
+  static_assert(TH % SH == 0 && TW % SW == 0, "tile/group mismatch");
+};
+
+struct ConvGeom {
+  int tiles_x, tiles_y, ntiles, nblk_n;
+  int Ho, Wo, rows_total;
+};
+
+template <class C>
+__device__ __forceinline__ int halo_src_offset(const sfh_conv_desc& d, int which, int p,
+                                               int r0, int x0) {
+  // p: halo pixel index; r0: first output row of the tile (flat row space, or
+  // img*2^16 + y for the per-image policy); x0: first output column.
+  const int hy = p / C::HW, hx = p - hy * C::HW;
+  if (p >= C::HPIX) return -1;
+  int b, y;
+  if (C::FLATROWS) {
+    const int r = r0 - C::PAD + hy;
+    if (r < 0) return -1;
+    b = r / (d.H + 1);
+    y = r - b * (d.H + 1);
+    if (b >= d.batch || y >= d.H) return -1;
+  } else {
+    b = r0 >> 16;
+    y = (r0 & 0xFFFF) * C::STRIDE - C::PAD + hy;
+    if (y < 0 || y >= d.H) return -1;
+  }
+  const int x = x0 * C::STRIDE - C::PAD + hx;
+  if (x < 0 || x >= d.W) return -1;
+  if (which == 0) {
+    if (d.pool0) return ((b * d.h0 + 2 * y) * d.w0 + 2 * x) * d.cs0;
+    return ((b * d.h0 + y) * d.w0 + x) * d.cs0;
+  }
+  const int ys = y - d.pad_top1, xs = x - d.pad_left1;
+  if (ys < 0 || ys >= d.h1 || xs < 0 || xs >= d.w1) return -1;
+  return ((b * d.h1 + ys) * d.w1 + xs) * d.cs1;
+}
+
+template <class C>
+__global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const sfh_conv_desc d, const ConvGeom g) {
+  extern __shared__ __attribute__((aligned(16))) float smem_f[];
+  f32x4* const halo = reinterpret_cast<f32x4*>(smem_f);
+  f32x4* const wlds = halo + C::HSLOTS;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wv = tid >> 6;
+  const int lq = lane & 15;  // pixel (B operand col) / cout (A operand row) within a group
+  const int lg = lane >> 4;  // k index of the MFMA = channel quad of the stage
+
+  // XCD-aware block -> (tile, cout block): blocks b and b+8 share an XCD (L2); keep the
+  // cout blocks of one pixel tile on one XCD so the halo is re-read from that L2.
+  const int bid = blockIdx.x;
+  const int xcd = bid & 7, k = bid >> 3;
+  const int nb = k % g.nblk_n;
+  const int tile = (k / g.nblk_n) * 8 + xcd;
+  if (tile >= g.ntiles) return;
+  const int ty = tile / g.tiles_x, tx = tile - ty * g.tiles_x;
+  const int x0 = tx * C::TW;
+  int r0;
+  if (C::FLATROWS) {
+    r0 = ty * C::TH;
+  } else {
+    const int tpi = g.tiles_y;  // tiles per image
+    const int img = ty / tpi;
+    r0 = (img << 16) | ((ty - img * tpi) * C::TH);
+  }
+  const int n0 = nb * 64;
+
+  // a stage = (16*NSUB-channel chunk, tap group); chunks of source 0 come first
+  const int nst0 = (d.c0 + C::CKS - 1) / C::CKS * C::TG;
+  const int nst1 = d.src1 ? (d.c1 + C::CKS - 1) / C::CKS * C::TG : 0;
+  const int nst = nst0 + nst1;
+  const f32x4* wg = reinterpret_cast<const f32x4*>(d.wpacked) +
+                    (size_t)nb * nst * (C::TPS * 256) + tid;
+
+  // ---- per-thread halo slot bookkeeping -------------------------------------------
+  int poff[C::NSL];
+  int which = 0;
+#pragma unroll
+  for (int i = 0; i < C::NSL; ++i) {
+    const int s = tid + 256 * i;
+    poff[i] = (s < C::HSLOTS) ? halo_src_offset<C>(d, 0, s % C::HPIXP, r0, x0) : -1;
+  }
+
+  f32x4 hreg[C::NSL];
+  f32x4 wreg[C::TPS];
+
+  auto load_stage = [&](int st) {
+    const float* src;
+    int cb, cs;
+    if (st < nst0) {
+      src = d.src0; cb = (st / C::TG) * C::CKS; cs = d.cs0;
+    } else {
+      src = d.src1; cb = ((st - nst0) / C::TG) * C::CKS; cs = d.cs1;
+    }
+    const bool pool = (st < nst0) && d.pool0;
+    if (C::TG == 1 || st % C::TG == 0) {  // the halo is shared by the tap groups of a chunk
+#pragma unroll
+    for (int i = 0; i < C::NSL; ++i) {
+      const int s = tid + 256 * i;
+      const int c = cb + 4 * (s / C::HPIXP);
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (poff[i] >= 0 && c < cs) {
+        const float* p = src + (size_t)(unsigned)poff[i] + c;
+        v = *reinterpret_cast<const f32x4*>(p);
+        if (pool) {
+          const f32x4 v1 = *reinterpret_cast<const f32x4*>(p + d.cs0);
+          const f32x4 v2 = *reinterpret_cast<const f32x4*>(p + (size_t)d.w0 * d.cs0);
+          const f32x4 v3 = *reinterpret_cast<const f32x4*>(p + (size_t)d.w0 * d.cs0 + d.cs0);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] = fmaxf(fmaxf(v[j], v1[j]), fmaxf(v2[j], v3[j]));
+        }
+      }
+      hreg[i] = v;
+    }
+    }
+    const f32x4* wp = wg + (size_t)st * (C::TPS * 256);
+#pragma unroll
+    for (int t = 0; t < C::TPS; ++t) wreg[t] = wp[t * 256];
+  };
+
+  // ---- per-lane LDS read bases (B operand = pixels) ----------------------------------
+  int pixbase[C::MT_M];
+#pragma unroll
+  for (int mi = 0; mi < C::MT_M; ++mi) {
+    const int s = wv * C::MT_M + mi;
+    const int sy = s / C::SUBX, sx = s - sy * C::SUBX;
+    const int oy = sy * C::SH + lq / C::SW, ox = sx * C::SW + lq % C::SW;
+    pixbase[mi] = lg * C::HPIXP + oy * C::STRIDE * C::HW + ox * C::STRIDE;
+  }
+
+  f32x4 acc[4][C::MT_M];
+#pragma unroll
+  for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+    for (int mi = 0; mi < C::MT_M; ++mi) acc[ni][mi] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  load_stage(0);
+  for (int st = 0; st < nst; ++st) {
+    __syncthreads();  // all waves finished reading the previous stage from LDS
+    if (C::TG == 1 || st % C::TG == 0) {
+#pragma unroll
+      for (int i = 0; i < C::NSL; ++i) {
+        const int s = tid + 256 * i;
+        if (s < C::HSLOTS) halo[s] = hreg[i];
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < C::TPS; ++t) wlds[t * 256 + tid] = wreg[t];
+    __syncthreads();
+
+    if (st + 1 < nst) {
+      if (st + 1 == nst0 && which == 0) {  // switch to source 1: recompute slot offsets
+        which = 1;
+#pragma unroll
+        for (int i = 0; i < C::NSL; ++i) {
+          const int s = tid + 256 * i;
+          poff[i] = (s < C::HSLOTS) ? halo_src_offset<C>(d, 1, s % C::HPIXP, r0, x0) : -1;
+        }
+      }
+      load_stage(st + 1);
+    }
+
+    const int tbase = (C::TG == 1) ? 0 : (st % C::TG) * C::TPS;
+#pragma unroll
+    for (int tl = 0; tl < C::TPS; ++tl) {
+      constexpr int KK = C::KS * C::KS;
+      const int t = tl;
+      const int tgl = tbase + tl;  // tap index within the chunk
+      const int sub = tgl / KK, kk = tgl % KK;
+      const int toff = sub * 4 * C::HPIXP + (kk / C::KS) * C::HW + (kk % C::KS);
+      f32x4 xv[C::MT_M], wv4[4];
+#pragma unroll
+      for (int mi = 0; mi < C::MT_M; ++mi) xv[mi] = halo[pixbase[mi] + toff];
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) wv4[ni] = wlds[(t * 4 + ni) * 64 + lane];
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+          for (int mi = 0; mi < C::MT_M; ++mi)
+            acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv4[ni][j], xv[mi][j],
+                                                               acc[ni][mi], 0, 0, 0);
+    }
+  }
+
+  // ---- epilogue: y = acc*scale + shift (+residual) (ReLU) -> NHWC 16-byte stores ----
+  f32x4 sc[4], sh[4];
+#pragma unroll
+  for (int ni = 0; ni < 4; ++ni) {
+    const int co = n0 + ni * 16 + 4 * lg;
+    sc[ni] = *reinterpret_cast<const f32x4*>(d.scale + co);
+    sh[ni] = *reinterpret_cast<const f32x4*>(d.shift + co);
+  }
+#pragma unroll
+  for (int mi = 0; mi < C::MT_M; ++mi) {
+    const int s = wv * C::MT_M + mi;
+    const int sy = s / C::SUBX, sx = s - sy * C::SUBX;
+    const int oy = sy * C::SH + lq / C::SW, ox = sx * C::SW + lq % C::SW;
+    const int x = x0 + ox;
+    int b, y;
+    bool ok = x < g.Wo;
+    if (C::FLATROWS) {
+      const int r = r0 + oy;
+      b = r / (g.Ho + 1);
+      y = r - b * (g.Ho + 1);
+      ok = ok && r < g.rows_total && y < g.Ho;
+    } else {
+      b = r0 >> 16;
+      y = (r0 & 0xFFFF) + oy;
+      ok = ok && y < g.Ho;
+    }
+    if (!ok) continue;
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+      int co = n0 + ni * 16 + 4 * lg;
+      size_t pix;
+      if (d.out_mode == SFH_OUT_UPSCATTER2) {
+        const int cr = d.cout >> 2;
+        const int qd = co / cr;
+        co -= qd * cr;
+        pix = ((size_t)(b * 2 * g.Ho + 2 * y + (qd >> 1)) * (2 * g.Wo) + 2 * x + (qd & 1));
+      } else {
+        pix = ((size_t)(b * g.Ho + y) * g.Wo + x);
+      }
+      const size_t off = pix * d.dst_cs + co;
+      f32x4 v = acc[ni][mi];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = v[j] * sc[ni][j] + sh[ni][j];
+      if (d.residual) {
+        const f32x4 rr = *reinterpret_cast<const f32x4*>(d.residual + off);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] += rr[j];
+      }
+      if (d.relu) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
+      }
+      *reinterpret_cast<f32x4*>(d.dst + off) = v;
+    }
+  }
+}
+
+// ------------------------------------------------------------------ weight packing
+// packed[nb][stage][tap][ng(4)][lane(64)][j(4)], tap = sub*KS*KS + ky*KS + kx:
+//   cout = nb*64 + ng*16 + (lane&15);  channel-in-source = stage_local*CKS + 16*sub + 4*(lane>>4) + j
+__global__ void pack_weights_kernel(const float* __restrict__ w, float* __restrict__ packed,
+                                    int ks, int nsub, int c0, int c1, int coutv, int transposed,
+                                    int aux, long total4) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;  // one float4 per thread
+  if (idx >= total4) return;
+  const int cks = 16 * nsub, kk2 = ks * ks, ntap = kk2 * nsub;
+  const int nst0 = (c0 + cks - 1) / cks, nst1 = c1 > 0 ? (c1 + cks - 1) / cks : 0;
+  const int nst = nst0 + nst1;
+  long r = idx;
+  const int lane = r & 63; r >>= 6;
+  const int ng = r & 3; r >>= 2;
+  const int tap = r % ntap; r /= ntap;
+  const int st = r % nst;
+  const int nb = r / nst;
+  const int sub = tap / kk2, kk = tap % kk2;
+  const int ky = kk / ks, kx = kk % ks;
+  const int cv = nb * 64 + ng * 16 + (lane & 15);
+  const int cin_total = c0 + c1;
+  f32x4 out = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    int cl = (st < nst0 ? st : st - nst0) * cks + 16 * sub + 4 * (lane >> 4) + j;
+    const int lim = st < nst0 ? c0 : c1;
+    if (cl >= lim) continue;
+    const int cin = st < nst0 ? cl : c0 + cl;
+    float v;
+    if (transposed == 2) {  // 7x7 stride-2 stem as a 4x4 conv over the 2x2 space-to-depth input
+      const int csd = c0 >> 2;                  // padded channels of the un-shuffled source
+      const int par = cl / csd, c = cl - par * csd;
+      const int ky7 = 2 * ky + (par >> 1) - 1, kx7 = 2 * kx + (par & 1) - 1;
+      if (c >= aux || ky7 < 0 || ky7 > 6 || kx7 < 0 || kx7 > 6) continue;
+      v = w[(((size_t)cv * aux + c) * 7 + ky7) * 7 + kx7];
+    } else if (transposed) {  // ConvTranspose2d weight (cin, cout, 2, 2); cv = (dy*2+dx)*cout + co
+      const int cout = coutv >> 2;
+      const int qd = cv / cout, co = cv - qd * cout;
+      v = w[(((size_t)cin * cout + co) * 2 + (qd >> 1)) * 2 + (qd & 1)];
+    } else {  // Conv2d weight (cout, cin, ks, ks)
+      v = w[(((size_t)cv * cin_total + cin) * ks + ky) * ks + kx];
+    }
+    out[j] = v;
+  }
+  reinterpret_cast<f32x4*>(packed)[idx] = out;
+}
+
+int nsub_for(int ksize) { return ksize == 1 ? 2 : 1; }
+bool ksize_ok(int k) { return k == 1 || k == 3 || k == 4; }
+
+template <class C>
+int launch_conv(const sfh_conv_desc& d, hipStream_t stream) {
+  ConvGeom g;
+  g.Ho = (d.H + C::PAD + C::PADA - C::KS) / C::STRIDE + 1;
+  g.Wo = (d.W + C::PAD + C::PADA - C::KS) / C::STRIDE + 1;
+  g.tiles_x = sfh_cdiv(g.Wo, C::TW);
+  if (C::FLATROWS) {
+    g.rows_total = d.batch * (g.Ho + 1);
+    g.tiles_y = sfh_cdiv(g.rows_total, C::TH);
+    g.ntiles = g.tiles_x * g.tiles_y;
+  } else {
+    g.rows_total = 0;
+    g.tiles_y = sfh_cdiv(g.Ho, C::TH);  // per image
+    g.ntiles = g.tiles_x * g.tiles_y * d.batch;
+    SFH_REQUIRE(g.Ho < 65536 && d.batch < 32768, "stride-2 conv: geometry too large");
+  }
+  g.nblk_n = d.cout / 64;
+  const long nblocks = (long)sfh_cdiv(g.ntiles, 8) * 8 * g.nblk_n;
+  SFH_REQUIRE(nblocks < (1L << 31), "conv grid too large");
+  static bool attr_set = false;  // idempotent; benign if raced
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_kernel<C>),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(conv_mfma_kernel<C>, dim3((unsigned)nblocks), dim3(256), C::LDS_BYTES, stream,
+                     d, g);
+  return sfh_check_launch("conv_mfma_kernel");
+}
+
+}  // namespace
+
+extern "C" int64_t sfh_packed_weight_floats(int ksize, int c0, int c1, int cout_virtual) {
+  if (!ksize_ok(ksize) || c0 <= 0 || c1 < 0 || cout_virtual <= 0 || cout_virtual % 64)
+    return -1;
+  const int nsub = nsub_for(ksize), cks = 16 * nsub;
+  const int64_t nst = (c0 + cks - 1) / cks + (c1 > 0 ? (c1 + cks - 1) / cks : 0);
+  return (int64_t)(cout_virtual / 64) * nst * (ksize * ksize * nsub) * 1024;
+}
+
+extern "C" int sfh_pack_conv_weights(const float* w, float* packed, int ksize, int c0, int c1,
+                                     int cout_virtual, int transposed, int aux, void* stream) {
+  const int64_t n = sfh_packed_weight_floats(ksize, c0, c1, cout_virtual);
+  SFH_REQUIRE(n > 0, "pack_conv_weights: bad geometry ks=%d c0=%d c1=%d cout=%d", ksize, c0, c1,
+              cout_virtual);
+  SFH_REQUIRE(w && packed, "pack_conv_weights: null pointer");
+  SFH_REQUIRE(transposed >= 0 && transposed <= 2, "pack_conv_weights: bad mode %d", transposed);
+  SFH_REQUIRE(transposed != 1 || (ksize == 1 && c1 == 0 && cout_virtual % 256 == 0),
+              "pack_conv_weights: transposed needs ksize=1, c1=0, cout multiple of 64");
+  SFH_REQUIRE(transposed != 2 || (ksize == 4 && c1 == 0 && c0 % 16 == 0 && aux > 0 && aux <= c0 / 4),
+              "pack_conv_weights: stem mode needs ksize=4, c0 = 4*padded cin, aux = real cin");
+  SFH_REQUIRE(c1 == 0 || c0 % (16 * nsub_for(ksize)) == 0,
+              "pack_conv_weights: c0 must be a multiple of the stage width when c1 > 0");
+  const long total4 = n / 4;
+  hipLaunchKernelGGL(pack_weights_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0,
+                     (hipStream_t)stream, w, packed, ksize, nsub_for(ksize), c0, c1, cout_virtual,
+                     transposed, aux, total4);
+  return sfh_check_launch("pack_weights_kernel");
+}
+
+extern "C" int sfh_conv_fwd(const sfh_conv_desc* dp, void* stream_) {
+  SFH_REQUIRE(dp, "conv_fwd: null descriptor");
+  const sfh_conv_desc& d = *dp;
+  hipStream_t stream = (hipStream_t)stream_;
+  SFH_REQUIRE(d.src0 && d.wpacked && d.scale && d.shift && d.dst, "conv_fwd: null pointer");
+  SFH_REQUIRE(d.batch > 0 && d.H > 0 && d.W > 0, "conv_fwd: empty geometry");
+  SFH_REQUIRE(d.cout > 0 && d.cout % 64 == 0, "conv_fwd: cout=%d must be a multiple of 64", d.cout);
+  SFH_REQUIRE(d.cs0 % 4 == 0 && d.cs0 >= 4 && d.dst_cs % 4 == 0, "conv_fwd: channel strides must be multiples of 4");
+  SFH_REQUIRE(d.c0 > 0 && d.c0 <= d.cs0, "conv_fwd: c0=%d cs0=%d", d.c0, d.cs0);
+  const int nsub = nsub_for(d.ksize);
+  if (d.src1) {
+    SFH_REQUIRE(d.c0 % (16 * nsub) == 0, "conv_fwd: c0 must be a multiple of %d with two sources", 16 * nsub);
+    SFH_REQUIRE(d.cs1 % 4 == 0 && d.c1 > 0 && d.c1 <= d.cs1, "conv_fwd: c1=%d cs1=%d", d.c1, d.cs1);
+    SFH_REQUIRE(d.h1 > 0 && d.w1 > 0 && d.pad_top1 >= 0 && d.pad_left1 >= 0 &&
+                    d.pad_top1 + d.h1 <= d.H && d.pad_left1 + d.w1 <= d.W,
+                "conv_fwd: source 1 (%dx%d at %d,%d) does not fit the %dx%d frame", d.h1, d.w1,
+                d.pad_top1, d.pad_left1, d.H, d.W);
+  }
+  if (d.pool0)
+    SFH_REQUIRE(d.h0 / 2 == d.H && d.w0 / 2 == d.W, "conv_fwd: pool0 needs floor(h0/2)==H, floor(w0/2)==W");
+  else
+    SFH_REQUIRE(d.h0 == d.H && d.w0 == d.W, "conv_fwd: source 0 is %dx%d, frame is %dx%d", d.h0, d.w0, d.H, d.W);
+  SFH_REQUIRE((int64_t)d.batch * d.h0 * d.w0 * d.cs0 < (1LL << 31), "conv_fwd: source 0 exceeds 2^31 elements");
+  if (d.out_mode == SFH_OUT_UPSCATTER2)
+    SFH_REQUIRE(d.ksize == 1 && d.stride == 1 && (d.cout / 4) % 64 == 0 && !d.residual,
+                "conv_fwd: up-scatter needs ksize=1, stride=1, cout/4 multiple of 64");
+  else
+    SFH_REQUIRE(d.out_mode == SFH_OUT_NHWC, "conv_fwd: bad out_mode %d", d.out_mode);
+
+#define SFH_CASE(KS, ST, TILE, SH, SW, TH, TW)                                   \
+  if (d.ksize == KS && d.stride == ST && d.tile == TILE)                         \
+    return launch_conv<ConvCfg<KS, ST, (KS == 1 ? 2 : 1), SH, SW, TH, TW>>(d, stream);
+  SFH_CASE(3, 1, SFH_TILE_8x32, 1, 16, 8, 32)
+  SFH_CASE(3, 1, SFH_TILE_16x16, 1, 16, 16, 16)
+  SFH_CASE(3, 1, SFH_TILE_32x8, 2, 8, 32, 8)
+  SFH_CASE(1, 1, SFH_TILE_8x32, 1, 16, 8, 32)
+  SFH_CASE(1, 1, SFH_TILE_16x16, 1, 16, 16, 16)
+  SFH_CASE(1, 1, SFH_TILE_32x8, 2, 8, 32, 8)
+  // 4x4 stem (7x7 s2 over the space-to-depth input)
+  SFH_CASE(4, 1, SFH_TILE_8x32, 1, 16, 8, 32)
+  SFH_CASE(4, 1, SFH_TILE_16x16, 1, 16, 16, 16)
+  SFH_CASE(4, 1, SFH_TILE_32x8, 2, 8, 32, 8)
+  // stride 2 (ResNet stage transitions): half-size tiles keep the halo within LDS
+  SFH_CASE(3, 2, SFH_TILE_8x32, 1, 16, 4, 32)
+  SFH_CASE(3, 2, SFH_TILE_16x16, 1, 16, 8, 16)
+  SFH_CASE(3, 2, SFH_TILE_32x8, 2, 8, 16, 8)
+  SFH_CASE(1, 2, SFH_TILE_8x32, 1, 16, 4, 32)
+  SFH_CASE(1, 2, SFH_TILE_16x16, 1, 16, 8, 16)
+  SFH_CASE(1, 2, SFH_TILE_32x8, 2, 8, 16, 8)
+#undef SFH_CASE
+  sfh_set_error("conv_fwd: unsupported ksize=%d stride=%d tile=%d", d.ksize, d.stride, d.tile);
+  return SFH_E_ARG;
+}

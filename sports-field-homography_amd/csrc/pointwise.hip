@@ -1,0 +1,353 @@
+// pointwise.hip - the bandwidth-bound kernels around the conv stack (all HBM-roofline work):
+// layout conversion, BatchNorm folding, OutConv (+argmax, +STN input assembly),
+// consistency cross-entropy, ResNet max-pool and avg-pool+Linear.
+#include "common.h"
+
+namespace {
+
+// ----------------------------------------------------------------- layout conversion
+// (B,C,H,W) -> (B,H,W,cs): one thread per pixel, coalesced reads per channel plane,
+// one 16-byte store per 4 channels.
+__global__ void nchw_to_nhwc_kernel(const float* __restrict__ src, float* __restrict__ dst,
+                                    int C, int HW, int cs, long npix) {
+  const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= npix) return;
+  const long b = p / HW, i = p - b * HW;
+  const float* s = src + b * (long)C * HW + i;
+  float* d = dst + p * cs;
+  for (int c4 = 0; c4 < cs; c4 += 4) {
+    f32x4 v;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = (c4 + j < C) ? s[(long)(c4 + j) * HW] : 0.f;
+    *reinterpret_cast<f32x4*>(d + c4) = v;
+  }
+}
+
+__global__ void nhwc_to_nchw_kernel(const float* __restrict__ src, float* __restrict__ dst,
+                                    int C, int HW, int cs, long npix) {
+  const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= npix) return;
+  const long b = p / HW, i = p - b * HW;
+  const float* s = src + p * cs;
+  float* d = dst + b * (long)C * HW + i;
+  for (int c4 = 0; c4 < C; c4 += 4) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(s + c4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (c4 + j < C) d[(long)(c4 + j) * HW] = v[j];
+  }
+}
+
+__global__ void space_to_depth2_kernel(const float* __restrict__ src, float* __restrict__ dst, int H,
+                                       int W, int cs, int H2, int W2, long total4) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;  // one float4 of the output
+  if (idx >= total4) return;
+  const int c4n = cs;  // float4 per output pixel = 4*cs/4
+  const int q = idx % c4n;
+  long r = idx / c4n;
+  const int X = r % W2; r /= W2;
+  const int Y = r % H2;
+  const long b = r / H2;
+  const int par = (q * 4) / cs, c = q * 4 - par * cs;
+  const int y = 2 * Y + (par >> 1), x = 2 * X + (par & 1);
+  f32x4 v = {0.f, 0.f, 0.f, 0.f};
+  if (y < H && x < W) v = *reinterpret_cast<const f32x4*>(src + ((b * H + y) * W + x) * cs + c);
+  reinterpret_cast<f32x4*>(dst)[idx] = v;
+}
+
+// ----------------------------------------------------------------- BatchNorm folding
+__global__ void fold_bn_kernel(const float* conv_bias, const float* gamma, const float* beta,
+                               const float* mean, const float* var, float eps, int n, int repeat,
+                               float* scale, float* shift) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n * repeat) return;
+  const int c = i % n;
+  const float cb = conv_bias ? conv_bias[c] : 0.f;
+  if (gamma) {
+    const float invstd = 1.0f / sqrtf(var[c] + eps);
+    const float a = gamma[c] * invstd;
+    scale[i] = a;
+    shift[i] = (cb - mean[c]) * a + beta[c];
+  } else {
+    scale[i] = 1.0f;
+    shift[i] = cb;
+  }
+}
+
+// ----------------------------------------------------------------- OutConv 1x1 (cin -> nc<=8)
+// 128 pixels per block; two threads per pixel, each reducing half of the input channels
+// straight from the NHWC row (16-byte loads), combined with one DPP shuffle.
+template <int NC>
+__global__ __launch_bounds__(256) void outconv_kernel(
+    const float* __restrict__ x, int cin, const float* __restrict__ w, const float* __restrict__ bias,
+    long npix, int HW, float* __restrict__ logits, uint8_t* __restrict__ amax,
+    float* __restrict__ stn_in, int stn_cs, const float* __restrict__ frame, int frame_cs) {
+  extern __shared__ __attribute__((aligned(16))) float wl[];  // [NC][cin]
+  for (int i = threadIdx.x; i < NC * cin; i += 256) wl[i] = w[i];
+  __syncthreads();
+  const long p = (long)blockIdx.x * 128 + (threadIdx.x >> 1);
+  const int half = threadIdx.x & 1;
+  const bool live = p < npix;
+  float acc[NC];
+#pragma unroll
+  for (int k = 0; k < NC; ++k) acc[k] = 0.f;
+  if (live) {
+    const int ch = cin >> 1;  // channels per half (multiple of 4)
+    const float* xp = x + p * cin + half * ch;
+    const float* wp = wl + half * ch;
+    for (int c = 0; c < ch; c += 4) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(xp + c);
+#pragma unroll
+      for (int k = 0; k < NC; ++k) {
+        const f32x4 ww = *reinterpret_cast<const f32x4*>(wp + k * cin + c);
+        acc[k] += v[0] * ww[0] + v[1] * ww[1] + v[2] * ww[2] + v[3] * ww[3];
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < NC; ++k) acc[k] += __shfl_xor(acc[k], 1);
+  if (!live || half) return;
+#pragma unroll
+  for (int k = 0; k < NC; ++k) acc[k] += bias[k];
+  const long b = p / HW, i = p - b * HW;
+  if (logits) {
+#pragma unroll
+    for (int k = 0; k < NC; ++k) logits[(b * NC + k) * HW + i] = acc[k];
+  }
+  if (amax) {
+    int best = 0;
+    float bv = acc[0];
+#pragma unroll
+    for (int k = 1; k < NC; ++k)
+      if (acc[k] > bv) { bv = acc[k]; best = k; }
+    amax[p] = (uint8_t)best;
+  }
+  if (stn_in) {
+    float* o = stn_in + p * stn_cs;
+    const float* f = frame + p * frame_cs;
+    float vals[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) vals[k] = 0.f;
+#pragma unroll
+    for (int k = 0; k < NC; ++k) vals[k] = acc[k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) vals[NC + k] = f[k];
+    for (int c = 0; c < stn_cs && c < 16; c += 4)
+      *reinterpret_cast<f32x4*>(o + c) = (f32x4){vals[c], vals[c + 1], vals[c + 2], vals[c + 3]};
+  }
+}
+
+// ----------------------------------------------------------------- consistency CE
+// per pixel: logsumexp(logits[:, p]) - logits[target, p]; block partial sums, then a
+// second deterministic pass sums each frame's partials and divides by H*W.
+constexpr int CE_BLOCK = 256;
+constexpr int CE_PIX_PER_BLOCK = 2048;
+
+__global__ __launch_bounds__(CE_BLOCK) void ce_partial_kernel(
+    const float* __restrict__ logits, const int32_t* __restrict__ mask, int nc, int H, int W,
+    int hm, int wm, int blocks_per_img, float* __restrict__ partial) {
+  const int b = blockIdx.x / blocks_per_img, blk = blockIdx.x - b * blocks_per_img;
+  const int HW = H * W;
+  const float* lg = logits + (long)b * nc * HW;
+  const int32_t* mk = mask + (long)b * hm * wm;
+  float sum = 0.f;
+  const int start = blk * CE_PIX_PER_BLOCK;
+  for (int i = start + threadIdx.x; i < min(start + CE_PIX_PER_BLOCK, HW); i += CE_BLOCK) {
+    int t;
+    if (hm == H && wm == W) {
+      t = mk[i];
+    } else {  // F.interpolate(mode='nearest'): src = floor(dst * in/out)
+      const int y = i / W, x = i - y * W;
+      const int ys = min((int)floorf(y * ((float)hm / H)), hm - 1);
+      const int xs = min((int)floorf(x * ((float)wm / W)), wm - 1);
+      t = mk[ys * wm + xs];
+    }
+    float m = lg[i];
+    for (int k = 1; k < nc; ++k) m = fmaxf(m, lg[(long)k * HW + i]);
+    float se = 0.f, xt = 0.f;
+    for (int k = 0; k < nc; ++k) {
+      const float v = lg[(long)k * HW + i];
+      se += expf(v - m);
+      if (k == t) xt = v;
+    }
+    sum += (m + logf(se)) - xt;
+  }
+  __shared__ float red[CE_BLOCK / 64];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) sum += __shfl_down(sum, o);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = sum;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float s = 0.f;
+    for (int i = 0; i < CE_BLOCK / 64; ++i) s += red[i];
+    partial[blockIdx.x] = s;
+  }
+}
+
+__global__ void ce_final_kernel(const float* __restrict__ partial, int blocks_per_img, float inv_hw,
+                                float* __restrict__ score) {
+  const int b = blockIdx.x;
+  float s = 0.f;
+  for (int i = threadIdx.x; i < blocks_per_img; i += 64) s += partial[b * blocks_per_img + i];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o);
+  if (threadIdx.x == 0) score[b] = s * inv_hw;
+}
+
+// ----------------------------------------------------------------- ResNet helpers
+__global__ void maxpool3x3s2_kernel(const float* __restrict__ x, float* __restrict__ y, int H, int W,
+                                    int C, int Ho, int Wo, long total4) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total4) return;
+  const int c4n = C >> 2;
+  const int c4 = idx % c4n;
+  long r = idx / c4n;
+  const int xo = r % Wo; r /= Wo;
+  const int yo = r % Ho;
+  const long b = r / Ho;
+  f32x4 m = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+  for (int dy = 0; dy < 3; ++dy) {
+    const int yy = 2 * yo - 1 + dy;
+    if (yy < 0 || yy >= H) continue;
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx) {
+      const int xx = 2 * xo - 1 + dx;
+      if (xx < 0 || xx >= W) continue;
+      const f32x4 v = *reinterpret_cast<const f32x4*>(x + ((b * H + yy) * W + xx) * C + 4 * c4);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) m[j] = fmaxf(m[j], v[j]);
+    }
+  }
+  *reinterpret_cast<f32x4*>(y + idx * 4) = m;
+}
+
+// one block per frame: channel means (coalesced over channels), then nout dot products.
+__global__ __launch_bounds__(256) void avgpool_linear_kernel(
+    const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias, int HW,
+    int C, int nout, float* __restrict__ out) {
+  extern __shared__ float mean[];  // [C]
+  const int b = blockIdx.x;
+  const float* xb = x + (long)b * HW * C;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float s = 0.f;
+    for (int i = 0; i < HW; ++i) s += xb[(long)i * C + c];
+    mean[c] = s / (float)HW;
+  }
+  __syncthreads();
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (int o = wv; o < nout; o += 4) {
+    float s = 0.f;
+    for (int c = lane; c < C; c += 64) s += mean[c] * w[o * C + c];
+#pragma unroll
+    for (int k = 32; k > 0; k >>= 1) s += __shfl_down(s, k);
+    if (lane == 0) out[b * nout + o] = s + bias[o];
+  }
+}
+
+}  // namespace
+
+extern "C" int sfh_nchw_to_nhwc(const float* src, float* dst, int batch, int C, int H, int W, int cs,
+                                void* stream) {
+  SFH_REQUIRE(src && dst && batch > 0 && C > 0 && H > 0 && W > 0, "nchw_to_nhwc: bad argument");
+  SFH_REQUIRE(cs >= C && cs % 4 == 0, "nchw_to_nhwc: cs=%d must be >= C=%d and a multiple of 4", cs, C);
+  const long npix = (long)batch * H * W;
+  hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0,
+                     (hipStream_t)stream, src, dst, C, H * W, cs, npix);
+  return sfh_check_launch("nchw_to_nhwc_kernel");
+}
+
+extern "C" int sfh_nhwc_to_nchw(const float* src, float* dst, int batch, int C, int H, int W, int cs,
+                                void* stream) {
+  SFH_REQUIRE(src && dst && batch > 0 && C > 0 && H > 0 && W > 0, "nhwc_to_nchw: bad argument");
+  SFH_REQUIRE(cs >= C && cs % 4 == 0, "nhwc_to_nchw: cs=%d must be >= C=%d and a multiple of 4", cs, C);
+  const long npix = (long)batch * H * W;
+  hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0,
+                     (hipStream_t)stream, src, dst, C, H * W, cs, npix);
+  return sfh_check_launch("nhwc_to_nchw_kernel");
+}
+
+extern "C" int sfh_space_to_depth2(const float* src, float* dst, int batch, int H, int W, int cs,
+                                   void* stream) {
+  SFH_REQUIRE(src && dst && batch > 0 && H > 0 && W > 0 && cs > 0 && cs % 4 == 0, "space_to_depth2: bad argument");
+  const int H2 = (H + 1) / 2, W2 = (W + 1) / 2;
+  const long total4 = (long)batch * H2 * W2 * cs;
+  hipLaunchKernelGGL(space_to_depth2_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0,
+                     (hipStream_t)stream, src, dst, H, W, cs, H2, W2, total4);
+  return sfh_check_launch("space_to_depth2_kernel");
+}
+
+extern "C" int sfh_fold_bn(const float* conv_bias, const float* gamma, const float* beta,
+                           const float* mean, const float* var, float eps, int n, int repeat,
+                           float* scale, float* shift, void* stream) {
+  SFH_REQUIRE(scale && shift && n > 0 && repeat > 0, "fold_bn: bad argument");
+  SFH_REQUIRE(!gamma || (beta && mean && var), "fold_bn: gamma given without beta/mean/var");
+  hipLaunchKernelGGL(fold_bn_kernel, dim3((unsigned)((n * repeat + 255) / 256)), dim3(256), 0,
+                     (hipStream_t)stream, conv_bias, gamma, beta, mean, var, eps, n, repeat, scale, shift);
+  return sfh_check_launch("fold_bn_kernel");
+}
+
+extern "C" int sfh_outconv_fwd(const float* x, int cin, const float* w, const float* bias, int nc,
+                               int batch, int H, int W, float* logits_nchw, uint8_t* argmax_u8,
+                               float* stn_in, int stn_cs, const float* frame_nhwc, int frame_cs,
+                               void* stream) {
+  SFH_REQUIRE(x && w && bias && batch > 0 && H > 0 && W > 0, "outconv: bad argument");
+  SFH_REQUIRE(cin % 8 == 0 && cin <= 1024, "outconv: cin=%d must be a multiple of 8", cin);
+  SFH_REQUIRE(nc >= 1 && nc <= 8, "outconv: nc=%d unsupported (1..8)", nc);
+  SFH_REQUIRE(!stn_in || (frame_nhwc && stn_cs % 4 == 0 && stn_cs >= nc + 3 && stn_cs <= 16 && frame_cs >= 3),
+              "outconv: bad stn_in geometry");
+  const long npix = (long)batch * H * W;
+  const unsigned grid = (unsigned)((npix + 127) / 128);
+  const size_t lds = (size_t)nc * cin * sizeof(float);
+#define SFH_OC(N)                                                                              \
+  case N:                                                                                      \
+    hipLaunchKernelGGL(outconv_kernel<N>, dim3(grid), dim3(256), lds, (hipStream_t)stream, x, cin, w, \
+                       bias, npix, H * W, logits_nchw, argmax_u8, stn_in, stn_cs, frame_nhwc,  \
+                       frame_cs);                                                              \
+    break;
+  switch (nc) {
+    SFH_OC(1) SFH_OC(2) SFH_OC(3) SFH_OC(4) SFH_OC(5) SFH_OC(6) SFH_OC(7) SFH_OC(8)
+  }
+#undef SFH_OC
+  return sfh_check_launch("outconv_kernel");
+}
+
+extern "C" int64_t sfh_ce_workspace_floats(int batch, int H, int W) {
+  if (batch <= 0 || H <= 0 || W <= 0) return -1;
+  return (int64_t)batch * sfh_cdiv(H * W, CE_PIX_PER_BLOCK);
+}
+
+extern "C" int sfh_consistency_ce_fwd(const float* logits, const int32_t* mask, int batch, int nc,
+                                      int H, int W, int hm, int wm, float* partial, float* score,
+                                      void* stream) {
+  SFH_REQUIRE(logits && mask && partial && score, "consistency_ce: null pointer");
+  SFH_REQUIRE(batch > 0 && nc > 0 && H > 0 && W > 0 && hm > 0 && wm > 0, "consistency_ce: bad geometry");
+  const int bpi = sfh_cdiv(H * W, CE_PIX_PER_BLOCK);
+  hipLaunchKernelGGL(ce_partial_kernel, dim3((unsigned)(batch * bpi)), dim3(CE_BLOCK), 0,
+                     (hipStream_t)stream, logits, mask, nc, H, W, hm, wm, bpi, partial);
+  int rc = sfh_check_launch("ce_partial_kernel");
+  if (rc) return rc;
+  hipLaunchKernelGGL(ce_final_kernel, dim3((unsigned)batch), dim3(64), 0, (hipStream_t)stream, partial,
+                     bpi, 1.0f / (float)(H * W), score);
+  return sfh_check_launch("ce_final_kernel");
+}
+
+extern "C" int sfh_maxpool3x3s2_fwd(const float* x, float* y, int batch, int H, int W, int C,
+                                    void* stream) {
+  SFH_REQUIRE(x && y && batch > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, "maxpool3x3s2: bad argument");
+  const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+  const long total4 = (long)batch * Ho * Wo * (C / 4);
+  hipLaunchKernelGGL(maxpool3x3s2_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0,
+                     (hipStream_t)stream, x, y, H, W, C, Ho, Wo, total4);
+  return sfh_check_launch("maxpool3x3s2_kernel");
+}
+
+extern "C" int sfh_avgpool_linear_fwd(const float* x, const float* w, const float* bias, int batch,
+                                      int H, int W, int C, int nout, float* out, void* stream) {
+  SFH_REQUIRE(x && w && bias && out && batch > 0 && H > 0 && W > 0 && C > 0 && nout > 0,
+              "avgpool_linear: bad argument");
+  SFH_REQUIRE(C <= 8192, "avgpool_linear: C too large");
+  hipLaunchKernelGGL(avgpool_linear_kernel, dim3((unsigned)batch), dim3(256), (size_t)C * sizeof(float),
+                     (hipStream_t)stream, x, w, bias, H * W, C, nout, out);
+  return sfh_check_launch("avgpool_linear_kernel");
+}

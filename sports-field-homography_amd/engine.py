@@ -1,0 +1,359 @@
+"""Launch plans for the HIP hot path: weight packing, NHWC workspaces and the sequence
+of C-ABI calls that implements ``forward_unet`` / ``ResNetSTN`` / warp / POI / CE.
+
+PyTorch is used here for device memory (``torch.empty``), the current HIP stream and the
+parameter storage only; every arithmetic step is a call into ``libsfh_amd.so``.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import ConvDesc
+
+BN_EPS = 1e-5
+
+# (tile id, rows, cols) of the stride-1 workgroup tiles; stride-2 tiles have half the rows.
+_TILES = ((_lib.TILE_8x32, 8, 32), (_lib.TILE_16x16, 16, 16), (_lib.TILE_32x8, 32, 8))
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _f32c(t, what):
+    if t.dtype != torch.float32 or not t.is_contiguous():
+        raise ValueError(f"{what}: expected a contiguous float32 tensor, got {t.dtype} "
+                         f"contiguous={t.is_contiguous()}")
+    if not t.is_cuda:
+        raise RuntimeError(f"{what}: tensor is on {t.device}; the HIP path needs a GPU tensor "
+                           "(there is no CPU fallback)")
+    return t
+
+
+def choose_tile(batch, ho, wo, stride):
+    """Pick the workgroup tile that wastes the fewest padded output pixels."""
+    best = None
+    for tid, th, tw in _TILES:
+        if stride == 2:
+            th //= 2
+            ty = batch * -(-ho // th)
+        else:
+            ty = -(-(batch * (ho + 1)) // th)  # flattened rows, one zero row per frame
+        cost = ty * th * (-(-wo // tw)) * tw
+        if best is None or cost < best[0]:
+            best = (cost, tid)
+    return best[1]
+
+
+class PackedConv:
+    """One conv-shaped layer: fragment-ordered weights + folded per-channel epilogue."""
+
+    def __init__(self, weight, bias, bn, ksize, c0, c1=0, relu=True, transposed=False, stride=1,
+                 stem_cin=0):
+        lib = _lib.load()
+        dev = weight.device
+        w = _f32c(weight.detach(), "conv weight")
+        self.ksize, self.c0, self.c1, self.relu, self.stride = ksize, c0, c1, relu, stride
+        self.transposed = transposed
+        mode, aux = (1 if transposed else 0), 0
+        if stem_cin:  # 7x7 s2 stem re-expressed as a 4x4 conv over the space-to-depth input
+            cout = w.shape[0]
+            assert ksize == 4 and tuple(w.shape[1:]) == (stem_cin, 7, 7) and c1 == 0
+            self.cout_real, self.cout = cout, cout
+            rep, mode, aux = 1, 2, stem_cin
+        elif transposed:
+            cin, cout = w.shape[0], w.shape[1]
+            assert ksize == 1 and cin == c0 and c1 == 0 and tuple(w.shape[2:]) == (2, 2)
+            self.cout_real, self.cout = cout, 4 * cout
+            rep = 4
+        else:
+            cout, cin = w.shape[0], w.shape[1]
+            assert cin == c0 + c1 and tuple(w.shape[2:]) == (ksize, ksize), (w.shape, c0, c1, ksize)
+            self.cout_real, self.cout = cout, cout
+            rep = 1
+        if self.cout_real % 64:
+            raise ValueError(f"conv with {self.cout_real} output channels: the MFMA kernel needs a multiple of 64")
+        n = lib.sfh_packed_weight_floats(ksize, c0, c1, self.cout)
+        if n <= 0:
+            raise ValueError(f"unsupported conv geometry ksize={ksize} c0={c0} c1={c1} cout={self.cout}")
+        self.wpacked = torch.empty(n, dtype=torch.float32, device=dev)
+        _lib.check(lib.sfh_pack_conv_weights(_ptr(w), _ptr(self.wpacked), ksize, c0, c1, self.cout,
+                                             mode, aux, _stream()), "pack_conv_weights")
+        self.scale = torch.empty(self.cout, dtype=torch.float32, device=dev)
+        self.shift = torch.empty(self.cout, dtype=torch.float32, device=dev)
+        b = _f32c(bias.detach(), "conv bias") if bias is not None else None
+        if bn is not None:
+            args = [_f32c(t.detach(), "bn tensor") for t in (bn.weight, bn.bias, bn.running_mean, bn.running_var)]
+            eps = float(bn.eps)
+        else:
+            args, eps = [None] * 4, 0.0
+        _lib.check(lib.sfh_fold_bn(_ptr(b), *[_ptr(a) for a in args], eps, self.cout_real, rep,
+                                   _ptr(self.scale), _ptr(self.shift), _stream()), "fold_bn")
+
+    def run(self, src0, batch, H, W, dst, src1=None, pool0=False, pad1=(0, 0), residual=None, tile=None):
+        """src0/src1/dst/residual: NHWC float32 tensors.  H, W: conv input frame."""
+        lib = _lib.load()
+        d = ConvDesc()
+        d.src0 = src0.data_ptr()
+        d.c0, d.cs0, d.h0, d.w0 = self.c0, src0.shape[3], src0.shape[1], src0.shape[2]
+        d.pool0 = 1 if pool0 else 0
+        if src1 is not None:
+            d.src1 = src1.data_ptr()
+            d.c1, d.cs1, d.h1, d.w1 = self.c1, src1.shape[3], src1.shape[1], src1.shape[2]
+            d.pad_top1, d.pad_left1 = pad1
+        else:
+            if self.c1:
+                raise ValueError("layer was packed for two sources")
+            d.src1 = None
+        d.batch, d.H, d.W = batch, H, W
+        d.ksize, d.stride = self.ksize, self.stride
+        pad2 = self.ksize // 2 + (self.ksize - 1) // 2  # pad before + pad after
+        ho = (H + pad2 - self.ksize) // self.stride + 1
+        wo = (W + pad2 - self.ksize) // self.stride + 1
+        d.tile = choose_tile(batch, ho, wo, self.stride) if tile is None else tile
+        d.wpacked, d.scale, d.shift = self.wpacked.data_ptr(), self.scale.data_ptr(), self.shift.data_ptr()
+        d.cout, d.relu = self.cout, 1 if self.relu else 0
+        d.residual = residual.data_ptr() if residual is not None else None
+        d.dst, d.dst_cs = dst.data_ptr(), dst.shape[3]
+        d.out_mode = _lib.OUT_UPSCATTER2 if self.transposed else _lib.OUT_NHWC
+        exp = (batch, 2 * ho, 2 * wo) if self.transposed else (batch, ho, wo)
+        if tuple(dst.shape[:3]) != exp or dst.shape[3] < self.cout_real:
+            raise ValueError(f"conv dst shape {tuple(dst.shape)} does not match {exp + (self.cout_real,)}")
+        _lib.check(lib.sfh_conv_fwd(ctypes.byref(d), _stream()), "conv_fwd")
+        return dst
+
+
+class _Workspace:
+    """Named NHWC buffers cached per (batch, H, W)."""
+
+    def __init__(self, device):
+        self.device = device
+        self.bufs = {}
+
+    def get(self, name, shape, dtype=torch.float32, zero=False):
+        key = (name, tuple(shape), dtype)
+        t = self.bufs.get(key)
+        if t is None:
+            t = (torch.zeros if zero else torch.empty)(shape, dtype=dtype, device=self.device)
+            self.bufs[key] = t
+        return t
+
+
+class UNetEngine:
+    """forward_unet (models/reconstructor.py:132-158) on the HIP kernels."""
+
+    def __init__(self, net, device):
+        if net.unet_bilinear:
+            raise NotImplementedError("unet_bilinear=True (SURVEY.md §8 row A3b) is not on the HIP path yet")
+        self.device = device
+        self.ws = _Workspace(device)
+        self.nc = net.mask_classes
+        L = {}
+
+        def dc(name, block, c0, c1=0):
+            (cv1, bn1), (cv2, bn2) = block.convs()
+            L[name + ".0"] = PackedConv(cv1.weight, cv1.bias, bn1, 3, c0, c1)
+            L[name + ".3"] = PackedConv(cv2.weight, cv2.bias, bn2, 3, cv1.out_channels)
+
+        dc("inc", net.inc, 3)
+        for i, cin in enumerate((64, 128, 256, 512), start=1):
+            dc(f"down{i}", getattr(net, f"down{i}").block, cin)
+        for i, cin in enumerate((1024, 512, 256, 128), start=1):
+            up = getattr(net, f"up{i}")
+            L[f"up{i}.up"] = PackedConv(up.up.weight, up.up.bias, None, 1, cin, relu=False, transposed=True)
+            dc(f"up{i}.conv", up.conv, cin // 2, cin // 2)
+        self.L = L
+        self.outc_w = _f32c(net.outc.conv.weight.detach(), "outc.weight")
+        self.outc_b = _f32c(net.outc.conv.bias.detach(), "outc.bias")
+        self.outuv = None
+        if net.outuv is not None:
+            self.outuv = (_f32c(net.outuv.conv.weight.detach(), "outuv.weight"),
+                          _f32c(net.outuv.conv.bias.detach(), "outuv.bias"))
+
+    def run(self, x, want_stn_in=False, want_argmax=False, want_uv=False):
+        """x: (B,3,H,W) float32 NCHW on the GPU.  Returns dict with logits (NCHW, fresh),
+        and optionally stn_in (NHWC8 workspace), argmax (B,H,W uint8), uv, plus the NHWC
+        workspace tensors x_top / y4 for callers that need them."""
+        lib = _lib.load()
+        x = _f32c(x, "input frames")
+        B, C, H, W = x.shape
+        if C != 3:
+            raise ValueError(f"expected 3 input channels, got {C}")
+        if H < 16 or W < 16:
+            raise ValueError("frames smaller than 16x16 cannot pass four 2x2 poolings")
+        ws, L, st = self.ws, self.L, _stream()
+        xin = ws.get("xin", (B, H, W, 4))
+        _lib.check(lib.sfh_nchw_to_nhwc(_ptr(x), _ptr(xin), B, 3, H, W, 4, st), "nchw_to_nhwc")
+
+        def dconv(name, src0, h, w, cout, src1=None, pool0=False, pad1=(0, 0)):
+            mid = ws.get(name + ".mid", (B, h, w, L[name + ".0"].cout_real))
+            out = ws.get(name + ".out", (B, h, w, cout))
+            L[name + ".0"].run(src0, B, h, w, mid, src1=src1, pool0=pool0, pad1=pad1)
+            L[name + ".3"].run(mid, B, h, w, out)
+            return out
+
+        feats = [dconv("inc", xin, H, W, 64)]
+        h, w = H, W
+        for i, cout in enumerate((128, 256, 512, 1024), start=1):
+            h, w = h // 2, w // 2
+            feats.append(dconv(f"down{i}", feats[-1], h, w, cout, pool0=True))
+        y = feats[4]
+        for i, cout in enumerate((512, 256, 128, 64), start=1):
+            skip = feats[4 - i]
+            hs, ws_ = skip.shape[1], skip.shape[2]
+            hy, wy = y.shape[1], y.shape[2]
+            upb = ws.get(f"up{i}.up", (B, 2 * hy, 2 * wy, cout))
+            L[f"up{i}.up"].run(y, B, hy, wy, upb)
+            dy, dx = hs - 2 * hy, ws_ - 2 * wy
+            y = dconv(f"up{i}.conv", skip, hs, ws_, cout, src1=upb, pad1=(dy // 2, dx // 2))
+        out = {"x_top": feats[4], "y4": y}
+        logits = torch.empty((B, self.nc, H, W), dtype=torch.float32, device=x.device)
+        amax = torch.empty((B, H, W), dtype=torch.uint8, device=x.device) if want_argmax else None
+        stn_in = ws.get("stn_in", (B, H, W, 8), zero=True) if want_stn_in else None
+        if want_stn_in and self.nc + 3 > 8:
+            raise NotImplementedError("mask_classes > 5 with resnet_input='img+mask' needs a wider STN input buffer")
+        _lib.check(lib.sfh_outconv_fwd(_ptr(y), 64, _ptr(self.outc_w), _ptr(self.outc_b), self.nc, B, H, W,
+                                       _ptr(logits), _ptr(amax), _ptr(stn_in), 8 if want_stn_in else 0,
+                                       _ptr(xin) if want_stn_in else None, 4, st), "outconv")
+        out["logits"] = logits
+        if want_argmax:
+            out["argmax"] = amax
+        if want_stn_in:
+            out["stn_in"] = stn_in
+        if want_uv and self.outuv is not None:
+            uv = torch.empty((B, 2, H, W), dtype=torch.float32, device=x.device)
+            _lib.check(lib.sfh_outconv_fwd(_ptr(y), 64, _ptr(self.outuv[0]), _ptr(self.outuv[1]), 2, B, H, W,
+                                           _ptr(uv), None, None, 0, None, 0, st), "outconv(uv)")
+            out["uv"] = uv
+        return out
+
+
+class ResNetEngine:
+    """ResNetSTN forward (models/resnet.py:235-254) on the HIP kernels (BasicBlock depths)."""
+
+    def __init__(self, rn, in_channels, device):
+        self.device = device
+        self.ws = _Workspace(device)
+        self.cin = in_channels
+        self.cs_in = -(-in_channels // 4) * 4
+        if (4 * self.cs_in) % 16:
+            self.cs_in = -(-in_channels // 8) * 8
+        L = {}
+        L["stem"] = PackedConv(rn.conv0.weight, None, rn.bn1, 4, 4 * self.cs_in, stem_cin=in_channels)
+        self.blocks = []
+        for li in range(1, 5):
+            for bi, blk in enumerate(getattr(rn, f"layer{li}")):
+                name = f"layer{li}.{bi}"
+                cin, planes = blk.conv1.in_channels, blk.conv1.out_channels
+                L[name + ".conv1"] = PackedConv(blk.conv1.weight, None, blk.bn1, 3, cin, stride=blk.stride)
+                L[name + ".conv2"] = PackedConv(blk.conv2.weight, None, blk.bn2, 3, planes)  # ReLU after the residual add
+                if blk.downsample is not None:
+                    ds = blk.downsample
+                    L[name + ".down"] = PackedConv(ds[0].weight, None, ds[1], 1, cin, relu=False, stride=blk.stride)
+                self.blocks.append((name, cin, planes, blk.stride, blk.downsample is not None))
+        self.L = L
+        self.reg_w = _f32c(rn.reg.weight.detach(), "reg.weight")
+        self.reg_b = _f32c(rn.reg.bias.detach(), "reg.bias")
+
+    def run(self, y_nhwc, B, H, W):
+        """y_nhwc: (B,H,W,cs_in) float32 with channels >= cin zero.  Returns theta (B,1,3,3)."""
+        lib = _lib.load()
+        ws, L, st = self.ws, self.L, _stream()
+        if y_nhwc.shape[3] != self.cs_in:
+            raise ValueError(f"STN input has {y_nhwc.shape[3]} stored channels, engine expects {self.cs_in}")
+        H2, W2 = (H + 1) // 2, (W + 1) // 2
+        s2d = ws.get("s2d", (B, H2, W2, 4 * self.cs_in))
+        _lib.check(lib.sfh_space_to_depth2(_ptr(y_nhwc), _ptr(s2d), B, H, W, self.cs_in, st), "space_to_depth2")
+        c1 = ws.get("stem", (B, H2, W2, 64))
+        L["stem"].run(s2d, B, H2, W2, c1)
+        h, w = (H2 - 1) // 2 + 1, (W2 - 1) // 2 + 1
+        x = ws.get("pool", (B, h, w, 64))
+        _lib.check(lib.sfh_maxpool3x3s2_fwd(_ptr(c1), _ptr(x), B, H2, W2, 64, st), "maxpool3x3s2")
+        for name, cin, planes, stride, has_down in self.blocks:
+            ho, wo = (h - 1) // stride + 1, (w - 1) // stride + 1
+            t = ws.get(name + ".t", (B, ho, wo, planes))
+            L[name + ".conv1"].run(x, B, h, w, t)
+            if has_down:
+                idn = ws.get(name + ".idn", (B, ho, wo, planes))
+                L[name + ".down"].run(x, B, h, w, idn)
+            else:
+                idn = x
+            out = ws.get(name + ".out", (B, ho, wo, planes))
+            L[name + ".conv2"].run(t, B, ho, wo, out, residual=idn)
+            x, h, w = out, ho, wo
+        theta = torch.empty((B, 9), dtype=torch.float32, device=x.device)
+        _lib.check(lib.sfh_avgpool_linear_fwd(_ptr(x), _ptr(self.reg_w), _ptr(self.reg_b), B, h, w,
+                                              x.shape[3], 9, _ptr(theta), st), "avgpool_linear")
+        return theta.view(B, 1, 3, 3)
+
+
+def nhwc_to_nchw(t, channels=None):
+    lib = _lib.load()
+    B, H, W, cs = t.shape
+    C = cs if channels is None else channels
+    out = torch.empty((B, C, H, W), dtype=torch.float32, device=t.device)
+    _lib.check(lib.sfh_nhwc_to_nchw(_ptr(t), _ptr(out), B, C, H, W, cs, _stream()), "nhwc_to_nchw")
+    return out
+
+
+def nchw_to_nhwc(t, cs=None):
+    lib = _lib.load()
+    t = _f32c(t, "nchw tensor")
+    B, C, H, W = t.shape
+    cs = cs or -(-C // 4) * 4
+    out = torch.empty((B, H, W, cs), dtype=torch.float32, device=t.device)
+    _lib.check(lib.sfh_nchw_to_nhwc(_ptr(t), _ptr(out), B, C, H, W, cs, _stream()), "nchw_to_nhwc")
+    return out
+
+
+def homography_warp(theta, template, h, w, nearest, scale=None, want_f32=True, want_i32=False,
+                    shared_template=False):
+    """theta (B,1,3,3)|(B,3,3); template (>=B,1,ht,wt).  Returns (f32 or None, i32 or None)."""
+    lib = _lib.load()
+    theta = _f32c(theta.reshape(-1, 3, 3).contiguous(), "theta")
+    template = _f32c(template, "court template")
+    B = theta.shape[0]
+    if template.dim() != 4 or template.shape[1] != 1:
+        raise ValueError(f"court template must be (B,1,H,W), got {tuple(template.shape)}")
+    if template.shape[0] < B and not shared_template:
+        raise ValueError(f"batch {B} exceeds the court template batch {template.shape[0]}")
+    ht, wt = template.shape[2], template.shape[3]
+    out_f = torch.empty((B, h, w), dtype=torch.float32, device=theta.device) if want_f32 else None
+    out_i = torch.empty((B, h, w), dtype=torch.int32, device=theta.device) if want_i32 else None
+    bstride = 0 if shared_template else ht * wt
+    _lib.check(lib.sfh_homography_warp_fwd(_ptr(theta), _ptr(template), bstride, ht, wt, B, h, w,
+                                           0 if nearest else 1, float(scale if scale is not None else 1.0),
+                                           _ptr(out_f), _ptr(out_i), _stream()), "homography_warp")
+    return out_f, out_i
+
+
+def poi_project(theta, poi, normalize=True):
+    lib = _lib.load()
+    theta = _f32c(theta.reshape(-1, 3, 3).contiguous(), "theta")
+    B = theta.shape[0]
+    if poi.shape[0] < B:
+        raise ValueError(f"batch {B} exceeds the court POI batch {poi.shape[0]}")
+    p = _f32c(poi[:B].contiguous(), "court_poi")
+    out = torch.empty_like(p)
+    _lib.check(lib.sfh_poi_project_fwd(_ptr(theta), _ptr(p), B, p.shape[1], 1 if normalize else 0,
+                                       _ptr(out), _stream()), "poi_project")
+    return out
+
+
+def consistency_ce(logits, mask_i32):
+    lib = _lib.load()
+    logits = _f32c(logits, "logits")
+    B, nc, H, W = logits.shape
+    if mask_i32.dtype != torch.int32 or not mask_i32.is_contiguous():
+        raise ValueError("warp mask must be a contiguous int32 tensor")
+    hm, wm = mask_i32.shape[1], mask_i32.shape[2]
+    partial = torch.empty(lib.sfh_ce_workspace_floats(B, H, W), dtype=torch.float32, device=logits.device)
+    score = torch.empty(B, dtype=torch.float32, device=logits.device)
+    _lib.check(lib.sfh_consistency_ce_fwd(_ptr(logits), _ptr(mask_i32), B, nc, H, W, hm, wm, _ptr(partial),
+                                          _ptr(score), _stream()), "consistency_ce")
+    return score

@@ -1,0 +1,258 @@
+"""Drop-in mirror of the reference's ``models.Reconstructor`` (models/reconstructor.py:30-247).
+
+Same constructor keywords, attributes, method names, returned dict keys, dtypes and
+``state_dict`` layout; the arithmetic runs in the HIP kernels of ``libsfh_amd.so``
+(see engine.py).  There is no fallback: calling the model on CPU tensors, or without
+the built library, raises.
+
+Not yet on the HIP path (raise ``NotImplementedError``):
+training-mode forward/backward, ``unet_bilinear=True``, Bottleneck ResNets, and input /
+output resizing when ``unet_size``/``target_size`` differ from the frame size.
+"""
+from enum import Enum
+
+import torch
+import torch.nn as nn
+
+from . import engine as E
+from .modules import DoubleConv, Down, Up, OutConv, resnet_stn
+
+
+class Input(Enum):
+    """ResNet input selection (reference: models/reconstructor.py:9-28)."""
+    IMG = 1
+    MASK = 2
+    IMG_AND_MASK = 3
+    IMG_AND_MASK_AND_UV = 4
+
+    @classmethod
+    def parse(cls, input):
+        table = {"img": cls.IMG, "mask": cls.MASK, "img+mask": cls.IMG_AND_MASK,
+                 "img+mask+uv": cls.IMG_AND_MASK_AND_UV}
+        if input is None:
+            return None
+        if input not in table:
+            raise NotImplementedError
+        return table[input]
+
+
+class Reconstructor(nn.Module):
+    """UNet segmentation + ResNet-STN homography regression + court-template warp."""
+
+    def __init__(self, court_img, court_poi,
+                 target_size=(640, 360),
+                 mask_classes=4,
+                 use_unet=True,
+                 unet_bilinear=False,
+                 unet_size=(640, 360),
+                 unet_uv=False,
+                 use_resnet=True,
+                 resnet_name='resnet34',
+                 resnet_input='img+mask',
+                 resnet_pretrained=None,
+                 use_warper=True,
+                 warp_size=(640, 360),
+                 warp_with_nearest=False):
+        super().__init__()
+        assert use_unet is not None or use_resnet is not None
+        # plain attributes, not buffers: they are absent from the state_dict
+        # (reference: models/reconstructor.py:55-56)
+        self.court_img = court_img
+        self.court_poi = court_poi
+        self.target_size = target_size
+        self.mask_classes = mask_classes
+        self.use_unet = use_unet
+        self.unet_size = unet_size
+        self.unet_uv = unet_uv
+        self.unet_bilinear = bool(unet_bilinear)
+        self.use_resnet = use_resnet
+        self.resnet_input = Input.parse(resnet_input)
+        self.resnet_name = resnet_name
+        self.warp_size = warp_size
+        self.warp_with_nearest = warp_with_nearest is True
+
+        if self.use_unet:
+            factor = 2 if unet_bilinear else 1
+            self.inc = DoubleConv(3, 64)
+            self.down1 = Down(64, 128)
+            self.down2 = Down(128, 256)
+            self.down3 = Down(256, 512)
+            self.down4 = Down(512, 1024 // factor)
+            self.up1 = Up(1024, 512 // factor, unet_bilinear)
+            self.up2 = Up(512, 256 // factor, unet_bilinear)
+            self.up3 = Up(256, 128 // factor, unet_bilinear)
+            self.up4 = Up(128, 64, unet_bilinear)
+            self.outc = OutConv(64, mask_classes)
+            self.outuv = OutConv(64, 2) if unet_uv else None
+
+        if self.use_resnet:
+            assert self.resnet_input is not None
+            if self.resnet_input == Input.IMG:
+                in_classes = 3
+            elif self.resnet_input == Input.MASK:
+                assert self.use_unet
+                in_classes = mask_classes
+            elif self.resnet_input == Input.IMG_AND_MASK:
+                assert self.use_unet
+                in_classes = mask_classes + 3
+            elif self.resnet_input == Input.IMG_AND_MASK_AND_UV:
+                assert self.use_unet and self.unet_uv
+                in_classes = mask_classes + 3 + 2
+            else:
+                assert False
+            self._stn_in_channels = in_classes
+            self.resnet_reg = resnet_stn(resnet_name, resnet_pretrained, in_classes)
+
+        # The reference holds a kornia HomographyWarper here (parameter-free, so it adds
+        # no state_dict entries); the HIP warp kernel needs only the flag.
+        self.warper = True if use_warper else None
+        self._warp_hw = (warp_size[1], warp_size[0])
+
+        self._engines = None       # (UNetEngine | None, ResNetEngine | None)
+        self._engine_stamp = None
+        self._tmpl_shared = None   # (data_ptr, shape) -> bool cache
+
+    # ------------------------------------------------------------------ engine plumbing
+    def _param_stamp(self):
+        dev = None
+        ver = 0
+        for t in list(self.parameters()) + list(self.buffers()):
+            ver += t._version
+            dev = t.device
+        return (dev, ver, self.training)
+
+    def _get_engines(self):
+        stamp = self._param_stamp()
+        if self._engines is None or stamp != self._engine_stamp:
+            dev = stamp[0]
+            if dev is None or dev.type != "cuda":
+                raise RuntimeError(
+                    f"Reconstructor parameters are on {dev}: move the model to the GPU with .to('cuda'); "
+                    "the HIP path has no CPU fallback")
+            with torch.cuda.device(dev):
+                un = E.UNetEngine(self, dev) if self.use_unet else None
+                rn = E.ResNetEngine(self.resnet_reg, self._stn_in_channels, dev) if self.use_resnet else None
+            self._engines = (un, rn)
+            self._engine_stamp = stamp
+        return self._engines
+
+    def _require_eval(self, what):
+        if self.training:
+            raise NotImplementedError(
+                f"{what} in training mode (batch-statistics BatchNorm + backward kernels, SURVEY.md §8 "
+                "row f2) is not implemented on the HIP path; call .eval() first")
+
+    def _check_sizes(self, x):
+        w, h = self.unet_size
+        if x.shape[3] != w or x.shape[2] != h:
+            raise NotImplementedError(
+                f"input {tuple(x.shape[2:])} != unet_size (H,W)=({h},{w}): the bilinear input resize "
+                "(models/reconstructor.py:134-136) is SURVEY.md §8 row f4, not on the HIP path yet")
+        tw, th = self.target_size
+        if (tw, th) != (w, h):
+            raise NotImplementedError("target_size != unet_size (nearest logits resize) is not on the HIP path yet")
+
+    def _template_is_shared(self, court_img, bs):
+        """The reference replicates ONE template over the batch (utils/dataset.py:59).  Detect
+        that once per template tensor so the warp reads a single (cache-resident) image."""
+        key = (court_img.data_ptr(), tuple(court_img.shape), court_img._version)
+        if self._tmpl_shared is None or self._tmpl_shared[0] != key:
+            same = bool(court_img.shape[0] == 1 or (court_img[1:] == court_img[:1]).all().item())
+            self._tmpl_shared = (key, same)
+        return self._tmpl_shared[1]
+
+    # ------------------------------------------------------------------ reference API
+    def warp(self, theta, court_img):
+        """Warp the template by the predicted homographies (reference: :109-118)."""
+        bs = theta.shape[0]
+        template = court_img[0:bs]
+        if template.shape[0] < bs:
+            raise ValueError(f"batch {bs} exceeds the court template batch {court_img.shape[0]}")
+        h, w = self._warp_hw
+        shared = self._template_is_shared(court_img, bs)
+        out, _ = E.homography_warp(theta, template.contiguous(), h, w, self.warp_with_nearest,
+                                   shared_template=shared)
+        return out
+
+    def transform_poi(self, theta, court_poi, normalize=True):
+        """Project the court PoI into the frame with inverse(theta) (reference: :120-130)."""
+        return E.poi_project(theta, court_poi, normalize)
+
+    def _run_unet(self, x, **kw):
+        self._check_sizes(x)
+        un, _ = self._get_engines()
+        with torch.cuda.device(x.device):
+            return un.run(x.contiguous(), **kw)
+
+    def forward_unet(self, x):
+        """Reference: models/reconstructor.py:132-158.  Returns (logits, x_top, uv) in NCHW."""
+        self._require_eval("forward_unet")
+        r = self._run_unet(x, want_uv=self.unet_uv)
+        x_top = E.nhwc_to_nchw(r["x_top"])
+        return r["logits"], x_top, r.get("uv")
+
+    def _stn(self, x, r):
+        """theta = resnet_reg(cat(...)) for the configured input mode (reference: :174-185)."""
+        _, rn = self._get_engines()
+        B, _, H, W = x.shape
+        if self.resnet_input == Input.IMG_AND_MASK:
+            y = r["stn_in"]
+        elif self.resnet_input == Input.IMG:
+            y = E.nchw_to_nhwc(x.contiguous(), rn.cs_in)
+        elif self.resnet_input == Input.MASK:
+            y = E.nchw_to_nhwc(r["logits"], rn.cs_in)
+        elif self.resnet_input == Input.IMG_AND_MASK_AND_UV:
+            y = E.nchw_to_nhwc(torch.cat((r["logits"], x, r["uv"]), 1).contiguous(), rn.cs_in)
+        else:
+            raise NotImplementedError
+        with torch.cuda.device(x.device):
+            return rn.run(y, B, H, W)
+
+    def forward(self, x):
+        """Inference-mode forward (reference: :160-194): logits, [uv], theta, poi, bilinear
+        (or nearest) warp_mask as float."""
+        self._require_eval("forward")
+        ret = {}
+        r = None
+        if self.use_unet:
+            r = self._run_unet(x, want_stn_in=self.resnet_input == Input.IMG_AND_MASK, want_uv=self.unet_uv)
+            ret['logits'] = r["logits"]
+            if "uv" in r:
+                ret['uv'] = r["uv"]
+        if self.use_resnet:
+            theta = self._stn(x, r)
+            ret['theta'] = theta
+            ret['poi'] = self.transform_poi(theta, self.court_poi)
+            if self.warper:
+                ret['warp_mask'] = self.warp(theta, self.court_img)
+        return ret
+
+    def predict(self, x, consistency=True, project_poi=False):
+        """Reference: models/reconstructor.py:196-247."""
+        self._require_eval("predict")
+        ret = {}
+        r = None
+        if self.use_unet:
+            r = self._run_unet(x, want_stn_in=self.resnet_input == Input.IMG_AND_MASK)
+            ret['logits'] = r["logits"]
+        if self.use_resnet:
+            if self.resnet_input == Input.IMG_AND_MASK_AND_UV:
+                raise NotImplementedError  # the reference's predict() has no uv branch either (:216)
+            theta = self._stn(x, r)
+            ret['theta'] = theta
+            if self.warper:
+                bs = theta.shape[0]
+                h, w = self._warp_hw
+                tmpl = self.court_img[0:bs]
+                if tmpl.shape[0] < bs:
+                    raise ValueError(f"batch {bs} exceeds the court template batch {self.court_img.shape[0]}")
+                # warp * mask_classes -> int32, fused in the kernel (reference: :223,240)
+                _, wm = E.homography_warp(theta, tmpl.contiguous(), h, w, self.warp_with_nearest,
+                                          scale=float(self.mask_classes), want_f32=False, want_i32=True,
+                                          shared_template=self._template_is_shared(self.court_img, bs))
+                if consistency and self.use_unet:
+                    ret['consist_score'] = E.consistency_ce(ret['logits'], wm)
+                ret['warp_mask'] = wm
+            if project_poi:
+                ret['poi'] = self.transform_poi(theta, self.court_poi)
+        return ret
