@@ -44,6 +44,8 @@ struct ConvCfg {
   // padding before / after: 3x3 -> 1/1, 1x1 -> 0/0, 4x4 (space-to-depth stem) -> 2/1
   static constexpr int PAD = KS / 2;
   static constexpr int PADA = (KS - 1) / 2;
+  // zero rows shared between consecutive frames in the flattened row space (>= pad)
+  static constexpr int ZROWS = PAD;
   static constexpr int NTAP = KS * KS * NSUB;
   // taps per LDS stage: the 16-tap 4x4 stem stages its weights in two halves
   static constexpr int TPS = NTAP > 9 ? NTAP / 2 : NTAP;
@@ -82,8 +84,8 @@ __device__ __forceinline__ int halo_src_offset(const sfh_conv_desc& d, int which
   if (C::FLATROWS) {
     const int r = r0 - C::PAD + hy;
     if (r < 0) return -1;
-    b = r / (d.H + 1);
-    y = r - b * (d.H + 1);
+    b = r / (d.H + C::ZROWS);
+    y = r - b * (d.H + C::ZROWS);
     if (b >= d.batch || y >= d.H) return -1;
   } else {
     b = r0 >> 16;
@@ -269,8 +271,8 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const sfh_conv_desc d
     bool ok = x < g.Wo;
     if (C::FLATROWS) {
       const int r = r0 + oy;
-      b = r / (g.Ho + 1);
-      y = r - b * (g.Ho + 1);
+      b = r / (g.Ho + C::ZROWS);
+      y = r - b * (g.Ho + C::ZROWS);
       ok = ok && r < g.rows_total && y < g.Ho;
     } else {
       b = r0 >> 16;
@@ -365,7 +367,7 @@ int launch_conv(const sfh_conv_desc& d, hipStream_t stream) {
   g.Wo = (d.W + C::PAD + C::PADA - C::KS) / C::STRIDE + 1;
   g.tiles_x = sfh_cdiv(g.Wo, C::TW);
   if (C::FLATROWS) {
-    g.rows_total = d.batch * (g.Ho + 1);
+    g.rows_total = d.batch * (g.Ho + C::ZROWS);
     g.tiles_y = sfh_cdiv(g.rows_total, C::TH);
     g.ntiles = g.tiles_x * g.tiles_y;
   } else {

@@ -35,7 +35,7 @@ def _f32c(t, what):
     return t
 
 
-def choose_tile(batch, ho, wo, stride):
+def choose_tile(batch, ho, wo, stride, zrows=1):
     """Pick the workgroup tile that wastes the fewest padded output pixels."""
     best = None
     for tid, th, tw in _TILES:
@@ -43,7 +43,7 @@ def choose_tile(batch, ho, wo, stride):
             th //= 2
             ty = batch * -(-ho // th)
         else:
-            ty = -(-(batch * (ho + 1)) // th)  # flattened rows, one zero row per frame
+            ty = -(-(batch * (ho + zrows)) // th)  # flattened rows, `zrows` shared zero rows per frame
         cost = ty * th * (-(-wo // tw)) * tw
         if best is None or cost < best[0]:
             best = (cost, tid)
@@ -115,7 +115,7 @@ class PackedConv:
         pad2 = self.ksize // 2 + (self.ksize - 1) // 2  # pad before + pad after
         ho = (H + pad2 - self.ksize) // self.stride + 1
         wo = (W + pad2 - self.ksize) // self.stride + 1
-        d.tile = choose_tile(batch, ho, wo, self.stride) if tile is None else tile
+        d.tile = choose_tile(batch, ho, wo, self.stride, self.ksize // 2) if tile is None else tile
         d.wpacked, d.scale, d.shift = self.wpacked.data_ptr(), self.scale.data_ptr(), self.shift.data_ptr()
         d.cout, d.relu = self.cout, 1 if self.relu else 0
         d.residual = residual.data_ptr() if residual is not None else None

@@ -1,0 +1,309 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle and the
+committed golden vectors.  Tolerances (BASELINE.json north_star): homography and warp
+within 1e-4 abs, nearest-mode warp / argmax / POI pixel integer-exact."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import torch_ref, warp_ref  # noqa: E402
+from sfh_amd import synth, modules  # noqa: E402
+
+torch.set_num_threads(max(1, min(16, os.cpu_count() or 1)))
+
+
+@pytest.fixture(scope="module")
+def E():
+    from sfh_amd import engine, _lib
+    _lib.load()
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return engine
+
+
+def _nhwc(x):
+    return x.permute(0, 2, 3, 1).contiguous().cuda()
+
+
+def _nchw(y):
+    return y.permute(0, 3, 1, 2).contiguous().cpu()
+
+
+def _maxerr(a, b):
+    return (torch.as_tensor(a).float() - torch.as_tensor(b).float()).abs().max().item()
+
+
+def _mods_to_cuda(m, seed):
+    sd = synth.synth_state_dict(m.state_dict(), seed)
+    m.load_state_dict(sd)
+    return m.cuda().eval(), sd
+
+
+# ---------------------------------------------------------------- conv building blocks
+def _run_double_conv(E, block, x_nhwc, B, H, W, c0, src1=None, c1=0, pool0=False, pad1=(0, 0), tile=None):
+    (cv1, bn1), (cv2, bn2) = block.convs()
+    l1 = E.PackedConv(cv1.weight, cv1.bias, bn1, 3, c0, c1)
+    l2 = E.PackedConv(cv2.weight, cv2.bias, bn2, 3, cv1.out_channels)
+    mid = torch.empty((B, H, W, cv1.out_channels), device="cuda")
+    out = torch.empty((B, H, W, cv2.out_channels), device="cuda")
+    l1.run(x_nhwc, B, H, W, mid, src1=src1, pool0=pool0, pad1=pad1, tile=tile)
+    l2.run(mid, B, H, W, out, tile=tile)
+    torch.cuda.synchronize()
+    return out
+
+
+@pytest.mark.parametrize("tile", [None, 0, 1, 2])
+def test_double_conv_golden(E, golden_blocks, tile):
+    g = golden_blocks
+    m, _ = _mods_to_cuda(modules.DoubleConv(3, 64), 11)
+    x = torch.from_numpy(g["dc_3_64.x"])
+    x4 = torch.zeros(2, 20, 24, 4)
+    x4[..., :3] = x.permute(0, 2, 3, 1)
+    y = _run_double_conv(E, m, x4.cuda(), 2, 20, 24, 3, tile=tile)
+    assert _maxerr(_nchw(y), g["dc_3_64.y"]) < 2e-5
+    m, _ = _mods_to_cuda(modules.DoubleConv(64, 128, 64), 12)
+    x = torch.from_numpy(g["dc_64_128_m64.x"])
+    y = _run_double_conv(E, m, _nhwc(x), 1, 17, 23, 64, tile=tile)
+    assert _maxerr(_nchw(y), g["dc_64_128_m64.y"]) < 5e-5
+
+
+def test_down_pool_on_load_golden(E, golden_blocks):
+    g = golden_blocks
+    m, _ = _mods_to_cuda(modules.Down(64, 128), 13)
+    x = torch.from_numpy(g["down_64_128.x"])
+    y = _run_double_conv(E, m.block, _nhwc(x), 1, 10, 9, 64, pool0=True)
+    assert _maxerr(_nchw(y), g["down_64_128.y"]) < 5e-5
+
+
+def test_up_transposed_conv_concat_golden(E, golden_blocks):
+    g = golden_blocks
+    m, _ = _mods_to_cuda(modules.Up(128, 64, False), 14)
+    x1 = torch.from_numpy(g["up_128_64.x1"])
+    x2 = torch.from_numpy(g["up_128_64.x2"])
+    up = E.PackedConv(m.up.weight, m.up.bias, None, 1, 128, relu=False, transposed=True)
+    upb = torch.empty((1, 20, 18, 64), device="cuda")
+    up.run(_nhwc(x1), 1, 10, 9, upb)
+    torch.cuda.synchronize()
+    ref_up = torch.nn.functional.conv_transpose2d(x1, m.up.weight.cpu(), m.up.bias.cpu(), stride=2)
+    assert _maxerr(_nchw(upb), ref_up) < 2e-5
+    y = _run_double_conv(E, m.conv, _nhwc(x2), 1, 21, 19, 64, src1=upb, c1=64, pad1=(0, 0))
+    assert _maxerr(_nchw(y), g["up_128_64.y"]) < 5e-5
+
+
+def test_outconv_argmax_golden(E, golden_blocks):
+    from sfh_amd import _lib
+    g = golden_blocks
+    m, _ = _mods_to_cuda(modules.OutConv(64, 4), 16)
+    x = torch.from_numpy(g["outc_64_4.x"])
+    xn = _nhwc(x)
+    logits = torch.empty((1, 4, 9, 13), device="cuda")
+    am = torch.empty((1, 9, 13), dtype=torch.uint8, device="cuda")
+    lib = _lib.load()
+    _lib.check(lib.sfh_outconv_fwd(E._ptr(xn), 64, E._ptr(m.conv.weight.detach()), E._ptr(m.conv.bias.detach()), 4,
+                                   1, 9, 13, E._ptr(logits), E._ptr(am), None, 0, None, 0, E._stream()), "outconv")
+    torch.cuda.synchronize()
+    assert _maxerr(logits.cpu(), g["outc_64_4.y"]) < 1e-5
+    assert torch.equal(am.cpu(), torch_ref.preds_to_masks(logits.cpu()))
+
+
+@pytest.mark.parametrize("hw", [(24, 40), (22, 37), (45, 80)])
+def test_conv_variants_vs_oracle(E, hw):
+    """stride-2 3x3, stride-2 1x1, residual epilogue - the ResNet block shapes."""
+    H, W = hw
+    torch.manual_seed(0)
+    blk = modules.BasicBlock(64, 128, 2, torch.nn.Sequential(torch.nn.Conv2d(64, 128, 1, stride=2, bias=False),
+                                                             torch.nn.BatchNorm2d(128)))
+    blk, sd = _mods_to_cuda(blk, 21)
+    sd = {"b." + k: v for k, v in sd.items()}
+    x = torch.from_numpy(synth._rng(21, f"x{H}x{W}").uniform(-1, 1, (2, 64, H, W)).astype(np.float32))
+    want = torch_ref._basic_block(x, sd, "b", 2)
+    xn = _nhwc(x)
+    ho, wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    c1 = E.PackedConv(blk.conv1.weight, None, blk.bn1, 3, 64, stride=2)
+    c2 = E.PackedConv(blk.conv2.weight, None, blk.bn2, 3, 128)
+    dn = E.PackedConv(blk.downsample[0].weight, None, blk.downsample[1], 1, 64, relu=False, stride=2)
+    t = torch.empty((2, ho, wo, 128), device="cuda")
+    idn = torch.empty_like(t)
+    out = torch.empty_like(t)
+    c1.run(xn, 2, H, W, t)
+    dn.run(xn, 2, H, W, idn)
+    c2.run(t, 2, ho, wo, out, residual=idn)
+    torch.cuda.synchronize()
+    assert _maxerr(_nchw(out), want) < 5e-5
+
+
+# ---------------------------------------------------------------- ResNet-STN
+@pytest.mark.parametrize("name,key,layers", [("resnet34", "resnet34_7.theta", (3, 4, 6, 3)),
+                                             ("resnet18", "resnet18_7.theta", (2, 2, 2, 2))])
+def test_resnet_stn_golden(E, golden_blocks, name, key, layers):
+    g = golden_blocks
+    rn, _ = _mods_to_cuda(modules.ResNetSTN(name, 7), 17 if name == "resnet34" else 18)
+    x = torch.from_numpy(g["resnet34_7.x"])
+    eng = E.ResNetEngine(rn, 7, torch.device("cuda"))
+    y = E.nchw_to_nhwc(x.cuda(), 8)
+    theta = eng.run(y, 2, 72, 128)
+    torch.cuda.synchronize()
+    assert _maxerr(theta.cpu(), g[key]) < 1e-4
+
+
+# ---------------------------------------------------------------- warp / POI / CE
+def _thetas():
+    ident = np.eye(3, dtype=np.float32)
+    t = [ident, synth.REALISTIC_THETAS[0], synth.REALISTIC_THETAS[1]]
+    g = synth._rng(5, "thetas")
+    for _ in range(9):
+        t.append((ident + g.normal(0, 0.15, (3, 3))).astype(np.float32))
+    ns = ident.copy(); ns[2] = [0.9, 0.0, 0.0]
+    t.append(ns)
+    far = ident.copy(); far[0, 2] = 5.0
+    t.append(far)
+    z = ident.copy(); z[2] = [0.0, 0.0, 0.0]   # Z == 0 everywhere -> scale 1 branch
+    t.append(z)
+    return torch.from_numpy(np.stack(t)).reshape(-1, 1, 3, 3)
+
+
+@pytest.mark.parametrize("mode", ["nearest", "bilinear"])
+@pytest.mark.parametrize("size", [(640, 360), (1280, 720), (97, 61)])
+@pytest.mark.parametrize("shared", [True, False])
+def test_warp_vs_oracle(E, mode, size, shared):
+    w, h = size
+    theta = _thetas()
+    B = theta.shape[0]
+    if (w, h) == (97, 61):
+        ids = synth._rng(3, "tmpl").integers(0, 4, (61 + 3, 97 + 5))
+        tmpl = torch.from_numpy(ids.astype(np.float32) / 4.0)[None, None].repeat(B, 1, 1, 1)
+    else:
+        tmpl = synth.load_court_template(f"ncaa_nc4_{w}x{h}", 4, B)
+    if not shared:
+        tmpl = tmpl.clone()
+        tmpl[1::2] = torch.flip(tmpl[1::2], dims=[3])
+    want = warp_ref.homography_warp(theta, tmpl, h, w, mode)
+    of, oi = E.homography_warp(theta.cuda(), tmpl.cuda(), h, w, mode == "nearest", scale=4.0,
+                               want_f32=True, want_i32=True, shared_template=shared)
+    torch.cuda.synchronize()
+    if mode == "nearest":
+        assert torch.equal(of.cpu(), want), f"{(of.cpu() != want).sum().item()} pixels differ"
+        assert torch.equal(oi.cpu(), (want * 4).to(torch.int32))
+    else:
+        assert _maxerr(of.cpu(), want) < 1e-5
+        assert (oi.cpu() - (want * 4).to(torch.int32)).abs().max().item() <= 1
+
+
+def test_poi_vs_oracle(E):
+    theta = _thetas()[:12]
+    poi = synth.load_court_poi("pitch", 12)
+    want = torch_ref.transform_poi(theta, poi)
+    got = E.poi_project(theta.cuda(), poi.cuda())
+    torch.cuda.synchronize()
+    assert _maxerr(got.cpu(), want) < 1e-4
+    ok = np.isfinite(want.numpy()).all(-1) & (np.abs(want.numpy()) < 4).all(-1)
+    px_w = np.rint(want.numpy()[ok] * np.array([640, 360]))
+    px_g = np.rint(got.cpu().numpy()[ok] * np.array([640, 360]))
+    # pixel coordinates int(round(p*W)) (predict.py:383): exact except on .5 ties within fp32 noise
+    frac = np.abs(want.numpy()[ok] * np.array([640, 360]) % 1 - 0.5)
+    assert np.array_equal(px_w[frac > 1e-3], px_g[frac > 1e-3])
+
+
+@pytest.mark.parametrize("resize", [False, True])
+def test_consistency_ce_vs_oracle(E, resize):
+    g = synth._rng(9, "ce")
+    B, nc, H, W = 3, 4, 90, 112
+    logits = torch.from_numpy(g.normal(0, 3, (B, nc, H, W)).astype(np.float32))
+    hm, wm = (45, 56) if resize else (H, W)
+    mask = torch.from_numpy(g.integers(0, nc, (B, hm, wm)).astype(np.int32))
+    m = mask.float()
+    if resize:
+        m = torch.nn.functional.interpolate(m.unsqueeze(1), size=(H, W), mode="nearest").squeeze(1)
+    want = torch.nn.functional.cross_entropy(logits, m.long(), reduction="none").mean(dim=(1, 2))
+    got = E.consistency_ce(logits.cuda(), mask.cuda())
+    torch.cuda.synchronize()
+    assert _maxerr(got.cpu(), want) < 1e-5
+
+
+# ---------------------------------------------------------------- whole model
+def _model(court_wh=(640, 360), B=2, **kw):
+    from sfh_amd.reconstructor import Reconstructor
+    w, h = court_wh
+    court = synth.load_court_template("ncaa_nc4_640x360", 4, B)
+    if (w, h) != (640, 360):
+        court = court[:, :, :h, :w].contiguous()
+    poi = synth.load_court_poi("pitch", B)
+    net = Reconstructor(court.cuda(), poi.cuda(), target_size=(w, h), unet_size=(w, h), warp_size=(w, h), **kw)
+    sd = synth.synth_state_dict(net.state_dict(), kw.pop("seed", 19) if False else 19)
+    return net, sd, court, poi
+
+
+def test_whole_net_small_golden(E, golden_blocks):
+    g = golden_blocks
+    net, sd, court, poi = _model((112, 90), warp_with_nearest=True)
+    net.load_state_dict(sd)
+    net.cuda().eval()
+    x = synth.smooth_frames(2, 90, 112, seed=19)
+    with torch.no_grad():
+        out = net.predict(x.cuda(), consistency=True, project_poi=True)
+    torch.cuda.synchronize()
+    assert _maxerr(out["logits"].cpu(), g["net_90x112.logits"]) < 2e-4
+    assert _maxerr(out["theta"].cpu(), g["net_90x112.theta"]) < 1e-4
+    want = torch_ref.predict(x, sd, court, poi, warp_size=(112, 90), unet_size=(112, 90), target_size=(112, 90),
+                             project_poi=True)
+    assert out["warp_mask"].dtype == torch.int32 and out["theta"].shape == (2, 1, 3, 3)
+    assert _maxerr(out["consist_score"].cpu(), want["consist_score"]) < 1e-3
+    assert _maxerr(out["poi"].cpu(), want["poi"]) < 1e-4
+    # warp of the GPU theta through the oracle must equal the GPU warp bit for bit
+    wm = (warp_ref.homography_warp(out["theta"].cpu(), court, 90, 112, "nearest") * 4).to(torch.int32)
+    assert torch.equal(out["warp_mask"].cpu(), wm)
+    # argmax: exact wherever the oracle's top-2 margin exceeds the measured logit error
+    lg = torch.from_numpy(g["net_90x112.logits"])
+    top2 = torch.topk(lg, 2, dim=1).values
+    safe = (top2[:, 0] - top2[:, 1]) > 1e-3
+    assert torch.equal(out["logits"].cpu().argmax(1)[safe], lg.argmax(1)[safe])
+
+
+def test_full_640x360_golden(E, golden_full):
+    """BASELINE config C2 shape (B=2 of the 16): every output against the committed vector."""
+    g = golden_full
+    net, _, court, poi = _model((640, 360), warp_with_nearest=True)
+    sd = synth.synth_state_dict(net.state_dict(), 0)
+    net.load_state_dict(sd)
+    net.cuda().eval()
+    x = synth.frames_to_float(synth.synth_frames_u8(2, 360, 640, seed=0))
+    with torch.no_grad():
+        out = net.predict(x.cuda(), consistency=True, project_poi=True)
+    torch.cuda.synchronize()
+    dtheta = _maxerr(out["theta"].cpu(), g["theta"])
+    assert dtheta < 1e-4, dtheta
+    assert _maxerr(out["logits"].cpu()[:, :, ::8, ::8], g["logits_sub"]) < 5e-4
+    assert _maxerr(out["consist_score"].cpu(), g["consist"]) < 2e-3
+    assert _maxerr(out["poi"].cpu(), g["poi"]) < 1e-4
+    am = np.unpackbits(g["argmax_2bit"], axis=-1).reshape(2, 360, 640, 2)
+    am = am[..., 0] * 2 + am[..., 1]
+    margin = g["margin_f16"].astype(np.float32)
+    mine = out["logits"].cpu().argmax(1).numpy()
+    safe = margin > 2e-3
+    assert np.array_equal(mine[safe], am[safe])
+    assert (mine != am).mean() < 1e-4
+    # warp mask: integer-exact wherever a 1e-4 change of theta cannot move the sample across a
+    # template edge; overall mismatch must be tiny
+    wm = out["warp_mask"].cpu().numpy()
+    assert (wm != g["warp_mask"]).mean() < 2e-3
+
+
+def test_model_api_errors(E):
+    from sfh_amd.reconstructor import Reconstructor
+    net, sd, court, poi = _model((112, 90))
+    net.load_state_dict(sd)
+    with pytest.raises(RuntimeError):
+        net.eval().predict(torch.zeros(1, 3, 90, 112))          # CPU model: no fallback
+    net.cuda()
+    with pytest.raises(NotImplementedError):
+        net.train().predict(torch.zeros(1, 3, 90, 112).cuda())   # training mode not on the HIP path
+    net.eval()
+    with pytest.raises(ValueError):
+        net.predict(torch.zeros(3, 3, 90, 112).cuda())           # batch > template batch (2)
+    with pytest.raises(NotImplementedError):
+        Reconstructor(court, poi, resnet_input="bogus")
+    bad = dict(sd); bad.pop("outc.conv.bias")
+    with pytest.raises(RuntimeError):
+        net.load_state_dict(bad)                                  # strict key check like the reference
