@@ -1,0 +1,22 @@
+#!/bin/bash
+# Collect the rocprofv3 evidence for one round on the GPU box (run through gpurun from the
+# repo root):  bash profiles/collect_pmc.sh r01
+# Separate passes, as MI355X_MICROARCH.md prescribes: kernel-trace+stats alone; FETCH_SIZE
+# alone (3 TCC slots); WRITE_SIZE alone (2 slots).  Outputs land in gpurun_out/<tag>_*/ and
+# are summarised into profiles/ by profiles/summarize_pmc.py (run back in the build container).
+set -e
+TAG=${1:-r01}
+ROOTD=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$ROOTD/gpurun_out
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+ARGS="--steps 3 --warmup 1 --no-cpu-baseline"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_trace -- python3 $ROOTD/bench.py $ARGS > $OUT/${TAG}_trace.log 2>&1
+echo "trace done"
+timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/${TAG}_fetch -- python3 $ROOTD/bench.py $ARGS > $OUT/${TAG}_fetch.log 2>&1
+echo "fetch done"
+timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/${TAG}_write -- python3 $ROOTD/bench.py $ARGS > $OUT/${TAG}_write.log 2>&1
+echo "write done"
+timeout -k 10 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVES GRBM_GUI_ACTIVE --output-format csv -d $OUT/${TAG}_mfma -- python3 $ROOTD/bench.py $ARGS > $OUT/${TAG}_mfma.log 2>&1
+echo "mfma done"
+ls $OUT/${TAG}_*/*/ | head -40

@@ -1,0 +1,34 @@
+"""Per-layer table from a rocprofv3 --kernel-trace CSV of bench.py (last step of the run).
+usage: python profiles/layer_table.py <kernel_trace.csv> [batch]"""
+import csv, re, sys
+rows = list(csv.DictReader(open(sys.argv[1])))
+B = int(sys.argv[2]) if len(sys.argv) > 2 else 16
+rows.sort(key=lambda r: int(r['Start_Timestamp']))
+idx = [i for i, r in enumerate(rows) if 'nchw_to_nhwc' in r['Kernel_Name']]
+step = rows[idx[-1]:]
+def gm(cin, cout, h, w, k=9): return cin * cout * h * w * k / 1e9
+L = [("inc.0", gm(3, 64, 360, 640)), ("inc.3", gm(64, 64, 360, 640)),
+     ("d1.0", gm(64, 128, 180, 320)), ("d1.3", gm(128, 128, 180, 320)),
+     ("d2.0", gm(128, 256, 90, 160)), ("d2.3", gm(256, 256, 90, 160)),
+     ("d3.0", gm(256, 512, 45, 80)), ("d3.3", gm(512, 512, 45, 80)),
+     ("d4.0", gm(512, 1024, 22, 40)), ("d4.3", gm(1024, 1024, 22, 40)),
+     ("u1.up", gm(1024, 512, 22, 40, 4)), ("u1.0", gm(1024, 512, 45, 80)), ("u1.3", gm(512, 512, 45, 80)),
+     ("u2.up", gm(512, 256, 45, 80, 4)), ("u2.0", gm(512, 256, 90, 160)), ("u2.3", gm(256, 256, 90, 160)),
+     ("u3.up", gm(256, 128, 90, 160, 4)), ("u3.0", gm(256, 128, 180, 320)), ("u3.3", gm(128, 128, 180, 320)),
+     ("u4.up", gm(128, 64, 180, 320, 4)), ("u4.0", gm(128, 64, 360, 640)), ("u4.3", gm(64, 64, 360, 640))]
+dur = lambda r: (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e6
+convs = [r for r in step if 'conv_mfma' in r['Kernel_Name']]
+tot = 0
+for (nm, g), r in zip(L, convs[:len(L)]):
+    d = dur(r)
+    cfg = re.search(r'ConvCfg<([^>]*)>', r['Kernel_Name']).group(1)
+    print(f"{nm:6s} cfg<{cfg:22s}> {d:7.3f} ms {2*g*B/d:7.1f} TFLOP/s grid={r.get('Grid_Size_X')} vgpr={r.get('VGPR_Count')} lds={r.get('LDS_Block_Size')}")
+    tot += d
+print(f"UNet conv launches: {tot:.3f} ms")
+t0 = int(step[0]['Start_Timestamp']); t1 = max(int(r['End_Timestamp']) for r in step)
+print(f"step span {(t1-t0)/1e6:.3f} ms over {len(step)} kernels; busy {sum(dur(r) for r in step):.3f} ms")
+rn = convs[len(L):]
+print(f"ResNet conv launches: {sum(dur(r) for r in rn):.3f} ms ({len(rn)} launches)")
+for r in step:
+    if 'conv_mfma' not in r['Kernel_Name']:
+        print(f"  {r['Kernel_Name'][:70]:70s} {dur(r)*1e3:9.1f} us")

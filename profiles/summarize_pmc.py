@@ -1,0 +1,99 @@
+"""Summarise the rocprofv3 passes collected by profiles/collect_pmc.sh into
+profiles/<tag>_*.txt and profiles/pmc_traffic.json (read by bench.py's roofline.traffic).
+
+HBM bytes per launch follow MI355X_MICROARCH.md §HBM: FETCH_SIZE and WRITE_SIZE are in KiB,
+collected in separate passes; on gfx950 FETCH_SIZE reports half the bytes of wide (16 B/lane)
+reads, so the read side is doubled:  hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024.
+
+usage: python profiles/summarize_pmc.py r01 [gpurun_out]
+"""
+import csv
+import glob
+import json
+import os
+import re
+import sys
+
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+src = sys.argv[2] if len(sys.argv) > 2 else "gpurun_out"
+here = os.path.dirname(os.path.abspath(__file__))
+
+
+def rows(kind):
+    f = glob.glob(os.path.join(src, f"{tag}_{kind}", "*", "*_counter_collection.csv"))
+    return list(csv.DictReader(open(f[0]))) if f else []
+
+
+def group(name):
+    m = re.search(r"ConvCfg<(\d+), (\d+)", name)
+    if "conv_mfma" in name and m:
+        return {("3", "1"): "doubleconv3x3", ("1", "1"): "convT2x2"}.get((m.group(1), m.group(2)), "resnet_other_conv")
+    for k in ("warp_kernel", "outconv", "maxpool", "avgpool", "space_to_depth", "nchw_to_nhwc", "pack_weights", "fold_bn", "ce_"):
+        if k in name:
+            return k
+    return None
+
+
+def per_group(kind, counter):
+    acc = {}
+    for r in rows(kind):
+        if r["Counter_Name"] != counter:
+            continue
+        g = group(r["Kernel_Name"])
+        if g is None:
+            continue
+        n, v, t = acc.get(g, (0, 0.0, 0.0))
+        acc[g] = (n + 1, v + float(r["Counter_Value"]), t + (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
+    return acc
+
+
+fetch = per_group("fetch", "FETCH_SIZE")
+write = per_group("write", "WRITE_SIZE")
+out = {}
+lines = [f"# {tag}: HBM traffic per launch from rocprofv3 --pmc (separate FETCH_SIZE / WRITE_SIZE passes)",
+         "# hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024   (gfx950: FETCH_SIZE counts 64 B per 128-B request)",
+         f"{'kernel group':22s} {'launches':>8s} {'FETCH KiB/launch':>18s} {'WRITE KiB/launch':>18s} {'HBM MB/launch':>14s} {'GB/s (pmc-run time)':>20s}"]
+for g in sorted(fetch):
+    n, fv, ft = fetch[g]
+    nw, wv, wt = write.get(g, (n, 0.0, ft))
+    hbm = (2 * fv / n + wv / max(nw, 1)) * 1024
+    out[g] = {"launches": n, "fetch_kib_per_launch": fv / n, "write_kib_per_launch": wv / max(nw, 1),
+              "hbm_bytes_per_launch": hbm, "avg_launch_ns_in_pmc_run": ft / n}
+    lines.append(f"{g:22s} {n:8d} {fv/n:18.1f} {wv/max(nw,1):18.1f} {hbm/1e6:14.2f} {hbm/(ft/n):20.1f}")
+open(os.path.join(here, f"{tag}_pmc_hbm_traffic.txt"), "w").write("\n".join(lines) + "\n")
+json.dump(out, open(os.path.join(here, "pmc_traffic.json"), "w"), indent=1)
+print("\n".join(lines))
+
+# MFMA busy
+mf = {}
+for r in rows("mfma"):
+    g = group(r["Kernel_Name"])
+    if g is None:
+        continue
+    d = mf.setdefault(g, {})
+    d[r["Counter_Name"]] = d.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
+    d["_n"] = d.get("_n", 0) + (1 if r["Counter_Name"] == "SQ_BUSY_CYCLES" else 0)
+    if r["Counter_Name"] == "SQ_BUSY_CYCLES":
+        d["_ns"] = d.get("_ns", 0) + int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+ml = [f"# {tag}: rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVES GRBM_GUI_ACTIVE (sums over launches)",
+      "# mfma_busy_per_simd_cycle = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 * 1024 SIMDs): fraction of SIMD-cycles with the matrix pipe busy",
+      f"{'kernel group':22s} {'launches':>8s} {'MFMA_BUSY':>16s} {'GRBM_GUI_ACTIVE':>16s} {'eff. clock GHz':>14s} {'mfma busy frac':>14s}"]
+for g, d in sorted(mf.items()):
+    if "SQ_VALU_MFMA_BUSY_CYCLES" not in d:
+        continue
+    gui = d.get("GRBM_GUI_ACTIVE", 0.0)
+    clk = gui / 8 / max(d.get("_ns", 1), 1)
+    frac = d["SQ_VALU_MFMA_BUSY_CYCLES"] / max(gui / 8 * 1024, 1)
+    ml.append(f"{g:22s} {d['_n']:8d} {d['SQ_VALU_MFMA_BUSY_CYCLES']:16.4g} {gui:16.4g} {clk:14.3f} {frac:14.3f}")
+open(os.path.join(here, f"{tag}_pmc_mfma_busy.txt"), "w").write("\n".join(ml) + "\n")
+print("\n".join(ml))
+
+# kernel stats summary copy
+ks = glob.glob(os.path.join(src, f"{tag}_trace", "*", "*_kernel_stats.csv"))
+if ks:
+    rr = list(csv.DictReader(open(ks[0])))
+    sl = [f"# {tag}: rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline",
+          f"{'calls':>6s} {'total ms':>10s} {'avg us':>10s} {'%':>6s}  kernel"]
+    for r in rr:
+        sl.append(f"{r['Calls']:>6s} {int(r['TotalDurationNs'])/1e6:10.3f} {float(r['AverageNs'])/1e3:10.1f} {float(r['Percentage']):6.2f}  {r['Name'][:150]}")
+    open(os.path.join(here, f"{tag}_kernel_stats.txt"), "w").write("\n".join(sl) + "\n")

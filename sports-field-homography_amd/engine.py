@@ -50,17 +50,37 @@ def choose_tile(batch, ho, wo, stride, zrows=1):
     return best[1]
 
 
+class ConvTimer:
+    """Optional HIP-event timing of conv launches on the launch stream (used by bench.py for the
+    live roofline figure).  Records (tag, algorithmic FLOPs, start event, end event)."""
+
+    def __init__(self):
+        self.records = []
+
+    def summary(self):
+        """-> {tag: (launches, total_flops, total_ms)}; call after a device synchronize."""
+        out = {}
+        for tag, flops, e0, e1 in self.records:
+            n, f, t = out.get(tag, (0, 0.0, 0.0))
+            out[tag] = (n + 1, f + flops, t + e0.elapsed_time(e1))
+        return out
+
+
 class PackedConv:
     """One conv-shaped layer: fragment-ordered weights + folded per-channel epilogue."""
 
+    timer = None   # set to a ConvTimer to time every launch (class-wide)
+
     def __init__(self, weight, bias, bn, ksize, c0, c1=0, relu=True, transposed=False, stride=1,
-                 stem_cin=0):
+                 stem_cin=0, tag="conv"):
         lib = _lib.load()
+        self.tag = tag
         dev = weight.device
         w = _f32c(weight.detach(), "conv weight")
         self.ksize, self.c0, self.c1, self.relu, self.stride = ksize, c0, c1, relu, stride
         self.transposed = transposed
         mode, aux = (1 if transposed else 0), 0
+        self.stem_cin = stem_cin
         if stem_cin:  # 7x7 s2 stem re-expressed as a 4x4 conv over the space-to-depth input
             cout = w.shape[0]
             assert ksize == 4 and tuple(w.shape[1:]) == (stem_cin, 7, 7) and c1 == 0
@@ -124,7 +144,17 @@ class PackedConv:
         exp = (batch, 2 * ho, 2 * wo) if self.transposed else (batch, ho, wo)
         if tuple(dst.shape[:3]) != exp or dst.shape[3] < self.cout_real:
             raise ValueError(f"conv dst shape {tuple(dst.shape)} does not match {exp + (self.cout_real,)}")
+        tm = PackedConv.timer
+        if tm is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
         _lib.check(lib.sfh_conv_fwd(ctypes.byref(d), _stream()), "conv_fwd")
+        if tm is not None:
+            e1.record()
+            # algorithmic work: 2 * MACs of the reference op (real cin, real taps)
+            kk = 49 if self.ksize == 4 else (4 if self.transposed else self.ksize * self.ksize)
+            cin = self.stem_cin if self.ksize == 4 else self.c0 + self.c1
+            tm.records.append((self.tag, 2.0 * batch * ho * wo * self.cout_real * kk * cin, e0, e1))
         return dst
 
 
@@ -157,15 +187,16 @@ class UNetEngine:
 
         def dc(name, block, c0, c1=0):
             (cv1, bn1), (cv2, bn2) = block.convs()
-            L[name + ".0"] = PackedConv(cv1.weight, cv1.bias, bn1, 3, c0, c1)
-            L[name + ".3"] = PackedConv(cv2.weight, cv2.bias, bn2, 3, cv1.out_channels)
+            L[name + ".0"] = PackedConv(cv1.weight, cv1.bias, bn1, 3, c0, c1, tag="doubleconv3x3")
+            L[name + ".3"] = PackedConv(cv2.weight, cv2.bias, bn2, 3, cv1.out_channels, tag="doubleconv3x3")
 
         dc("inc", net.inc, 3)
         for i, cin in enumerate((64, 128, 256, 512), start=1):
             dc(f"down{i}", getattr(net, f"down{i}").block, cin)
         for i, cin in enumerate((1024, 512, 256, 128), start=1):
             up = getattr(net, f"up{i}")
-            L[f"up{i}.up"] = PackedConv(up.up.weight, up.up.bias, None, 1, cin, relu=False, transposed=True)
+            L[f"up{i}.up"] = PackedConv(up.up.weight, up.up.bias, None, 1, cin, relu=False, transposed=True,
+                                        tag="convT2x2")
             dc(f"up{i}.conv", up.conv, cin // 2, cin // 2)
         self.L = L
         self.outc_w = _f32c(net.outc.conv.weight.detach(), "outc.weight")
@@ -244,17 +275,18 @@ class ResNetEngine:
         if (4 * self.cs_in) % 16:
             self.cs_in = -(-in_channels // 8) * 8
         L = {}
-        L["stem"] = PackedConv(rn.conv0.weight, None, rn.bn1, 4, 4 * self.cs_in, stem_cin=in_channels)
+        L["stem"] = PackedConv(rn.conv0.weight, None, rn.bn1, 4, 4 * self.cs_in, stem_cin=in_channels, tag="resnet")
         self.blocks = []
         for li in range(1, 5):
             for bi, blk in enumerate(getattr(rn, f"layer{li}")):
                 name = f"layer{li}.{bi}"
                 cin, planes = blk.conv1.in_channels, blk.conv1.out_channels
-                L[name + ".conv1"] = PackedConv(blk.conv1.weight, None, blk.bn1, 3, cin, stride=blk.stride)
-                L[name + ".conv2"] = PackedConv(blk.conv2.weight, None, blk.bn2, 3, planes)  # ReLU after the residual add
+                L[name + ".conv1"] = PackedConv(blk.conv1.weight, None, blk.bn1, 3, cin, stride=blk.stride, tag="resnet")
+                L[name + ".conv2"] = PackedConv(blk.conv2.weight, None, blk.bn2, 3, planes, tag="resnet")  # ReLU after the residual add
                 if blk.downsample is not None:
                     ds = blk.downsample
-                    L[name + ".down"] = PackedConv(ds[0].weight, None, ds[1], 1, cin, relu=False, stride=blk.stride)
+                    L[name + ".down"] = PackedConv(ds[0].weight, None, ds[1], 1, cin, relu=False, stride=blk.stride,
+                                                   tag="resnet")
                 self.blocks.append((name, cin, planes, blk.stride, blk.downsample is not None))
         self.L = L
         self.reg_w = _f32c(rn.reg.weight.detach(), "reg.weight")
