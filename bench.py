@@ -69,7 +69,7 @@ def main():
 
     import torch
     import torch.distributed as dist
-    from sfh_amd import synth, engine
+    from sfh_amd import synth, engine, sharding
     from sfh_amd.reconstructor import Reconstructor
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -100,12 +100,12 @@ def main():
     nbatches = 2
     frames = [synth.frames_to_float(synth.synth_frames_u8(B, H, W, seed=1000 * rank + k)).to(dev)
               for k in range(nbatches)]
-    gathered = [torch.empty((B, 9), device=dev) for _ in range(world)] if world > 1 else None
+    gbuf = [torch.empty((B, 10), device=dev) for _ in range(world)] if world > 1 else None
 
     def step(k):
         out = net.predict(frames[k % nbatches], consistency=args.consistency, project_poi=args.consistency)
-        if world > 1:  # the one exchange step of the sharded path: thetas to every rank
-            dist.all_gather(gathered, out["theta"].reshape(B, 9))
+        if world > 1:  # the one exchange step of the sharded path: theta (+score) rows to every rank
+            dist.all_gather(gbuf, sharding.pack_results(out["theta"], out.get("consist_score")))
         return out
 
     with torch.no_grad():

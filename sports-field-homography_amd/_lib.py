@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsfh_amd.so")
+# SFH_AMD_LIB overrides the library file (used only to load the diagnostic build for profiling)
+LIB_PATH = os.environ.get("SFH_AMD_LIB") or os.path.join(_HERE, "libsfh_amd.so")
 
 TILE_8x32, TILE_16x16, TILE_32x8 = 0, 1, 2
 OUT_NHWC, OUT_UPSCATTER2 = 0, 1

@@ -50,5 +50,20 @@ def build(force=False, verbose=True):
     return LIB
 
 
+def build_diag(verbose=True):
+    """Diagnostic variant with in-kernel s_memtime stamps (profiles/diag_stamps.py); never loaded
+    by the product path."""
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    out = os.path.join(_HERE, "libsfh_amd_diag.so")
+    cmd = [hipcc] + FLAGS + ["-DSFH_DIAG_STAMPS", "-shared", "-o", out] + [os.path.join(CSRC, s) for s in SOURCES]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return out
+
+
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
+    if "--diag" in sys.argv:
+        build_diag()
+    else:
+        build(force="--force" in sys.argv)

@@ -33,7 +33,45 @@
 // Row space: for stride 1 the output rows of all frames are flattened with ONE shared
 // zero row between consecutive frames (row index r = b*(H+1) + y, y == H is the zero
 // row), so row tiles may straddle frames and only the last tile is partial.
+#include <stdlib.h>
+
 #include "common.h"
+
+// Diagnostic build only (-DSFH_DIAG_STAMPS, libsfh_amd_diag.so): per-segment s_memtime sums of
+// the stage loop, accumulated per wave and added to g_stamps by lane 0.  Never compiled into
+// the shipped library.
+#ifdef SFH_DIAG_STAMPS
+__device__ unsigned long long g_stamps[16];
+#define SFH_STAMP(i)                                                                         \
+  do {                                                                                       \
+    unsigned long long t_;                                                                   \
+    __builtin_amdgcn_sched_barrier(0);                                                       \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");               \
+    __builtin_amdgcn_sched_barrier(0);                                                       \
+    seg_[i] += t_ - tprev_;                                                                  \
+    tprev_ = t_;                                                                             \
+  } while (0)
+#define SFH_STAMP_INIT()                                                                     \
+  unsigned long long seg_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev_;                             \
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tprev_)::"memory")
+#define SFH_STAMP_FLUSH()                                                                    \
+  do {                                                                                       \
+    if ((threadIdx.x & 63) == 0)                                                             \
+      for (int i_ = 0; i_ < 8; ++i_) atomicAdd(&g_stamps[i_], seg_[i_]);                     \
+  } while (0)
+extern "C" int sfh_debug_read_stamps(unsigned long long* host_out, int reset) {
+  if (hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 16) != hipSuccess) return -2;
+  if (reset) {
+    unsigned long long z[16] = {0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), z, sizeof(z)) != hipSuccess) return -2;
+  }
+  return 0;
+}
+#else
+#define SFH_STAMP(i) do {} while (0)
+#define SFH_STAMP_INIT() do {} while (0)
+#define SFH_STAMP_FLUSH() do {} while (0)
+#endif
 
 namespace {
 
@@ -109,6 +147,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const sfh_conv_desc d
   f32x4* const halo = reinterpret_cast<f32x4*>(smem_f);
   f32x4* const wlds = halo + C::HSLOTS;
 
+  SFH_STAMP_INIT();
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wv = tid >> 6;
@@ -204,8 +243,10 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const sfh_conv_desc d
     for (int mi = 0; mi < C::MT_M; ++mi) acc[ni][mi] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   load_stage(0);
+  SFH_STAMP(0);  // prologue
   for (int st = 0; st < nst; ++st) {
     __syncthreads();  // all waves finished reading the previous stage from LDS
+    SFH_STAMP(1);  // barrier 1 (skew between the waves of the block)
     if (C::TG == 1 || st % C::TG == 0) {
 #pragma unroll
       for (int i = 0; i < C::NSL; ++i) {
@@ -215,7 +256,9 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const sfh_conv_desc d
     }
 #pragma unroll
     for (int t = 0; t < C::TPS; ++t) wlds[t * 256 + tid] = wreg[t];
+    SFH_STAMP(2);  // wait for prefetched data + LDS writes
     __syncthreads();
+    SFH_STAMP(3);  // barrier 2
 
     if (st + 1 < nst) {
       if (st + 1 == nst0 && which == 0) {  // switch to source 1: recompute slot offsets
@@ -228,29 +271,51 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const sfh_conv_desc d
       }
       load_stage(st + 1);
     }
+    SFH_STAMP(4);  // address arithmetic + issue of the next stage's global loads
 
+    // MFMA block of this stage.  The LDS operand reads of tap t+1 are issued before the
+    // 16*MT_M MFMAs of tap t (two register sets, static indices) so their latency hides
+    // under ~2000 cycles of matrix work instead of stalling each tap boundary.
     const int tbase = (C::TG == 1) ? 0 : (st % C::TG) * C::TPS;
-#pragma unroll
-    for (int tl = 0; tl < C::TPS; ++tl) {
+    f32x4 xv[2][C::MT_M], wv4[2][4];
+    auto ld_tap = [&](int tl, int buf) {
       constexpr int KK = C::KS * C::KS;
-      const int t = tl;
       const int tgl = tbase + tl;  // tap index within the chunk
       const int sub = tgl / KK, kk = tgl % KK;
       const int toff = sub * 4 * C::HPIXP + (kk / C::KS) * C::HW + (kk % C::KS);
-      f32x4 xv[C::MT_M], wv4[4];
 #pragma unroll
-      for (int mi = 0; mi < C::MT_M; ++mi) xv[mi] = halo[pixbase[mi] + toff];
+      for (int mi = 0; mi < C::MT_M; ++mi) xv[buf][mi] = halo[pixbase[mi] + toff];
 #pragma unroll
-      for (int ni = 0; ni < 4; ++ni) wv4[ni] = wlds[(t * 4 + ni) * 64 + lane];
+      for (int ni = 0; ni < 4; ++ni) wv4[buf][ni] = wlds[(tl * 4 + ni) * 64 + lane];
+    };
+    ld_tap(0, 0);
+    __builtin_amdgcn_sched_group_barrier(0x100, C::MT_M + 4, 0);  // DS_READ: tap 0 operands
+#pragma unroll
+    for (int tl = 0; tl < C::TPS; ++tl) {
+      const int cur = tl & 1;
+      if (tl + 1 < C::TPS) ld_tap(tl + 1, cur ^ 1);
 #pragma unroll
       for (int j = 0; j < 4; ++j)
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
           for (int mi = 0; mi < C::MT_M; ++mi)
-            acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv4[ni][j], xv[mi][j],
+            acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv4[cur][ni][j], xv[cur][mi][j],
                                                                acc[ni][mi], 0, 0, 0);
+      // pin the interleave: one LDS read of the NEXT tap behind each of the first MFMAs of this tap
+      constexpr int NMF = 16 * C::MT_M, NRD = C::MT_M + 4;
+      if (tl + 1 < C::TPS) {
+#pragma unroll
+        for (int i = 0; i < NRD; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // DS_READ
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, NMF - NRD, 0);
+      } else {
+        __builtin_amdgcn_sched_group_barrier(0x008, NMF, 0);
+      }
     }
+    SFH_STAMP(5);  // MFMA block (incl. matrix-pipe sharing with the co-resident wave)
   }
 
   // ---- epilogue: y = acc*scale + shift (+residual) (ReLU) -> NHWC 16-byte stores ----
@@ -308,6 +373,8 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const sfh_conv_desc d
       *reinterpret_cast<f32x4*>(d.dst + off) = v;
     }
   }
+  SFH_STAMP(6);  // epilogue
+  SFH_STAMP_FLUSH();
 }
 
 // ------------------------------------------------------------------ weight packing
@@ -382,11 +449,13 @@ int launch_conv(const sfh_conv_desc& d, hipStream_t stream) {
   static bool attr_set = false;  // idempotent; benign if raced
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_kernel<C>),
-                        hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
-  hipLaunchKernelGGL(conv_mfma_kernel<C>, dim3((unsigned)nblocks), dim3(256), C::LDS_BYTES, stream,
-                     d, g);
+  // debug knob (experiments only): extra dynamic LDS per workgroup to lower residency
+  static const int extra_lds = getenv("SFH_DEBUG_CONV_EXTRA_LDS") ? atoi(getenv("SFH_DEBUG_CONV_EXTRA_LDS")) : 0;
+  hipLaunchKernelGGL(conv_mfma_kernel<C>, dim3((unsigned)nblocks), dim3(256), C::LDS_BYTES + extra_lds,
+                     stream, d, g);
   return sfh_check_launch("conv_mfma_kernel");
 }
 

@@ -1,0 +1,78 @@
+"""Frame sharding over the GPUs of one node.
+
+``predict`` has no cross-frame operation (eval-mode BatchNorm uses running statistics), so a
+batch shards by frame with NO data-path collective: rank r of W processes frames
+[r*n, (r+1)*n).  The only exchange is the gather of the per-frame results that the caller
+needs on every rank / on rank 0: theta (9 floats) and consist_score (1 float) = 40 B per
+frame.  One process per GPU; backend "nccl" (= RCCL over xGMI) on GPUs, "gloo" in the CPU
+tests.  The payload is latency-bound (5 KB for 128 frames), so a single all_gather per batch
+is used - on the fully connected xGMI mesh RCCL resolves it in one hop.
+"""
+import torch
+import torch.distributed as dist
+
+
+def shard_range(n_frames, rank, world):
+    """Contiguous, balanced split of n_frames; the first (n_frames % world) ranks get one more."""
+    base, rem = divmod(n_frames, world)
+    start = rank * base + min(rank, rem)
+    return start, start + base + (1 if rank < rem else 0)
+
+
+def pack_results(theta, consist_score=None):
+    """(n,1,3,3) [+ (n,)] -> (n,10) float32 rows [theta(9), score]."""
+    n = theta.shape[0]
+    out = torch.zeros((n, 10), dtype=torch.float32, device=theta.device)
+    out[:, :9] = theta.reshape(n, 9)
+    if consist_score is not None:
+        out[:, 9] = consist_score
+    return out
+
+
+def gather_results(theta, consist_score=None, group=None, n_max=None):
+    """All ranks receive (theta_all (N,1,3,3), score_all (N,)) in frame order.
+
+    Ragged shards (n differs across ranks) are padded to ``n_max`` rows; pass the per-rank
+    frame counts via ``counts`` implicit in shard_range when known, otherwise they are
+    exchanged first (one tiny all_gather of an int)."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rows = pack_results(theta, consist_score)
+    if world == 1:
+        return theta, rows[:, 9].clone()
+    n = rows.shape[0]
+    cnt = torch.tensor([n], dtype=torch.int64, device=rows.device)
+    counts = [torch.zeros_like(cnt) for _ in range(world)]
+    dist.all_gather(counts, cnt, group=group)
+    counts = [int(c.item()) for c in counts]
+    n_max = max(counts)
+    if n < n_max:
+        rows = torch.cat([rows, rows.new_zeros((n_max - n, 10))], 0)
+    bufs = [torch.empty_like(rows) for _ in range(world)]
+    dist.all_gather(bufs, rows.contiguous(), group=group)
+    allrows = torch.cat([b[:c] for b, c in zip(bufs, counts)], 0)
+    return allrows[:, :9].reshape(-1, 1, 3, 3), allrows[:, 9].clone()
+
+
+def predict_sharded(net, frames, consistency=True, group=None):
+    """Run ``net.predict`` on this rank's shard of ``frames`` (a tensor holding the WHOLE batch
+    or a callable rank_range -> shard tensor) and gather theta/consist_score from all ranks.
+    Per-frame masks (logits, warp_mask) stay on the rank that computed them."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    if callable(frames):
+        x, (s, e) = frames(rank, world)
+    else:
+        s, e = shard_range(frames.shape[0], rank, world)
+        x = frames[s:e]
+    out = net.predict(x, consistency=consistency) if e > s else {}
+    if e > s:
+        theta = out["theta"]
+        score = out.get("consist_score")
+    else:  # empty shard (more ranks than frames)
+        dev = frames.device if not callable(frames) else x.device
+        theta = torch.zeros((0, 1, 3, 3), device=dev)
+        score = torch.zeros((0,), device=dev) if consistency else None
+    theta_all, score_all = gather_results(theta, score, group=group)
+    out["theta_all"], out["consist_score_all"] = theta_all, score_all
+    out["shard"] = (s, e)
+    return out

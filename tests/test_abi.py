@@ -1,0 +1,69 @@
+"""CPU-side checks of the C-ABI boundary: the library loads without a GPU and exports
+exactly the entry points declared in include/sfh_amd.h; argument validation fails loudly."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from conftest import ROOT
+
+
+def _declared():
+    txt = open(os.path.join(ROOT, "include", "sfh_amd.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(sfh_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_header_symbols_are_exported_and_bound():
+    from sfh_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        import sfh_amd.build as b
+        b.build(verbose=False)
+    lib = _lib.load()
+    names = _declared()
+    assert len(names) >= 15
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/sfh_amd.h but not exported"
+    assert sorted(_lib.SIGNATURES) == names, "ctypes signature table and header disagree"
+    assert lib.sfh_version() >= 100
+
+
+def test_conv_desc_layout_matches_header():
+    """Field order of the ctypes mirror == field order of struct sfh_conv_desc."""
+    from sfh_amd import _lib
+    txt = open(os.path.join(ROOT, "include", "sfh_amd.h")).read()
+    body = txt[txt.index("typedef struct sfh_conv_desc {"):txt.index("} sfh_conv_desc;")]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S).replace("typedef struct sfh_conv_desc {", "")
+    fields = []
+    for decl in body.split(";"):
+        decl = decl.strip()
+        m = re.match(r"(const float\*|float\*|int32_t)\s+(.*)", decl)
+        if m:
+            fields += [f.strip() for f in m.group(2).split(",")]
+    assert fields == [f[0] for f in _lib.ConvDesc._fields_]
+
+
+def test_argument_validation_without_gpu():
+    from sfh_amd import _lib
+    lib = _lib.load()
+    assert lib.sfh_packed_weight_floats(3, 64, 0, 64) == 4 * 9 * 1024
+    assert lib.sfh_packed_weight_floats(3, 64, 64, 128) == 2 * 8 * 9 * 1024
+    assert lib.sfh_packed_weight_floats(5, 64, 0, 64) == -1       # unsupported kernel size
+    assert lib.sfh_packed_weight_floats(3, 64, 0, 48) == -1       # cout not a multiple of 64
+    d = _lib.ConvDesc()
+    rc = lib.sfh_conv_fwd(ctypes.byref(d), None)                  # all-null descriptor
+    assert rc == -1 and b"null" in lib.sfh_last_error()
+    with pytest.raises(ValueError):
+        _lib.check(rc, "conv_fwd")
+    rc = lib.sfh_homography_warp_fwd(None, None, 0, 360, 640, 16, 360, 640, 0, 4.0, None, None, None)
+    assert rc == -1
+
+
+def test_model_refuses_cpu_execution():
+    import torch
+    from sfh_amd import synth
+    from sfh_amd.reconstructor import Reconstructor
+    net = Reconstructor(synth.load_court_template(batch_size=1), synth.load_court_poi(batch_size=1)).eval()
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        net.predict(torch.zeros(1, 3, 360, 640))

@@ -1,0 +1,67 @@
+"""World-size-2 gloo tests (CPU) of the frame-sharding / gather logic that the multi-GPU
+bench path uses with RCCL."""
+import os
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from sfh_amd import sharding
+
+
+def test_shard_range_covers_everything():
+    for n in (0, 1, 7, 16, 128, 129):
+        for w in (1, 2, 3, 8):
+            spans = [sharding.shard_range(n, r, w) for r in range(w)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [e - s for s, e in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+class _FakeNet:
+    """predict() stand-in: theta and score are pure functions of the frame content."""
+
+    def predict(self, x, consistency=True):
+        n = x.shape[0]
+        key = x.reshape(n, -1)[:, 0]
+        theta = (key.reshape(n, 1, 1, 1) + torch.arange(9.0).reshape(1, 1, 3, 3)).float()
+        out = {"theta": theta}
+        if consistency:
+            out["consist_score"] = key * 0.5
+        return out
+
+
+def _worker(rank, world, port, n_frames, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        frames = torch.arange(float(n_frames)).reshape(n_frames, 1, 1, 1).expand(n_frames, 3, 2, 2).contiguous()
+        out = sharding.predict_sharded(_FakeNet(), frames, consistency=True)
+        q.put((rank, out["shard"], out["theta_all"].tolist(), out["consist_score_all"].tolist()))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_frames", [8, 5, 1])
+def test_predict_sharded_gloo_world2(n_frames):
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000) + n_frames
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_frames, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    want_theta = (torch.arange(float(n_frames)).reshape(-1, 1, 1, 1) + torch.arange(9.0).reshape(1, 1, 3, 3))
+    spans = sorted(r[1] for r in res)
+    assert spans[0][0] == 0 and spans[-1][1] == n_frames and spans[0][1] == spans[1][0]
+    for _, _, theta_all, score_all in res:
+        assert torch.equal(torch.tensor(theta_all), want_theta)
+        assert torch.equal(torch.tensor(score_all), torch.arange(float(n_frames)) * 0.5)
