@@ -109,36 +109,144 @@ struct ConvCfg {
 struct ConvGeom {
   int tiles_x, tiles_y, ntiles, nblk_n;
   int Ho, Wo, rows_total;
+  int rows_per_img;     // flat row space: H + shared zero rows
+  unsigned rows_magic;  // floor(2^32 / rows_per_img) + 1: r / rows_per_img == umulhi(r, magic)
+  unsigned bytes0, bytes1;  // byte sizes of the two source tensors (buffer range check)
 };
 
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+constexpr unsigned kOOB = 0xFFFFFFF0u;  // voffset of a halo slot that must read zeros
+
+// 16-byte buffer load: out-of-range offsets (kOOB) return zeros without a branch; the
+// per-stage channel advance rides in the scalar offset, so staging needs no vector ALU work
+// (fp32 MFMA and VALU instructions contend for the same SIMD issue: every VALU instruction
+// in the stage loop is matrix time lost).
+__device__ __forceinline__ f32x4 bload(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)voff, (int)soff, 0));
+}
+
 template <class C>
-__device__ __forceinline__ int halo_src_offset(const sfh_conv_desc& d, int which, int p,
-                                               int r0, int x0) {
-  // p: halo pixel index; r0: first output row of the tile (flat row space, or
-  // img*2^16 + y for the per-image policy); x0: first output column.
+__device__ __forceinline__ unsigned halo_voffset(const sfh_conv_desc& d, const ConvGeom& g, int which,
+                                                 int slot, int r0, int x0) {
+  // slot -> (channel plane, halo pixel); returns the byte offset of the pixel's channel quad
+  // of the FIRST stage in the source tensor, or kOOB.  r0: first output row of the tile (flat
+  // row space, or img*2^16 + y for the per-image policy); x0: first output column.
+  if (slot >= C::HSLOTS) return kOOB;
+  const int plane = slot / C::HPIXP, p = slot - plane * C::HPIXP;
+  if (p >= C::HPIX) return kOOB;
+  const int cs = which == 0 ? d.cs0 : d.cs1;
+  if (cs < C::CKS && 4 * plane >= cs) return kOOB;  // narrow source (e.g. RGB stored as 4)
   const int hy = p / C::HW, hx = p - hy * C::HW;
-  if (p >= C::HPIX) return -1;
   int b, y;
   if (C::FLATROWS) {
     const int r = r0 - C::PAD + hy;
-    if (r < 0) return -1;
-    b = r / (d.H + C::ZROWS);
-    y = r - b * (d.H + C::ZROWS);
-    if (b >= d.batch || y >= d.H) return -1;
+    if (r < 0) return kOOB;
+    b = (int)__umulhi((unsigned)r, g.rows_magic);
+    y = r - b * g.rows_per_img;
+    if (b >= d.batch || y >= d.H) return kOOB;
   } else {
     b = r0 >> 16;
     y = (r0 & 0xFFFF) * C::STRIDE - C::PAD + hy;
-    if (y < 0 || y >= d.H) return -1;
+    if (y < 0 || y >= d.H) return kOOB;
   }
   const int x = x0 * C::STRIDE - C::PAD + hx;
-  if (x < 0 || x >= d.W) return -1;
+  if (x < 0 || x >= d.W) return kOOB;
+  unsigned pix;
   if (which == 0) {
-    if (d.pool0) return ((b * d.h0 + 2 * y) * d.w0 + 2 * x) * d.cs0;
-    return ((b * d.h0 + y) * d.w0 + x) * d.cs0;
+    pix = d.pool0 ? (unsigned)((b * d.h0 + 2 * y) * d.w0 + 2 * x) : (unsigned)((b * d.h0 + y) * d.w0 + x);
+  } else {
+    const int ys = y - d.pad_top1, xs = x - d.pad_left1;
+    if (ys < 0 || ys >= d.h1 || xs < 0 || xs >= d.w1) return kOOB;
+    pix = (unsigned)((b * d.h1 + ys) * d.w1 + xs);
   }
-  const int ys = y - d.pad_top1, xs = x - d.pad_left1;
-  if (ys < 0 || ys >= d.h1 || xs < 0 || xs >= d.w1) return -1;
-  return ((b * d.h1 + ys) * d.w1 + xs) * d.cs1;
+  return (pix * (unsigned)cs + 4u * plane) * 4u;
+}
+
+struct TileCoord {
+  int nb, r0, x0;
+  bool live;
+};
+
+// XCD-aware block -> (tile, cout block): blocks b and b+8 share an XCD (L2); keep the cout
+// blocks of one pixel tile on one XCD so the halo is re-read from that L2.
+template <class C>
+__device__ __forceinline__ TileCoord decode_block(const ConvGeom& g) {
+  TileCoord t;
+  const int bid = blockIdx.x;
+  const int xcd = bid & 7, k = bid >> 3;
+  t.nb = k % g.nblk_n;
+  const int tile = (k / g.nblk_n) * 8 + xcd;
+  t.live = tile < g.ntiles;
+  const int ty = tile / g.tiles_x, tx = tile - ty * g.tiles_x;
+  t.x0 = tx * C::TW;
+  if (C::FLATROWS) {
+    t.r0 = ty * C::TH;
+  } else {
+    const int img = ty / g.tiles_y;  // tiles_y = tiles per image
+    t.r0 = (img << 16) | ((ty - img * g.tiles_y) * C::TH);
+  }
+  return t;
+}
+
+template <class C>
+__device__ __forceinline__ void conv_epilogue(const sfh_conv_desc& d, const ConvGeom& g,
+                                              f32x4 (&acc)[4][C::MT_M], int r0, int x0, int n0, int wv,
+                                              int lq, int lg) {
+  // ---- epilogue: y = acc*scale + shift (+residual) (ReLU) -> NHWC 16-byte stores ----
+  f32x4 sc[4], sh[4];
+#pragma unroll
+  for (int ni = 0; ni < 4; ++ni) {
+    const int co = n0 + ni * 16 + 4 * lg;
+    sc[ni] = *reinterpret_cast<const f32x4*>(d.scale + co);
+    sh[ni] = *reinterpret_cast<const f32x4*>(d.shift + co);
+  }
+#pragma unroll
+  for (int mi = 0; mi < C::MT_M; ++mi) {
+    const int s = wv * C::MT_M + mi;
+    const int sy = s / C::SUBX, sx = s - sy * C::SUBX;
+    const int oy = sy * C::SH + lq / C::SW, ox = sx * C::SW + lq % C::SW;
+    const int x = x0 + ox;
+    int b, y;
+    bool ok = x < g.Wo;
+    if (C::FLATROWS) {
+      const int r = r0 + oy;
+      b = (int)__umulhi((unsigned)r, g.rows_magic);
+      y = r - b * g.rows_per_img;
+      ok = ok && r < g.rows_total && y < g.Ho;
+    } else {
+      b = r0 >> 16;
+      y = (r0 & 0xFFFF) + oy;
+      ok = ok && y < g.Ho;
+    }
+    if (!ok) continue;
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+      int co = n0 + ni * 16 + 4 * lg;
+      size_t pix;
+      if (d.out_mode == SFH_OUT_UPSCATTER2) {
+        const int cr = d.cout >> 2;
+        const int qd = co / cr;
+        co -= qd * cr;
+        pix = ((size_t)(b * 2 * g.Ho + 2 * y + (qd >> 1)) * (2 * g.Wo) + 2 * x + (qd & 1));
+      } else {
+        pix = ((size_t)(b * g.Ho + y) * g.Wo + x);
+      }
+      const size_t off = pix * d.dst_cs + co;
+      f32x4 v = acc[ni][mi];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = v[j] * sc[ni][j] + sh[ni][j];
+      if (d.residual) {
+        const f32x4 rr = *reinterpret_cast<const f32x4*>(d.residual + off);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] += rr[j];
+      }
+      if (d.relu) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
+      }
+      *reinterpret_cast<f32x4*>(d.dst + off) = v;
+    }
+  }
 }
 
 template <class C>
@@ -177,53 +285,54 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const sfh_conv_desc d
   const int nst0 = (d.c0 + C::CKS - 1) / C::CKS * C::TG;
   const int nst1 = d.src1 ? (d.c1 + C::CKS - 1) / C::CKS * C::TG : 0;
   const int nst = nst0 + nst1;
-  const f32x4* wg = reinterpret_cast<const f32x4*>(d.wpacked) +
-                    (size_t)nb * nst * (C::TPS * 256) + tid;
 
-  // ---- per-thread halo slot bookkeeping -------------------------------------------
-  int poff[C::NSL];
+  // buffer descriptors (wave-uniform: kernel arguments and blockIdx only)
+  const __amdgpu_buffer_rsrc_t rs0 =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.src0), 0, (int)g.bytes0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(d.src1 ? d.src1 : d.src0), 0, (int)(d.src1 ? g.bytes1 : 0u), 0x00020000);
+  const unsigned wstage_bytes = C::TPS * 4096u;
+  const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(d.wpacked) + (size_t)nb * nst * (C::TPS * 1024), 0, (int)(nst * wstage_bytes),
+      0x00020000);
+  const unsigned wvoff = tid * 16u;
+  // pool-on-load: the 2x2 window's other three pixels as scalar byte deltas
+  const unsigned pd1 = d.cs0 * 4u, pd2 = (unsigned)d.w0 * d.cs0 * 4u;
+
+  // ---- per-thread halo slot byte offsets (recomputed when the source switches) ----------
+  unsigned hoff[C::NSL];
   int which = 0;
 #pragma unroll
-  for (int i = 0; i < C::NSL; ++i) {
-    const int s = tid + 256 * i;
-    poff[i] = (s < C::HSLOTS) ? halo_src_offset<C>(d, 0, s % C::HPIXP, r0, x0) : -1;
-  }
+  for (int i = 0; i < C::NSL; ++i) hoff[i] = halo_voffset<C>(d, g, 0, tid + 256 * i, r0, x0);
 
   f32x4 hreg[C::NSL];
   f32x4 wreg[C::TPS];
 
   auto load_stage = [&](int st) {
-    const float* src;
-    int cb, cs;
-    if (st < nst0) {
-      src = d.src0; cb = (st / C::TG) * C::CKS; cs = d.cs0;
-    } else {
-      src = d.src1; cb = ((st - nst0) / C::TG) * C::CKS; cs = d.cs1;
-    }
-    const bool pool = (st < nst0) && d.pool0;
+    const bool first = st < nst0;
+    const unsigned cb = (unsigned)((first ? st : st - nst0) / C::TG) * (C::CKS * 4u);  // channel byte offset
     if (C::TG == 1 || st % C::TG == 0) {  // the halo is shared by the tap groups of a chunk
+      if (first && d.pool0) {
 #pragma unroll
-    for (int i = 0; i < C::NSL; ++i) {
-      const int s = tid + 256 * i;
-      const int c = cb + 4 * (s / C::HPIXP);
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (poff[i] >= 0 && c < cs) {
-        const float* p = src + (size_t)(unsigned)poff[i] + c;
-        v = *reinterpret_cast<const f32x4*>(p);
-        if (pool) {
-          const f32x4 v1 = *reinterpret_cast<const f32x4*>(p + d.cs0);
-          const f32x4 v2 = *reinterpret_cast<const f32x4*>(p + (size_t)d.w0 * d.cs0);
-          const f32x4 v3 = *reinterpret_cast<const f32x4*>(p + (size_t)d.w0 * d.cs0 + d.cs0);
+        for (int i = 0; i < C::NSL; ++i) {
+          const f32x4 a0 = bload(rs0, hoff[i], cb), a1 = bload(rs0, hoff[i], cb + pd1);
+          const f32x4 a2 = bload(rs0, hoff[i], cb + pd2), a3 = bload(rs0, hoff[i], cb + pd2 + pd1);
+          f32x4 v;
 #pragma unroll
-          for (int j = 0; j < 4; ++j) v[j] = fmaxf(fmaxf(v[j], v1[j]), fmaxf(v2[j], v3[j]));
+          for (int j = 0; j < 4; ++j) v[j] = fmaxf(fmaxf(a0[j], a1[j]), fmaxf(a2[j], a3[j]));
+          hreg[i] = v;
         }
-      }
-      hreg[i] = v;
-    }
-    }
-    const f32x4* wp = wg + (size_t)st * (C::TPS * 256);
+      } else if (first) {
 #pragma unroll
-    for (int t = 0; t < C::TPS; ++t) wreg[t] = wp[t * 256];
+        for (int i = 0; i < C::NSL; ++i) hreg[i] = bload(rs0, hoff[i], cb);
+      } else {
+#pragma unroll
+        for (int i = 0; i < C::NSL; ++i) hreg[i] = bload(rs1, hoff[i], cb);
+      }
+    }
+    const unsigned wb = (unsigned)st * wstage_bytes;
+#pragma unroll
+    for (int t = 0; t < C::TPS; ++t) wreg[t] = bload(rsw, wvoff, wb + t * 4096u);
   };
 
   // ---- per-lane LDS read bases (B operand = pixels) ----------------------------------
@@ -245,6 +354,11 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const sfh_conv_desc d
   load_stage(0);
   SFH_STAMP(0);  // prologue
   for (int st = 0; st < nst; ++st) {
+    // Staging code runs at raised priority: with two waves per SIMD it otherwise loses VALU /
+    // SALU issue arbitration to the co-resident wave's MFMA stream (measured: ~45 % of wave
+    // time spent issuing ~300 staging instructions).  The MFMA stream has issue slack (8 of
+    // every 32 cycles), so it loses nothing.
+    __builtin_amdgcn_s_setprio(3);
     __syncthreads();  // all waves finished reading the previous stage from LDS
     SFH_STAMP(1);  // barrier 1 (skew between the waves of the block)
     if (C::TG == 1 || st % C::TG == 0) {
@@ -264,13 +378,11 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const sfh_conv_desc d
       if (st + 1 == nst0 && which == 0) {  // switch to source 1: recompute slot offsets
         which = 1;
 #pragma unroll
-        for (int i = 0; i < C::NSL; ++i) {
-          const int s = tid + 256 * i;
-          poff[i] = (s < C::HSLOTS) ? halo_src_offset<C>(d, 1, s % C::HPIXP, r0, x0) : -1;
-        }
+        for (int i = 0; i < C::NSL; ++i) hoff[i] = halo_voffset<C>(d, g, 1, tid + 256 * i, r0, x0);
       }
       load_stage(st + 1);
     }
+    __builtin_amdgcn_s_setprio(0);
     SFH_STAMP(4);  // address arithmetic + issue of the next stage's global loads
 
     // MFMA block of this stage.  The LDS operand reads of tap t+1 are issued before the
@@ -318,63 +430,163 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const sfh_conv_desc d
     SFH_STAMP(5);  // MFMA block (incl. matrix-pipe sharing with the co-resident wave)
   }
 
-  // ---- epilogue: y = acc*scale + shift (+residual) (ReLU) -> NHWC 16-byte stores ----
-  f32x4 sc[4], sh[4];
+  conv_epilogue<C>(d, g, acc, r0, x0, n0, wv, lq, lg);
+  SFH_STAMP(6);  // epilogue
+  SFH_STAMP_FLUSH();
+}
+
+// ------------------------------------------------------------------------------------------
+// v2: one workgroup (4 waves, one per SIMD) per CU, LDS double-buffered, staging by LDS-DMA.
+//
+// Measured on v1 (profiles/diag_stamps.py): with two waves per SIMD a wave cannot make progress
+// through its staging code while the co-resident wave streams fp32 MFMAs, so the two waves
+// effectively take turns and every non-MFMA instruction is matrix time lost.  v2 therefore keeps
+// ONE wave per SIMD and puts everything else into the gaps of its own MFMA stream:
+//   * stage s+1 goes global -> LDS by `buffer_load_dwordx4 ... lds` (no VGPRs, no ds_write, no
+//     address arithmetic: per-slot byte offsets are loop-invariant VGPRs, the channel advance is a
+//     scalar offset, out-of-frame slots carry an out-of-range offset and land as zeros);
+//   * those 15 DMA instructions and the 72 operand ds_read_b128 are interleaved one per MFMA;
+//   * one barrier per stage: [vmcnt(0); barrier] guarantees stage s+1 has landed for every wave
+//     and that every wave has finished reading the buffer the next DMA batch overwrites.
+template <class C>
+__global__ __launch_bounds__(256, 2) void conv_mfma_v2_kernel(const sfh_conv_desc d, const ConvGeom g) {
+  static_assert(C::TG == 1, "v2 handles single tap-group configurations");
+  extern __shared__ __attribute__((aligned(16))) float smem_f[];
+  // halo region padded to whole 256-slot DMA rounds so every wave-piece is in bounds (the
+  // padding slots carry the out-of-range offset, land as zeros and are never read)
+  constexpr int HPADSLOTS = C::NSL * 256;
+  constexpr int BUF = HPADSLOTS + C::TPS * 256;  // f32x4 per stage buffer
+  f32x4* const lds = reinterpret_cast<f32x4*>(smem_f);
+  typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: LDS-DMA bases stay in SGPRs
+  const int lq = lane & 15, lg = lane >> 4;
+  const TileCoord tc = decode_block<C>(g);
+  if (!tc.live) return;
+  const int nb = tc.nb, r0 = tc.r0, x0 = tc.x0, n0 = nb * 64;
+
+  const int nst0 = (d.c0 + C::CKS - 1) / C::CKS;
+  const int nst1 = d.src1 ? (d.c1 + C::CKS - 1) / C::CKS : 0;
+  const int nst = nst0 + nst1;
+
+  const __amdgpu_buffer_rsrc_t rs0 =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.src0), 0, (int)g.bytes0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(d.src1 ? d.src1 : d.src0), 0, (int)(d.src1 ? g.bytes1 : 0u), 0x00020000);
+  const unsigned wstage_bytes = C::TPS * 4096u;
+  const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(d.wpacked) + (size_t)nb * nst * (C::TPS * 1024), 0, (int)(nst * wstage_bytes),
+      0x00020000);
+  const unsigned wvoff = tid * 16u;
+
+  unsigned hoff0[C::NSL], hoff1[C::NSL];
 #pragma unroll
-  for (int ni = 0; ni < 4; ++ni) {
-    const int co = n0 + ni * 16 + 4 * lg;
-    sc[ni] = *reinterpret_cast<const f32x4*>(d.scale + co);
-    sh[ni] = *reinterpret_cast<const f32x4*>(d.shift + co);
+  for (int i = 0; i < C::NSL; ++i) {
+    hoff0[i] = halo_voffset<C>(d, g, 0, tid + 256 * i, r0, x0);
+    hoff1[i] = d.src1 ? halo_voffset<C>(d, g, 1, tid + 256 * i, r0, x0) : kOOB;
   }
+
+  // issue the DMA batch of stage `st` into buffer `b` (wave-uniform LDS bases)
+  auto dma_stage = [&](int st, int b) {
+    f32x4* const hb = lds + b * BUF;
+    f32x4* const wb = hb + HPADSLOTS;
+    const bool first = st < nst0;
+    const unsigned cb = (unsigned)(first ? st : st - nst0) * (C::CKS * 4u);
+    const __amdgpu_buffer_rsrc_t rs = first ? rs0 : rs1;
+#pragma unroll
+    for (int i = 0; i < C::NSL; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(hb + wv * 64 + 256 * i), 16,
+                                               (int)(first ? hoff0[i] : hoff1[i]), (int)cb, 0, 0);
+    const unsigned wbyte = (unsigned)st * wstage_bytes;
+#pragma unroll
+    for (int t = 0; t < C::TPS; ++t)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_ptr_t)(wb + t * 256 + wv * 64), 16, (int)wvoff,
+                                               (int)(wbyte + t * 4096u), 0, 0);
+  };
+
+  int pixbase[C::MT_M];
 #pragma unroll
   for (int mi = 0; mi < C::MT_M; ++mi) {
     const int s = wv * C::MT_M + mi;
     const int sy = s / C::SUBX, sx = s - sy * C::SUBX;
     const int oy = sy * C::SH + lq / C::SW, ox = sx * C::SW + lq % C::SW;
-    const int x = x0 + ox;
-    int b, y;
-    bool ok = x < g.Wo;
-    if (C::FLATROWS) {
-      const int r = r0 + oy;
-      b = r / (g.Ho + C::ZROWS);
-      y = r - b * (g.Ho + C::ZROWS);
-      ok = ok && r < g.rows_total && y < g.Ho;
-    } else {
-      b = r0 >> 16;
-      y = (r0 & 0xFFFF) + oy;
-      ok = ok && y < g.Ho;
-    }
-    if (!ok) continue;
+    pixbase[mi] = lg * C::HPIXP + oy * C::STRIDE * C::HW + ox * C::STRIDE;
+  }
+
+  f32x4 acc[4][C::MT_M];
 #pragma unroll
-    for (int ni = 0; ni < 4; ++ni) {
-      int co = n0 + ni * 16 + 4 * lg;
-      size_t pix;
-      if (d.out_mode == SFH_OUT_UPSCATTER2) {
-        const int cr = d.cout >> 2;
-        const int qd = co / cr;
-        co -= qd * cr;
-        pix = ((size_t)(b * 2 * g.Ho + 2 * y + (qd >> 1)) * (2 * g.Wo) + 2 * x + (qd & 1));
+  for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+    for (int mi = 0; mi < C::MT_M; ++mi) acc[ni][mi] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  constexpr int NDMA = C::NSL + C::TPS;           // DMA instructions per stage (upper bound)
+  constexpr int NMF = 16 * C::MT_M, NRD = C::MT_M + 4;
+  static_assert(NRD + NDMA < NMF && C::TPS >= 2, "not enough MFMAs in a tap to carry the interleave");
+
+  auto stage = [&](int st, int cur) {
+    const f32x4* const halo = lds + cur * BUF;
+    const f32x4* const wlds = halo + HPADSLOTS;
+    f32x4 xv[2][C::MT_M], wv4[2][4];
+    auto ld_tap = [&](int tl, int buf) {
+      constexpr int KK = C::KS * C::KS;
+      const int sub = tl / KK, kk = tl % KK;
+      const int toff = sub * 4 * C::HPIXP + (kk / C::KS) * C::HW + (kk % C::KS);
+#pragma unroll
+      for (int mi = 0; mi < C::MT_M; ++mi) xv[buf][mi] = halo[pixbase[mi] + toff];
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) wv4[buf][ni] = wlds[(tl * 4 + ni) * 64 + lane];
+    };
+    ld_tap(0, 0);
+    // unconditional (no branch inside the MFMA block): past the last stage the batch re-reads
+    // the final stage into the idle buffer
+    dma_stage(st + 1 < nst ? st + 1 : st, cur ^ 1);
+    __builtin_amdgcn_sched_group_barrier(0x100, NRD, 0);  // DS_READ: tap 0 operands
+#pragma unroll
+    for (int tl = 0; tl < C::TPS; ++tl) {
+      const int cb_ = tl & 1;
+      if (tl + 1 < C::TPS) ld_tap(tl + 1, cb_ ^ 1);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+          for (int mi = 0; mi < C::MT_M; ++mi)
+            acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv4[cb_][ni][j], xv[cb_][mi][j],
+                                                               acc[ni][mi], 0, 0, 0);
+      if (tl + 1 < C::TPS) {
+#pragma unroll
+        for (int i = 0; i < NRD; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // DS_READ (next tap)
+        }
+      }
+      if (tl == 0) {  // the next stage's DMA batch rides behind the following MFMAs
+#pragma unroll
+        for (int i = 0; i < NDMA; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
+          __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // VMEM read (LDS-DMA)
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, NMF - NRD - NDMA, 0);
+      } else if (tl + 1 < C::TPS) {
+        __builtin_amdgcn_sched_group_barrier(0x008, NMF - NRD, 0);
       } else {
-        pix = ((size_t)(b * g.Ho + y) * g.Wo + x);
+        __builtin_amdgcn_sched_group_barrier(0x008, NMF, 0);
       }
-      const size_t off = pix * d.dst_cs + co;
-      f32x4 v = acc[ni][mi];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) v[j] = v[j] * sc[ni][j] + sh[ni][j];
-      if (d.residual) {
-        const f32x4 rr = *reinterpret_cast<const f32x4*>(d.residual + off);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] += rr[j];
-      }
-      if (d.relu) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
-      }
-      *reinterpret_cast<f32x4*>(d.dst + off) = v;
+    }
+  };
+
+  dma_stage(0, 0);
+  for (int st = 0; st < nst; st += 2) {
+    __syncthreads();  // stage st landed (vmcnt(0) + barrier); buffer 1 free for the next DMA batch
+    stage(st, 0);
+    if (st + 1 < nst) {
+      __syncthreads();
+      stage(st + 1, 1);
     }
   }
-  SFH_STAMP(6);  // epilogue
-  SFH_STAMP_FLUSH();
+  conv_epilogue<C>(d, g, acc, r0, x0, n0, wv, lq, lg);
 }
 
 // ------------------------------------------------------------------ weight packing
@@ -434,18 +646,48 @@ int launch_conv(const sfh_conv_desc& d, hipStream_t stream) {
   g.Wo = (d.W + C::PAD + C::PADA - C::KS) / C::STRIDE + 1;
   g.tiles_x = sfh_cdiv(g.Wo, C::TW);
   if (C::FLATROWS) {
-    g.rows_total = d.batch * (g.Ho + C::ZROWS);
+    g.rows_per_img = g.Ho + C::ZROWS;
+    g.rows_total = d.batch * g.rows_per_img;
+    g.rows_magic = (unsigned)((1ULL << 32) / (unsigned)g.rows_per_img) + 1u;
+    SFH_REQUIRE((unsigned long long)(g.rows_total + 64) * g.rows_per_img < (1ULL << 32),
+                "conv_fwd: flattened row space too large for the reciprocal division");
     g.tiles_y = sfh_cdiv(g.rows_total, C::TH);
     g.ntiles = g.tiles_x * g.tiles_y;
   } else {
     g.rows_total = 0;
+    g.rows_per_img = g.Ho;
+    g.rows_magic = 0;
     g.tiles_y = sfh_cdiv(g.Ho, C::TH);  // per image
     g.ntiles = g.tiles_x * g.tiles_y * d.batch;
     SFH_REQUIRE(g.Ho < 65536 && d.batch < 32768, "stride-2 conv: geometry too large");
   }
+  const unsigned long long b0 = 4ULL * d.batch * d.h0 * d.w0 * d.cs0;
+  const unsigned long long b1 = d.src1 ? 4ULL * d.batch * d.h1 * d.w1 * d.cs1 : 0ULL;
+  SFH_REQUIRE(b0 < kOOB && b1 < kOOB,
+              "conv_fwd: a source tensor of %llu bytes exceeds the 4 GiB buffer-descriptor range; split the batch",
+              b0 > b1 ? b0 : b1);
+  g.bytes0 = (unsigned)b0;
+  g.bytes1 = (unsigned)b1;
   g.nblk_n = d.cout / 64;
   const long nblocks = (long)sfh_cdiv(g.ntiles, 8) * 8 * g.nblk_n;
   SFH_REQUIRE(nblocks < (1L << 31), "conv grid too large");
+  // v2 (one workgroup per CU, LDS-DMA double buffering) is kept as an experiment: measured
+  // 115.8 TFLOP/s on the DoubleConv launches against 123.1 for v1 (two workgroups per CU,
+  // register-staged buffer loads), so v1 is the default.  SFH_DEBUG_CONV_V2=1 selects v2.
+  static const bool force_v1 = !(getenv("SFH_DEBUG_CONV_V2") && atoi(getenv("SFH_DEBUG_CONV_V2")));
+  if constexpr (C::TG == 1 && 2 * (C::NSL * 256 + C::TPS * 256) * 16 <= 160 * 1024) {
+    if (!d.pool0 && !force_v1) {
+      static bool attr2_set = false;
+      if (!attr2_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_v2_kernel<C>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr2_set = true;
+      }
+      hipLaunchKernelGGL(conv_mfma_v2_kernel<C>, dim3((unsigned)nblocks), dim3(256), 2 * (C::NSL * 256 + C::TPS * 256) * 16,
+                         stream, d, g);
+      return sfh_check_launch("conv_mfma_v2_kernel");
+    }
+  }
   static bool attr_set = false;  // idempotent; benign if raced
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_kernel<C>),
@@ -497,6 +739,8 @@ extern "C" int sfh_conv_fwd(const sfh_conv_desc* dp, void* stream_) {
   SFH_REQUIRE(d.batch > 0 && d.H > 0 && d.W > 0, "conv_fwd: empty geometry");
   SFH_REQUIRE(d.cout > 0 && d.cout % 64 == 0, "conv_fwd: cout=%d must be a multiple of 64", d.cout);
   SFH_REQUIRE(d.cs0 % 4 == 0 && d.cs0 >= 4 && d.dst_cs % 4 == 0, "conv_fwd: channel strides must be multiples of 4");
+  SFH_REQUIRE(d.cs0 < 16 || d.cs0 % 16 == 0, "conv_fwd: cs0=%d must be < 16 or a multiple of 16", d.cs0);
+  SFH_REQUIRE(!d.src1 || d.cs1 < 16 || d.cs1 % 16 == 0, "conv_fwd: cs1=%d must be < 16 or a multiple of 16", d.cs1);
   SFH_REQUIRE(d.c0 > 0 && d.c0 <= d.cs0, "conv_fwd: c0=%d cs0=%d", d.c0, d.cs0);
   const int nsub = nsub_for(d.ksize);
   if (d.src1) {
@@ -511,7 +755,6 @@ extern "C" int sfh_conv_fwd(const sfh_conv_desc* dp, void* stream_) {
     SFH_REQUIRE(d.h0 / 2 == d.H && d.w0 / 2 == d.W, "conv_fwd: pool0 needs floor(h0/2)==H, floor(w0/2)==W");
   else
     SFH_REQUIRE(d.h0 == d.H && d.w0 == d.W, "conv_fwd: source 0 is %dx%d, frame is %dx%d", d.h0, d.w0, d.H, d.W);
-  SFH_REQUIRE((int64_t)d.batch * d.h0 * d.w0 * d.cs0 < (1LL << 31), "conv_fwd: source 0 exceeds 2^31 elements");
   if (d.out_mode == SFH_OUT_UPSCATTER2)
     SFH_REQUIRE(d.ksize == 1 && d.stride == 1 && (d.cout / 4) % 64 == 0 && !d.residual,
                 "conv_fwd: up-scatter needs ksize=1, stride=1, cout/4 multiple of 64");
