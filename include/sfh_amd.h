@@ -36,6 +36,13 @@ extern "C" {
 #define SFH_TILE_16x16 1  /* 16 rows x 16 cols, 1x16 groups              */
 #define SFH_TILE_32x8 2   /* 32 rows x 8 cols, 2x8 groups (narrow maps)  */
 
+/* Tensor formats of conv sources / destinations.
+ * F32: fp32 NHWC (B,H,W,cs).
+ * S3 : "split-3" bf16 (B,H,W,3,cs): v = plane0 + plane1 + plane2 exactly, plane0 = bf16(v),
+ *      plane1 = bf16(v - plane0), plane2 = bf16(v - plane0 - plane1). */
+#define SFH_FMT_F32 0
+#define SFH_FMT_S3 1
+
 /* Output modes of sfh_conv_fwd. */
 #define SFH_OUT_NHWC 0        /* dst[b][y][x][co]                                        */
 #define SFH_OUT_UPSCATTER2 1  /* transposed conv k2 s2: virtual cout = (dy*2+dx)*Cout+co  */
@@ -64,8 +71,13 @@ typedef struct sfh_conv_desc {
   const float* residual;
   /* destination */
   float* dst;
-  int32_t dst_cs;   /* channel stride (floats per pixel) of dst */
+  int32_t dst_cs;   /* channel stride (elements per pixel and plane) of dst */
   int32_t out_mode; /* SFH_OUT_* */
+  /* formats (SFH_FMT_*): both sources share src_fmt; residual and dst_pool share dst_fmt */
+  int32_t src_fmt, dst_fmt;
+  /* optional second output: MaxPool2d(2) (floor) of dst, (B, Ho/2, Wo/2, pool_cs) */
+  float* dst_pool;
+  int32_t pool_cs;
 } sfh_conv_desc;
 
 const char* sfh_last_error(void);
@@ -77,6 +89,19 @@ int sfh_version(void);
  * (unet/unet_parts.py:59-67, via src1), nn.ConvTranspose2d of Up (unet/unet_parts.py:52),
  * and the conv/BN/ReLU/residual of BasicBlock (models/resnet.py:64-82).                  */
 int sfh_conv_fwd(const sfh_conv_desc* d, void* stream);
+
+/* fp32-accurate convolution on the bf16 matrix cores: sources in S3 format, weights packed by
+ * sfh_pack_s3_weights, six bf16 MFMAs per 32 k (w0x2 + w1x1 + w2x0 + w0x1 + w1x0 + w0x0) with fp32
+ * accumulation.  Same descriptor and epilogue as sfh_conv_fwd; ksize 1 or 3, stride 1, c0/c1
+ * multiples of 32, no pool0 (use the producer's dst_pool).  Replaces the same reference calls. */
+int sfh_conv_s3_fwd(const sfh_conv_desc* d, void* stream);
+int64_t sfh_packed_s3_weight_bytes(int ksize, int c0, int c1, int cout_virtual);
+/* mode 0: OIHW conv weight; mode 1: IOHW ConvTranspose2d weight (ksize 1, cout_virtual = 4*cout) */
+int sfh_pack_s3_weights(const float* w, void* packed, int ksize, int c0, int c1, int cout_virtual,
+                        int mode, void* stream);
+/* fp32 (npix, cs) <-> S3 (npix, 3, cs) conversion */
+int sfh_f32_to_s3(const float* src, void* dst, int64_t npix, int cs, void* stream);
+int sfh_s3_to_f32(const void* src, float* dst, int64_t npix, int cs, void* stream);
 
 /* Number of floats of the packed weight buffer for a conv with the given geometry. */
 int64_t sfh_packed_weight_floats(int ksize, int c0, int c1, int cout_virtual);

@@ -12,6 +12,7 @@ LIB_PATH = os.environ.get("SFH_AMD_LIB") or os.path.join(_HERE, "libsfh_amd.so")
 
 TILE_8x32, TILE_16x16, TILE_32x8 = 0, 1, 2
 OUT_NHWC, OUT_UPSCATTER2 = 0, 1
+FMT_F32, FMT_S3 = 0, 1
 
 _p = C.c_void_p
 _i = C.c_int32
@@ -26,6 +27,7 @@ class ConvDesc(C.Structure):
         ("wpacked", _p), ("scale", _p), ("shift", _p), ("cout", _i), ("relu", _i),
         ("residual", _p),
         ("dst", _p), ("dst_cs", _i), ("out_mode", _i),
+        ("src_fmt", _i), ("dst_fmt", _i), ("dst_pool", _p), ("pool_cs", _i),
     ]
 
 
@@ -34,6 +36,11 @@ SIGNATURES = {
     "sfh_last_error": (C.c_char_p, []),
     "sfh_version": (C.c_int, []),
     "sfh_conv_fwd": (C.c_int, [C.POINTER(ConvDesc), _p]),
+    "sfh_conv_s3_fwd": (C.c_int, [C.POINTER(ConvDesc), _p]),
+    "sfh_packed_s3_weight_bytes": (C.c_int64, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    "sfh_pack_s3_weights": (C.c_int, [_p, _p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _p]),
+    "sfh_f32_to_s3": (C.c_int, [_p, _p, C.c_int64, C.c_int, _p]),
+    "sfh_s3_to_f32": (C.c_int, [_p, _p, C.c_int64, C.c_int, _p]),
     "sfh_packed_weight_floats": (C.c_int64, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "sfh_pack_conv_weights": (C.c_int, [_p, _p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _p]),
     "sfh_space_to_depth2": (C.c_int, [_p, _p, C.c_int, C.c_int, C.c_int, C.c_int, _p]),

@@ -10,7 +10,7 @@ import sys
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB = os.path.join(_HERE, "libsfh_amd.so")
-SOURCES = ["capi.hip", "conv_mfma.hip", "pointwise.hip", "warp.hip"]
+SOURCES = ["capi.hip", "conv_mfma.hip", "conv_s3.hip", "pointwise.hip", "warp.hip"]
 # warp.hip's coordinate arithmetic must not be contracted into FMAs (bit-exact nearest
 # sampling against oracle/warp_ref.py); the flag is harmless elsewhere.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-ffp-contract=off",
@@ -26,7 +26,7 @@ def _stale(target, deps):
 
 def build(force=False, verbose=True):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    headers = [os.path.join(CSRC, "common.h"),
+    headers = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "conv_epilogue.h"),
                os.path.join(os.path.dirname(_HERE), "include", "sfh_amd.h")]
     objs = []
     procs = []

@@ -36,6 +36,7 @@
 #include <stdlib.h>
 
 #include "common.h"
+#include "conv_epilogue.h"
 
 // Diagnostic build only (-DSFH_DIAG_STAMPS, libsfh_amd_diag.so): per-segment s_memtime sums of
 // the stage loop, accumulated per wave and added to g_stamps by lane 0.  Never compiled into
@@ -186,67 +187,6 @@ __device__ __forceinline__ TileCoord decode_block(const ConvGeom& g) {
     t.r0 = (img << 16) | ((ty - img * g.tiles_y) * C::TH);
   }
   return t;
-}
-
-template <class C>
-__device__ __forceinline__ void conv_epilogue(const sfh_conv_desc& d, const ConvGeom& g,
-                                              f32x4 (&acc)[4][C::MT_M], int r0, int x0, int n0, int wv,
-                                              int lq, int lg) {
-  // ---- epilogue: y = acc*scale + shift (+residual) (ReLU) -> NHWC 16-byte stores ----
-  f32x4 sc[4], sh[4];
-#pragma unroll
-  for (int ni = 0; ni < 4; ++ni) {
-    const int co = n0 + ni * 16 + 4 * lg;
-    sc[ni] = *reinterpret_cast<const f32x4*>(d.scale + co);
-    sh[ni] = *reinterpret_cast<const f32x4*>(d.shift + co);
-  }
-#pragma unroll
-  for (int mi = 0; mi < C::MT_M; ++mi) {
-    const int s = wv * C::MT_M + mi;
-    const int sy = s / C::SUBX, sx = s - sy * C::SUBX;
-    const int oy = sy * C::SH + lq / C::SW, ox = sx * C::SW + lq % C::SW;
-    const int x = x0 + ox;
-    int b, y;
-    bool ok = x < g.Wo;
-    if (C::FLATROWS) {
-      const int r = r0 + oy;
-      b = (int)__umulhi((unsigned)r, g.rows_magic);
-      y = r - b * g.rows_per_img;
-      ok = ok && r < g.rows_total && y < g.Ho;
-    } else {
-      b = r0 >> 16;
-      y = (r0 & 0xFFFF) + oy;
-      ok = ok && y < g.Ho;
-    }
-    if (!ok) continue;
-#pragma unroll
-    for (int ni = 0; ni < 4; ++ni) {
-      int co = n0 + ni * 16 + 4 * lg;
-      size_t pix;
-      if (d.out_mode == SFH_OUT_UPSCATTER2) {
-        const int cr = d.cout >> 2;
-        const int qd = co / cr;
-        co -= qd * cr;
-        pix = ((size_t)(b * 2 * g.Ho + 2 * y + (qd >> 1)) * (2 * g.Wo) + 2 * x + (qd & 1));
-      } else {
-        pix = ((size_t)(b * g.Ho + y) * g.Wo + x);
-      }
-      const size_t off = pix * d.dst_cs + co;
-      f32x4 v = acc[ni][mi];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) v[j] = v[j] * sc[ni][j] + sh[ni][j];
-      if (d.residual) {
-        const f32x4 rr = *reinterpret_cast<const f32x4*>(d.residual + off);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] += rr[j];
-      }
-      if (d.relu) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
-      }
-      *reinterpret_cast<f32x4*>(d.dst + off) = v;
-    }
-  }
 }
 
 template <class C>
@@ -430,7 +370,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const sfh_conv_desc d
     SFH_STAMP(5);  // MFMA block (incl. matrix-pipe sharing with the co-resident wave)
   }
 
-  conv_epilogue<C>(d, g, acc, r0, x0, n0, wv, lq, lg);
+  sfh_conv_epilogue<C, 4, C::MT_M>(d, g, acc, n0, wv * C::MT_M, r0, x0, lq, lg);
   SFH_STAMP(6);  // epilogue
   SFH_STAMP_FLUSH();
 }
@@ -579,14 +519,17 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_v2_kernel(const sfh_conv_des
 
   dma_stage(0, 0);
   for (int st = 0; st < nst; st += 2) {
+    // explicit drain: hipcc's own wait before the barrier does not always cover every LDS-DMA
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();  // stage st landed (vmcnt(0) + barrier); buffer 1 free for the next DMA batch
     stage(st, 0);
     if (st + 1 < nst) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
       stage(st + 1, 1);
     }
   }
-  conv_epilogue<C>(d, g, acc, r0, x0, n0, wv, lq, lg);
+  sfh_conv_epilogue<C, 4, C::MT_M>(d, g, acc, n0, wv * C::MT_M, r0, x0, lq, lg);
 }
 
 // ------------------------------------------------------------------ weight packing
@@ -755,6 +698,8 @@ extern "C" int sfh_conv_fwd(const sfh_conv_desc* dp, void* stream_) {
     SFH_REQUIRE(d.h0 / 2 == d.H && d.w0 / 2 == d.W, "conv_fwd: pool0 needs floor(h0/2)==H, floor(w0/2)==W");
   else
     SFH_REQUIRE(d.h0 == d.H && d.w0 == d.W, "conv_fwd: source 0 is %dx%d, frame is %dx%d", d.h0, d.w0, d.H, d.W);
+  SFH_REQUIRE(d.src_fmt == SFH_FMT_F32, "conv_fwd: the fp32 kernel reads fp32 NHWC sources (src_fmt=%d)", d.src_fmt);
+  SFH_REQUIRE(!d.dst_pool, "conv_fwd: fused pool output is provided by sfh_conv_s3_fwd only");
   if (d.out_mode == SFH_OUT_UPSCATTER2)
     SFH_REQUIRE(d.ksize == 1 && d.stride == 1 && (d.cout / 4) % 64 == 0 && !d.residual,
                 "conv_fwd: up-scatter needs ksize=1, stride=1, cout/4 multiple of 64");

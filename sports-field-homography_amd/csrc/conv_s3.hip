@@ -1,0 +1,467 @@
+// conv_s3.hip - fp32-accurate convolution on the bf16 matrix cores ("split-3", S3).
+//
+// Every fp32 value v is stored as three bf16 planes v = v0 + v1 + v2 (v0 = bf16(v),
+// v1 = bf16(v - v0), v2 = bf16(v - v0 - v1): exact, 3 x 8 significand bits).  A product of two
+// such numbers is accumulated from the six partial products whose weight is >= 2^-16 of the
+// full product,
+//        w*x  ~=  w0x2 + w1x1 + w2x0 + w0x1 + w1x0 + w0x0            (dropped terms <= 2^-24),
+// each an exact bf16 x bf16 product accumulated in fp32 by v_mfma_f32_16x16x32_bf16.  The result
+// has the accuracy of an fp32 fmaf chain (oracle study in DESIGN.md: mean |err| 4.7e-7 vs 5.3e-7
+// for the fp32 MFMA chain at K = 4608) at 6 bf16 MFMAs per 32 k instead of 8 fp32 MFMAs of twice
+// the cycles: the ceiling is 2.5 PFLOP/s / 6 = 417 TFLOP/s of fp32-equivalent work, 2.65x the
+// fp32 matrix peak.
+//
+// Data movement is designed around 6 bytes per element:
+//   * activations live in HBM as S3 tensors (B,H,W,3,C) bf16; the producer's epilogue splits;
+//   * the input halo of a 32-channel stage goes global -> LDS by buffer_load ... lds (LDS-DMA,
+//     no VGPRs, out-of-frame slots read zeros through the descriptor's range check), double
+//     buffered: one barrier per stage, DMA of stage s+1 issued inside the MFMA stream of stage s;
+//   * weights never touch LDS: the four waves of a workgroup form a 2(M) x 2(N) grid, each wave
+//     loads its own pre-packed, pre-split 1 KB fragments (16 couts x 32 k x bf16) straight from
+//     L2 into registers one tap ahead.
+// Workgroup tile: 256 pixels x 64 couts, one workgroup (4 waves, one per SIMD) per CU.
+#include <stdlib.h>
+
+#include <type_traits>
+
+#include "common.h"
+#include "conv_epilogue.h"
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+namespace {
+
+constexpr unsigned kOOB = 0xFFFFFFF0u;
+
+template <int KS_, int STRIDE_, int SH_, int SW_, int TH_, int TW_>
+struct S3Cfg {
+  static constexpr int KS = KS_, STRIDE = STRIDE_;
+  static constexpr int SH = SH_, SW = SW_, TH = TH_, TW = TW_;
+  static constexpr int PAD = KS / 2;
+  static constexpr int NTAP = KS * KS;
+  static constexpr int CKS = 32;  // channels per stage = k of one MFMA
+  static constexpr int HH = (TH - 1) * STRIDE + KS;
+  static constexpr int HW = (TW - 1) * STRIDE + KS;
+  static constexpr int HPIX = HH * HW;
+  static constexpr int HPIXP = (HPIX + 15) / 16 * 16;
+  static constexpr int HSLOTS = 12 * HPIXP;  // [3 planes][4 channel groups of 8][pixels] x 16 B
+  static constexpr int NSL = (HSLOTS + 255) / 256;
+  static constexpr int BUF = NSL * 256;      // slots per LDS buffer (DMA rounds are whole)
+  static constexpr int LDS_BYTES = 2 * BUF * 16;
+  static constexpr int SUBX = TW / SW;
+  static constexpr int NSUBT = (TH / SH) * SUBX;
+  static constexpr int MT_M = NSUBT / 2;     // pixel groups per wave (2 x 2 wave grid)
+  static constexpr bool FLATROWS = (STRIDE == 1);
+  static_assert(SH * SW == 16 && NSUBT == 16, "tile = 16 pixel groups of 16");
+};
+
+struct S3Geom {
+  int tiles_x, tiles_y, ntiles, nblk_n;
+  int Ho, Wo, rows_total, rows_per_img;
+  unsigned rows_magic;
+  unsigned bytes0, bytes1;
+};
+
+__device__ __forceinline__ bf16x8 as_bf(const u32x4& v) { return __builtin_bit_cast(bf16x8, v); }
+
+template <class C>
+__device__ __forceinline__ unsigned s3_halo_voffset(const sfh_conv_desc& d, const S3Geom& g, int which,
+                                                    int slot, int r0, int x0) {
+  if (slot >= C::HSLOTS) return kOOB;
+  const int pl = slot / C::HPIXP, p = slot - pl * C::HPIXP;  // pl = plane*4 + channel group
+  if (p >= C::HPIX) return kOOB;
+  const int hy = p / C::HW, hx = p - hy * C::HW;
+  int b, y;
+  if (C::FLATROWS) {
+    const int r = r0 - C::PAD + hy;
+    if (r < 0) return kOOB;
+    b = (int)__umulhi((unsigned)r, g.rows_magic);
+    y = r - b * g.rows_per_img;
+    if (b >= d.batch || y >= d.H) return kOOB;
+  } else {
+    b = r0 >> 16;
+    y = (r0 & 0xFFFF) * C::STRIDE - C::PAD + hy;
+    if (y < 0 || y >= d.H) return kOOB;
+  }
+  const int x = x0 * C::STRIDE - C::PAD + hx;
+  if (x < 0 || x >= d.W) return kOOB;
+  unsigned pix, cs;
+  if (which == 0) {
+    pix = (unsigned)((b * d.h0 + y) * d.w0 + x);
+    cs = d.cs0;
+  } else {
+    const int ys = y - d.pad_top1, xs = x - d.pad_left1;
+    if (ys < 0 || ys >= d.h1 || xs < 0 || xs >= d.w1) return kOOB;
+    pix = (unsigned)((b * d.h1 + ys) * d.w1 + xs);
+    cs = d.cs1;
+  }
+  // byte offset of (pixel, plane, channel group) in the S3 tensor (B,H,W,3,cs) bf16
+  return ((pix * 3u + (unsigned)(pl >> 2)) * cs + 8u * (pl & 3)) * 2u;
+}
+
+}  // namespace
+
+namespace {
+
+template <class C>
+__global__ __launch_bounds__(256, 2) void conv_s3_kernel(const sfh_conv_desc d, const S3Geom g) {
+  extern __shared__ __attribute__((aligned(16))) float smem_f[];
+  u32x4* const lds = reinterpret_cast<u32x4*>(smem_f);
+  typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wv >> 1, wn = wv & 1;
+  const int lq = lane & 15, lg = lane >> 4;
+
+  const int bid = blockIdx.x;
+  const int xcd = bid & 7, kk_ = bid >> 3;
+  // within an XCD the pixel tiles of ONE cout block run back to back: the ~30 workgroups resident
+  // on the XCD stream the same weight fragments, which then stay in its 4 MB L2 (weights are the
+  // dominant L2->CU stream of this kernel: 12 KB per tap per workgroup)
+  const int tpx = (g.ntiles + 7) >> 3;  // tiles per XCD
+  const int nb = kk_ / tpx;
+  const int tile = (kk_ - nb * tpx) * 8 + xcd;
+  if (tile >= g.ntiles) return;
+  const int ty = tile / g.tiles_x, tx = tile - ty * g.tiles_x;
+  const int x0 = tx * C::TW;
+  int r0;
+  if (C::FLATROWS) {
+    r0 = ty * C::TH;
+  } else {
+    const int img = ty / g.tiles_y;
+    r0 = (img << 16) | ((ty - img * g.tiles_y) * C::TH);
+  }
+  const int n0 = nb * 64;
+
+  const int nst0 = d.c0 / C::CKS;
+  const int nst1 = d.src1 ? d.c1 / C::CKS : 0;
+  const int nst = nst0 + nst1;
+
+  const __amdgpu_buffer_rsrc_t rs0 =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.src0), 0, (int)g.bytes0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(d.src1 ? d.src1 : d.src0), 0, (int)(d.src1 ? g.bytes1 : 0u), 0x00020000);
+  // packed weights of this cout block: [stage][tap][plane 3][cout group 4][lane 64][8 bf16]
+  constexpr unsigned WTAP = 3u * 4u * 1024u;  // bytes per (stage, tap)
+  const unsigned wtotal = (unsigned)nst * C::NTAP * WTAP;
+  const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<char*>(reinterpret_cast<const char*>(d.wpacked)) + (size_t)nb * wtotal, 0, (int)wtotal,
+      0x00020000);
+  const unsigned wvoff = lane * 16u + (unsigned)(2 * wn) * 1024u;
+
+  // byte offsets of this thread's halo slots in the CURRENT source (recomputed once when the
+  // stage loop crosses from source 0 to source 1)
+  unsigned hoff[C::NSL];
+#pragma unroll
+  for (int i = 0; i < C::NSL; ++i) hoff[i] = s3_halo_voffset<C>(d, g, 0, tid + 256 * i, r0, x0);
+
+  // LDS-DMA piece i (64 slots of this wave) of stage st into buffer b
+  auto dma_piece = [&](int st, int b, int i) {
+    u32x4* const hb = lds + b * C::BUF;
+    const bool first = st < nst0;
+    const unsigned cb = (unsigned)(first ? st : st - nst0) * (C::CKS * 2u);  // channel byte offset
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(first ? rs0 : rs1, (lds_ptr_t)(hb + wv * 64 + 256 * i), 16,
+                                             (int)hoff[i], (int)cb, 0, 0);
+  };
+  auto dma_stage = [&](int st, int b) {
+#pragma unroll
+    for (int i = 0; i < C::NSL; ++i) dma_piece(st, b, i);
+  };
+
+  // weight fragments of one tap for this wave: [plane][cout group of the wave]
+  auto load_w = [&](u32x4 (&w)[3][2], unsigned soff) {
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni)
+        w[p][ni] = __builtin_amdgcn_raw_buffer_load_b128(rsw, (int)(wvoff + ni * 1024u), (int)(soff + p * 4096u), 0);
+  };
+
+  // LDS slot of this lane's pixel in pixel group 0 of the wave; group mi adds a compile-time
+  // offset (the wave's MT_M groups start on a tile-row boundary), so every operand read is
+  // `base + immediate`
+  const int pixbase0 = lg * C::HPIXP +
+                       ((wm * C::MT_M / C::SUBX) * C::SH + lq / C::SW) * C::STRIDE * C::HW +
+                       (lq % C::SW) * C::STRIDE;
+  static_assert(C::MT_M % C::SUBX == 0, "a wave's pixel groups must start on a tile-row boundary");
+
+  f32x4 acc[2][C::MT_M];
+#pragma unroll
+  for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+    for (int mi = 0; mi < C::MT_M; ++mi) acc[ni][mi] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  u32x4 wa[3][2], wb[3][2];  // weight fragments: current tap / next tap
+  unsigned wsoff = 0;         // byte offset of the NEXT (stage, tap) fragment set
+  const unsigned wlast = wtotal - WTAP;
+  load_w(wa, 0);
+  wsoff = WTAP <= wlast ? WTAP : wlast;
+
+  // One stage = NTAP taps x MT_M pixel groups; per (tap, group): 3 operand reads + 12 MFMAs.
+  // The reads of step s+1 are issued behind the first MFMAs of step s (two register sets,
+  // static indices), the next tap's weight fragments one tap ahead, the next stage's DMA batch
+  // behind the first steps of the stage.  SW selects which weight register set holds tap 0
+  // (NTAP is odd, so the sets swap roles every stage).
+  auto stage = [&](int st, int cur, auto sw_tag) {
+    constexpr bool SW = decltype(sw_tag)::value;
+    constexpr int NSTEP = C::NTAP * C::MT_M;
+    const u32x4* const halo = lds + cur * C::BUF;
+    u32x4 xq[2][3];
+    auto ld_x = [&](int s, int buf) {
+      const int t = s / C::MT_M, mi = s % C::MT_M;
+      const int toff = (t / C::KS) * C::HW + (t % C::KS);
+      const int moff = (mi / C::SUBX) * C::SH * C::STRIDE * C::HW + (mi % C::SUBX) * C::SW * C::STRIDE;
+#pragma unroll
+      for (int p = 0; p < 3; ++p) xq[buf][p] = halo[pixbase0 + (p * 4 * C::HPIXP + moff + toff)];
+    };
+    ld_x(0, 0);
+    const int stn = st + 1 < nst ? st + 1 : st;  // unconditional DMA: no branch in the MFMA block
+#pragma unroll
+    for (int s = 0; s < NSTEP; ++s) {
+      const int t = s / C::MT_M, mi = s % C::MT_M;
+      const int xb = s & 1;
+      u32x4 (&wc)[3][2] = ((t & 1) != (SW ? 1 : 0)) ? wb : wa;
+      u32x4 (&wnx)[3][2] = ((t & 1) != (SW ? 1 : 0)) ? wa : wb;
+      if (s + 1 < NSTEP) ld_x(s + 1, xb ^ 1);
+      if (mi == 0) {
+        load_w(wnx, wsoff);  // next tap (or tap 0 of the next stage): one tap of MFMAs ahead
+        wsoff = (wsoff + WTAP <= wlast) ? wsoff + WTAP : wlast;
+      }
+      // the next stage's LDS-DMA pieces, spread over the first steps
+      constexpr int PPS = (C::NSL + NSTEP - 1) / NSTEP;
+#pragma unroll
+      for (int q = 0; q < PPS; ++q)
+        if (s * PPS + q < C::NSL) dma_piece(stn, cur ^ 1, s * PPS + q);
+      // six partial products, smallest first; the two cout groups are interleaved so that
+      // consecutive MFMAs never depend on each other
+      constexpr int PW[6] = {0, 1, 2, 0, 1, 0}, PX[6] = {2, 1, 0, 1, 0, 0};
+#pragma unroll
+      for (int k6 = 0; k6 < 6; ++k6)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+          acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf(wc[PW[k6]][ni]), as_bf(xq[xb][PX[k6]]),
+                                                               acc[ni][mi], 0, 0, 0);
+      // keep each step's memory instructions inside the step, operand reads of the next step
+      // right behind the first MFMA so that ~11 MFMAs (176 cycles) cover their LDS latency
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 11, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  static_assert(C::NTAP % 2 == 1, "tap loop alternates the two weight register sets per stage");
+
+  dma_stage(0, 0);
+  auto maybe_switch = [&](int st) {  // the DMA issued during stage st targets stage st+1
+    if (d.src1 && st + 1 == nst0) {
+#pragma unroll
+      for (int i = 0; i < C::NSL; ++i) hoff[i] = s3_halo_voffset<C>(d, g, 1, tid + 256 * i, r0, x0);
+    }
+  };
+  // hipcc's own wait before the barrier covers only part of the outstanding LDS-DMA (observed:
+  // s_waitcnt vmcnt(6) with DMA pieces younger than that in flight -> stale halo data in stages
+  // >= 2), so the drain is explicit: every DMA piece of this wave has landed, then the barrier.
+  auto stage_barrier = [&]() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  };
+  for (int st = 0; st < nst; st += 2) {
+    maybe_switch(st);
+    stage_barrier();  // stage st landed for every wave; the other buffer is free
+    stage(st, 0, std::false_type{});
+    if (st + 1 < nst) {
+      maybe_switch(st + 1);
+      stage_barrier();
+      stage(st + 1, 1, std::true_type{});
+    }
+  }
+  sfh_conv_epilogue<C, 2, C::MT_M>(d, g, acc, n0 + 32 * wn, wm * C::MT_M, r0, x0, lq, lg);
+}
+
+// ------------------------------------------------------------------ weight packing (split)
+// packed[nb][stage][tap][plane 3][cout group 4][lane 64][j 8] bf16
+//   cout = nb*64 + ng*16 + (lane&15);  channel-in-source = stage_local*32 + 8*(lane>>4) + j
+__global__ void pack_s3_weights_kernel(const float* __restrict__ w, unsigned short* __restrict__ packed,
+                                       int ks, int c0, int c1, int coutv, int transposed, long total) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;  // one (lane, j-octet, all planes)
+  if (idx >= total) return;
+  const int ntap = ks * ks;
+  const int nst0 = c0 / 32, nst1 = c1 / 32, nst = nst0 + nst1;
+  long r = idx;
+  const int lane = r & 63; r >>= 6;
+  const int ng = r & 3; r >>= 2;
+  const int tap = r % ntap; r /= ntap;
+  const int st = r % nst;
+  const int nb = r / nst;
+  const int ky = tap / ks, kx = tap % ks;
+  const int cv = nb * 64 + ng * 16 + (lane & 15);
+  const int cin_total = c0 + c1;
+  const long base = ((((long)nb * nst + st) * ntap + tap) * 3) * 4096 + (long)ng * 1024 + lane * 16;  // bytes / 1
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int cl = (st < nst0 ? st : st - nst0) * 32 + 8 * (lane >> 4) + j;
+    const int cin = st < nst0 ? cl : c0 + cl;
+    float v;
+    if (transposed) {
+      const int cout = coutv >> 2;
+      const int qd = cv / cout, co = cv - qd * cout;
+      v = w[(((size_t)cin * cout + co) * 2 + (qd >> 1)) * 2 + (qd & 1)];
+    } else {
+      v = w[(((size_t)cv * cin_total + cin) * ks + ky) * ks + kx];
+    }
+    const __bf16 v0 = (__bf16)v;
+    const float r1 = v - (float)v0;
+    const __bf16 v1 = (__bf16)r1;
+    const __bf16 v2 = (__bf16)(r1 - (float)v1);
+    packed[(base + 0 * 4096) / 2 + j] = __builtin_bit_cast(unsigned short, v0);
+    packed[(base + 1 * 4096) / 2 + j] = __builtin_bit_cast(unsigned short, v1);
+    packed[(base + 2 * 4096) / 2 + j] = __builtin_bit_cast(unsigned short, v2);
+  }
+}
+
+// fp32 NHWC (B,H,W,cs) -> S3 (B,H,W,3,cs) and back (tests, network input, debugging)
+__global__ void f32_to_s3_kernel(const float* __restrict__ src, unsigned short* __restrict__ dst, int cs,
+                                 long total) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const long pix = i / cs;
+  const int c = i - pix * cs;
+  const float v = src[i];
+  const __bf16 v0 = (__bf16)v;
+  const float r1 = v - (float)v0;
+  const __bf16 v1 = (__bf16)r1;
+  const __bf16 v2 = (__bf16)(r1 - (float)v1);
+  dst[(pix * 3 + 0) * cs + c] = __builtin_bit_cast(unsigned short, v0);
+  dst[(pix * 3 + 1) * cs + c] = __builtin_bit_cast(unsigned short, v1);
+  dst[(pix * 3 + 2) * cs + c] = __builtin_bit_cast(unsigned short, v2);
+}
+
+__global__ void s3_to_f32_kernel(const unsigned short* __restrict__ src, float* __restrict__ dst, int cs,
+                                 long total) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const long pix = i / cs;
+  const int c = i - pix * cs;
+  float v = 0.f;
+#pragma unroll
+  for (int p = 2; p >= 0; --p)
+    v += __builtin_bit_cast(float, (unsigned)src[(pix * 3 + p) * cs + c] << 16);
+  dst[i] = v;
+}
+
+template <class C>
+int launch_s3(const sfh_conv_desc& d, hipStream_t stream) {
+  S3Geom g;
+  g.Ho = (d.H + 2 * C::PAD - C::KS) / C::STRIDE + 1;
+  g.Wo = (d.W + 2 * C::PAD - C::KS) / C::STRIDE + 1;
+  g.tiles_x = sfh_cdiv(g.Wo, C::TW);
+  if (C::FLATROWS) {
+    int zr = C::PAD;
+    if ((g.Ho + zr) & 1) ++zr;  // even rows per frame: 2x2 pool windows never straddle a tile edge
+    if (zr == 0) zr = (g.Ho & 1) ? 1 : 0;
+    g.rows_per_img = g.Ho + zr;
+    g.rows_total = d.batch * g.rows_per_img;
+    g.rows_magic = (unsigned)((1ULL << 32) / (unsigned)g.rows_per_img) + 1u;
+    SFH_REQUIRE((unsigned long long)(g.rows_total + 64) * g.rows_per_img < (1ULL << 32),
+                "conv_s3: flattened row space too large");
+    g.tiles_y = sfh_cdiv(g.rows_total, C::TH);
+    g.ntiles = g.tiles_x * g.tiles_y;
+  } else {
+    g.rows_total = 0;
+    g.rows_per_img = g.Ho;
+    g.rows_magic = 0;
+    g.tiles_y = sfh_cdiv(g.Ho, C::TH);
+    g.ntiles = g.tiles_x * g.tiles_y * d.batch;
+    SFH_REQUIRE(g.Ho < 65536 && d.batch < 32768, "conv_s3: geometry too large");
+  }
+  const unsigned long long b0 = 6ULL * d.batch * d.h0 * d.w0 * d.cs0;
+  const unsigned long long b1 = d.src1 ? 6ULL * d.batch * d.h1 * d.w1 * d.cs1 : 0ULL;
+  SFH_REQUIRE(b0 < kOOB && b1 < kOOB, "conv_s3: a source tensor of %llu bytes exceeds the 4 GiB descriptor range; split the batch",
+              b0 > b1 ? b0 : b1);
+  g.bytes0 = (unsigned)b0;
+  g.bytes1 = (unsigned)b1;
+  g.nblk_n = d.cout / 64;
+  const long nblocks = (long)sfh_cdiv(g.ntiles, 8) * 8 * g.nblk_n;
+  SFH_REQUIRE(nblocks < (1L << 31), "conv_s3: grid too large");
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_s3_kernel<C>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(conv_s3_kernel<C>, dim3((unsigned)nblocks), dim3(256), C::LDS_BYTES, stream, d, g);
+  return sfh_check_launch("conv_s3_kernel");
+}
+
+}  // namespace
+
+extern "C" int64_t sfh_packed_s3_weight_bytes(int ksize, int c0, int c1, int cout_virtual) {
+  if ((ksize != 1 && ksize != 3) || c0 <= 0 || c0 % 32 || c1 < 0 || c1 % 32 || cout_virtual <= 0 ||
+      cout_virtual % 64)
+    return -1;
+  return (int64_t)(cout_virtual / 64) * ((c0 + c1) / 32) * (ksize * ksize) * 3 * 4096;
+}
+
+extern "C" int sfh_pack_s3_weights(const float* w, void* packed, int ksize, int c0, int c1, int cout_virtual,
+                                   int mode, void* stream) {
+  const int64_t n = sfh_packed_s3_weight_bytes(ksize, c0, c1, cout_virtual);
+  SFH_REQUIRE(n > 0, "pack_s3_weights: bad geometry ks=%d c0=%d c1=%d cout=%d", ksize, c0, c1, cout_virtual);
+  SFH_REQUIRE(w && packed, "pack_s3_weights: null pointer");
+  SFH_REQUIRE(mode == 0 || (mode == 1 && ksize == 1 && c1 == 0 && cout_virtual % 256 == 0),
+              "pack_s3_weights: bad mode");
+  const long total = n / 48;  // one thread per (lane, 8 channels) of all three planes
+  hipLaunchKernelGGL(pack_s3_weights_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                     (hipStream_t)stream, w, (unsigned short*)packed, ksize, c0, c1, cout_virtual, mode, total);
+  return sfh_check_launch("pack_s3_weights_kernel");
+}
+
+extern "C" int sfh_f32_to_s3(const float* src, void* dst, int64_t npix, int cs, void* stream) {
+  SFH_REQUIRE(src && dst && npix > 0 && cs > 0, "f32_to_s3: bad argument");
+  const long total = npix * cs;
+  hipLaunchKernelGGL(f32_to_s3_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     src, (unsigned short*)dst, cs, total);
+  return sfh_check_launch("f32_to_s3_kernel");
+}
+
+extern "C" int sfh_s3_to_f32(const void* src, float* dst, int64_t npix, int cs, void* stream) {
+  SFH_REQUIRE(src && dst && npix > 0 && cs > 0, "s3_to_f32: bad argument");
+  const long total = npix * cs;
+  hipLaunchKernelGGL(s3_to_f32_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const unsigned short*)src, dst, cs, total);
+  return sfh_check_launch("s3_to_f32_kernel");
+}
+
+extern "C" int sfh_conv_s3_fwd(const sfh_conv_desc* dp, void* stream_) {
+  SFH_REQUIRE(dp, "conv_s3_fwd: null descriptor");
+  const sfh_conv_desc& d = *dp;
+  hipStream_t stream = (hipStream_t)stream_;
+  SFH_REQUIRE(d.src0 && d.wpacked && d.scale && d.shift && d.dst, "conv_s3_fwd: null pointer");
+  SFH_REQUIRE(d.batch > 0 && d.H > 0 && d.W > 0, "conv_s3_fwd: empty geometry");
+  SFH_REQUIRE(d.cout > 0 && d.cout % 64 == 0, "conv_s3_fwd: cout=%d must be a multiple of 64", d.cout);
+  SFH_REQUIRE(d.c0 > 0 && d.c0 % 32 == 0 && d.cs0 >= d.c0, "conv_s3_fwd: c0=%d must be a multiple of 32 (cs0=%d)", d.c0, d.cs0);
+  SFH_REQUIRE(!d.pool0, "conv_s3_fwd: pool-on-load is not available for S3 sources (use the producer's dst_pool)");
+  SFH_REQUIRE(d.h0 == d.H && d.w0 == d.W, "conv_s3_fwd: source 0 is %dx%d, frame is %dx%d", d.h0, d.w0, d.H, d.W);
+  if (d.src1) {
+    SFH_REQUIRE(d.c1 > 0 && d.c1 % 32 == 0 && d.cs1 >= d.c1, "conv_s3_fwd: c1=%d must be a multiple of 32", d.c1);
+    SFH_REQUIRE(d.h1 > 0 && d.w1 > 0 && d.pad_top1 >= 0 && d.pad_left1 >= 0 && d.pad_top1 + d.h1 <= d.H &&
+                    d.pad_left1 + d.w1 <= d.W, "conv_s3_fwd: source 1 does not fit the frame");
+  }
+  if (d.out_mode == SFH_OUT_UPSCATTER2)
+    SFH_REQUIRE(d.ksize == 1 && d.stride == 1 && (d.cout / 4) % 64 == 0 && !d.residual && !d.dst_pool,
+                "conv_s3_fwd: up-scatter needs ksize=1, stride=1, cout/4 multiple of 64");
+#define SFH_S3CASE(KS, ST, TILE, SH, SW, TH, TW) \
+  if (d.ksize == KS && d.stride == ST && d.tile == TILE) return launch_s3<S3Cfg<KS, ST, SH, SW, TH, TW>>(d, stream);
+  SFH_S3CASE(3, 1, SFH_TILE_8x32, 1, 16, 8, 32)
+  SFH_S3CASE(3, 1, SFH_TILE_16x16, 1, 16, 16, 16)
+  SFH_S3CASE(3, 1, SFH_TILE_32x8, 2, 8, 32, 8)
+  SFH_S3CASE(1, 1, SFH_TILE_8x32, 1, 16, 8, 32)
+  SFH_S3CASE(1, 1, SFH_TILE_16x16, 1, 16, 16, 16)
+  SFH_S3CASE(1, 1, SFH_TILE_32x8, 2, 8, 32, 8)
+#undef SFH_S3CASE
+  sfh_set_error("conv_s3_fwd: unsupported ksize=%d stride=%d tile=%d", d.ksize, d.stride, d.tile);
+  return SFH_E_ARG;
+}

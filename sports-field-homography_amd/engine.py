@@ -72,9 +72,12 @@ class PackedConv:
     timer = None   # set to a ConvTimer to time every launch (class-wide)
 
     def __init__(self, weight, bias, bn, ksize, c0, c1=0, relu=True, transposed=False, stride=1,
-                 stem_cin=0, tag="conv"):
+                 stem_cin=0, tag="conv", s3=False):
+        """s3=True: sources are split-bf16 (S3) tensors and the contraction runs as six bf16 MFMAs
+        per product (sfh_conv_s3_fwd); otherwise fp32 sources and fp32 MFMA (sfh_conv_fwd)."""
         lib = _lib.load()
         self.tag = tag
+        self.s3 = bool(s3)
         dev = weight.device
         w = _f32c(weight.detach(), "conv weight")
         self.ksize, self.c0, self.c1, self.relu, self.stride = ksize, c0, c1, relu, stride
@@ -98,12 +101,22 @@ class PackedConv:
             rep = 1
         if self.cout_real % 64:
             raise ValueError(f"conv with {self.cout_real} output channels: the MFMA kernel needs a multiple of 64")
-        n = lib.sfh_packed_weight_floats(ksize, c0, c1, self.cout)
-        if n <= 0:
-            raise ValueError(f"unsupported conv geometry ksize={ksize} c0={c0} c1={c1} cout={self.cout}")
-        self.wpacked = torch.empty(n, dtype=torch.float32, device=dev)
-        _lib.check(lib.sfh_pack_conv_weights(_ptr(w), _ptr(self.wpacked), ksize, c0, c1, self.cout,
-                                             mode, aux, _stream()), "pack_conv_weights")
+        if self.s3:
+            if stem_cin or stride != 1:
+                raise ValueError("the split-bf16 kernel covers ksize 1/3, stride 1")
+            n = lib.sfh_packed_s3_weight_bytes(ksize, c0, c1, self.cout)
+            if n <= 0:
+                raise ValueError(f"unsupported S3 conv geometry ksize={ksize} c0={c0} c1={c1} cout={self.cout}")
+            self.wpacked = torch.empty(n, dtype=torch.uint8, device=dev)
+            _lib.check(lib.sfh_pack_s3_weights(_ptr(w), _ptr(self.wpacked), ksize, c0, c1, self.cout, mode,
+                                               _stream()), "pack_s3_weights")
+        else:
+            n = lib.sfh_packed_weight_floats(ksize, c0, c1, self.cout)
+            if n <= 0:
+                raise ValueError(f"unsupported conv geometry ksize={ksize} c0={c0} c1={c1} cout={self.cout}")
+            self.wpacked = torch.empty(n, dtype=torch.float32, device=dev)
+            _lib.check(lib.sfh_pack_conv_weights(_ptr(w), _ptr(self.wpacked), ksize, c0, c1, self.cout,
+                                                 mode, aux, _stream()), "pack_conv_weights")
         self.scale = torch.empty(self.cout, dtype=torch.float32, device=dev)
         self.shift = torch.empty(self.cout, dtype=torch.float32, device=dev)
         b = _f32c(bias.detach(), "conv bias") if bias is not None else None
@@ -115,16 +128,24 @@ class PackedConv:
         _lib.check(lib.sfh_fold_bn(_ptr(b), *[_ptr(a) for a in args], eps, self.cout_real, rep,
                                    _ptr(self.scale), _ptr(self.shift), _stream()), "fold_bn")
 
-    def run(self, src0, batch, H, W, dst, src1=None, pool0=False, pad1=(0, 0), residual=None, tile=None):
-        """src0/src1/dst/residual: NHWC float32 tensors.  H, W: conv input frame."""
+    def run(self, src0, batch, H, W, dst, src1=None, pool0=False, pad1=(0, 0), residual=None, tile=None,
+            dst_pool=None):
+        """src0/src1: NHWC float32 tensors (or S3 tensors (B,H,W,3,C) bf16 when the layer is s3);
+        dst/residual/dst_pool: float32 NHWC, or S3 when their dtype is bfloat16.  H, W: conv input frame."""
         lib = _lib.load()
         d = ConvDesc()
         d.src0 = src0.data_ptr()
-        d.c0, d.cs0, d.h0, d.w0 = self.c0, src0.shape[3], src0.shape[1], src0.shape[2]
+        d.c0, d.cs0, d.h0, d.w0 = self.c0, src0.shape[-1], src0.shape[1], src0.shape[2]
+        if (src0.dtype == torch.bfloat16) != self.s3:
+            raise ValueError(f"layer s3={self.s3} got a source of dtype {src0.dtype}")
+        d.src_fmt = _lib.FMT_S3 if self.s3 else _lib.FMT_F32
+        d.dst_fmt = _lib.FMT_S3 if dst.dtype == torch.bfloat16 else _lib.FMT_F32
+        if dst_pool is not None:
+            d.dst_pool, d.pool_cs = dst_pool.data_ptr(), dst_pool.shape[-1]
         d.pool0 = 1 if pool0 else 0
         if src1 is not None:
             d.src1 = src1.data_ptr()
-            d.c1, d.cs1, d.h1, d.w1 = self.c1, src1.shape[3], src1.shape[1], src1.shape[2]
+            d.c1, d.cs1, d.h1, d.w1 = self.c1, src1.shape[-1], src1.shape[1], src1.shape[2]
             d.pad_top1, d.pad_left1 = pad1
         else:
             if self.c1:
@@ -135,20 +156,24 @@ class PackedConv:
         pad2 = self.ksize // 2 + (self.ksize - 1) // 2  # pad before + pad after
         ho = (H + pad2 - self.ksize) // self.stride + 1
         wo = (W + pad2 - self.ksize) // self.stride + 1
-        d.tile = choose_tile(batch, ho, wo, self.stride, self.ksize // 2) if tile is None else tile
+        zr = self.ksize // 2
+        if self.s3:  # even rows per frame (fused 2x2 pool windows never straddle a tile edge)
+            zr += (ho + zr) & 1
+        d.tile = choose_tile(batch, ho, wo, self.stride, zr) if tile is None else tile
         d.wpacked, d.scale, d.shift = self.wpacked.data_ptr(), self.scale.data_ptr(), self.shift.data_ptr()
         d.cout, d.relu = self.cout, 1 if self.relu else 0
         d.residual = residual.data_ptr() if residual is not None else None
-        d.dst, d.dst_cs = dst.data_ptr(), dst.shape[3]
+        d.dst, d.dst_cs = dst.data_ptr(), dst.shape[-1]
         d.out_mode = _lib.OUT_UPSCATTER2 if self.transposed else _lib.OUT_NHWC
         exp = (batch, 2 * ho, 2 * wo) if self.transposed else (batch, ho, wo)
-        if tuple(dst.shape[:3]) != exp or dst.shape[3] < self.cout_real:
+        if tuple(dst.shape[:3]) != exp or dst.shape[-1] < self.cout_real:
             raise ValueError(f"conv dst shape {tuple(dst.shape)} does not match {exp + (self.cout_real,)}")
+        fwd = lib.sfh_conv_s3_fwd if self.s3 else lib.sfh_conv_fwd
         tm = PackedConv.timer
         if tm is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-        _lib.check(lib.sfh_conv_fwd(ctypes.byref(d), _stream()), "conv_fwd")
+        _lib.check(fwd(ctypes.byref(d), _stream()), "conv_s3_fwd" if self.s3 else "conv_fwd")
         if tm is not None:
             e1.record()
             # algorithmic work: 2 * MACs of the reference op (real cin, real taps)
@@ -177,26 +202,33 @@ class _Workspace:
 class UNetEngine:
     """forward_unet (models/reconstructor.py:132-158) on the HIP kernels."""
 
-    def __init__(self, net, device):
+    def __init__(self, net, device, precision="bf16x6"):
+        """precision: "bf16x6" - activations in split-bf16 (S3) format, contractions as six bf16
+        MFMAs per product with fp32 accumulation (fp32-equivalent accuracy); "fp32" - fp32
+        activations and fp32 MFMA throughout."""
         if net.unet_bilinear:
             raise NotImplementedError("unet_bilinear=True (SURVEY.md §8 row A3b) is not on the HIP path yet")
+        if precision not in ("bf16x6", "fp32"):
+            raise ValueError(f"precision={precision!r}: expected 'bf16x6' or 'fp32'")
         self.device = device
         self.ws = _Workspace(device)
         self.nc = net.mask_classes
+        self.s3 = precision == "bf16x6"
+        s3 = self.s3
         L = {}
 
-        def dc(name, block, c0, c1=0):
+        def dc(name, block, c0, c1=0, first_s3=s3):
             (cv1, bn1), (cv2, bn2) = block.convs()
-            L[name + ".0"] = PackedConv(cv1.weight, cv1.bias, bn1, 3, c0, c1, tag="doubleconv3x3")
-            L[name + ".3"] = PackedConv(cv2.weight, cv2.bias, bn2, 3, cv1.out_channels, tag="doubleconv3x3")
+            L[name + ".0"] = PackedConv(cv1.weight, cv1.bias, bn1, 3, c0, c1, tag="doubleconv3x3", s3=first_s3)
+            L[name + ".3"] = PackedConv(cv2.weight, cv2.bias, bn2, 3, cv1.out_channels, tag="doubleconv3x3", s3=s3)
 
-        dc("inc", net.inc, 3)
+        dc("inc", net.inc, 3, first_s3=False)  # 3-channel input: fp32 kernel (writes S3 when s3)
         for i, cin in enumerate((64, 128, 256, 512), start=1):
             dc(f"down{i}", getattr(net, f"down{i}").block, cin)
         for i, cin in enumerate((1024, 512, 256, 128), start=1):
             up = getattr(net, f"up{i}")
             L[f"up{i}.up"] = PackedConv(up.up.weight, up.up.bias, None, 1, cin, relu=False, transposed=True,
-                                        tag="convT2x2")
+                                        tag="convT2x2", s3=s3)
             dc(f"up{i}.conv", up.conv, cin // 2, cin // 2)
         self.L = L
         self.outc_w = _f32c(net.outc.conv.weight.detach(), "outc.weight")
@@ -221,27 +253,42 @@ class UNetEngine:
         xin = ws.get("xin", (B, H, W, 4))
         _lib.check(lib.sfh_nchw_to_nhwc(_ptr(x), _ptr(xin), B, 3, H, W, 4, st), "nchw_to_nhwc")
 
-        def dconv(name, src0, h, w, cout, src1=None, pool0=False, pad1=(0, 0)):
-            mid = ws.get(name + ".mid", (B, h, w, L[name + ".0"].cout_real))
-            out = ws.get(name + ".out", (B, h, w, cout))
-            L[name + ".0"].run(src0, B, h, w, mid, src1=src1, pool0=pool0, pad1=pad1)
-            L[name + ".3"].run(mid, B, h, w, out)
-            return out
+        s3 = self.s3
 
-        feats = [dconv("inc", xin, H, W, 64)]
+        def act(name, shape_bhw, c, f32=False):
+            """activation workspace: S3 (B,H,W,3,C) bf16 in bf16x6 mode, else fp32 NHWC"""
+            if s3 and not f32:
+                return ws.get(name, tuple(shape_bhw) + (3, c), torch.bfloat16)
+            return ws.get(name, tuple(shape_bhw) + (c,))
+
+        def dconv(name, src0, h, w, cout, src1=None, pool0=False, pad1=(0, 0), want_pool=False, out_f32=False):
+            mid = act(name + ".mid", (B, h, w), L[name + ".0"].cout_real)
+            out = act(name + ".out", (B, h, w), cout, f32=out_f32)
+            pooled = act(name + ".pool", (B, h // 2, w // 2), cout) if (want_pool and s3) else None
+            L[name + ".0"].run(src0, B, h, w, mid, src1=src1, pool0=pool0, pad1=pad1)
+            L[name + ".3"].run(mid, B, h, w, out, dst_pool=pooled)
+            return out, pooled
+
+        # encoder: in bf16x6 mode every Down's MaxPool2d(2) is written by the producer's epilogue;
+        # in fp32 mode it is applied while the consumer loads its halo (pool0)
+        f0, p0 = dconv("inc", xin, H, W, 64, want_pool=True)
+        feats, pooled = [f0], [p0]
         h, w = H, W
         for i, cout in enumerate((128, 256, 512, 1024), start=1):
             h, w = h // 2, w // 2
-            feats.append(dconv(f"down{i}", feats[-1], h, w, cout, pool0=True))
+            src = pooled[-1] if s3 else feats[-1]
+            f, p = dconv(f"down{i}", src, h, w, cout, pool0=not s3, want_pool=i < 4)
+            feats.append(f)
+            pooled.append(p)
         y = feats[4]
         for i, cout in enumerate((512, 256, 128, 64), start=1):
             skip = feats[4 - i]
             hs, ws_ = skip.shape[1], skip.shape[2]
             hy, wy = y.shape[1], y.shape[2]
-            upb = ws.get(f"up{i}.up", (B, 2 * hy, 2 * wy, cout))
+            upb = act(f"up{i}.up", (B, 2 * hy, 2 * wy), cout)
             L[f"up{i}.up"].run(y, B, hy, wy, upb)
             dy, dx = hs - 2 * hy, ws_ - 2 * wy
-            y = dconv(f"up{i}.conv", skip, hs, ws_, cout, src1=upb, pad1=(dy // 2, dx // 2))
+            y, _ = dconv(f"up{i}.conv", skip, hs, ws_, cout, src1=upb, pad1=(dy // 2, dx // 2), out_f32=(i == 4))
         out = {"x_top": feats[4], "y4": y}
         logits = torch.empty((B, self.nc, H, W), dtype=torch.float32, device=x.device)
         amax = torch.empty((B, H, W), dtype=torch.uint8, device=x.device) if want_argmax else None
@@ -324,7 +371,28 @@ class ResNetEngine:
         return theta.view(B, 1, 3, 3)
 
 
+def s3_to_f32(t):
+    """(B,H,W,3,C) bf16 split tensor -> (B,H,W,C) float32 (exact sum of the planes)."""
+    lib = _lib.load()
+    B, H, W, _, C = t.shape
+    out = torch.empty((B, H, W, C), dtype=torch.float32, device=t.device)
+    _lib.check(lib.sfh_s3_to_f32(_ptr(t), _ptr(out), B * H * W, C, _stream()), "s3_to_f32")
+    return out
+
+
+def f32_to_s3(t):
+    """(B,H,W,C) float32 -> (B,H,W,3,C) bf16 split tensor."""
+    lib = _lib.load()
+    t = _f32c(t, "nhwc tensor")
+    B, H, W, C = t.shape
+    out = torch.empty((B, H, W, 3, C), dtype=torch.bfloat16, device=t.device)
+    _lib.check(lib.sfh_f32_to_s3(_ptr(t), _ptr(out), B * H * W, C, _stream()), "f32_to_s3")
+    return out
+
+
 def nhwc_to_nchw(t, channels=None):
+    if t.dtype == torch.bfloat16:
+        t = s3_to_f32(t)
     lib = _lib.load()
     B, H, W, cs = t.shape
     C = cs if channels is None else channels

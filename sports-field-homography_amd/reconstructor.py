@@ -9,6 +9,7 @@ Not yet on the HIP path (raise ``NotImplementedError``; SURVEY.md §8 rows f2/f4
 training-mode forward/backward, ``unet_bilinear=True``, Bottleneck ResNets, and input /
 output resizing when ``unet_size``/``target_size`` differ from the frame size.
 """
+import os
 from enum import Enum
 
 import torch
@@ -108,6 +109,11 @@ class Reconstructor(nn.Module):
         self.warper = True if use_warper else None
         self._warp_hw = (warp_size[1], warp_size[0])
 
+        # Arithmetic of the conv stack: "bf16x6" (default) = split-bf16 activations, six bf16 MFMAs
+        # per product, fp32 accumulation (fp32-equivalent accuracy, see csrc/conv_s3.hip);
+        # "fp32" = fp32 MFMA throughout.  Plain attribute (or env SFH_PRECISION) so the constructor
+        # signature stays the reference's.
+        self.precision = os.environ.get("SFH_PRECISION", "bf16x6")
         self._engines = None       # (UNetEngine | None, ResNetEngine | None)
         self._engine_stamp = None
         self._tmpl_shared = None   # (data_ptr, shape) -> bool cache
@@ -119,7 +125,7 @@ class Reconstructor(nn.Module):
         for t in list(self.parameters()) + list(self.buffers()):
             ver += t._version
             dev = t.device
-        return (dev, ver, self.training)
+        return (dev, ver, self.training, self.precision)
 
     def _get_engines(self):
         stamp = self._param_stamp()
@@ -130,7 +136,7 @@ class Reconstructor(nn.Module):
                     f"Reconstructor parameters are on {dev}: move the model to the GPU with .to('cuda'); "
                     "the HIP path has no CPU fallback")
             with torch.cuda.device(dev):
-                un = E.UNetEngine(self, dev) if self.use_unet else None
+                un = E.UNetEngine(self, dev, self.precision) if self.use_unet else None
                 rn = E.ResNetEngine(self.resnet_reg, self._stn_in_channels, dev) if self.use_resnet else None
             self._engines = (un, rn)
             self._engine_stamp = stamp

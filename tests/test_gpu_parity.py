@@ -69,6 +69,54 @@ def test_double_conv_golden(E, golden_blocks, tile):
     assert _maxerr(_nchw(y), g["dc_64_128_m64.y"]) < 5e-5
 
 
+# ---------------------------------------------------------------- split-bf16 (S3) conv path
+def _run_double_conv_s3(E, block, x_nhwc, B, H, W, c0, src1=None, c1=0, pad1=(0, 0), tile=None, pool=False):
+    (cv1, bn1), (cv2, bn2) = block.convs()
+    l1 = E.PackedConv(cv1.weight, cv1.bias, bn1, 3, c0, c1, s3=True)
+    l2 = E.PackedConv(cv2.weight, cv2.bias, bn2, 3, cv1.out_channels, s3=True)
+    mid = torch.empty((B, H, W, 3, cv1.out_channels), dtype=torch.bfloat16, device="cuda")
+    out = torch.empty((B, H, W, cv2.out_channels), device="cuda")
+    l1.run(E.f32_to_s3(x_nhwc), B, H, W, mid, src1=None if src1 is None else E.f32_to_s3(src1), pad1=pad1, tile=tile)
+    pooled = torch.empty((B, H // 2, W // 2, cv2.out_channels), device="cuda") if pool else None
+    l2.run(mid, B, H, W, out, tile=tile, dst_pool=pooled)
+    torch.cuda.synchronize()
+    return out, pooled
+
+
+@pytest.mark.parametrize("tile", [None, 0, 1, 2])
+def test_double_conv_s3_golden(E, golden_blocks, tile):
+    g = golden_blocks
+    m, _ = _mods_to_cuda(modules.DoubleConv(64, 128, 64), 12)
+    x = torch.from_numpy(g["dc_64_128_m64.x"])
+    y, yp = _run_double_conv_s3(E, m, _nhwc(x), 1, 17, 23, 64, tile=tile, pool=True)
+    assert _maxerr(_nchw(y), g["dc_64_128_m64.y"]) < 5e-5
+    want_pool = torch.nn.functional.max_pool2d(_nchw(y), 2)
+    assert torch.equal(_nchw(yp), want_pool)          # fused MaxPool2d(2) of the same values: exact
+
+
+def test_up_transposed_conv_concat_s3_golden(E, golden_blocks):
+    g = golden_blocks
+    m, _ = _mods_to_cuda(modules.Up(128, 64, False), 14)
+    x1 = torch.from_numpy(g["up_128_64.x1"])
+    x2 = torch.from_numpy(g["up_128_64.x2"])
+    up = E.PackedConv(m.up.weight, m.up.bias, None, 1, 128, relu=False, transposed=True, s3=True)
+    upb = torch.empty((1, 20, 18, 3, 64), dtype=torch.bfloat16, device="cuda")
+    up.run(E.f32_to_s3(_nhwc(x1)), 1, 10, 9, upb)
+    torch.cuda.synchronize()
+    ref_up = torch.nn.functional.conv_transpose2d(x1, m.up.weight.cpu(), m.up.bias.cpu(), stride=2)
+    assert _maxerr(_nchw(E.s3_to_f32(upb)), ref_up) < 2e-5
+    y, _ = _run_double_conv_s3(E, m.conv, _nhwc(x2), 1, 21, 19, 64, src1=E.s3_to_f32(upb), c1=64)
+    assert _maxerr(_nchw(y), g["up_128_64.y"]) < 5e-5
+
+
+def test_s3_split_is_exact(E):
+    g = synth._rng(4, "s3")
+    x = torch.from_numpy((g.normal(0, 1, (2, 5, 7, 64)) * np.exp(g.uniform(-20, 20, (2, 5, 7, 64)))).astype(np.float32)).cuda()
+    s = E.f32_to_s3(x)
+    assert torch.equal(E.s3_to_f32(s), x)
+    assert torch.equal(s.float().sum(3), x)
+
+
 def test_down_pool_on_load_golden(E, golden_blocks):
     g = golden_blocks
     m, _ = _mods_to_cuda(modules.Down(64, 128), 13)
@@ -231,13 +279,15 @@ def _model(court_wh=(640, 360), B=2, **kw):
         court = court[:, :, :h, :w].contiguous()
     poi = synth.load_court_poi("pitch", B)
     net = Reconstructor(court.cuda(), poi.cuda(), target_size=(w, h), unet_size=(w, h), warp_size=(w, h), **kw)
-    sd = synth.synth_state_dict(net.state_dict(), kw.pop("seed", 19) if False else 19)
+    sd = synth.synth_state_dict(net.state_dict(), 19)
     return net, sd, court, poi
 
 
-def test_whole_net_small_golden(E, golden_blocks):
+@pytest.mark.parametrize("precision", ["bf16x6", "fp32"])
+def test_whole_net_small_golden(E, golden_blocks, precision):
     g = golden_blocks
     net, sd, court, poi = _model((112, 90), warp_with_nearest=True)
+    net.precision = precision
     net.load_state_dict(sd)
     net.cuda().eval()
     x = synth.smooth_frames(2, 90, 112, seed=19)
@@ -261,10 +311,12 @@ def test_whole_net_small_golden(E, golden_blocks):
     assert torch.equal(out["logits"].cpu().argmax(1)[safe], lg.argmax(1)[safe])
 
 
-def test_full_640x360_golden(E, golden_full):
+@pytest.mark.parametrize("precision", ["bf16x6", "fp32"])
+def test_full_640x360_golden(E, golden_full, precision):
     """BASELINE config C2 shape (B=2 of the 16): every output against the committed vector."""
     g = golden_full
     net, _, court, poi = _model((640, 360), warp_with_nearest=True)
+    net.precision = precision
     sd = synth.synth_state_dict(net.state_dict(), 0)
     net.load_state_dict(sd)
     net.cuda().eval()
