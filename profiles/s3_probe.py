@@ -109,8 +109,10 @@ def speed():
         yf = torch.empty(B, h, w, cout, device="cuda")
         fl = 2.0 * B * h * w * cout * 9 * cin
         t3 = bench(lambda: s3.run(xs, B, h, w, y, dst_fmt=1))
+        t3f = bench(lambda: s3.run(xs, B, h, w, yf, dst_fmt=0))
+        print(f"   (fp32 destination instead of S3: {t3f:7.3f} ms {fl/t3f/1e9:7.1f} TF-equiv)")
         tf = bench(lambda: f32.run(x, B, h, w, yf))
-        print(f"{name:18s} s3 {t3:7.3f} ms {fl/t3/1e9:7.1f} TF-equiv | fp32 {tf:7.3f} ms {fl/tf/1e9:7.1f} TF | speedup {tf/t3:4.2f}x")
+        print(f"{name:18s} s3 {t3:7.3f} ms {fl/t3/1e9:7.1f} TF-equiv | fp32 {tf:7.3f} ms {fl/tf/1e9:7.1f} TF | speedup {tf/t3:4.2f}x", flush=True)
 
 
 if __name__ == "__main__":

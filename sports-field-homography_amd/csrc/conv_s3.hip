@@ -105,7 +105,11 @@ __device__ __forceinline__ unsigned s3_halo_voffset(const sfh_conv_desc& d, cons
 
 namespace {
 
-template <class C>
+// DB = true : one workgroup per CU, two LDS buffers, the next stage's DMA rides inside the MFMA
+//             stream, one barrier per stage - best for long K (>= 4 stages).
+// DB = false: one LDS buffer, two workgroups per CU: stage DMA / prologue / epilogue of one
+//             workgroup hide under the other's MFMAs - best for short K (64..128 channels, 1x1).
+template <class C, bool DB>
 __global__ __launch_bounds__(256, 2) void conv_s3_kernel(const sfh_conv_desc d, const S3Geom g) {
   extern __shared__ __attribute__((aligned(16))) float smem_f[];
   u32x4* const lds = reinterpret_cast<u32x4*>(smem_f);
@@ -233,9 +237,11 @@ __global__ __launch_bounds__(256, 2) void conv_s3_kernel(const sfh_conv_desc d, 
       }
       // the next stage's LDS-DMA pieces, spread over the first steps
       constexpr int PPS = (C::NSL + NSTEP - 1) / NSTEP;
+      if (DB) {
 #pragma unroll
-      for (int q = 0; q < PPS; ++q)
-        if (s * PPS + q < C::NSL) dma_piece(stn, cur ^ 1, s * PPS + q);
+        for (int q = 0; q < PPS; ++q)
+          if (s * PPS + q < C::NSL) dma_piece(stn, cur ^ 1, s * PPS + q);
+      }
       // six partial products, smallest first; the two cout groups are interleaved so that
       // consecutive MFMAs never depend on each other
       constexpr int PW[6] = {0, 1, 2, 0, 1, 0}, PX[6] = {2, 1, 0, 1, 0, 0};
@@ -269,14 +275,40 @@ __global__ __launch_bounds__(256, 2) void conv_s3_kernel(const sfh_conv_desc d, 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   };
-  for (int st = 0; st < nst; st += 2) {
-    maybe_switch(st);
-    stage_barrier();  // stage st landed for every wave; the other buffer is free
-    stage(st, 0, std::false_type{});
-    if (st + 1 < nst) {
-      maybe_switch(st + 1);
+  if (DB) {
+    for (int st = 0; st < nst; st += 2) {
+      maybe_switch(st);
+      stage_barrier();  // stage st landed for every wave; the other buffer is free
+      stage(st, 0, std::false_type{});
+      if (st + 1 < nst) {
+        maybe_switch(st + 1);
+        stage_barrier();
+        stage(st + 1, 1, std::true_type{});
+      }
+    }
+  } else {
+    // single buffer: [DMA stage st] [drain + barrier] [compute] [barrier: buffer free again]
+    for (int st = 0; st < nst; st += 2) {
       stage_barrier();
-      stage(st + 1, 1, std::true_type{});
+      stage(st, 0, std::false_type{});
+      if (st + 1 < nst) {
+        if (d.src1 && st + 1 == nst0) {
+#pragma unroll
+          for (int i = 0; i < C::NSL; ++i) hoff[i] = s3_halo_voffset<C>(d, g, 1, tid + 256 * i, r0, x0);
+        }
+        __syncthreads();
+        dma_stage(st + 1, 0);
+        stage_barrier();
+        stage(st + 1, 0, std::true_type{});
+      }
+      if (st + 2 < nst) {
+        if (d.src1 && st + 2 == nst0) {
+#pragma unroll
+          for (int i = 0; i < C::NSL; ++i) hoff[i] = s3_halo_voffset<C>(d, g, 1, tid + 256 * i, r0, x0);
+        }
+        __syncthreads();
+        dma_stage(st + 2, 0);
+      }
     }
   }
   sfh_conv_epilogue<C, 2, C::MT_M>(d, g, acc, n0 + 32 * wn, wm * C::MT_M, r0, x0, lq, lg);
@@ -353,7 +385,7 @@ __global__ void s3_to_f32_kernel(const unsigned short* __restrict__ src, float* 
   dst[i] = v;
 }
 
-template <class C>
+template <class C, bool DB>
 int launch_s3(const sfh_conv_desc& d, hipStream_t stream) {
   S3Geom g;
   g.Ho = (d.H + 2 * C::PAD - C::KS) / C::STRIDE + 1;
@@ -389,11 +421,12 @@ int launch_s3(const sfh_conv_desc& d, hipStream_t stream) {
   SFH_REQUIRE(nblocks < (1L << 31), "conv_s3: grid too large");
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_s3_kernel<C>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_s3_kernel<C, DB>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
-  hipLaunchKernelGGL(conv_s3_kernel<C>, dim3((unsigned)nblocks), dim3(256), C::LDS_BYTES, stream, d, g);
+  hipLaunchKernelGGL((conv_s3_kernel<C, DB>), dim3((unsigned)nblocks), dim3(256),
+                     DB ? C::LDS_BYTES : C::LDS_BYTES / 2, stream, d, g);
   return sfh_check_launch("conv_s3_kernel");
 }
 
@@ -453,8 +486,17 @@ extern "C" int sfh_conv_s3_fwd(const sfh_conv_desc* dp, void* stream_) {
   if (d.out_mode == SFH_OUT_UPSCATTER2)
     SFH_REQUIRE(d.ksize == 1 && d.stride == 1 && (d.cout / 4) % 64 == 0 && !d.residual && !d.dst_pool,
                 "conv_s3_fwd: up-scatter needs ksize=1, stride=1, cout/4 multiple of 64");
-#define SFH_S3CASE(KS, ST, TILE, SH, SW, TH, TW) \
-  if (d.ksize == KS && d.stride == ST && d.tile == TILE) return launch_s3<S3Cfg<KS, ST, SH, SW, TH, TW>>(d, stream);
+  // buffering policy: short K -> two single-buffered workgroups per CU; long K -> one
+  // double-buffered workgroup.  SFH_DEBUG_S3_DB=0/1 forces one variant (experiments).
+  const int nstages = (d.c0 + (d.src1 ? d.c1 : 0)) / 32;
+  static const char* force = getenv("SFH_DEBUG_S3_DB");
+  const bool db = force ? atoi(force) != 0 : nstages * d.ksize * d.ksize >= 100;
+#define SFH_S3CASE(KS, ST, TILE, SH, SW, TH, TW)                      \
+  if (d.ksize == KS && d.stride == ST && d.tile == TILE) {             \
+    using CFG = S3Cfg<KS, ST, SH, SW, TH, TW>;                         \
+    if (db) return launch_s3<CFG, true>(d, stream);                    \
+    return launch_s3<CFG, false>(d, stream);                           \
+  }
   SFH_S3CASE(3, 1, SFH_TILE_8x32, 1, 16, 8, 32)
   SFH_S3CASE(3, 1, SFH_TILE_16x16, 1, 16, 16, 16)
   SFH_S3CASE(3, 1, SFH_TILE_32x8, 2, 8, 32, 8)
