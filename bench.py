@@ -3,7 +3,9 @@
 
 Workload (BASELINE.json configs[1]): ``Reconstructor.predict(x, consistency=False,
 project_poi=False)`` = UNet segmentation + ResNet34-STN + nearest homography warp of the
-court template, on synthetic uint8-derived frames already resident in HBM, fp32.
+court template, on synthetic uint8-derived frames already resident in HBM.  Arithmetic: the
+default "bf16x6" mode (fp32-equivalent split-bf16 contraction, see csrc/conv_s3.hip) or fp32 MFMA
+throughout with SFH_PRECISION=fp32.
 One "step" = one batch of 16 frames per GPU.  With N > 1 (launched by torch.distributed.run,
 one process per GPU) every rank processes its own 16 frames (weak scaling) and the 3x3
 thetas are all-gathered over RCCL each step.
@@ -23,6 +25,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_*_f32 dense peak
+BF16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA peak
+# bf16x6 mode: one fp32-accurate product = 6 bf16 MFMA products, so the MFMA roofline of the
+# ALGORITHMIC (fp32-equivalent) work is the bf16 peak / 6
+BF16X6_PEAK_TFLOPS = BF16_MFMA_PEAK_TFLOPS / 6.0
 
 
 def usable_cores():
@@ -135,10 +141,17 @@ def main():
     summ = timer.summary()
     n, fl, ms = summ.get("doubleconv3x3", (0, 0.0, 1.0))
     achieved = fl / (ms * 1e-3) / 1e12 if n else 0.0
-    roofline = {"bound": "mfma", "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS,
-                "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
+    x6 = net.precision == "bf16x6"
+    peak = BF16X6_PEAK_TFLOPS if x6 else FP32_MFMA_PEAK_TFLOPS
+    roofline = {"bound": "mfma", "achieved": round(achieved, 2), "peak": round(peak, 1),
+                "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
                 "traffic": pmc_traffic("doubleconv3x3") if (W, H, B) == (640, 360, 16) else None,
-                "kernel": "conv_mfma_kernel<3x3,s1> (DoubleConv)", "launches": n,
+                "peak_basis": ("2500 TFLOP/s dense bf16 MFMA / 6 bf16 products per fp32-accurate product; the "
+                               "launches execute 6x the algorithmic FLOPs on the bf16 matrix cores "
+                               f"(= {achieved * 6:.0f} TFLOP/s of bf16 MFMA work, {achieved * 6 / BF16_MFMA_PEAK_TFLOPS:.1%} of 2.5 PFLOP/s)"
+                               if x6 else "157.3 TFLOP/s dense fp32 MFMA (v_mfma_f32_16x16x4_f32)"),
+                "kernel": ("conv_s3_kernel<3x3> (DoubleConv, split-bf16)" if x6 else "conv_mfma_kernel<3x3,s1> (DoubleConv)"),
+                "launches": n,
                 "avg_launch_ms": round(ms / max(n, 1), 4),
                 "algorithmic_gflop_per_launch": round(fl / max(n, 1) / 1e9, 2),
                 "share_of_step_time": round(ms * 1e-3 / elapsed, 4)}
@@ -182,7 +195,9 @@ def main():
             "metric": "frames/sec at 640x360 batch=16 (1/2/4/8 GPU) + homography L1 vs ref",
             "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16x6->f32 (3-way bf16 split operands, 6 bf16 MFMA products, fp32 accumulate; fp32-equivalent)"
+                     if x6 else "f32",
             "data": "synthetic",
             "config": {"workload": f"predict(): UNet seg + ResNet34-STN + nearest warp, {W}x{H}, "
                                    f"batch {B}/GPU, req_outputs=theta,warp_mask"

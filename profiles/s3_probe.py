@@ -15,9 +15,7 @@ st = E._stream
 
 
 def to_s3(x):  # (B,H,W,C) f32 -> (B,H,W,3,C) bf16
-    out = torch.empty(x.shape[:3] + (3, x.shape[3]), dtype=torch.bfloat16, device=x.device)
-    _lib.check(lib.sfh_f32_to_s3(E._ptr(x), E._ptr(out), x.numel() // x.shape[3], x.shape[3], st()), "f32_to_s3")
-    return out
+    return E.f32_to_s3(x)
 
 
 class S3Conv:
@@ -35,14 +33,14 @@ class S3Conv:
 
     def run(self, xs3, B, H, W, dst, dst_fmt=0, pool=None, tile=None):
         d = ConvDesc()
-        d.src0 = xs3.data_ptr(); d.c0 = self.c0; d.cs0 = xs3.shape[4]; d.h0 = H; d.w0 = W
+        d.src0 = xs3.data_ptr(); d.c0 = self.c0; d.cs0 = E._chan(xs3); d.h0 = H; d.w0 = W
         d.batch, d.H, d.W, d.ksize, d.stride = B, H, W, self.ks, 1
         d.tile = E.choose_tile(B, H, W, 1, 2) if tile is None else tile
         d.wpacked, d.scale, d.shift = self.wp.data_ptr(), self.scale.data_ptr(), self.shift.data_ptr()
         d.cout, d.relu = self.cout, 1
-        d.dst = dst.data_ptr(); d.dst_cs = dst.shape[-1]; d.src_fmt = 1; d.dst_fmt = dst_fmt
+        d.dst = dst.data_ptr(); d.dst_cs = E._chan(dst); d.src_fmt = 1; d.dst_fmt = dst_fmt
         if pool is not None:
-            d.dst_pool = pool.data_ptr(); d.pool_cs = pool.shape[-1]
+            d.dst_pool = pool.data_ptr(); d.pool_cs = E._chan(pool)
         _lib.check(lib.sfh_conv_s3_fwd(ctypes.byref(d), st()), "conv_s3")
 
 
@@ -86,14 +84,14 @@ def accuracy():
         e = (y.double().cpu() - ref).abs()
         print(f"accuracy K={9*cin}: {name:12s} max abs err {e.max().item():.3e} mean {e.mean().item():.3e} (|ref| mean {ref.abs().mean().item():.3f})")
     # S3 output + fused pool
-    ys3 = torch.empty(B, h, w, 3, cout, dtype=torch.bfloat16, device="cuda")
-    yp = torch.empty(B, h // 2, w // 2, 3, cout, dtype=torch.bfloat16, device="cuda")
+    ys3 = E.s3_empty(B, h, w, cout, "cuda")
+    yp = E.s3_empty(B, h // 2, w // 2, cout, "cuda")
     s3.run(to_s3(x), B, h, w, ys3, dst_fmt=1, pool=yp)
     torch.cuda.synchronize()
-    rec = ys3.float().sum(3)
+    rec = E.s3_to_f32(ys3)
     print("s3 output planes reconstruct fp32 output exactly:", torch.equal(rec, y3))
     pooled = torch.nn.functional.max_pool2d(y3.permute(0, 3, 1, 2), 2).permute(0, 2, 3, 1)
-    print("fused pool == maxpool(fp32 out):", torch.equal(yp.float().sum(3), pooled))
+    print("fused pool == maxpool(fp32 out):", torch.equal(E.s3_to_f32(yp), pooled))
 
 
 def speed():
@@ -104,7 +102,7 @@ def speed():
         wt, bias, bn, x = layer(cin, cout, h, w, B)
         s3 = S3Conv(wt, bias, bn, 3, cin)
         xs = to_s3(x)
-        y = torch.empty(B, h, w, 3, cout, dtype=torch.bfloat16, device="cuda")
+        y = E.s3_empty(B, h, w, cout, "cuda")
         f32 = E.PackedConv(wt, bias, bn, 3, cin)
         yf = torch.empty(B, h, w, cout, device="cuda")
         fl = 2.0 * B * h * w * cout * 9 * cin

@@ -10,52 +10,49 @@
 
 typedef unsigned int sfh_u32x2 __attribute__((ext_vector_type(2)));
 
-__device__ __forceinline__ float sfh_bf16_bits_to_f32(unsigned short h) {
-  return __builtin_bit_cast(float, (unsigned)h << 16);
+typedef float sfh_f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 sfh_bf16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int sfh_u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ unsigned sfh_cvt_pk(float a, float b) {  // v_cvt_pk_bf16_f32 (RNE)
+  return __builtin_bit_cast(unsigned, __builtin_convertvector((sfh_f32x2){a, b}, sfh_bf16x2));
 }
 
-// split 4 fp32 into three bf16 planes and store 8 bytes per plane at element offset `e`
-// (plane stride `ps` elements)
-__device__ __forceinline__ void sfh_store_s3(unsigned short* __restrict__ base, size_t e, size_t ps,
-                                             const f32x4& v) {
-  unsigned short h[3][4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const __bf16 v0 = (__bf16)v[j];
-    const float r1 = v[j] - (float)v0;
-    const __bf16 v1 = (__bf16)r1;
-    const __bf16 v2 = (__bf16)(r1 - (float)v1);
-    h[0][j] = __builtin_bit_cast(unsigned short, v0);
-    h[1][j] = __builtin_bit_cast(unsigned short, v1);
-    h[2][j] = __builtin_bit_cast(unsigned short, v2);
-  }
+// three-plane split of 4 fp32 values with packed conversions: out[p] = 4 bf16 (8 bytes) of plane p
+__device__ __forceinline__ void sfh_split4(const f32x4& v, sfh_u32x2 (&out)[3]) {
+  f32x4 r = v;
 #pragma unroll
   for (int p = 0; p < 3; ++p) {
-    sfh_u32x2 w;
-    w[0] = (unsigned)h[p][0] | ((unsigned)h[p][1] << 16);
-    w[1] = (unsigned)h[p][2] | ((unsigned)h[p][3] << 16);
-    *reinterpret_cast<sfh_u32x2*>(base + e + p * ps) = w;
+    const unsigned w0 = sfh_cvt_pk(r[0], r[1]), w1 = sfh_cvt_pk(r[2], r[3]);
+    out[p][0] = w0;
+    out[p][1] = w1;
+    if (p < 2) {
+      r[0] -= __builtin_bit_cast(float, w0 << 16);
+      r[1] -= __builtin_bit_cast(float, w0 & 0xFFFF0000u);
+      r[2] -= __builtin_bit_cast(float, w1 << 16);
+      r[3] -= __builtin_bit_cast(float, w1 & 0xFFFF0000u);
+    }
   }
 }
 
-__device__ __forceinline__ f32x4 sfh_load_s3(const unsigned short* __restrict__ base, size_t e, size_t ps) {
-  f32x4 v = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int p = 2; p >= 0; --p) {
-    const sfh_u32x2 w = *reinterpret_cast<const sfh_u32x2*>(base + e + p * ps);
-    v[0] += __builtin_bit_cast(float, w[0] << 16);
-    v[1] += __builtin_bit_cast(float, w[0] & 0xFFFF0000u);
-    v[2] += __builtin_bit_cast(float, w[1] << 16);
-    v[3] += __builtin_bit_cast(float, w[1] & 0xFFFF0000u);
-  }
-  return v;
-}
+constexpr unsigned kSfhOOB = 0xFFFFFFF0u;  // byte offset that the buffer range check rejects
 
 // CFG supplies SUBX, SH, SW, FLATROWS; G supplies Ho, Wo, rows_total, rows_per_img, rows_magic.
+// All global accesses are buffer loads/stores with 32-bit byte offsets: a pixel outside the frame
+// carries kSfhOOB and its stores are dropped by the descriptor's range check (no branches, no
+// 64-bit address arithmetic); the plane / cout-group advance rides in the scalar offset.
 template <class CFG, int NI, int MT, class G>
 __device__ __forceinline__ void sfh_conv_epilogue(const sfh_conv_desc& d, const G& g, f32x4 (&acc)[NI][MT],
                                                   int n0, int msub0, int r0, int x0, int lq, int lg) {
   const bool s3 = d.dst_fmt == SFH_FMT_S3;
+  // S3 layout (B,H,W,cs/32,3,32) bf16: channel c of plane p sits at (c/32)*192 + p*64 + (c%32)*2
+  const unsigned esz = s3 ? 2u : 4u;            // bytes per element
+  const unsigned cs = (unsigned)d.dst_cs;
+  const unsigned pixb = (s3 ? 3u : 1u) * cs * esz;  // bytes per pixel
+  constexpr unsigned planeb = 64u;                  // S3 plane stride inside a 32-channel block
+  const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(d.dst, 0, (int)kSfhOOB, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rr_ = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(d.residual ? d.residual : d.dst), 0, (int)(d.residual ? kSfhOOB : 0u), 0x00020000);
   f32x4 sc[NI], sh[NI];
 #pragma unroll
   for (int ni = 0; ni < NI; ++ni) {
@@ -63,8 +60,21 @@ __device__ __forceinline__ void sfh_conv_epilogue(const sfh_conv_desc& d, const 
     sc[ni] = *reinterpret_cast<const f32x4*>(d.scale + co);
     sh[ni] = *reinterpret_cast<const f32x4*>(d.shift + co);
   }
+  // transposed-conv scatter: the wave's couts [n0, n0 + 16*NI) lie in one (dy,dx) quadrant
+  int corel = n0, qd = 0;
+  if (d.out_mode == SFH_OUT_UPSCATTER2) {
+    const int cr = d.cout >> 2;
+    qd = n0 / cr;
+    corel = n0 - qd * cr;
+  }
+  // byte offset of channel (corel + 4*lg) inside the pixel; group ni adds s3off(ni)
+  const unsigned c_lane = (unsigned)(corel + 4 * lg);
+  const unsigned lane_co = s3 ? (c_lane >> 5) * 192u + (c_lane & 31u) * 2u : c_lane * 4u;
+  auto ni_off = [&](int ni) -> unsigned {  // cout group ni = +16 channels (corel is a multiple of 32)
+    return s3 ? (unsigned)(ni >> 1) * 192u + (unsigned)(ni & 1) * 32u : (unsigned)ni * 64u;
+  };
   int pb[MT], py[MT], px[MT];
-  bool pok[MT];
+  unsigned voff[MT];
 #pragma unroll
   for (int mi = 0; mi < MT; ++mi) {
     const int s = msub0 + mi;
@@ -83,53 +93,64 @@ __device__ __forceinline__ void sfh_conv_epilogue(const sfh_conv_desc& d, const 
       y = (r0 & 0xFFFF) + oy;
       ok = ok && y < g.Ho;
     }
-    pb[mi] = b; py[mi] = y; px[mi] = x; pok[mi] = ok;
+    pb[mi] = b; py[mi] = y; px[mi] = x;
+    unsigned pix;
+    if (d.out_mode == SFH_OUT_UPSCATTER2)
+      pix = (unsigned)((b * 2 * g.Ho + 2 * y + (qd >> 1)) * (2 * g.Wo) + 2 * x + (qd & 1));
+    else
+      pix = (unsigned)((b * g.Ho + y) * g.Wo + x);
+    voff[mi] = ok ? pix * pixb + lane_co : kSfhOOB;
   }
-  const size_t cs = (size_t)d.dst_cs;
   // ---- pass 1: finish the values in place and store them
 #pragma unroll
   for (int mi = 0; mi < MT; ++mi) {
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) {
-      int co = n0 + ni * 16 + 4 * lg;
-      size_t pix;
-      if (d.out_mode == SFH_OUT_UPSCATTER2) {
-        const int cr = d.cout >> 2;
-        const int qd = co / cr;
-        co -= qd * cr;
-        pix = ((size_t)(pb[mi] * 2 * g.Ho + 2 * py[mi] + (qd >> 1)) * (2 * g.Wo) + 2 * px[mi] + (qd & 1));
-      } else {
-        pix = ((size_t)(pb[mi] * g.Ho + py[mi]) * g.Wo + px[mi]);
-      }
+      const unsigned nioff = ni_off(ni);
       f32x4 v = acc[ni][mi];
 #pragma unroll
       for (int j = 0; j < 4; ++j) v[j] = v[j] * sc[ni][j] + sh[ni][j];
-      if (d.residual && pok[mi]) {
-        f32x4 rr;
-        if (s3)
-          rr = sfh_load_s3(reinterpret_cast<const unsigned short*>(d.residual), pix * 3 * cs + co, cs);
-        else
-          rr = *reinterpret_cast<const f32x4*>(d.residual + pix * cs + co);
+      if (d.residual) {
+        if (s3) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] += rr[j];
+          for (int p = 2; p >= 0; --p) {
+            const sfh_u32x2 w = __builtin_bit_cast(
+                sfh_u32x2, __builtin_amdgcn_raw_buffer_load_b64(rr_, (int)voff[mi], (int)(nioff + p * planeb), 0));
+            v[0] += __builtin_bit_cast(float, w[0] << 16);
+            v[1] += __builtin_bit_cast(float, w[0] & 0xFFFF0000u);
+            v[2] += __builtin_bit_cast(float, w[1] << 16);
+            v[3] += __builtin_bit_cast(float, w[1] & 0xFFFF0000u);
+          }
+        } else {
+          const f32x4 q = __builtin_bit_cast(
+              f32x4, __builtin_amdgcn_raw_buffer_load_b128(rr_, (int)voff[mi], (int)nioff, 0));
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] += q[j];
+        }
       }
       if (d.relu) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
       }
       acc[ni][mi] = v;
-      if (pok[mi]) {
-        if (s3)
-          sfh_store_s3(reinterpret_cast<unsigned short*>(d.dst), pix * 3 * cs + co, cs, v);
-        else
-          *reinterpret_cast<f32x4*>(d.dst + pix * cs + co) = v;
+      if (s3) {
+        sfh_u32x2 pl[3];
+        sfh_split4(v, pl);
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+          __builtin_amdgcn_raw_buffer_store_b64(pl[p], rd, (int)voff[mi], (int)(nioff + p * planeb), 0);
+      } else {
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(sfh_u32x4, v), rd, (int)voff[mi], (int)nioff, 0);
       }
     }
   }
   // ---- pass 2: fused MaxPool2d(2) output (floor): rows (y, y+1) x cols (x, x+1), y and x even
   if (d.dst_pool) {
     const int Hp = g.Ho >> 1, Wp = g.Wo >> 1;
-    const size_t pcs = (size_t)d.pool_cs;
+    const unsigned pcs = (unsigned)d.pool_cs;
+    const unsigned ppixb = (s3 ? 3u : 1u) * pcs * esz;
+    constexpr unsigned pplaneb = 64u;
+    const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc(d.dst_pool, 0, (int)kSfhOOB, 0x00020000);
 #pragma unroll
     for (int mi = 0; mi < MT; ++mi) {
       // vertical partner: the pixel group one tile row below (SH == 1) or lane ^ 8 (2x8 groups)
@@ -138,6 +159,13 @@ __device__ __forceinline__ void sfh_conv_epilogue(const sfh_conv_desc& d, const 
       if (!top) continue;
       constexpr int VSTEP = CFG::SH == 2 ? 0 : CFG::SUBX;
       if (CFG::SH == 1 && mi + VSTEP >= MT) continue;
+      const int y = py[mi], x = px[mi];
+      const bool writer = voff[mi] != kSfhOOB && !(x & 1) && !(y & 1) && (y >> 1) < Hp && (x >> 1) < Wp &&
+                          (CFG::SH == 2 ? (lq < 8) : true);
+      const unsigned pc = (unsigned)(n0 + 4 * lg);
+      const unsigned pv = writer ? (unsigned)((pb[mi] * Hp + (y >> 1)) * Wp + (x >> 1)) * ppixb +
+                                       (s3 ? (pc >> 5) * 192u + (pc & 31u) * 2u : pc * 4u)
+                                 : kSfhOOB;
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni) {
         f32x4 m = acc[ni][mi];
@@ -151,16 +179,15 @@ __device__ __forceinline__ void sfh_conv_epilogue(const sfh_conv_desc& d, const 
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) m[j] = fmaxf(m[j], __shfl_xor(m[j], 1));
-        const int y = py[mi], x = px[mi];
-        const bool writer = pok[mi] && !(x & 1) && !(y & 1) && (y >> 1) < Hp && (x >> 1) < Wp &&
-                            (CFG::SH == 2 ? (lq < 8) : true);
-        if (writer) {
-          const int co = n0 + ni * 16 + 4 * lg;
-          const size_t pp = ((size_t)(pb[mi] * Hp + (y >> 1)) * Wp + (x >> 1));
-          if (s3)
-            sfh_store_s3(reinterpret_cast<unsigned short*>(d.dst_pool), pp * 3 * pcs + co, pcs, m);
-          else
-            *reinterpret_cast<f32x4*>(d.dst_pool + pp * pcs + co) = m;
+        const unsigned nioff = ni_off(ni);
+        if (s3) {
+          sfh_u32x2 pl[3];
+          sfh_split4(m, pl);
+#pragma unroll
+          for (int p = 0; p < 3; ++p)
+            __builtin_amdgcn_raw_buffer_store_b64(pl[p], rp, (int)pv, (int)(nioff + p * pplaneb), 0);
+        } else {
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(sfh_u32x4, m), rp, (int)pv, (int)nioff, 0);
         }
       }
     }

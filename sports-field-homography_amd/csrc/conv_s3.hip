@@ -12,7 +12,9 @@
 // fp32 matrix peak.
 //
 // Data movement is designed around 6 bytes per element:
-//   * activations live in HBM as S3 tensors (B,H,W,3,C) bf16; the producer's epilogue splits;
+//   * activations live in HBM as S3 tensors (B,H,W,C/32,3,32) bf16 - per pixel and 32-channel block
+//     192 contiguous bytes = exactly one DMA stage of the consumer and one wave's epilogue output;
+//     the producer's epilogue splits;
 //   * the input halo of a 32-channel stage goes global -> LDS by buffer_load ... lds (LDS-DMA,
 //     no VGPRs, out-of-frame slots read zeros through the descriptor's range check), double
 //     buffered: one barrier per stage, DMA of stage s+1 issued inside the MFMA stream of stage s;
@@ -97,8 +99,9 @@ __device__ __forceinline__ unsigned s3_halo_voffset(const sfh_conv_desc& d, cons
     pix = (unsigned)((b * d.h1 + ys) * d.w1 + xs);
     cs = d.cs1;
   }
-  // byte offset of (pixel, plane, channel group) in the S3 tensor (B,H,W,3,cs) bf16
-  return ((pix * 3u + (unsigned)(pl >> 2)) * cs + 8u * (pl & 3)) * 2u;
+  // byte offset of (pixel, plane, channel group of 8) inside channel block 0 of the S3 tensor
+  // (B,H,W,cs/32,3,32) bf16: a pixel is cs/32 blocks of 192 B, a block is 3 planes x 64 B
+  return pix * (6u * cs) + (unsigned)(pl >> 2) * 64u + 16u * (pl & 3);
 }
 
 }  // namespace
@@ -167,7 +170,7 @@ __global__ __launch_bounds__(256, 2) void conv_s3_kernel(const sfh_conv_desc d, 
   auto dma_piece = [&](int st, int b, int i) {
     u32x4* const hb = lds + b * C::BUF;
     const bool first = st < nst0;
-    const unsigned cb = (unsigned)(first ? st : st - nst0) * (C::CKS * 2u);  // channel byte offset
+    const unsigned cb = (unsigned)(first ? st : st - nst0) * 192u;  // stage = one 32-channel block
     __builtin_amdgcn_raw_ptr_buffer_load_lds(first ? rs0 : rs1, (lds_ptr_t)(hb + wv * 64 + 256 * i), 16,
                                              (int)hoff[i], (int)cb, 0, 0);
   };
@@ -367,9 +370,10 @@ __global__ void f32_to_s3_kernel(const float* __restrict__ src, unsigned short* 
   const float r1 = v - (float)v0;
   const __bf16 v1 = (__bf16)r1;
   const __bf16 v2 = (__bf16)(r1 - (float)v1);
-  dst[(pix * 3 + 0) * cs + c] = __builtin_bit_cast(unsigned short, v0);
-  dst[(pix * 3 + 1) * cs + c] = __builtin_bit_cast(unsigned short, v1);
-  dst[(pix * 3 + 2) * cs + c] = __builtin_bit_cast(unsigned short, v2);
+  const long e = pix * 3 * cs + (long)(c >> 5) * 96 + (c & 31);  // (pix, c/32, plane, c%32)
+  dst[e] = __builtin_bit_cast(unsigned short, v0);
+  dst[e + 32] = __builtin_bit_cast(unsigned short, v1);
+  dst[e + 64] = __builtin_bit_cast(unsigned short, v2);
 }
 
 __global__ void s3_to_f32_kernel(const unsigned short* __restrict__ src, float* __restrict__ dst, int cs,
@@ -378,10 +382,10 @@ __global__ void s3_to_f32_kernel(const unsigned short* __restrict__ src, float* 
   if (i >= total) return;
   const long pix = i / cs;
   const int c = i - pix * cs;
+  const long e = pix * 3 * cs + (long)(c >> 5) * 96 + (c & 31);
   float v = 0.f;
 #pragma unroll
-  for (int p = 2; p >= 0; --p)
-    v += __builtin_bit_cast(float, (unsigned)src[(pix * 3 + p) * cs + c] << 16);
+  for (int p = 2; p >= 0; --p) v += __builtin_bit_cast(float, (unsigned)src[e + 32 * p] << 16);
   dst[i] = v;
 }
 
@@ -453,7 +457,7 @@ extern "C" int sfh_pack_s3_weights(const float* w, void* packed, int ksize, int 
 }
 
 extern "C" int sfh_f32_to_s3(const float* src, void* dst, int64_t npix, int cs, void* stream) {
-  SFH_REQUIRE(src && dst && npix > 0 && cs > 0, "f32_to_s3: bad argument");
+  SFH_REQUIRE(src && dst && npix > 0 && cs > 0 && cs % 32 == 0, "f32_to_s3: cs must be a multiple of 32");
   const long total = npix * cs;
   hipLaunchKernelGGL(f32_to_s3_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                      src, (unsigned short*)dst, cs, total);
@@ -461,7 +465,7 @@ extern "C" int sfh_f32_to_s3(const float* src, void* dst, int64_t npix, int cs, 
 }
 
 extern "C" int sfh_s3_to_f32(const void* src, float* dst, int64_t npix, int cs, void* stream) {
-  SFH_REQUIRE(src && dst && npix > 0 && cs > 0, "s3_to_f32: bad argument");
+  SFH_REQUIRE(src && dst && npix > 0 && cs > 0 && cs % 32 == 0, "s3_to_f32: cs must be a multiple of 32");
   const long total = npix * cs;
   hipLaunchKernelGGL(s3_to_f32_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                      (const unsigned short*)src, dst, cs, total);

@@ -35,6 +35,18 @@ def _f32c(t, what):
     return t
 
 
+def _chan(t):
+    """channels per pixel of an activation tensor: fp32 NHWC (B,H,W,C) or S3 (B,H,W,C/32,3,32) bf16"""
+    return t.shape[3] * 32 if t.dtype == torch.bfloat16 else t.shape[3]
+
+
+def s3_empty(b, h, w, c, device):
+    """uninitialised split-bf16 activation tensor for c channels (c multiple of 32)"""
+    if c % 32:
+        raise ValueError(f"S3 tensors need a multiple of 32 channels, got {c}")
+    return torch.empty((b, h, w, c // 32, 3, 32), dtype=torch.bfloat16, device=device)
+
+
 def choose_tile(batch, ho, wo, stride, zrows=1):
     """Pick the workgroup tile that wastes the fewest padded output pixels."""
     best = None
@@ -135,17 +147,17 @@ class PackedConv:
         lib = _lib.load()
         d = ConvDesc()
         d.src0 = src0.data_ptr()
-        d.c0, d.cs0, d.h0, d.w0 = self.c0, src0.shape[-1], src0.shape[1], src0.shape[2]
+        d.c0, d.cs0, d.h0, d.w0 = self.c0, _chan(src0), src0.shape[1], src0.shape[2]
         if (src0.dtype == torch.bfloat16) != self.s3:
             raise ValueError(f"layer s3={self.s3} got a source of dtype {src0.dtype}")
         d.src_fmt = _lib.FMT_S3 if self.s3 else _lib.FMT_F32
         d.dst_fmt = _lib.FMT_S3 if dst.dtype == torch.bfloat16 else _lib.FMT_F32
         if dst_pool is not None:
-            d.dst_pool, d.pool_cs = dst_pool.data_ptr(), dst_pool.shape[-1]
+            d.dst_pool, d.pool_cs = dst_pool.data_ptr(), _chan(dst_pool)
         d.pool0 = 1 if pool0 else 0
         if src1 is not None:
             d.src1 = src1.data_ptr()
-            d.c1, d.cs1, d.h1, d.w1 = self.c1, src1.shape[-1], src1.shape[1], src1.shape[2]
+            d.c1, d.cs1, d.h1, d.w1 = self.c1, _chan(src1), src1.shape[1], src1.shape[2]
             d.pad_top1, d.pad_left1 = pad1
         else:
             if self.c1:
@@ -163,11 +175,15 @@ class PackedConv:
         d.wpacked, d.scale, d.shift = self.wpacked.data_ptr(), self.scale.data_ptr(), self.shift.data_ptr()
         d.cout, d.relu = self.cout, 1 if self.relu else 0
         d.residual = residual.data_ptr() if residual is not None else None
-        d.dst, d.dst_cs = dst.data_ptr(), dst.shape[-1]
+        d.dst, d.dst_cs = dst.data_ptr(), _chan(dst)
         d.out_mode = _lib.OUT_UPSCATTER2 if self.transposed else _lib.OUT_NHWC
         exp = (batch, 2 * ho, 2 * wo) if self.transposed else (batch, ho, wo)
-        if tuple(dst.shape[:3]) != exp or dst.shape[-1] < self.cout_real:
+        if tuple(dst.shape[:3]) != exp or _chan(dst) < self.cout_real:
             raise ValueError(f"conv dst shape {tuple(dst.shape)} does not match {exp + (self.cout_real,)}")
+        for t in (dst, dst_pool, residual, src0, src1):
+            if t is not None and t.numel() * t.element_size() >= 0xFFFFFFF0:
+                raise ValueError(f"tensor of {t.numel() * t.element_size()} bytes exceeds the 4 GiB buffer-descriptor "
+                                 "range of the conv kernels; split the batch")
         fwd = lib.sfh_conv_s3_fwd if self.s3 else lib.sfh_conv_fwd
         tm = PackedConv.timer
         if tm is not None:
@@ -258,7 +274,7 @@ class UNetEngine:
         def act(name, shape_bhw, c, f32=False):
             """activation workspace: S3 (B,H,W,3,C) bf16 in bf16x6 mode, else fp32 NHWC"""
             if s3 and not f32:
-                return ws.get(name, tuple(shape_bhw) + (3, c), torch.bfloat16)
+                return ws.get(name, tuple(shape_bhw) + (c // 32, 3, 32), torch.bfloat16)
             return ws.get(name, tuple(shape_bhw) + (c,))
 
         def dconv(name, src0, h, w, cout, src1=None, pool0=False, pad1=(0, 0), want_pool=False, out_f32=False):
@@ -372,20 +388,21 @@ class ResNetEngine:
 
 
 def s3_to_f32(t):
-    """(B,H,W,3,C) bf16 split tensor -> (B,H,W,C) float32 (exact sum of the planes)."""
+    """(B,H,W,C/32,3,32) bf16 split tensor -> (B,H,W,C) float32 (exact sum of the planes)."""
     lib = _lib.load()
-    B, H, W, _, C = t.shape
+    B, H, W = t.shape[:3]
+    C = _chan(t)
     out = torch.empty((B, H, W, C), dtype=torch.float32, device=t.device)
     _lib.check(lib.sfh_s3_to_f32(_ptr(t), _ptr(out), B * H * W, C, _stream()), "s3_to_f32")
     return out
 
 
 def f32_to_s3(t):
-    """(B,H,W,C) float32 -> (B,H,W,3,C) bf16 split tensor."""
+    """(B,H,W,C) float32 -> (B,H,W,C/32,3,32) bf16 split tensor."""
     lib = _lib.load()
     t = _f32c(t, "nhwc tensor")
     B, H, W, C = t.shape
-    out = torch.empty((B, H, W, 3, C), dtype=torch.bfloat16, device=t.device)
+    out = s3_empty(B, H, W, C, t.device)
     _lib.check(lib.sfh_f32_to_s3(_ptr(t), _ptr(out), B * H * W, C, _stream()), "f32_to_s3")
     return out
 

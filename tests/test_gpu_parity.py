@@ -74,7 +74,7 @@ def _run_double_conv_s3(E, block, x_nhwc, B, H, W, c0, src1=None, c1=0, pad1=(0,
     (cv1, bn1), (cv2, bn2) = block.convs()
     l1 = E.PackedConv(cv1.weight, cv1.bias, bn1, 3, c0, c1, s3=True)
     l2 = E.PackedConv(cv2.weight, cv2.bias, bn2, 3, cv1.out_channels, s3=True)
-    mid = torch.empty((B, H, W, 3, cv1.out_channels), dtype=torch.bfloat16, device="cuda")
+    mid = E.s3_empty(B, H, W, cv1.out_channels, "cuda")
     out = torch.empty((B, H, W, cv2.out_channels), device="cuda")
     l1.run(E.f32_to_s3(x_nhwc), B, H, W, mid, src1=None if src1 is None else E.f32_to_s3(src1), pad1=pad1, tile=tile)
     pooled = torch.empty((B, H // 2, W // 2, cv2.out_channels), device="cuda") if pool else None
@@ -100,7 +100,7 @@ def test_up_transposed_conv_concat_s3_golden(E, golden_blocks):
     x1 = torch.from_numpy(g["up_128_64.x1"])
     x2 = torch.from_numpy(g["up_128_64.x2"])
     up = E.PackedConv(m.up.weight, m.up.bias, None, 1, 128, relu=False, transposed=True, s3=True)
-    upb = torch.empty((1, 20, 18, 3, 64), dtype=torch.bfloat16, device="cuda")
+    upb = E.s3_empty(1, 20, 18, 64, "cuda")
     up.run(E.f32_to_s3(_nhwc(x1)), 1, 10, 9, upb)
     torch.cuda.synchronize()
     ref_up = torch.nn.functional.conv_transpose2d(x1, m.up.weight.cpu(), m.up.bias.cpu(), stride=2)
@@ -114,7 +114,7 @@ def test_s3_split_is_exact(E):
     x = torch.from_numpy((g.normal(0, 1, (2, 5, 7, 64)) * np.exp(g.uniform(-20, 20, (2, 5, 7, 64)))).astype(np.float32)).cuda()
     s = E.f32_to_s3(x)
     assert torch.equal(E.s3_to_f32(s), x)
-    assert torch.equal(s.float().sum(3), x)
+    assert torch.equal(s.float().sum(4).reshape(x.shape), x)       # (B,H,W,C/32,3,32) -> planes summed
 
 
 def test_down_pool_on_load_golden(E, golden_blocks):
