@@ -330,7 +330,14 @@ class UNetEngine:
 class ResNetEngine:
     """ResNetSTN forward (models/resnet.py:235-254) on the HIP kernels (BasicBlock depths)."""
 
-    def __init__(self, rn, in_channels, device):
+    def __init__(self, rn, in_channels, device, precision="bf16x6"):
+        """precision "bf16x6": the stride-1 3x3 convs (29 of the 36 conv launches of ResNet34) run on
+        the split-bf16 kernel with S3 activations; stem, stride-2 and 1x1-downsample convs stay on the
+        fp32 kernel (reading an fp32 copy of the stage input, writing S3)."""
+        if precision not in ("bf16x6", "fp32"):
+            raise ValueError(f"precision={precision!r}: expected 'bf16x6' or 'fp32'")
+        self.s3 = precision == "bf16x6"
+        s3 = self.s3
         self.device = device
         self.ws = _Workspace(device)
         self.cin = in_channels
@@ -344,8 +351,10 @@ class ResNetEngine:
             for bi, blk in enumerate(getattr(rn, f"layer{li}")):
                 name = f"layer{li}.{bi}"
                 cin, planes = blk.conv1.in_channels, blk.conv1.out_channels
-                L[name + ".conv1"] = PackedConv(blk.conv1.weight, None, blk.bn1, 3, cin, stride=blk.stride, tag="resnet")
-                L[name + ".conv2"] = PackedConv(blk.conv2.weight, None, blk.bn2, 3, planes, tag="resnet")  # ReLU after the residual add
+                L[name + ".conv1"] = PackedConv(blk.conv1.weight, None, blk.bn1, 3, cin, stride=blk.stride, tag="resnet",
+                                                s3=s3 and blk.stride == 1)
+                L[name + ".conv2"] = PackedConv(blk.conv2.weight, None, blk.bn2, 3, planes, tag="resnet",
+                                                s3=s3)  # ReLU after the residual add
                 if blk.downsample is not None:
                     ds = blk.downsample
                     L[name + ".down"] = PackedConv(ds[0].weight, None, ds[1], 1, cin, relu=False, stride=blk.stride,
@@ -369,18 +378,37 @@ class ResNetEngine:
         h, w = (H2 - 1) // 2 + 1, (W2 - 1) // 2 + 1
         x = ws.get("pool", (B, h, w, 64))
         _lib.check(lib.sfh_maxpool3x3s2_fwd(_ptr(c1), _ptr(x), B, H2, W2, 64, st), "maxpool3x3s2")
+        s3 = self.s3
+
+        def act(name, hh, ww, c):
+            if s3:
+                return ws.get(name, (B, hh, ww, c // 32, 3, 32), torch.bfloat16)
+            return ws.get(name, (B, hh, ww, c))
+
+        if s3:  # the pooled stem output enters the S3 domain (small tensor: 1/16 of the frame area)
+            xs = act("pool.s3", h, w, 64)
+            _lib.check(lib.sfh_f32_to_s3(_ptr(x), _ptr(xs), B * h * w, 64, st), "f32_to_s3")
+            x = xs
         for name, cin, planes, stride, has_down in self.blocks:
             ho, wo = (h - 1) // stride + 1, (w - 1) // stride + 1
-            t = ws.get(name + ".t", (B, ho, wo, planes))
-            L[name + ".conv1"].run(x, B, h, w, t)
+            src = x
+            if s3 and stride != 1:  # fp32 copy of the stage input for the two stride-2 fp32 launches
+                src = ws.get(name + ".xf", (B, h, w, cin))
+                _lib.check(lib.sfh_s3_to_f32(_ptr(x), _ptr(src), B * h * w, cin, st), "s3_to_f32")
+            t = act(name + ".t", ho, wo, planes)
+            L[name + ".conv1"].run(src, B, h, w, t)
             if has_down:
-                idn = ws.get(name + ".idn", (B, ho, wo, planes))
-                L[name + ".down"].run(x, B, h, w, idn)
+                idn = act(name + ".idn", ho, wo, planes)
+                L[name + ".down"].run(src, B, h, w, idn)
             else:
                 idn = x
-            out = ws.get(name + ".out", (B, ho, wo, planes))
+            out = act(name + ".out", ho, wo, planes)
             L[name + ".conv2"].run(t, B, ho, wo, out, residual=idn)
             x, h, w = out, ho, wo
+        if s3:
+            xf = ws.get("final.f32", (B, h, w, _chan(x)))
+            _lib.check(lib.sfh_s3_to_f32(_ptr(x), _ptr(xf), B * h * w, _chan(x), st), "s3_to_f32")
+            x = xf
         theta = torch.empty((B, 9), dtype=torch.float32, device=x.device)
         _lib.check(lib.sfh_avgpool_linear_fwd(_ptr(x), _ptr(self.reg_w), _ptr(self.reg_b), B, h, w,
                                               x.shape[3], 9, _ptr(theta), st), "avgpool_linear")

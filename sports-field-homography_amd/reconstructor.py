@@ -137,7 +137,7 @@ class Reconstructor(nn.Module):
                     "the HIP path has no CPU fallback")
             with torch.cuda.device(dev):
                 un = E.UNetEngine(self, dev, self.precision) if self.use_unet else None
-                rn = E.ResNetEngine(self.resnet_reg, self._stn_in_channels, dev) if self.use_resnet else None
+                rn = E.ResNetEngine(self.resnet_reg, self._stn_in_channels, dev, self.precision) if self.use_resnet else None
             self._engines = (un, rn)
             self._engine_stamp = stamp
         return self._engines

@@ -183,13 +183,14 @@ def test_conv_variants_vs_oracle(E, hw):
 
 
 # ---------------------------------------------------------------- ResNet-STN
+@pytest.mark.parametrize("precision", ["bf16x6", "fp32"])
 @pytest.mark.parametrize("name,key,layers", [("resnet34", "resnet34_7.theta", (3, 4, 6, 3)),
                                              ("resnet18", "resnet18_7.theta", (2, 2, 2, 2))])
-def test_resnet_stn_golden(E, golden_blocks, name, key, layers):
+def test_resnet_stn_golden(E, golden_blocks, name, key, layers, precision):
     g = golden_blocks
     rn, _ = _mods_to_cuda(modules.ResNetSTN(name, 7), 17 if name == "resnet34" else 18)
     x = torch.from_numpy(g["resnet34_7.x"])
-    eng = E.ResNetEngine(rn, 7, torch.device("cuda"))
+    eng = E.ResNetEngine(rn, 7, torch.device("cuda"), precision)
     y = E.nchw_to_nhwc(x.cuda(), 8)
     theta = eng.run(y, 2, 72, 128)
     torch.cuda.synchronize()
