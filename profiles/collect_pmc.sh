@@ -9,6 +9,7 @@ TAG=${1:-r01}
 ROOTD=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOTD/gpurun_out
 mkdir -p $OUT
+rm -rf $OUT/${TAG}_trace $OUT/${TAG}_fetch $OUT/${TAG}_write $OUT/${TAG}_mfma
 cd /tmp && export TMPDIR=/tmp
 ARGS="--steps 3 --warmup 1 --no-cpu-baseline"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_trace -- python3 $ROOTD/bench.py $ARGS > $OUT/${TAG}_trace.log 2>&1

@@ -2,7 +2,7 @@
 usage: python profiles/layer_table.py <kernel_trace.csv> [batch]"""
 import csv, re, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
-B = int(sys.argv[2]) if len(sys.argv) > 2 else 16
+B = int(sys.argv[2]) if len(sys.argv) > 2 and sys.argv[2].isdigit() else 16
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
 idx = [i for i, r in enumerate(rows) if 'nchw_to_nhwc' in r['Kernel_Name']]
 step = rows[idx[-1]:]

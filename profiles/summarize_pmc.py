@@ -20,14 +20,17 @@ here = os.path.dirname(os.path.abspath(__file__))
 
 
 def rows(kind):
-    f = glob.glob(os.path.join(src, f"{tag}_{kind}", "*", "*_counter_collection.csv"))
-    return list(csv.DictReader(open(f[0]))) if f else []
+    f = sorted(glob.glob(os.path.join(src, f"{tag}_{kind}", "*", "*_counter_collection.csv")), key=os.path.getmtime)
+    return list(csv.DictReader(open(f[-1]))) if f else []
 
 
 def group(name):
     m = re.search(r"ConvCfg<(\d+), (\d+)", name)
     if "conv_mfma" in name and m:
-        return {("3", "1"): "doubleconv3x3", ("1", "1"): "convT2x2"}.get((m.group(1), m.group(2)), "resnet_other_conv")
+        return {("3", "1"): "fp32_conv3x3", ("1", "1"): "fp32_conv1x1"}.get((m.group(1), m.group(2)), "fp32_other_conv")
+    m = re.search(r"S3Cfg<(\d+), (\d+)", name)
+    if "conv_s3" in name and m:
+        return "s3_conv3x3" if m.group(1) == "3" else "s3_conv1x1"
     for k in ("warp_kernel", "outconv", "maxpool", "avgpool", "space_to_depth", "nchw_to_nhwc", "pack_weights", "fold_bn", "ce_"):
         if k in name:
             return k
@@ -61,6 +64,10 @@ for g in sorted(fetch):
               "hbm_bytes_per_launch": hbm, "avg_launch_ns_in_pmc_run": ft / n}
     lines.append(f"{g:22s} {n:8d} {fv/n:18.1f} {wv/max(nw,1):18.1f} {hbm/1e6:14.2f} {hbm/(ft/n):20.1f}")
 open(os.path.join(here, f"{tag}_pmc_hbm_traffic.txt"), "w").write("\n".join(lines) + "\n")
+if "s3_conv3x3" in out:   # the DoubleConv launches of the default (bf16x6) mode
+    out["doubleconv3x3"] = out["s3_conv3x3"]
+elif "fp32_conv3x3" in out:
+    out["doubleconv3x3"] = out["fp32_conv3x3"]
 json.dump(out, open(os.path.join(here, "pmc_traffic.json"), "w"), indent=1)
 print("\n".join(lines))
 
@@ -89,9 +96,9 @@ open(os.path.join(here, f"{tag}_pmc_mfma_busy.txt"), "w").write("\n".join(ml) + 
 print("\n".join(ml))
 
 # kernel stats summary copy
-ks = glob.glob(os.path.join(src, f"{tag}_trace", "*", "*_kernel_stats.csv"))
+ks = sorted(glob.glob(os.path.join(src, f"{tag}_trace", "*", "*_kernel_stats.csv")), key=os.path.getmtime)
 if ks:
-    rr = list(csv.DictReader(open(ks[0])))
+    rr = list(csv.DictReader(open(ks[-1])))
     sl = [f"# {tag}: rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline",
           f"{'calls':>6s} {'total ms':>10s} {'avg us':>10s} {'%':>6s}  kernel"]
     for r in rr:
