@@ -214,10 +214,27 @@ class Reconstructor(nn.Module):
         with torch.cuda.device(x.device):
             return rn.run(y, B, H, W)
 
+    # The conv kernels address every activation tensor through 32-bit buffer descriptors
+    # (< 4 GiB).  Larger batches (e.g. 16 frames at 1280x720: the 64-channel full-resolution tensor
+    # is 5.7 GB in S3 format) are processed in sub-batches and concatenated.
+    def _max_frames(self, x):
+        per_frame = x.shape[2] * x.shape[3] * 64 * (6 if self.precision == "bf16x6" else 4)
+        return max(1, 0xFFFFFFF0 // per_frame - 0)
+
+    def _chunked(self, fn, x, *args):
+        mf = self._max_frames(x)
+        if x.shape[0] <= mf:
+            return fn(x, 0, *args)
+        outs = [fn(x[i:i + mf], i, *args) for i in range(0, x.shape[0], mf)]
+        return {k: torch.cat([o[k] for o in outs], 0) for k in outs[0]}
+
     def forward(self, x):
         """Inference-mode forward (reference: :160-194): logits, [uv], theta, poi, bilinear
         (or nearest) warp_mask as float."""
         self._require_eval("forward")
+        return self._chunked(self._forward_one, x)
+
+    def _forward_one(self, x, off):
         ret = {}
         r = None
         if self.use_unet:
@@ -228,14 +245,17 @@ class Reconstructor(nn.Module):
         if self.use_resnet:
             theta = self._stn(x, r)
             ret['theta'] = theta
-            ret['poi'] = self.transform_poi(theta, self.court_poi)
+            ret['poi'] = self.transform_poi(theta, self.court_poi[off:])
             if self.warper:
-                ret['warp_mask'] = self.warp(theta, self.court_img)
+                ret['warp_mask'] = self.warp(theta, self.court_img[off:])
         return ret
 
     def predict(self, x, consistency=True, project_poi=False):
         """Reference: models/reconstructor.py:196-247."""
         self._require_eval("predict")
+        return self._chunked(self._predict_one, x, consistency, project_poi)
+
+    def _predict_one(self, x, off, consistency, project_poi):
         ret = {}
         r = None
         if self.use_unet:
@@ -249,7 +269,7 @@ class Reconstructor(nn.Module):
             if self.warper:
                 bs = theta.shape[0]
                 h, w = self._warp_hw
-                tmpl = self.court_img[0:bs]
+                tmpl = self.court_img[off:off + bs]
                 if tmpl.shape[0] < bs:
                     raise ValueError(f"batch {bs} exceeds the court template batch {self.court_img.shape[0]}")
                 # warp * mask_classes -> int32, fused in the kernel (reference: :223,240)
@@ -260,5 +280,5 @@ class Reconstructor(nn.Module):
                     ret['consist_score'] = E.consistency_ce(ret['logits'], wm)
                 ret['warp_mask'] = wm
             if project_poi:
-                ret['poi'] = self.transform_poi(theta, self.court_poi)
+                ret['poi'] = self.transform_poi(theta, self.court_poi[off:])
         return ret

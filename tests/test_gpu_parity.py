@@ -343,6 +343,29 @@ def test_full_640x360_golden(E, golden_full, precision):
     assert (wm != g["warp_mask"]).mean() < 2e-3
 
 
+def test_forward_eval_and_batch_chunking(E):
+    """forward() (bilinear warp + POI, models/reconstructor.py:160-194) against the oracle, and the
+    sub-batch path used when an activation tensor would exceed the 4 GiB descriptor range."""
+    net, sd, court, poi = _model((112, 90), B=4)
+    net.load_state_dict(sd)
+    net.cuda().eval()
+    x = synth.smooth_frames(4, 90, 112, seed=23)
+    with torch.no_grad():
+        out = net.forward(x.cuda())
+        want = torch_ref.forward(x, sd, court, poi, warp_size=(112, 90), unet_size=(112, 90), target_size=(112, 90))
+        assert set(out) == set(want) == {"logits", "theta", "poi", "warp_mask"}
+        assert out["warp_mask"].dtype == torch.float32
+        assert _maxerr(out["theta"].cpu(), want["theta"]) < 1e-4
+        assert _maxerr(out["poi"].cpu(), want["poi"]) < 1e-4
+        wm = warp_ref.homography_warp(out["theta"].cpu(), court, 90, 112, "bilinear")
+        assert _maxerr(out["warp_mask"].cpu(), wm) < 1e-5
+        whole = net.predict(x.cuda(), consistency=True, project_poi=True)
+        net._max_frames = lambda _x: 3            # force two sub-batches (3 + 1 frames)
+        parts = net.predict(x.cuda(), consistency=True, project_poi=True)
+    for k in whole:
+        assert parts[k].shape == whole[k].shape and torch.equal(parts[k], whole[k]), k
+
+
 def test_model_api_errors(E):
     from sfh_amd.reconstructor import Reconstructor
     net, sd, court, poi = _model((112, 90))
