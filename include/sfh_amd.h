@@ -103,6 +103,12 @@ int sfh_pack_s3_weights(const float* w, void* packed, int ksize, int c0, int c1,
 int sfh_f32_to_s3(const float* src, void* dst, int64_t npix, int cs, void* stream);
 int sfh_s3_to_f32(const void* src, float* dst, int64_t npix, int cs, void* stream);
 
+/* First UNet layer (inc.double_conv.0, unet/unet_parts.py:15; 3 input channels stored as 4):
+ * tap-packed fp32 MFMA kernel, k = channel, one MFMA k-step per tap.  Same descriptor/epilogue as
+ * sfh_conv_fwd; wpacked from sfh_pack_c4_weights ((cout/64)*9*256 floats), w is OIHW (cout,cin<=4,3,3). */
+int sfh_conv3x3_c4_fwd(const sfh_conv_desc* d, void* stream);
+int sfh_pack_c4_weights(const float* w, float* packed, int cin, int cout, void* stream);
+
 /* Number of floats of the packed weight buffer for a conv with the given geometry. */
 int64_t sfh_packed_weight_floats(int ksize, int c0, int c1, int cout_virtual);
 

@@ -532,6 +532,92 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_v2_kernel(const sfh_conv_des
   sfh_conv_epilogue<C, 4, C::MT_M>(d, g, acc, n0, wv * C::MT_M, r0, x0, lq, lg);
 }
 
+// ------------------------------------------------------------------------------------------
+// First UNet layer (3 input channels stored as 4): tap-packed K.  The generic kernel spends a
+// 16-channel stage (4 MFMA k-steps) per tap on 3 real channels; here one MFMA k-step (k = 4) IS
+// one tap: k index = channel (r, g, b, 0), nine k-steps in total.  All weights of the 64 couts
+// (9 taps x 4 cout groups, one float per lane each) stay in registers; the halo is 5.4 KB of LDS.
+struct C4Cfg {  // tile geometry seen by the shared epilogue: 8 rows x 32 cols, 1x16 pixel groups
+  static constexpr int SUBX = 2, SH = 1, SW = 16, TH = 8, TW = 32;
+  static constexpr bool FLATROWS = true;
+  static constexpr int HW = 34, HPIX = 10 * 34;
+};
+
+__global__ __launch_bounds__(256, 2) void conv3x3_c4_kernel(const sfh_conv_desc d, const ConvGeom g) {
+  __shared__ __attribute__((aligned(16))) f32x4 halo[C4Cfg::HPIX + 12];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wv = tid >> 6;
+  const int lq = lane & 15, lg = lane >> 4;
+  const int bid = blockIdx.x;
+  const int xcd = bid & 7, k = bid >> 3;
+  const int nb = k % g.nblk_n;
+  const int tile = (k / g.nblk_n) * 8 + xcd;
+  if (tile >= g.ntiles) return;
+  const int ty = tile / g.tiles_x, tx = tile - ty * g.tiles_x;
+  const int x0 = tx * C4Cfg::TW, r0 = ty * C4Cfg::TH;
+  const int n0 = nb * 64;
+
+  const __amdgpu_buffer_rsrc_t rs0 =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.src0), 0, (int)g.bytes0, 0x00020000);
+  // halo: one float4 (the pixel's 4 stored channels) per slot, zeros outside the frame
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int p = tid + 256 * i;
+    if (p < C4Cfg::HPIX) {
+      const int hy = p / C4Cfg::HW, hx = p - hy * C4Cfg::HW;
+      const int r = r0 - 1 + hy, x = x0 - 1 + hx;
+      unsigned off = kOOB;
+      if (r >= 0 && x >= 0 && x < d.W) {
+        const int b = (int)__umulhi((unsigned)r, g.rows_magic);
+        const int y = r - b * g.rows_per_img;
+        if (b < d.batch && y < d.H) off = (unsigned)((b * d.H + y) * d.W + x) * 16u;
+      }
+      halo[p] = bload(rs0, off, 0);
+    }
+  }
+  // weights: packed [nb][tap 9][cout group 4][lane 64] floats (lane = 16*channel + cout)
+  const float* wp = d.wpacked + (size_t)nb * (9 * 256) + lane;
+  float wr[9][4];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) wr[t][ni] = wp[(t * 4 + ni) * 64];
+  __syncthreads();
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) acc[ni][mi] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const float* hf = reinterpret_cast<const float*>(halo);
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    float xv[4];
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+      const int s = wv * 4 + mi;
+      const int pix = (s / 2 + t / 3) * C4Cfg::HW + (s % 2) * 16 + lq + t % 3;
+      xv[mi] = hf[pix * 4 + lg];
+    }
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi)
+        acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[t][ni], xv[mi], acc[ni][mi], 0, 0, 0);
+  }
+  sfh_conv_epilogue<C4Cfg, 4, 4>(d, g, acc, n0, wv * 4, r0, x0, lq, lg);
+}
+
+__global__ void pack_c4_weights_kernel(const float* __restrict__ w, float* __restrict__ packed, int cin,
+                                       int cout, int total) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int lane = idx & 63, ng = (idx >> 6) & 3, t = (idx >> 8) % 9, nb = idx / (9 * 256);
+  const int co = nb * 64 + ng * 16 + (lane & 15), c = lane >> 4;
+  packed[idx] = (c < cin && co < cout) ? w[((size_t)(co * cin + c) * 3 + t / 3) * 3 + t % 3] : 0.f;
+}
+
 // ------------------------------------------------------------------ weight packing
 // packed[nb][stage][tap][ng(4)][lane(64)][j(4)], tap = sub*KS*KS + ky*KS + kx:
 //   cout = nb*64 + ng*16 + (lane&15);  channel-in-source = stage_local*CKS + 16*sub + 4*(lane>>4) + j
@@ -672,6 +758,43 @@ extern "C" int sfh_pack_conv_weights(const float* w, float* packed, int ksize, i
                      (hipStream_t)stream, w, packed, ksize, nsub_for(ksize), c0, c1, cout_virtual,
                      transposed, aux, total4);
   return sfh_check_launch("pack_weights_kernel");
+}
+
+extern "C" int sfh_pack_c4_weights(const float* w, float* packed, int cin, int cout, void* stream) {
+  SFH_REQUIRE(w && packed && cin >= 1 && cin <= 4 && cout > 0 && cout % 64 == 0,
+              "pack_c4_weights: needs 1..4 input channels and a multiple of 64 output channels");
+  const int total = (cout / 64) * 9 * 256;
+  hipLaunchKernelGGL(pack_c4_weights_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                     (hipStream_t)stream, w, packed, cin, cout, total);
+  return sfh_check_launch("pack_c4_weights_kernel");
+}
+
+extern "C" int sfh_conv3x3_c4_fwd(const sfh_conv_desc* dp, void* stream_) {
+  SFH_REQUIRE(dp, "conv3x3_c4_fwd: null descriptor");
+  const sfh_conv_desc& d = *dp;
+  SFH_REQUIRE(d.src0 && d.wpacked && d.scale && d.shift && d.dst, "conv3x3_c4_fwd: null pointer");
+  SFH_REQUIRE(d.ksize == 3 && d.stride == 1 && d.cs0 == 4 && d.c0 <= 4 && !d.src1 && !d.pool0 && !d.dst_pool &&
+                  d.src_fmt == SFH_FMT_F32 && d.out_mode == SFH_OUT_NHWC && d.h0 == d.H && d.w0 == d.W,
+              "conv3x3_c4_fwd: needs a single fp32 NHWC source with 4 stored channels, 3x3 stride 1");
+  SFH_REQUIRE(d.cout > 0 && d.cout % 64 == 0 && d.batch > 0 && d.H > 0 && d.W > 0, "conv3x3_c4_fwd: bad geometry");
+  ConvGeom g;
+  g.Ho = d.H;
+  g.Wo = d.W;
+  g.tiles_x = sfh_cdiv(g.Wo, C4Cfg::TW);
+  g.rows_per_img = g.Ho + 1 + (g.Ho & 1 ? 0 : 1);  // even rows per frame
+  g.rows_total = d.batch * g.rows_per_img;
+  g.rows_magic = (unsigned)((1ULL << 32) / (unsigned)g.rows_per_img) + 1u;
+  SFH_REQUIRE((unsigned long long)(g.rows_total + 64) * g.rows_per_img < (1ULL << 32), "conv3x3_c4_fwd: too many rows");
+  g.tiles_y = sfh_cdiv(g.rows_total, C4Cfg::TH);
+  g.ntiles = g.tiles_x * g.tiles_y;
+  const unsigned long long b0 = 16ULL * d.batch * d.H * d.W;
+  SFH_REQUIRE(b0 < kOOB, "conv3x3_c4_fwd: source exceeds the 4 GiB descriptor range");
+  g.bytes0 = (unsigned)b0;
+  g.bytes1 = 0;
+  g.nblk_n = d.cout / 64;
+  const long nblocks = (long)sfh_cdiv(g.ntiles, 8) * 8 * g.nblk_n;
+  hipLaunchKernelGGL(conv3x3_c4_kernel, dim3((unsigned)nblocks), dim3(256), 0, (hipStream_t)stream_, d, g);
+  return sfh_check_launch("conv3x3_c4_kernel");
 }
 
 extern "C" int sfh_conv_fwd(const sfh_conv_desc* dp, void* stream_) {

@@ -220,7 +220,10 @@ __global__ __launch_bounds__(256, 2) void conv_s3_kernel(const sfh_conv_desc d, 
     constexpr bool SW = decltype(sw_tag)::value;
     constexpr int NSTEP = C::NTAP * C::MT_M;
     const u32x4* const halo = lds + cur * C::BUF;
-    u32x4 xq[2][3];
+    // operand ring of three register sets: the reads of step s+2 are issued in step s, i.e. two
+    // steps (~380 cycles of MFMA) ahead of their use - one step is not enough to cover the LDS
+    // latency with four waves reading (measured: 358 cycles per 192-cycle step before)
+    u32x4 xq[3][3];
     auto ld_x = [&](int s, int buf) {
       const int t = s / C::MT_M, mi = s % C::MT_M;
       const int toff = (t / C::KS) * C::HW + (t % C::KS);
@@ -229,14 +232,15 @@ __global__ __launch_bounds__(256, 2) void conv_s3_kernel(const sfh_conv_desc d, 
       for (int p = 0; p < 3; ++p) xq[buf][p] = halo[pixbase0 + (p * 4 * C::HPIXP + moff + toff)];
     };
     ld_x(0, 0);
+    if (NSTEP > 1) ld_x(1, 1);
     const int stn = st + 1 < nst ? st + 1 : st;  // unconditional DMA: no branch in the MFMA block
 #pragma unroll
     for (int s = 0; s < NSTEP; ++s) {
       const int t = s / C::MT_M, mi = s % C::MT_M;
-      const int xb = s & 1;
+      const int xb = s % 3;
       u32x4 (&wc)[3][2] = ((t & 1) != (SW ? 1 : 0)) ? wb : wa;
       u32x4 (&wnx)[3][2] = ((t & 1) != (SW ? 1 : 0)) ? wa : wb;
-      if (s + 1 < NSTEP) ld_x(s + 1, xb ^ 1);
+      if (s + 2 < NSTEP) ld_x(s + 2, (s + 2) % 3);
       if (mi == 0) {
         load_w(wnx, wsoff);  // next tap (or tap 0 of the next stage): one tap of MFMAs ahead
         wsoff = (wsoff + WTAP <= wlast) ? wsoff + WTAP : wlast;

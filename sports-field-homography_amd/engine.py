@@ -113,7 +113,13 @@ class PackedConv:
             rep = 1
         if self.cout_real % 64:
             raise ValueError(f"conv with {self.cout_real} output channels: the MFMA kernel needs a multiple of 64")
-        if self.s3:
+        # 3x3 conv over <= 4 input channels (the UNet's first layer): tap-packed kernel
+        self.c4 = (not self.s3 and not stem_cin and not transposed and ksize == 3 and stride == 1
+                   and c1 == 0 and c0 <= 4)
+        if self.c4:
+            self.wpacked = torch.empty((self.cout // 64) * 9 * 256, dtype=torch.float32, device=dev)
+            _lib.check(lib.sfh_pack_c4_weights(_ptr(w), _ptr(self.wpacked), c0, self.cout, _stream()), "pack_c4_weights")
+        elif self.s3:
             if stem_cin or stride != 1:
                 raise ValueError("the split-bf16 kernel covers ksize 1/3, stride 1")
             n = lib.sfh_packed_s3_weight_bytes(ksize, c0, c1, self.cout)
@@ -185,6 +191,10 @@ class PackedConv:
                 raise ValueError(f"tensor of {t.numel() * t.element_size()} bytes exceeds the 4 GiB buffer-descriptor "
                                  "range of the conv kernels; split the batch")
         fwd = lib.sfh_conv_s3_fwd if self.s3 else lib.sfh_conv_fwd
+        if self.c4:
+            if src0.shape[-1] != 4 or pool0 or dst_pool is not None:
+                raise ValueError("the <=4-channel first-layer kernel needs an fp32 NHWC source with 4 stored channels")
+            fwd = lib.sfh_conv3x3_c4_fwd
         tm = PackedConv.timer
         if tm is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
