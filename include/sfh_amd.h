@@ -38,8 +38,10 @@ extern "C" {
 
 /* Tensor formats of conv sources / destinations.
  * F32: fp32 NHWC (B,H,W,cs).
- * S3 : "split-3" bf16 (B,H,W,3,cs): v = plane0 + plane1 + plane2 exactly, plane0 = bf16(v),
- *      plane1 = bf16(v - plane0), plane2 = bf16(v - plane0 - plane1). */
+ * S3 : "split-3" bf16 (B, H, cs/32, 3 planes, 4 groups, W, 8): v = plane0 + plane1 + plane2 exactly,
+ *      plane0 = bf16(v), plane1 = bf16(v - plane0), plane2 = bf16(v - plane0 - plane1); channel c of
+ *      pixel (y, x) lives in block c/32, group (c%32)/8, lane c%8 - each (block, plane, group) of an
+ *      image row is W x 16 contiguous bytes. */
 #define SFH_FMT_F32 0
 #define SFH_FMT_S3 1
 
@@ -99,9 +101,9 @@ int64_t sfh_packed_s3_weight_bytes(int ksize, int c0, int c1, int cout_virtual);
 /* mode 0: OIHW conv weight; mode 1: IOHW ConvTranspose2d weight (ksize 1, cout_virtual = 4*cout) */
 int sfh_pack_s3_weights(const float* w, void* packed, int ksize, int c0, int c1, int cout_virtual,
                         int mode, void* stream);
-/* fp32 (npix, cs) <-> S3 (npix, 3, cs) conversion */
-int sfh_f32_to_s3(const float* src, void* dst, int64_t npix, int cs, void* stream);
-int sfh_s3_to_f32(const void* src, float* dst, int64_t npix, int cs, void* stream);
+/* fp32 NHWC (rows = B*H, W, cs) <-> S3 (rows, cs/32, 3, 4, W, 8) conversion */
+int sfh_f32_to_s3(const float* src, void* dst, int64_t rows, int W, int cs, void* stream);
+int sfh_s3_to_f32(const void* src, float* dst, int64_t rows, int W, int cs, void* stream);
 
 /* First UNet layer (inc.double_conv.0, unet/unet_parts.py:15; 3 input channels stored as 4):
  * tap-packed fp32 MFMA kernel, k = channel, one MFMA k-step per tap.  Same descriptor/epilogue as

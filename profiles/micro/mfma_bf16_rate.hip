@@ -71,7 +71,14 @@ __global__ __launch_bounds__(256, 2) void kstage(float* out, int nstages, const 
   __syncthreads();
   const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(gx), 0, (int)gxbytes, 0x00020000);
   unsigned hoff[17];
-  for (int i = 0; i < 17; ++i) hoff[i] = ((blockIdx.x * 340u + (tid + 256u * i) % 352u) * 384u + ((tid + 256u * i) / 352u) * 16u) % (gxbytes - 4096u);
+  for (int i = 0; i < 17; ++i) {
+    if (DMA == 2) {  // 4 lanes cover the 64 contiguous bytes of one (pixel, plane): 16 pixels per piece
+      const unsigned sl = tid + 256u * i;
+      hoff[i] = ((blockIdx.x * 340u + (sl >> 2) % 352u) * 384u + ((sl >> 2) / 352u) * 64u + (sl & 3u) * 16u) % (gxbytes - 4096u);
+    } else {
+      hoff[i] = ((blockIdx.x * 340u + (tid + 256u * i) % 352u) * 384u + ((tid + 256u * i) / 352u) * 16u) % (gxbytes - 4096u);
+    }
+  }
   f32x4 acc[2][8];
   for (int a = 0; a < 2; ++a) for (int b = 0; b < 8; ++b) acc[a][b] = (f32x4){0, 0, 0, 0};
   u32x4 wa[3][2], wb[3][2], x[3][3];
@@ -156,10 +163,12 @@ int main() {
   float* gx; const unsigned gxbytes = 512u << 20; hipMalloc(&gx, gxbytes); hipMemset(gx, 0x3c, gxbytes);
   hipFuncSetAttribute((const void*)kstage<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   hipFuncSetAttribute((const void*)kstage<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  hipFuncSetAttribute((const void*)kstage<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   for (int blocks : {256, 1024}) {
     printf("stage-structured (1 WG/CU, 139 KB LDS), blocks=%d, 32 stages\n", blocks);
     run("barrier per stage, no DMA", [&] { hipLaunchKernelGGL(kstage<0>, dim3(blocks), dim3(256), 139264, 0, out, 32, gw, seed, gx, gxbytes); }, blocks, 32);
     run("barrier per stage + 17 LDS-DMA pieces", [&] { hipLaunchKernelGGL(kstage<1>, dim3(blocks), dim3(256), 139264, 0, out, 32, gw, seed, gx, gxbytes); }, blocks, 32);
+    run("  same, pieces = 16 pixels x 64 contiguous B", [&] { hipLaunchKernelGGL(kstage<2>, dim3(blocks), dim3(256), 139264, 0, out, 32, gw, seed, gx, gxbytes); }, blocks, 32);
   }
   return 0;
 }

@@ -39,8 +39,8 @@ SIGNATURES = {
     "sfh_conv_s3_fwd": (C.c_int, [C.POINTER(ConvDesc), _p]),
     "sfh_packed_s3_weight_bytes": (C.c_int64, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "sfh_pack_s3_weights": (C.c_int, [_p, _p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _p]),
-    "sfh_f32_to_s3": (C.c_int, [_p, _p, C.c_int64, C.c_int, _p]),
-    "sfh_s3_to_f32": (C.c_int, [_p, _p, C.c_int64, C.c_int, _p]),
+    "sfh_f32_to_s3": (C.c_int, [_p, _p, C.c_int64, C.c_int, C.c_int, _p]),
+    "sfh_s3_to_f32": (C.c_int, [_p, _p, C.c_int64, C.c_int, C.c_int, _p]),
     "sfh_conv3x3_c4_fwd": (C.c_int, [C.POINTER(ConvDesc), _p]),
     "sfh_pack_c4_weights": (C.c_int, [_p, _p, C.c_int, C.c_int, _p]),
     "sfh_packed_weight_floats": (C.c_int64, [C.c_int, C.c_int, C.c_int, C.c_int]),

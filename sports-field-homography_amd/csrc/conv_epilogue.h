@@ -45,11 +45,15 @@ template <class CFG, int NI, int MT, class G>
 __device__ __forceinline__ void sfh_conv_epilogue(const sfh_conv_desc& d, const G& g, f32x4 (&acc)[NI][MT],
                                                   int n0, int msub0, int r0, int x0, int lq, int lg) {
   const bool s3 = d.dst_fmt == SFH_FMT_S3;
-  // S3 layout (B,H,W,cs/32,3,32) bf16: channel c of plane p sits at (c/32)*192 + p*64 + (c%32)*2
-  const unsigned esz = s3 ? 2u : 4u;            // bytes per element
+  // S3 layout (B, H, cs/32, 3 planes, 4 groups of 8 ch, W, 8) bf16: for one image row every
+  // (channel block, plane, group) is a contiguous run of W x 16 bytes, so that 16 consecutive pixels
+  // of a lane group are 256 contiguous bytes (lane groups lg and lg^1 hold the two 8-byte halves of
+  // each 16-byte element) and the consumers' LDS-DMA pieces are contiguous along x.
   const unsigned cs = (unsigned)d.dst_cs;
-  const unsigned pixb = (s3 ? 3u : 1u) * cs * esz;  // bytes per pixel
-  constexpr unsigned planeb = 64u;                  // S3 plane stride inside a 32-channel block
+  const unsigned wdst = (unsigned)(d.out_mode == SFH_OUT_UPSCATTER2 ? 2 * g.Wo : g.Wo);
+  const unsigned run = wdst * 16u;                            // bytes of one (block, plane, group) run
+  const unsigned rowb = s3 ? (cs >> 5) * 12u * run : wdst * cs * 4u;  // bytes per image row
+  const unsigned planeb = 4u * run;                           // S3: next plane
   const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(d.dst, 0, (int)kSfhOOB, 0x00020000);
   const __amdgpu_buffer_rsrc_t rr_ = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float*>(d.residual ? d.residual : d.dst), 0, (int)(d.residual ? kSfhOOB : 0u), 0x00020000);
@@ -67,12 +71,15 @@ __device__ __forceinline__ void sfh_conv_epilogue(const sfh_conv_desc& d, const 
     qd = n0 / cr;
     corel = n0 - qd * cr;
   }
-  // byte offset of channel (corel + 4*lg) inside the pixel; group ni adds s3off(ni)
+  // byte offset of channel (corel + 4*lg) relative to the pixel's row/x position; cout group ni
+  // adds ni_off(ni) (+16 channels = +2 groups; corel is a multiple of 32)
   const unsigned c_lane = (unsigned)(corel + 4 * lg);
-  const unsigned lane_co = s3 ? (c_lane >> 5) * 192u + (c_lane & 31u) * 2u : c_lane * 4u;
-  auto ni_off = [&](int ni) -> unsigned {  // cout group ni = +16 channels (corel is a multiple of 32)
-    return s3 ? (unsigned)(ni >> 1) * 192u + (unsigned)(ni & 1) * 32u : (unsigned)ni * 64u;
+  const unsigned lane_co = s3 ? ((c_lane >> 5) * 12u + ((c_lane & 31u) >> 3)) * run + ((c_lane >> 2) & 1u) * 8u
+                              : c_lane * 4u;
+  auto ni_off = [&](int ni) -> unsigned {
+    return s3 ? ((unsigned)(ni >> 1) * 12u + (unsigned)(ni & 1) * 2u) * run : (unsigned)ni * 64u;
   };
+  const unsigned xb = s3 ? 16u : cs * 4u;  // bytes per pixel step along x
   int pb[MT], py[MT], px[MT];
   unsigned voff[MT];
 #pragma unroll
@@ -94,12 +101,15 @@ __device__ __forceinline__ void sfh_conv_epilogue(const sfh_conv_desc& d, const 
       ok = ok && y < g.Ho;
     }
     pb[mi] = b; py[mi] = y; px[mi] = x;
-    unsigned pix;
-    if (d.out_mode == SFH_OUT_UPSCATTER2)
-      pix = (unsigned)((b * 2 * g.Ho + 2 * y + (qd >> 1)) * (2 * g.Wo) + 2 * x + (qd & 1));
-    else
-      pix = (unsigned)((b * g.Ho + y) * g.Wo + x);
-    voff[mi] = ok ? pix * pixb + lane_co : kSfhOOB;
+    unsigned rowi, xo;
+    if (d.out_mode == SFH_OUT_UPSCATTER2) {
+      rowi = (unsigned)(b * 2 * g.Ho + 2 * y + (qd >> 1));
+      xo = (unsigned)(2 * x + (qd & 1));
+    } else {
+      rowi = (unsigned)(b * g.Ho + y);
+      xo = (unsigned)x;
+    }
+    voff[mi] = ok ? rowi * rowb + xo * xb + lane_co : kSfhOOB;
   }
   // ---- pass 1: finish the values in place and store them
 #pragma unroll
@@ -148,8 +158,13 @@ __device__ __forceinline__ void sfh_conv_epilogue(const sfh_conv_desc& d, const 
   if (d.dst_pool) {
     const int Hp = g.Ho >> 1, Wp = g.Wo >> 1;
     const unsigned pcs = (unsigned)d.pool_cs;
-    const unsigned ppixb = (s3 ? 3u : 1u) * pcs * esz;
-    constexpr unsigned pplaneb = 64u;
+    const unsigned prun = (unsigned)Wp * 16u;
+    const unsigned prowb = s3 ? (pcs >> 5) * 12u * prun : (unsigned)Wp * pcs * 4u;
+    const unsigned pplaneb = 4u * prun;
+    const unsigned pxb = s3 ? 16u : pcs * 4u;
+    auto pni_off = [&](int ni) -> unsigned {
+      return s3 ? ((unsigned)(ni >> 1) * 12u + (unsigned)(ni & 1) * 2u) * prun : (unsigned)ni * 64u;
+    };
     const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc(d.dst_pool, 0, (int)kSfhOOB, 0x00020000);
 #pragma unroll
     for (int mi = 0; mi < MT; ++mi) {
@@ -163,8 +178,9 @@ __device__ __forceinline__ void sfh_conv_epilogue(const sfh_conv_desc& d, const 
       const bool writer = voff[mi] != kSfhOOB && !(x & 1) && !(y & 1) && (y >> 1) < Hp && (x >> 1) < Wp &&
                           (CFG::SH == 2 ? (lq < 8) : true);
       const unsigned pc = (unsigned)(n0 + 4 * lg);
-      const unsigned pv = writer ? (unsigned)((pb[mi] * Hp + (y >> 1)) * Wp + (x >> 1)) * ppixb +
-                                       (s3 ? (pc >> 5) * 192u + (pc & 31u) * 2u : pc * 4u)
+      const unsigned pv = writer ? (unsigned)(pb[mi] * Hp + (y >> 1)) * prowb + (unsigned)(x >> 1) * pxb +
+                                       (s3 ? ((pc >> 5) * 12u + ((pc & 31u) >> 3)) * prun + ((pc >> 2) & 1u) * 8u
+                                           : pc * 4u)
                                  : kSfhOOB;
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni) {
@@ -179,7 +195,7 @@ __device__ __forceinline__ void sfh_conv_epilogue(const sfh_conv_desc& d, const 
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) m[j] = fmaxf(m[j], __shfl_xor(m[j], 1));
-        const unsigned nioff = ni_off(ni);
+        const unsigned nioff = pni_off(ni);
         if (s3) {
           sfh_u32x2 pl[3];
           sfh_split4(m, pl);

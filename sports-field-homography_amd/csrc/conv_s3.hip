@@ -12,9 +12,11 @@
 // fp32 matrix peak.
 //
 // Data movement is designed around 6 bytes per element:
-//   * activations live in HBM as S3 tensors (B,H,W,C/32,3,32) bf16 - per pixel and 32-channel block
-//     192 contiguous bytes = exactly one DMA stage of the consumer and one wave's epilogue output;
-//     the producer's epilogue splits;
+//   * activations live in HBM as S3 tensors (B, H, C/32, 3 planes, 4 groups of 8 ch, W, 8) bf16:
+//     every (plane, group) of an image row is a contiguous run along x, so an LDS-DMA piece (64
+//     consecutive halo pixels of one plane/group) and a lane group's epilogue stores are long
+//     contiguous runs (measured: pixel-strided 16-byte pieces cost 17 % of the MFMA rate, contiguous
+//     ones nothing); the producer's epilogue splits;
 //   * the input halo of a 32-channel stage goes global -> LDS by buffer_load ... lds (LDS-DMA,
 //     no VGPRs, out-of-frame slots read zeros through the descriptor's range check), double
 //     buffered: one barrier per stage, DMA of stage s+1 issued inside the MFMA stream of stage s;
@@ -90,19 +92,22 @@ __device__ __forceinline__ unsigned s3_halo_voffset(const sfh_conv_desc& d, cons
   }
   const int x = x0 * C::STRIDE - C::PAD + hx;
   if (x < 0 || x >= d.W) return kOOB;
-  unsigned pix, cs;
+  // S3 layout (B, H, cs/32, 3, 4, W, 8) bf16: byte offset of (row, channel block 0, plane/group pl, x)
+  unsigned rowi, xs_, ws_, nblk;
   if (which == 0) {
-    pix = (unsigned)((b * d.h0 + y) * d.w0 + x);
-    cs = d.cs0;
+    rowi = (unsigned)(b * d.h0 + y);
+    xs_ = (unsigned)x;
+    ws_ = (unsigned)d.w0;
+    nblk = (unsigned)d.cs0 >> 5;
   } else {
     const int ys = y - d.pad_top1, xs = x - d.pad_left1;
     if (ys < 0 || ys >= d.h1 || xs < 0 || xs >= d.w1) return kOOB;
-    pix = (unsigned)((b * d.h1 + ys) * d.w1 + xs);
-    cs = d.cs1;
+    rowi = (unsigned)(b * d.h1 + ys);
+    xs_ = (unsigned)xs;
+    ws_ = (unsigned)d.w1;
+    nblk = (unsigned)d.cs1 >> 5;
   }
-  // byte offset of (pixel, plane, channel group of 8) inside channel block 0 of the S3 tensor
-  // (B,H,W,cs/32,3,32) bf16: a pixel is cs/32 blocks of 192 B, a block is 3 planes x 64 B
-  return pix * (6u * cs) + (unsigned)(pl >> 2) * 64u + 16u * (pl & 3);
+  return ((rowi * nblk * 12u + (unsigned)pl) * ws_ + xs_) * 16u;
 }
 
 }  // namespace
@@ -173,7 +178,8 @@ __global__ __launch_bounds__(256, 2) void conv_s3_kernel(const sfh_conv_desc d, 
   auto dma_piece = [&](int st, int b, int i) {
     u32x4* const hb = lds + b * C::BUF;
     const bool first = st < nst0;
-    const unsigned cb = (unsigned)(first ? st : st - nst0) * 192u;  // stage = one 32-channel block
+    // stage = one 32-channel block = 12 (plane, group) runs of W x 16 bytes of the row
+    const unsigned cb = first ? (unsigned)st * (192u * (unsigned)d.w0) : (unsigned)(st - nst0) * (192u * (unsigned)d.w1);
     __builtin_amdgcn_raw_ptr_buffer_load_lds(first ? rs0 : rs1, (lds_ptr_t)(hb + wv * 64 + 256 * i), 16,
                                              (int)hoff[i], (int)cb, 0, 0);
   };
@@ -366,33 +372,40 @@ __global__ void pack_s3_weights_kernel(const float* __restrict__ w, unsigned sho
 }
 
 // fp32 NHWC (B,H,W,cs) -> S3 (B,H,W,3,cs) and back (tests, network input, debugging)
-__global__ void f32_to_s3_kernel(const float* __restrict__ src, unsigned short* __restrict__ dst, int cs,
+// element (row, x, c, plane) of an S3 tensor (rows, cs/32, 3, 4, W, 8)
+__device__ __forceinline__ long s3_elem(long row, int x, int c, int plane, int W, int cs) {
+  return ((((row * (cs >> 5) + (c >> 5)) * 3 + plane) * 4 + ((c & 31) >> 3)) * W + x) * 8 + (c & 7);
+}
+
+__global__ void f32_to_s3_kernel(const float* __restrict__ src, unsigned short* __restrict__ dst, int W, int cs,
                                  long total) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total) return;
   const long pix = i / cs;
   const int c = i - pix * cs;
+  const long row = pix / W;
+  const int x = pix - row * W;
   const float v = src[i];
   const __bf16 v0 = (__bf16)v;
   const float r1 = v - (float)v0;
   const __bf16 v1 = (__bf16)r1;
   const __bf16 v2 = (__bf16)(r1 - (float)v1);
-  const long e = pix * 3 * cs + (long)(c >> 5) * 96 + (c & 31);  // (pix, c/32, plane, c%32)
-  dst[e] = __builtin_bit_cast(unsigned short, v0);
-  dst[e + 32] = __builtin_bit_cast(unsigned short, v1);
-  dst[e + 64] = __builtin_bit_cast(unsigned short, v2);
+  dst[s3_elem(row, x, c, 0, W, cs)] = __builtin_bit_cast(unsigned short, v0);
+  dst[s3_elem(row, x, c, 1, W, cs)] = __builtin_bit_cast(unsigned short, v1);
+  dst[s3_elem(row, x, c, 2, W, cs)] = __builtin_bit_cast(unsigned short, v2);
 }
 
-__global__ void s3_to_f32_kernel(const unsigned short* __restrict__ src, float* __restrict__ dst, int cs,
+__global__ void s3_to_f32_kernel(const unsigned short* __restrict__ src, float* __restrict__ dst, int W, int cs,
                                  long total) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total) return;
   const long pix = i / cs;
   const int c = i - pix * cs;
-  const long e = pix * 3 * cs + (long)(c >> 5) * 96 + (c & 31);
+  const long row = pix / W;
+  const int x = pix - row * W;
   float v = 0.f;
 #pragma unroll
-  for (int p = 2; p >= 0; --p) v += __builtin_bit_cast(float, (unsigned)src[e + 32 * p] << 16);
+  for (int p = 2; p >= 0; --p) v += __builtin_bit_cast(float, (unsigned)src[s3_elem(row, x, c, p, W, cs)] << 16);
   dst[i] = v;
 }
 
@@ -466,19 +479,19 @@ extern "C" int sfh_pack_s3_weights(const float* w, void* packed, int ksize, int 
   return sfh_check_launch("pack_s3_weights_kernel");
 }
 
-extern "C" int sfh_f32_to_s3(const float* src, void* dst, int64_t npix, int cs, void* stream) {
-  SFH_REQUIRE(src && dst && npix > 0 && cs > 0 && cs % 32 == 0, "f32_to_s3: cs must be a multiple of 32");
-  const long total = npix * cs;
+extern "C" int sfh_f32_to_s3(const float* src, void* dst, int64_t rows, int W, int cs, void* stream) {
+  SFH_REQUIRE(src && dst && rows > 0 && W > 0 && cs > 0 && cs % 32 == 0, "f32_to_s3: cs must be a multiple of 32");
+  const long total = rows * W * cs;
   hipLaunchKernelGGL(f32_to_s3_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                     src, (unsigned short*)dst, cs, total);
+                     src, (unsigned short*)dst, W, cs, total);
   return sfh_check_launch("f32_to_s3_kernel");
 }
 
-extern "C" int sfh_s3_to_f32(const void* src, float* dst, int64_t npix, int cs, void* stream) {
-  SFH_REQUIRE(src && dst && npix > 0 && cs > 0 && cs % 32 == 0, "s3_to_f32: cs must be a multiple of 32");
-  const long total = npix * cs;
+extern "C" int sfh_s3_to_f32(const void* src, float* dst, int64_t rows, int W, int cs, void* stream) {
+  SFH_REQUIRE(src && dst && rows > 0 && W > 0 && cs > 0 && cs % 32 == 0, "s3_to_f32: cs must be a multiple of 32");
+  const long total = rows * W * cs;
   hipLaunchKernelGGL(s3_to_f32_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                     (const unsigned short*)src, dst, cs, total);
+                     (const unsigned short*)src, dst, W, cs, total);
   return sfh_check_launch("s3_to_f32_kernel");
 }
 

@@ -36,15 +36,24 @@ def _f32c(t, what):
 
 
 def _chan(t):
-    """channels per pixel of an activation tensor: fp32 NHWC (B,H,W,C) or S3 (B,H,W,C/32,3,32) bf16"""
-    return t.shape[3] * 32 if t.dtype == torch.bfloat16 else t.shape[3]
+    """channels per pixel of an activation tensor: fp32 NHWC (B,H,W,C) or S3 (B,H,C/32,3,4,W,8) bf16"""
+    return t.shape[2] * 32 if t.dtype == torch.bfloat16 else t.shape[3]
+
+
+def _hw(t):
+    """(H, W) of an activation tensor in either format"""
+    return (t.shape[1], t.shape[5]) if t.dtype == torch.bfloat16 else (t.shape[1], t.shape[2])
+
+
+def s3_shape(b, h, w, c):
+    if c % 32:
+        raise ValueError(f"S3 tensors need a multiple of 32 channels, got {c}")
+    return (b, h, c // 32, 3, 4, w, 8)
 
 
 def s3_empty(b, h, w, c, device):
     """uninitialised split-bf16 activation tensor for c channels (c multiple of 32)"""
-    if c % 32:
-        raise ValueError(f"S3 tensors need a multiple of 32 channels, got {c}")
-    return torch.empty((b, h, w, c // 32, 3, 32), dtype=torch.bfloat16, device=device)
+    return torch.empty(s3_shape(b, h, w, c), dtype=torch.bfloat16, device=device)
 
 
 def choose_tile(batch, ho, wo, stride, zrows=1):
@@ -153,7 +162,8 @@ class PackedConv:
         lib = _lib.load()
         d = ConvDesc()
         d.src0 = src0.data_ptr()
-        d.c0, d.cs0, d.h0, d.w0 = self.c0, _chan(src0), src0.shape[1], src0.shape[2]
+        d.c0, d.cs0 = self.c0, _chan(src0)
+        d.h0, d.w0 = _hw(src0)
         if (src0.dtype == torch.bfloat16) != self.s3:
             raise ValueError(f"layer s3={self.s3} got a source of dtype {src0.dtype}")
         d.src_fmt = _lib.FMT_S3 if self.s3 else _lib.FMT_F32
@@ -163,7 +173,8 @@ class PackedConv:
         d.pool0 = 1 if pool0 else 0
         if src1 is not None:
             d.src1 = src1.data_ptr()
-            d.c1, d.cs1, d.h1, d.w1 = self.c1, _chan(src1), src1.shape[1], src1.shape[2]
+            d.c1, d.cs1 = self.c1, _chan(src1)
+            d.h1, d.w1 = _hw(src1)
             d.pad_top1, d.pad_left1 = pad1
         else:
             if self.c1:
@@ -184,7 +195,7 @@ class PackedConv:
         d.dst, d.dst_cs = dst.data_ptr(), _chan(dst)
         d.out_mode = _lib.OUT_UPSCATTER2 if self.transposed else _lib.OUT_NHWC
         exp = (batch, 2 * ho, 2 * wo) if self.transposed else (batch, ho, wo)
-        if tuple(dst.shape[:3]) != exp or _chan(dst) < self.cout_real:
+        if (dst.shape[0],) + _hw(dst) != exp or _chan(dst) < self.cout_real:
             raise ValueError(f"conv dst shape {tuple(dst.shape)} does not match {exp + (self.cout_real,)}")
         for t in (dst, dst_pool, residual, src0, src1):
             if t is not None and t.numel() * t.element_size() >= 0xFFFFFFF0:
@@ -284,7 +295,7 @@ class UNetEngine:
         def act(name, shape_bhw, c, f32=False):
             """activation workspace: S3 (B,H,W,3,C) bf16 in bf16x6 mode, else fp32 NHWC"""
             if s3 and not f32:
-                return ws.get(name, tuple(shape_bhw) + (c // 32, 3, 32), torch.bfloat16)
+                return ws.get(name, s3_shape(*shape_bhw, c), torch.bfloat16)
             return ws.get(name, tuple(shape_bhw) + (c,))
 
         def dconv(name, src0, h, w, cout, src1=None, pool0=False, pad1=(0, 0), want_pool=False, out_f32=False):
@@ -309,8 +320,8 @@ class UNetEngine:
         y = feats[4]
         for i, cout in enumerate((512, 256, 128, 64), start=1):
             skip = feats[4 - i]
-            hs, ws_ = skip.shape[1], skip.shape[2]
-            hy, wy = y.shape[1], y.shape[2]
+            hs, ws_ = _hw(skip)
+            hy, wy = _hw(y)
             upb = act(f"up{i}.up", (B, 2 * hy, 2 * wy), cout)
             L[f"up{i}.up"].run(y, B, hy, wy, upb)
             dy, dx = hs - 2 * hy, ws_ - 2 * wy
@@ -392,19 +403,19 @@ class ResNetEngine:
 
         def act(name, hh, ww, c):
             if s3:
-                return ws.get(name, (B, hh, ww, c // 32, 3, 32), torch.bfloat16)
+                return ws.get(name, s3_shape(B, hh, ww, c), torch.bfloat16)
             return ws.get(name, (B, hh, ww, c))
 
         if s3:  # the pooled stem output enters the S3 domain (small tensor: 1/16 of the frame area)
             xs = act("pool.s3", h, w, 64)
-            _lib.check(lib.sfh_f32_to_s3(_ptr(x), _ptr(xs), B * h * w, 64, st), "f32_to_s3")
+            _lib.check(lib.sfh_f32_to_s3(_ptr(x), _ptr(xs), B * h, w, 64, st), "f32_to_s3")
             x = xs
         for name, cin, planes, stride, has_down in self.blocks:
             ho, wo = (h - 1) // stride + 1, (w - 1) // stride + 1
             src = x
             if s3 and stride != 1:  # fp32 copy of the stage input for the two stride-2 fp32 launches
                 src = ws.get(name + ".xf", (B, h, w, cin))
-                _lib.check(lib.sfh_s3_to_f32(_ptr(x), _ptr(src), B * h * w, cin, st), "s3_to_f32")
+                _lib.check(lib.sfh_s3_to_f32(_ptr(x), _ptr(src), B * h, w, cin, st), "s3_to_f32")
             t = act(name + ".t", ho, wo, planes)
             L[name + ".conv1"].run(src, B, h, w, t)
             if has_down:
@@ -417,7 +428,7 @@ class ResNetEngine:
             x, h, w = out, ho, wo
         if s3:
             xf = ws.get("final.f32", (B, h, w, _chan(x)))
-            _lib.check(lib.sfh_s3_to_f32(_ptr(x), _ptr(xf), B * h * w, _chan(x), st), "s3_to_f32")
+            _lib.check(lib.sfh_s3_to_f32(_ptr(x), _ptr(xf), B * h, w, _chan(x), st), "s3_to_f32")
             x = xf
         theta = torch.empty((B, 9), dtype=torch.float32, device=x.device)
         _lib.check(lib.sfh_avgpool_linear_fwd(_ptr(x), _ptr(self.reg_w), _ptr(self.reg_b), B, h, w,
@@ -426,22 +437,23 @@ class ResNetEngine:
 
 
 def s3_to_f32(t):
-    """(B,H,W,C/32,3,32) bf16 split tensor -> (B,H,W,C) float32 (exact sum of the planes)."""
+    """(B,H,C/32,3,4,W,8) bf16 split tensor -> (B,H,W,C) float32 (exact sum of the planes)."""
     lib = _lib.load()
-    B, H, W = t.shape[:3]
+    B = t.shape[0]
+    H, W = _hw(t)
     C = _chan(t)
     out = torch.empty((B, H, W, C), dtype=torch.float32, device=t.device)
-    _lib.check(lib.sfh_s3_to_f32(_ptr(t), _ptr(out), B * H * W, C, _stream()), "s3_to_f32")
+    _lib.check(lib.sfh_s3_to_f32(_ptr(t), _ptr(out), B * H, W, C, _stream()), "s3_to_f32")
     return out
 
 
 def f32_to_s3(t):
-    """(B,H,W,C) float32 -> (B,H,W,C/32,3,32) bf16 split tensor."""
+    """(B,H,W,C) float32 -> (B,H,C/32,3,4,W,8) bf16 split tensor."""
     lib = _lib.load()
     t = _f32c(t, "nhwc tensor")
     B, H, W, C = t.shape
     out = s3_empty(B, H, W, C, t.device)
-    _lib.check(lib.sfh_f32_to_s3(_ptr(t), _ptr(out), B * H * W, C, _stream()), "f32_to_s3")
+    _lib.check(lib.sfh_f32_to_s3(_ptr(t), _ptr(out), B * H, W, C, _stream()), "f32_to_s3")
     return out
 
 

@@ -114,7 +114,9 @@ def test_s3_split_is_exact(E):
     x = torch.from_numpy((g.normal(0, 1, (2, 5, 7, 64)) * np.exp(g.uniform(-20, 20, (2, 5, 7, 64)))).astype(np.float32)).cuda()
     s = E.f32_to_s3(x)
     assert torch.equal(E.s3_to_f32(s), x)
-    assert torch.equal(s.float().sum(4).reshape(x.shape), x)       # (B,H,W,C/32,3,32) -> planes summed
+    # (B,H,C/32,3,4,W,8): sum the planes, then bring (block, group, x, lane) back to (x, channel)
+    rec = s.float().sum(3).permute(0, 1, 4, 2, 3, 5).reshape(x.shape)
+    assert torch.equal(rec, x)
 
 
 def test_down_pool_on_load_golden(E, golden_blocks):
