@@ -17,11 +17,13 @@ L = [("inc.0", gm(3, 64, 360, 640)), ("inc.3", gm(64, 64, 360, 640)),
      ("u3.up", gm(256, 128, 90, 160, 4)), ("u3.0", gm(256, 128, 180, 320)), ("u3.3", gm(128, 128, 180, 320)),
      ("u4.up", gm(128, 64, 180, 320, 4)), ("u4.0", gm(128, 64, 360, 640)), ("u4.3", gm(64, 64, 360, 640))]
 dur = lambda r: (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e6
-convs = [r for r in step if 'conv_mfma' in r['Kernel_Name'] or 'conv_s3' in r['Kernel_Name']]
+is_conv = lambda n: 'conv_mfma' in n or 'conv_s3' in n or 'conv3x3_c4' in n
+convs = [r for r in step if is_conv(r['Kernel_Name'])]
 tot = 0
 for (nm, g), r in zip(L, convs[:len(L)]):
     d = dur(r)
-    cfg = re.search(r'Cfg<([^>]*)>', r['Kernel_Name']).group(1)
+    m_ = re.search(r'Cfg<([^>]*)>', r['Kernel_Name'])
+    cfg = m_.group(1) if m_ else 'c4 tap-packed'
     print(f"{nm:6s} cfg<{cfg:22s}> {d:7.3f} ms {2*g*B/d:7.1f} TFLOP/s grid={r.get('Grid_Size_X')} vgpr={r.get('VGPR_Count')} lds={r.get('LDS_Block_Size')}")
     tot += d
 print(f"UNet conv launches: {tot:.3f} ms")
@@ -30,5 +32,5 @@ print(f"step span {(t1-t0)/1e6:.3f} ms over {len(step)} kernels; busy {sum(dur(r
 rn = convs[len(L):]
 print(f"ResNet conv launches: {sum(dur(r) for r in rn):.3f} ms ({len(rn)} launches)")
 for r in step:
-    if 'conv_mfma' not in r['Kernel_Name'] and 'conv_s3' not in r['Kernel_Name']:
+    if not is_conv(r['Kernel_Name']):
         print(f"  {r['Kernel_Name'][:70]:70s} {dur(r)*1e3:9.1f} us")

@@ -517,7 +517,7 @@ extern "C" int sfh_conv_s3_fwd(const sfh_conv_desc* dp, void* stream_) {
   // double-buffered workgroup.  SFH_DEBUG_S3_DB=0/1 forces one variant (experiments).
   const int nstages = (d.c0 + (d.src1 ? d.c1 : 0)) / 32;
   static const char* force = getenv("SFH_DEBUG_S3_DB");
-  const bool db = force ? atoi(force) != 0 : nstages * d.ksize * d.ksize >= 100;
+  const bool db = force ? atoi(force) != 0 : false;  // measured: two single-buffered workgroups per CU are never slower since the row-major S3 layout
 #define SFH_S3CASE(KS, ST, TILE, SH, SW, TH, TW)                      \
   if (d.ksize == KS && d.stride == ST && d.tile == TILE) {             \
     using CFG = S3Cfg<KS, ST, SH, SW, TH, TW>;                         \
