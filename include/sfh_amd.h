@@ -144,6 +144,15 @@ int sfh_nchw_to_nhwc(const float* src, float* dst, int batch, int C, int H, int 
 int sfh_nhwc_to_nchw(const float* src, float* dst, int batch, int C, int H, int W, int cs,
                      void* stream);
 
+/* F.interpolate on NCHW planes (planes = B*C): mode 1 = 'bilinear' (align_corners as given; the input
+ * resize of forward_unet, models/reconstructor.py:136, uses False), mode 0 = 'nearest' (the logits / uv
+ * resize, models/reconstructor.py:153,156). */
+int sfh_resize_nchw(const float* src, float* dst, int64_t planes, int hs, int ws, int hd, int wd, int mode,
+                    int align_corners, void* stream);
+/* nn.Upsample(scale_factor=2, mode='bilinear', align_corners=True) of the bilinear Up variant
+ * (unet/unet_parts.py:49) on fp32 NHWC: (B,H,W,C) -> (B,2H,2W,C). */
+int sfh_upsample2x_bilinear_nhwc(const float* src, float* dst, int batch, int H, int W, int C, void* stream);
+
 /* OutConv (unet/unet_parts.py:74-77): 1x1 conv cin -> nc (nc <= 8) + bias.
  * x: NHWC (B,H,W,cin), w: (nc,cin,1,1), logits_nchw: (B,nc,H,W) or NULL.
  * Optional fused consumers:

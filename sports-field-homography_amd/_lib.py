@@ -49,6 +49,8 @@ SIGNATURES = {
     "sfh_fold_bn": (C.c_int, [_p, _p, _p, _p, _p, C.c_float, C.c_int, C.c_int, _p, _p, _p]),
     "sfh_nchw_to_nhwc": (C.c_int, [_p, _p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _p]),
     "sfh_nhwc_to_nchw": (C.c_int, [_p, _p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _p]),
+    "sfh_resize_nchw": (C.c_int, [_p, _p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _p]),
+    "sfh_upsample2x_bilinear_nhwc": (C.c_int, [_p, _p, C.c_int, C.c_int, C.c_int, C.c_int, _p]),
     "sfh_outconv_fwd": (C.c_int, [_p, C.c_int, _p, _p, C.c_int, C.c_int, C.c_int, C.c_int, _p, _p,
                                   _p, C.c_int, _p, C.c_int, _p]),
     "sfh_homography_warp_fwd": (C.c_int, [_p, _p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int,

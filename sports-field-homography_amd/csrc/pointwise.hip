@@ -55,6 +55,88 @@ __global__ void space_to_depth2_kernel(const float* __restrict__ src, float* __r
   reinterpret_cast<f32x4*>(dst)[idx] = v;
 }
 
+// ----------------------------------------------------------------- resizing (K12, A3b)
+// Source index arithmetic of ATen's upsample kernels (area_pixel_compute_source_index):
+//   align_corners: src = dst * (in-1)/(out-1);  else: src = max(0, (dst+0.5)*in/out - 0.5)
+__device__ __forceinline__ void bilinear_taps(int dst, int in, int out, int align, int& i0, int& i1, float& l1) {
+  float src;
+  if (align) {
+    const float sc = out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.f;
+    src = sc * (float)dst;
+  } else {
+    const float sc = (float)in / (float)out;
+    src = sc * ((float)dst + 0.5f) - 0.5f;
+    if (src < 0.f) src = 0.f;
+  }
+  i0 = (int)src;
+  if (i0 > in - 1) i0 = in - 1;
+  i1 = i0 + (i0 < in - 1 ? 1 : 0);
+  l1 = src - (float)i0;
+}
+
+// planes = B*C images of (hs, ws) -> (hd, wd): F.interpolate(x, size, mode='bilinear') on NCHW
+__global__ void resize_bilinear_nchw_kernel(const float* __restrict__ src, float* __restrict__ dst, int hs,
+                                            int ws, int hd, int wd, int align, long total) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int x = i % wd;
+  const long r = i / wd;
+  const int y = r % hd;
+  const long pl = r / hd;
+  int y0, y1, x0, x1;
+  float ly, lx;
+  bilinear_taps(y, hs, hd, align, y0, y1, ly);
+  bilinear_taps(x, ws, wd, align, x0, x1, lx);
+  const float* p = src + pl * (long)hs * ws;
+  const float top = (1.f - lx) * p[y0 * ws + x0] + lx * p[y0 * ws + x1];
+  const float bot = (1.f - lx) * p[y1 * ws + x0] + lx * p[y1 * ws + x1];
+  dst[i] = (1.f - ly) * top + ly * bot;
+}
+
+// F.interpolate(x, size, mode='nearest') on NCHW: src = min(floor(dst * in/out), in-1)
+__global__ void resize_nearest_nchw_kernel(const float* __restrict__ src, float* __restrict__ dst, int hs,
+                                           int ws, int hd, int wd, long total) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int x = i % wd;
+  const long r = i / wd;
+  const int y = r % hd;
+  const long pl = r / hd;
+  const int ys = min((int)floorf(y * ((float)hs / hd)), hs - 1);
+  const int xs = min((int)floorf(x * ((float)ws / wd)), ws - 1);
+  dst[i] = src[pl * (long)hs * ws + ys * ws + xs];
+}
+
+// nn.Upsample(scale_factor=2, mode='bilinear', align_corners=True) on fp32 NHWC (unet_parts.py:49)
+__global__ void upsample2x_nhwc_kernel(const float* __restrict__ src, float* __restrict__ dst, int H, int W, int C,
+                                       long total4) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;  // one float4 of the output
+  if (i >= total4) return;
+  const int c4n = C >> 2;
+  const int c4 = i % c4n;
+  long r = i / c4n;
+  const int x = r % (2 * W); r /= (2 * W);
+  const int y = r % (2 * H);
+  const long b = r / (2 * H);
+  int y0, y1, x0, x1;
+  float ly, lx;
+  bilinear_taps(y, H, 2 * H, 1, y0, y1, ly);
+  bilinear_taps(x, W, 2 * W, 1, x0, x1, lx);
+  const float* p = src + b * (long)H * W * C + 4 * c4;
+  const f32x4 v00 = *reinterpret_cast<const f32x4*>(p + ((long)y0 * W + x0) * C);
+  const f32x4 v01 = *reinterpret_cast<const f32x4*>(p + ((long)y0 * W + x1) * C);
+  const f32x4 v10 = *reinterpret_cast<const f32x4*>(p + ((long)y1 * W + x0) * C);
+  const f32x4 v11 = *reinterpret_cast<const f32x4*>(p + ((long)y1 * W + x1) * C);
+  f32x4 o;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float top = (1.f - lx) * v00[j] + lx * v01[j];
+    const float bot = (1.f - lx) * v10[j] + lx * v11[j];
+    o[j] = (1.f - ly) * top + ly * bot;
+  }
+  reinterpret_cast<f32x4*>(dst)[i] = o;
+}
+
 // ----------------------------------------------------------------- BatchNorm folding
 __global__ void fold_bn_kernel(const float* conv_bias, const float* gamma, const float* beta,
                                const float* mean, const float* var, float eps, int n, int repeat,
@@ -275,6 +357,30 @@ extern "C" int sfh_space_to_depth2(const float* src, float* dst, int batch, int 
   hipLaunchKernelGGL(space_to_depth2_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0,
                      (hipStream_t)stream, src, dst, H, W, cs, H2, W2, total4);
   return sfh_check_launch("space_to_depth2_kernel");
+}
+
+extern "C" int sfh_resize_nchw(const float* src, float* dst, int64_t planes, int hs, int ws, int hd, int wd,
+                               int mode, int align_corners, void* stream) {
+  SFH_REQUIRE(src && dst && planes > 0 && hs > 0 && ws > 0 && hd > 0 && wd > 0, "resize_nchw: bad argument");
+  SFH_REQUIRE(mode == 0 || mode == 1, "resize_nchw: mode %d (0 nearest, 1 bilinear)", mode);
+  const long total = planes * hd * wd;
+  const unsigned grid = (unsigned)((total + 255) / 256);
+  if (mode == 1)
+    hipLaunchKernelGGL(resize_bilinear_nchw_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, src, dst, hs, ws,
+                       hd, wd, align_corners, total);
+  else
+    hipLaunchKernelGGL(resize_nearest_nchw_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, src, dst, hs, ws, hd,
+                       wd, total);
+  return sfh_check_launch("resize_nchw_kernel");
+}
+
+extern "C" int sfh_upsample2x_bilinear_nhwc(const float* src, float* dst, int batch, int H, int W, int C,
+                                            void* stream) {
+  SFH_REQUIRE(src && dst && batch > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, "upsample2x: bad argument");
+  const long total4 = (long)batch * 2 * H * 2 * W * (C / 4);
+  hipLaunchKernelGGL(upsample2x_nhwc_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0,
+                     (hipStream_t)stream, src, dst, H, W, C, total4);
+  return sfh_check_launch("upsample2x_nhwc_kernel");
 }
 
 extern "C" int sfh_fold_bn(const float* conv_bias, const float* gamma, const float* beta,

@@ -243,8 +243,7 @@ class UNetEngine:
         """precision: "bf16x6" - activations in split-bf16 (S3) format, contractions as six bf16
         MFMAs per product with fp32 accumulation (fp32-equivalent accuracy); "fp32" - fp32
         activations and fp32 MFMA throughout."""
-        if net.unet_bilinear:
-            raise NotImplementedError("unet_bilinear=True (SURVEY.md §8 row A3b) is not on the HIP path yet")
+        self.bilinear = bool(net.unet_bilinear)
         if precision not in ("bf16x6", "fp32"):
             raise ValueError(f"precision={precision!r}: expected 'bf16x6' or 'fp32'")
         self.device = device
@@ -264,9 +263,10 @@ class UNetEngine:
             dc(f"down{i}", getattr(net, f"down{i}").block, cin)
         for i, cin in enumerate((1024, 512, 256, 128), start=1):
             up = getattr(net, f"up{i}")
-            L[f"up{i}.up"] = PackedConv(up.up.weight, up.up.bias, None, 1, cin, relu=False, transposed=True,
-                                        tag="convT2x2", s3=s3)
-            dc(f"up{i}.conv", up.conv, cin // 2, cin // 2)
+            if not self.bilinear:  # bilinear variant (A3b): parameter-free 2x upsampling kernel instead
+                L[f"up{i}.up"] = PackedConv(up.up.weight, up.up.bias, None, 1, cin, relu=False, transposed=True,
+                                            tag="convT2x2", s3=s3)
+            dc(f"up{i}.conv", up.conv, cin // 2, cin // 2)  # cat([skip, up]): cin/2 channels each in both variants
         self.L = L
         self.outc_w = _f32c(net.outc.conv.weight.detach(), "outc.weight")
         self.outc_b = _f32c(net.outc.conv.bias.detach(), "outc.bias")
@@ -311,19 +311,32 @@ class UNetEngine:
         f0, p0 = dconv("inc", xin, H, W, 64, want_pool=True)
         feats, pooled = [f0], [p0]
         h, w = H, W
-        for i, cout in enumerate((128, 256, 512, 1024), start=1):
+        for i in range(1, 5):
             h, w = h // 2, w // 2
             src = pooled[-1] if s3 else feats[-1]
+            cout = L[f"down{i}.3"].cout_real
             f, p = dconv(f"down{i}", src, h, w, cout, pool0=not s3, want_pool=i < 4)
             feats.append(f)
             pooled.append(p)
         y = feats[4]
-        for i, cout in enumerate((512, 256, 128, 64), start=1):
+        for i in range(1, 5):
             skip = feats[4 - i]
             hs, ws_ = _hw(skip)
             hy, wy = _hw(y)
-            upb = act(f"up{i}.up", (B, 2 * hy, 2 * wy), cout)
-            L[f"up{i}.up"].run(y, B, hy, wy, upb)
+            cout = L[f"up{i}.conv.3"].cout_real
+            cup = _chan(y) if self.bilinear else L[f"up{i}.up"].cout_real
+            upb = act(f"up{i}.up", (B, 2 * hy, 2 * wy), cup)
+            if self.bilinear:  # nn.Upsample(2x, bilinear, align_corners=True) on an fp32 view of y
+                yf = y
+                if s3:
+                    yf = ws.get(f"up{i}.yf", (B, hy, wy, cup))
+                    _lib.check(lib.sfh_s3_to_f32(_ptr(y), _ptr(yf), B * hy, wy, cup, st), "s3_to_f32")
+                uf = ws.get(f"up{i}.uf", (B, 2 * hy, 2 * wy, cup)) if s3 else upb
+                _lib.check(lib.sfh_upsample2x_bilinear_nhwc(_ptr(yf), _ptr(uf), B, hy, wy, cup, st), "upsample2x")
+                if s3:
+                    _lib.check(lib.sfh_f32_to_s3(_ptr(uf), _ptr(upb), B * 2 * hy, 2 * wy, cup, st), "f32_to_s3")
+            else:
+                L[f"up{i}.up"].run(y, B, hy, wy, upb)
             dy, dx = hs - 2 * hy, ws_ - 2 * wy
             y, _ = dconv(f"up{i}.conv", skip, hs, ws_, cout, src1=upb, pad1=(dy // 2, dx // 2), out_f32=(i == 4))
         out = {"x_top": feats[4], "y4": y}
@@ -454,6 +467,18 @@ def f32_to_s3(t):
     B, H, W, C = t.shape
     out = s3_empty(B, H, W, C, t.device)
     _lib.check(lib.sfh_f32_to_s3(_ptr(t), _ptr(out), B * H, W, C, _stream()), "f32_to_s3")
+    return out
+
+
+def resize_nchw(t, size_hw, mode, align_corners=False):
+    """F.interpolate(t, size=size_hw, mode=mode[, align_corners]) for NCHW float32 tensors."""
+    lib = _lib.load()
+    t = _f32c(t.contiguous(), "nchw tensor")
+    B, C, hs, ws = t.shape
+    hd, wd = size_hw
+    out = torch.empty((B, C, hd, wd), dtype=torch.float32, device=t.device)
+    _lib.check(lib.sfh_resize_nchw(_ptr(t), _ptr(out), B * C, hs, ws, hd, wd, 1 if mode == "bilinear" else 0,
+                                   1 if align_corners else 0, _stream()), "resize_nchw")
     return out
 
 

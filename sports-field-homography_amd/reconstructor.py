@@ -6,8 +6,7 @@ Same constructor keywords, attributes, method names, returned dict keys, dtypes 
 the built library, raises.
 
 Not yet on the HIP path (raise ``NotImplementedError``):
-training-mode forward/backward, ``unet_bilinear=True``, Bottleneck ResNets, and input /
-output resizing when ``unet_size``/``target_size`` differ from the frame size.
+training-mode forward/backward and Bottleneck ResNets.
 """
 import os
 from enum import Enum
@@ -148,15 +147,10 @@ class Reconstructor(nn.Module):
                 f"{what} in training mode (batch-statistics BatchNorm + backward kernels, SURVEY.md §8 "
                 "row f2) is not implemented on the HIP path; call .eval() first")
 
-    def _check_sizes(self, x):
+    def _needs_resize(self, x):
+        """True when forward_unet has to resize its input or output (models/reconstructor.py:134-156)."""
         w, h = self.unet_size
-        if x.shape[3] != w or x.shape[2] != h:
-            raise NotImplementedError(
-                f"input {tuple(x.shape[2:])} != unet_size (H,W)=({h},{w}): the bilinear input resize "
-                "(models/reconstructor.py:134-136) is SURVEY.md §8 row f4, not on the HIP path yet")
-        tw, th = self.target_size
-        if (tw, th) != (w, h):
-            raise NotImplementedError("target_size != unet_size (nearest logits resize) is not on the HIP path yet")
+        return (x.shape[3] != w or x.shape[2] != h) or tuple(self.target_size) != (w, h)
 
     def _template_is_shared(self, court_img, bs):
         """The reference replicates ONE template over the batch (utils/dataset.py:59).  Detect
@@ -185,10 +179,25 @@ class Reconstructor(nn.Module):
         return E.poi_project(theta, court_poi, normalize)
 
     def _run_unet(self, x, **kw):
-        self._check_sizes(x)
+        """forward_unet core.  Input bilinear resize to unet_size and nearest resize of logits / uv to
+        target_size as in models/reconstructor.py:134-156; with a resize active the fused STN input
+        (built from the UNet-sized frame) is not valid and is dropped."""
         un, _ = self._get_engines()
+        w, h = self.unet_size
         with torch.cuda.device(x.device):
-            return un.run(x.contiguous(), **kw)
+            xin = x.contiguous()
+            if x.shape[3] != w or x.shape[2] != h:
+                xin = E.resize_nchw(xin, (h, w), "bilinear", align_corners=False)
+                kw["want_stn_in"] = False
+            tw, th = self.target_size
+            if (tw, th) != (w, h):
+                kw["want_stn_in"] = False
+            r = un.run(xin, **kw)
+            if (tw, th) != (w, h):
+                r["logits"] = E.resize_nchw(r["logits"], (th, tw), "nearest")
+                if "uv" in r:
+                    r["uv"] = E.resize_nchw(r["uv"], (th, tw), "nearest")
+            return r
 
     def forward_unet(self, x):
         """Reference: models/reconstructor.py:132-158.  Returns (logits, x_top, uv) in NCHW."""
@@ -201,8 +210,10 @@ class Reconstructor(nn.Module):
         """theta = resnet_reg(cat(...)) for the configured input mode (reference: :174-185)."""
         _, rn = self._get_engines()
         B, _, H, W = x.shape
-        if self.resnet_input == Input.IMG_AND_MASK:
+        if self.resnet_input == Input.IMG_AND_MASK and "stn_in" in r:
             y = r["stn_in"]
+        elif self.resnet_input == Input.IMG_AND_MASK:  # resized logits: assemble like the reference (:179,214)
+            y = E.nchw_to_nhwc(torch.cat((r["logits"], x), 1).contiguous(), rn.cs_in)
         elif self.resnet_input == Input.IMG:
             y = E.nchw_to_nhwc(x.contiguous(), rn.cs_in)
         elif self.resnet_input == Input.MASK:

@@ -368,6 +368,58 @@ def test_forward_eval_and_batch_chunking(E):
         assert parts[k].shape == whole[k].shape and torch.equal(parts[k], whole[k]), k
 
 
+def test_bilinear_up_variant_golden(E, golden_blocks):
+    """Up(bilinear=True) (unet/unet_parts.py:48-50): 2x align_corners upsampling + DoubleConv
+    with mid_channels, against the reference-class golden vector."""
+    from sfh_amd import _lib
+    g = golden_blocks
+    m, _ = _mods_to_cuda(modules.Up(128, 64, True), 15)
+    x1 = torch.from_numpy(g["upbl_128_64.x1"])
+    x2 = torch.from_numpy(g["upbl_128_64.x2"])
+    lib = _lib.load()
+    x1n = _nhwc(x1)
+    upb = torch.empty((1, 20, 18, 64), device="cuda")
+    _lib.check(lib.sfh_upsample2x_bilinear_nhwc(E._ptr(x1n), E._ptr(upb), 1, 10, 9, 64, E._stream()), "upsample2x")
+    torch.cuda.synchronize()
+    want_up = torch.nn.functional.interpolate(x1, scale_factor=2, mode="bilinear", align_corners=True)
+    assert _maxerr(_nchw(upb), want_up) < 1e-6
+    y = _run_double_conv(E, m.conv, _nhwc(x2), 1, 21, 19, 64, src1=upb, c1=64, pad1=(0, 0))
+    assert _maxerr(_nchw(y), g["upbl_128_64.y"]) < 5e-5
+
+
+@pytest.mark.parametrize("precision", ["bf16x6", "fp32"])
+def test_bilinear_unet_and_resize_paths(E, precision):
+    """unet_bilinear=True end to end, plus input bilinear resize / logits nearest resize /
+    warp_size != target_size (K12) against the oracle."""
+    from sfh_amd.reconstructor import Reconstructor
+    B = 2
+    court = synth.load_court_template("ncaa_nc4_640x360", 4, B)[:, :, :120, :160].contiguous()
+    poi = synth.load_court_poi("pitch", B)
+    kw = dict(target_size=(128, 96), unet_size=(112, 80), warp_size=(160, 120), warp_with_nearest=True,
+              unet_bilinear=True)
+    net = Reconstructor(court.cuda(), poi.cuda(), **kw)
+    net.precision = precision
+    sd = synth.synth_state_dict(net.state_dict(), 29)
+    net.load_state_dict(sd)
+    net.cuda().eval()
+    x = synth.smooth_frames(B, 96, 128, seed=29)
+    with torch.no_grad():
+        out = net.predict(x.cuda(), consistency=True, project_poi=True)
+        # oracle with the bilinear Up wiring
+        xr = torch.nn.functional.interpolate(x, size=(80, 112), mode="bilinear", align_corners=False)
+        logits, _, _ = torch_ref.forward_unet(xr, sd, (112, 80), (112, 80), bilinear=True)
+        logits = torch.nn.functional.interpolate(logits, size=(96, 128), mode="nearest")
+        theta = torch_ref.resnet_stn(torch.cat((logits, x), 1), sd)
+    assert out["logits"].shape == (B, 4, 96, 128) and out["warp_mask"].shape == (B, 120, 160)
+    assert _maxerr(out["logits"].cpu(), logits) < 3e-4
+    assert _maxerr(out["theta"].cpu(), theta) < 1e-4
+    wm = (warp_ref.homography_warp(out["theta"].cpu(), court, 120, 160, "nearest") * 4)
+    assert torch.equal(out["warp_mask"].cpu(), wm.to(torch.int32))
+    m = torch.nn.functional.interpolate(wm.unsqueeze(1), size=(96, 128), mode="nearest").squeeze(1)
+    ce = torch.nn.functional.cross_entropy(out["logits"].cpu(), m.long(), reduction="none").mean(dim=(1, 2))
+    assert _maxerr(out["consist_score"].cpu(), ce) < 1e-4
+
+
 def test_model_api_errors(E):
     from sfh_amd.reconstructor import Reconstructor
     net, sd, court, poi = _model((112, 90))
