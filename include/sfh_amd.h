@@ -35,6 +35,8 @@ extern "C" {
 #define SFH_TILE_8x32 0   /* 8 rows x 32 cols, MFMA pixel groups of 1x16 */
 #define SFH_TILE_16x16 1  /* 16 rows x 16 cols, 1x16 groups              */
 #define SFH_TILE_32x8 2   /* 32 rows x 8 cols, 2x8 groups (narrow maps)  */
+#define SFH_TILE_8x16 3   /* 8 rows x 16 cols, 1x16 groups (split-bf16 kernel: small maps, stride 2) */
+#define SFH_TILE_16x8 4   /* 16 rows x 8 cols, 2x8 groups  (split-bf16 kernel: small maps, stride 2) */
 
 /* Tensor formats of conv sources / destinations.
  * F32: fp32 NHWC (B,H,W,cs).
@@ -94,13 +96,15 @@ int sfh_conv_fwd(const sfh_conv_desc* d, void* stream);
 
 /* fp32-accurate convolution on the bf16 matrix cores: sources in S3 format, weights packed by
  * sfh_pack_s3_weights, six bf16 MFMAs per 32 k (w0x2 + w1x1 + w2x0 + w0x1 + w1x0 + w0x0) with fp32
- * accumulation.  Same descriptor and epilogue as sfh_conv_fwd; ksize 1 or 3, stride 1, c0/c1
- * multiples of 32, no pool0 (use the producer's dst_pool).  Replaces the same reference calls. */
+ * accumulation.  Same descriptor and epilogue as sfh_conv_fwd; ksize 1, 3 (stride 1 or 2) or 4 (stem),
+ * c0/c1 multiples of 32, no pool0 (use the producer's dst_pool).  Replaces the same reference calls. */
 int sfh_conv_s3_fwd(const sfh_conv_desc* d, void* stream);
 int64_t sfh_packed_s3_weight_bytes(int ksize, int c0, int c1, int cout_virtual);
-/* mode 0: OIHW conv weight; mode 1: IOHW ConvTranspose2d weight (ksize 1, cout_virtual = 4*cout) */
+/* mode 0: OIHW conv weight; mode 1: IOHW ConvTranspose2d weight (ksize 1, cout_virtual = 4*cout);
+ * mode 2: the 7x7 s2 stem as a 4x4 conv over the space-to-depth input (ksize 4, aux = real cin),
+ * as in sfh_pack_conv_weights. */
 int sfh_pack_s3_weights(const float* w, void* packed, int ksize, int c0, int c1, int cout_virtual,
-                        int mode, void* stream);
+                        int mode, int aux, void* stream);
 /* fp32 NHWC (rows = B*H, W, cs) <-> S3 (rows, cs/32, 3, 4, W, 8) conversion */
 int sfh_f32_to_s3(const float* src, void* dst, int64_t rows, int W, int cs, void* stream);
 int sfh_s3_to_f32(const void* src, float* dst, int64_t rows, int W, int cs, void* stream);
@@ -136,6 +140,10 @@ int sfh_space_to_depth2(const float* src, float* dst, int batch, int H, int W, i
 int sfh_fold_bn(const float* conv_bias, const float* gamma, const float* beta,
                 const float* mean, const float* var, float eps, int n, int repeat,
                 float* scale, float* shift, void* stream);
+
+/* Decoded frames uint8 (B,H,W,C) -> float32 (B,C,H,W) = value/255: the dataset's preprocessing
+ * (utils/dataset.py:154-159, :323-330: `img.transpose((2,0,1)) / 255` -> FloatTensor) on the GPU. */
+int sfh_u8hwc_to_f32nchw(const uint8_t* src, float* dst, int batch, int C, int H, int W, void* stream);
 
 /* (B, C, H, W) fp32 -> (B, H, W, cs) fp32, channels >= C zero-filled. */
 int sfh_nchw_to_nhwc(const float* src, float* dst, int batch, int C, int H, int W, int cs,

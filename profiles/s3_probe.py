@@ -24,7 +24,7 @@ class S3Conv:
         n = lib.sfh_packed_s3_weight_bytes(ks, c0, c1, cout)
         assert n > 0
         self.wp = torch.empty(n, dtype=torch.uint8, device=w.device)
-        _lib.check(lib.sfh_pack_s3_weights(E._ptr(w), E._ptr(self.wp), ks, c0, c1, cout, 0, st()), "pack_s3")
+        _lib.check(lib.sfh_pack_s3_weights(E._ptr(w), E._ptr(self.wp), ks, c0, c1, cout, 0, 0, st()), "pack_s3")
         self.scale = torch.empty(cout, device=w.device)
         self.shift = torch.empty(cout, device=w.device)
         _lib.check(lib.sfh_fold_bn(E._ptr(bias), E._ptr(bn.weight), E._ptr(bn.bias), E._ptr(bn.running_mean),
@@ -35,7 +35,7 @@ class S3Conv:
         d = ConvDesc()
         d.src0 = xs3.data_ptr(); d.c0 = self.c0; d.cs0 = E._chan(xs3); d.h0 = H; d.w0 = W
         d.batch, d.H, d.W, d.ksize, d.stride = B, H, W, self.ks, 1
-        d.tile = E.choose_tile(B, H, W, 1, 2) if tile is None else tile
+        d.tile = E.choose_tile_s3(B, H, W, 1, 2, self.cout // 64) if tile is None else tile
         d.wpacked, d.scale, d.shift = self.wp.data_ptr(), self.scale.data_ptr(), self.shift.data_ptr()
         d.cout, d.relu = self.cout, 1
         d.dst = dst.data_ptr(); d.dst_cs = E._chan(dst); d.src_fmt = 1; d.dst_fmt = dst_fmt

@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # SFH_AMD_LIB overrides the library file (used only to load the diagnostic build for profiling)
 LIB_PATH = os.environ.get("SFH_AMD_LIB") or os.path.join(_HERE, "libsfh_amd.so")
 
-TILE_8x32, TILE_16x16, TILE_32x8 = 0, 1, 2
+TILE_8x32, TILE_16x16, TILE_32x8, TILE_8x16, TILE_16x8 = 0, 1, 2, 3, 4
 OUT_NHWC, OUT_UPSCATTER2 = 0, 1
 FMT_F32, FMT_S3 = 0, 1
 
@@ -38,7 +38,7 @@ SIGNATURES = {
     "sfh_conv_fwd": (C.c_int, [C.POINTER(ConvDesc), _p]),
     "sfh_conv_s3_fwd": (C.c_int, [C.POINTER(ConvDesc), _p]),
     "sfh_packed_s3_weight_bytes": (C.c_int64, [C.c_int, C.c_int, C.c_int, C.c_int]),
-    "sfh_pack_s3_weights": (C.c_int, [_p, _p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _p]),
+    "sfh_pack_s3_weights": (C.c_int, [_p, _p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _p]),
     "sfh_f32_to_s3": (C.c_int, [_p, _p, C.c_int64, C.c_int, C.c_int, _p]),
     "sfh_s3_to_f32": (C.c_int, [_p, _p, C.c_int64, C.c_int, C.c_int, _p]),
     "sfh_conv3x3_c4_fwd": (C.c_int, [C.POINTER(ConvDesc), _p]),
@@ -47,6 +47,7 @@ SIGNATURES = {
     "sfh_pack_conv_weights": (C.c_int, [_p, _p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _p]),
     "sfh_space_to_depth2": (C.c_int, [_p, _p, C.c_int, C.c_int, C.c_int, C.c_int, _p]),
     "sfh_fold_bn": (C.c_int, [_p, _p, _p, _p, _p, C.c_float, C.c_int, C.c_int, _p, _p, _p]),
+    "sfh_u8hwc_to_f32nchw": (C.c_int, [_p, _p, C.c_int, C.c_int, C.c_int, C.c_int, _p]),
     "sfh_nchw_to_nhwc": (C.c_int, [_p, _p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _p]),
     "sfh_nhwc_to_nchw": (C.c_int, [_p, _p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _p]),
     "sfh_resize_nchw": (C.c_int, [_p, _p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _p]),

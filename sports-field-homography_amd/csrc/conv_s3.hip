@@ -43,7 +43,8 @@ template <int KS_, int STRIDE_, int SH_, int SW_, int TH_, int TW_>
 struct S3Cfg {
   static constexpr int KS = KS_, STRIDE = STRIDE_;
   static constexpr int SH = SH_, SW = SW_, TH = TH_, TW = TW_;
-  static constexpr int PAD = KS / 2;
+  static constexpr int PAD = KS / 2;          // padding before (3x3: 1, 1x1: 0, 4x4 stem: 2)
+  static constexpr int PADA = (KS - 1) / 2;   // padding after  (3x3: 1, 1x1: 0, 4x4 stem: 1)
   static constexpr int NTAP = KS * KS;
   static constexpr int CKS = 32;  // channels per stage = k of one MFMA
   static constexpr int HH = (TH - 1) * STRIDE + KS;
@@ -58,7 +59,7 @@ struct S3Cfg {
   static constexpr int NSUBT = (TH / SH) * SUBX;
   static constexpr int MT_M = NSUBT / 2;     // pixel groups per wave (2 x 2 wave grid)
   static constexpr bool FLATROWS = (STRIDE == 1);
-  static_assert(SH * SW == 16 && NSUBT == 16, "tile = 16 pixel groups of 16");
+  static_assert(SH * SW == 16 && (NSUBT == 16 || NSUBT == 8), "tile = 8 or 16 pixel groups of 16");
 };
 
 struct S3Geom {
@@ -275,7 +276,8 @@ __global__ __launch_bounds__(256, 2) void conv_s3_kernel(const sfh_conv_desc d, 
       __builtin_amdgcn_sched_barrier(0);
     }
   };
-  static_assert(C::NTAP % 2 == 1, "tap loop alternates the two weight register sets per stage");
+  // odd tap counts (1, 9) swap the roles of the two weight register sets every stage, even ones (16) do not
+  constexpr bool SWAPS = (C::NTAP % 2) == 1;
 
   dma_stage(0, 0);
   auto maybe_switch = [&](int st) {  // the DMA issued during stage st targets stage st+1
@@ -299,7 +301,7 @@ __global__ __launch_bounds__(256, 2) void conv_s3_kernel(const sfh_conv_desc d, 
       if (st + 1 < nst) {
         maybe_switch(st + 1);
         stage_barrier();
-        stage(st + 1, 1, std::true_type{});
+        stage(st + 1, 1, std::integral_constant<bool, SWAPS>{});
       }
     }
   } else {
@@ -315,7 +317,7 @@ __global__ __launch_bounds__(256, 2) void conv_s3_kernel(const sfh_conv_desc d, 
         __syncthreads();
         dma_stage(st + 1, 0);
         stage_barrier();
-        stage(st + 1, 0, std::true_type{});
+        stage(st + 1, 0, std::integral_constant<bool, SWAPS>{});
       }
       if (st + 2 < nst) {
         if (d.src1 && st + 2 == nst0) {
@@ -334,7 +336,7 @@ __global__ __launch_bounds__(256, 2) void conv_s3_kernel(const sfh_conv_desc d, 
 // packed[nb][stage][tap][plane 3][cout group 4][lane 64][j 8] bf16
 //   cout = nb*64 + ng*16 + (lane&15);  channel-in-source = stage_local*32 + 8*(lane>>4) + j
 __global__ void pack_s3_weights_kernel(const float* __restrict__ w, unsigned short* __restrict__ packed,
-                                       int ks, int c0, int c1, int coutv, int transposed, long total) {
+                                       int ks, int c0, int c1, int coutv, int transposed, int aux, long total) {
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;  // one (lane, j-octet, all planes)
   if (idx >= total) return;
   const int ntap = ks * ks;
@@ -354,7 +356,13 @@ __global__ void pack_s3_weights_kernel(const float* __restrict__ w, unsigned sho
     const int cl = (st < nst0 ? st : st - nst0) * 32 + 8 * (lane >> 4) + j;
     const int cin = st < nst0 ? cl : c0 + cl;
     float v;
-    if (transposed) {
+    if (transposed == 2) {  // 7x7 s2 stem as a 4x4 conv over the 2x2 space-to-depth input (aux = real cin)
+      const int csd = c0 >> 2;
+      const int par = cl / csd, c = cl - par * csd;
+      const int ky7 = 2 * ky + (par >> 1) - 1, kx7 = 2 * kx + (par & 1) - 1;
+      v = (c < aux && ky7 >= 0 && ky7 <= 6 && kx7 >= 0 && kx7 <= 6)
+              ? w[(((size_t)cv * aux + c) * 7 + ky7) * 7 + kx7] : 0.f;
+    } else if (transposed) {
       const int cout = coutv >> 2;
       const int qd = cv / cout, co = cv - qd * cout;
       v = w[(((size_t)cin * cout + co) * 2 + (qd >> 1)) * 2 + (qd & 1)];
@@ -412,8 +420,8 @@ __global__ void s3_to_f32_kernel(const unsigned short* __restrict__ src, float* 
 template <class C, bool DB>
 int launch_s3(const sfh_conv_desc& d, hipStream_t stream) {
   S3Geom g;
-  g.Ho = (d.H + 2 * C::PAD - C::KS) / C::STRIDE + 1;
-  g.Wo = (d.W + 2 * C::PAD - C::KS) / C::STRIDE + 1;
+  g.Ho = (d.H + C::PAD + C::PADA - C::KS) / C::STRIDE + 1;
+  g.Wo = (d.W + C::PAD + C::PADA - C::KS) / C::STRIDE + 1;
   g.tiles_x = sfh_cdiv(g.Wo, C::TW);
   if (C::FLATROWS) {
     int zr = C::PAD;
@@ -444,6 +452,12 @@ int launch_s3(const sfh_conv_desc& d, hipStream_t stream) {
   g.nb_fast = d.out_mode == SFH_OUT_UPSCATTER2;
   const long nblocks = (long)sfh_cdiv(g.ntiles, 8) * 8 * g.nblk_n;
   SFH_REQUIRE(nblocks < (1L << 31), "conv_s3: grid too large");
+  // small grids (at most ~one workgroup per CU anyway, e.g. ResNet layer3/4): the double-buffered
+  // variant overlaps each stage's DMA latency with the previous stage's MFMAs
+  if constexpr (!DB && C::LDS_BYTES <= 160 * 1024) {
+    static const char* force = getenv("SFH_DEBUG_S3_DB");
+    if (!force && nblocks <= 320) return launch_s3<C, true>(d, stream);
+  }
   // (an LDS-free variant for 1x1 / transposed convs that streams both operands straight into
   // registers was measured slower: 3.69 ms vs 2.96 ms per step for the four ConvTranspose launches)
   static bool attr_set = false;
@@ -460,22 +474,23 @@ int launch_s3(const sfh_conv_desc& d, hipStream_t stream) {
 }  // namespace
 
 extern "C" int64_t sfh_packed_s3_weight_bytes(int ksize, int c0, int c1, int cout_virtual) {
-  if ((ksize != 1 && ksize != 3) || c0 <= 0 || c0 % 32 || c1 < 0 || c1 % 32 || cout_virtual <= 0 ||
+  if ((ksize != 1 && ksize != 3 && ksize != 4) || c0 <= 0 || c0 % 32 || c1 < 0 || c1 % 32 || cout_virtual <= 0 ||
       cout_virtual % 64)
     return -1;
   return (int64_t)(cout_virtual / 64) * ((c0 + c1) / 32) * (ksize * ksize) * 3 * 4096;
 }
 
 extern "C" int sfh_pack_s3_weights(const float* w, void* packed, int ksize, int c0, int c1, int cout_virtual,
-                                   int mode, void* stream) {
+                                   int mode, int aux, void* stream) {
   const int64_t n = sfh_packed_s3_weight_bytes(ksize, c0, c1, cout_virtual);
   SFH_REQUIRE(n > 0, "pack_s3_weights: bad geometry ks=%d c0=%d c1=%d cout=%d", ksize, c0, c1, cout_virtual);
   SFH_REQUIRE(w && packed, "pack_s3_weights: null pointer");
-  SFH_REQUIRE(mode == 0 || (mode == 1 && ksize == 1 && c1 == 0 && cout_virtual % 256 == 0),
-              "pack_s3_weights: bad mode");
+  SFH_REQUIRE((mode == 0 && ksize != 4) || (mode == 1 && ksize == 1 && c1 == 0 && cout_virtual % 256 == 0) ||
+                  (mode == 2 && ksize == 4 && c1 == 0 && aux > 0 && aux <= c0 / 4),
+              "pack_s3_weights: bad mode/geometry (mode %d, ksize %d)", mode, ksize);
   const long total = n / 48;  // one thread per (lane, 8 channels) of all three planes
   hipLaunchKernelGGL(pack_s3_weights_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
-                     (hipStream_t)stream, w, (unsigned short*)packed, ksize, c0, c1, cout_virtual, mode, total);
+                     (hipStream_t)stream, w, (unsigned short*)packed, ksize, c0, c1, cout_virtual, mode, aux, total);
   return sfh_check_launch("pack_s3_weights_kernel");
 }
 
@@ -505,6 +520,8 @@ extern "C" int sfh_conv_s3_fwd(const sfh_conv_desc* dp, void* stream_) {
   SFH_REQUIRE(d.c0 > 0 && d.c0 % 32 == 0 && d.cs0 >= d.c0, "conv_s3_fwd: c0=%d must be a multiple of 32 (cs0=%d)", d.c0, d.cs0);
   SFH_REQUIRE(!d.pool0, "conv_s3_fwd: pool-on-load is not available for S3 sources (use the producer's dst_pool)");
   SFH_REQUIRE(d.h0 == d.H && d.w0 == d.W, "conv_s3_fwd: source 0 is %dx%d, frame is %dx%d", d.h0, d.w0, d.H, d.W);
+  SFH_REQUIRE(d.stride == 1 || (d.stride == 2 && !d.src1 && !d.dst_pool && d.out_mode == SFH_OUT_NHWC),
+              "conv_s3_fwd: stride 2 supports a single source, plain output");
   if (d.src1) {
     SFH_REQUIRE(d.c1 > 0 && d.c1 % 32 == 0 && d.cs1 >= d.c1, "conv_s3_fwd: c1=%d must be a multiple of 32", d.c1);
     SFH_REQUIRE(d.h1 > 0 && d.w1 > 0 && d.pad_top1 >= 0 && d.pad_left1 >= 0 && d.pad_top1 + d.h1 <= d.H &&
@@ -530,6 +547,18 @@ extern "C" int sfh_conv_s3_fwd(const sfh_conv_desc* dp, void* stream_) {
   SFH_S3CASE(1, 1, SFH_TILE_8x32, 1, 16, 8, 32)
   SFH_S3CASE(1, 1, SFH_TILE_16x16, 1, 16, 16, 16)
   SFH_S3CASE(1, 1, SFH_TILE_32x8, 2, 8, 32, 8)
+  // half-size tiles (8 pixel groups) for small feature maps: twice the workgroups
+  SFH_S3CASE(3, 1, SFH_TILE_8x16, 1, 16, 8, 16)
+  SFH_S3CASE(3, 1, SFH_TILE_16x8, 2, 8, 16, 8)
+  // 4x4 stem over the space-to-depth input
+  SFH_S3CASE(4, 1, SFH_TILE_8x32, 1, 16, 8, 32)
+  SFH_S3CASE(4, 1, SFH_TILE_16x16, 1, 16, 16, 16)
+  SFH_S3CASE(4, 1, SFH_TILE_32x8, 2, 8, 32, 8)
+  // stride 2 (ResNet stage transitions): 8-group tiles keep the halo within LDS
+  SFH_S3CASE(3, 2, SFH_TILE_8x16, 1, 16, 8, 16)
+  SFH_S3CASE(3, 2, SFH_TILE_16x8, 2, 8, 16, 8)
+  SFH_S3CASE(1, 2, SFH_TILE_8x16, 1, 16, 8, 16)
+  SFH_S3CASE(1, 2, SFH_TILE_16x8, 2, 8, 16, 8)
 #undef SFH_S3CASE
   sfh_set_error("conv_s3_fwd: unsupported ksize=%d stride=%d tile=%d", d.ksize, d.stride, d.tile);
   return SFH_E_ARG;

@@ -23,6 +23,18 @@ __global__ void nchw_to_nhwc_kernel(const float* __restrict__ src, float* __rest
   }
 }
 
+// uint8 HWC frames -> float32 CHW in [0,1]: the dataset's `img.transpose(2,0,1) / 255` then
+// FloatTensor (utils/dataset.py:154-159, :323-330) on the GPU; IEEE division, so identical bits.
+__global__ void u8hwc_to_f32nchw_kernel(const uint8_t* __restrict__ src, float* __restrict__ dst, int C, int HW,
+                                        long npix) {
+  const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= npix) return;
+  const long b = p / HW, i = p - b * HW;
+  const uint8_t* s = src + p * C;
+  float* d = dst + b * (long)C * HW + i;
+  for (int c = 0; c < C; ++c) d[(long)c * HW] = (float)s[c] / 255.0f;
+}
+
 __global__ void nhwc_to_nchw_kernel(const float* __restrict__ src, float* __restrict__ dst,
                                     int C, int HW, int cs, long npix) {
   const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -337,6 +349,14 @@ extern "C" int sfh_nchw_to_nhwc(const float* src, float* dst, int batch, int C, 
   hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0,
                      (hipStream_t)stream, src, dst, C, H * W, cs, npix);
   return sfh_check_launch("nchw_to_nhwc_kernel");
+}
+
+extern "C" int sfh_u8hwc_to_f32nchw(const uint8_t* src, float* dst, int batch, int C, int H, int W, void* stream) {
+  SFH_REQUIRE(src && dst && batch > 0 && C > 0 && H > 0 && W > 0, "u8hwc_to_f32nchw: bad argument");
+  const long npix = (long)batch * H * W;
+  hipLaunchKernelGGL(u8hwc_to_f32nchw_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0,
+                     (hipStream_t)stream, src, dst, C, H * W, npix);
+  return sfh_check_launch("u8hwc_to_f32nchw_kernel");
 }
 
 extern "C" int sfh_nhwc_to_nchw(const float* src, float* dst, int batch, int C, int H, int W, int cs,

@@ -56,8 +56,13 @@ def s3_empty(b, h, w, c, device):
     return torch.empty(s3_shape(b, h, w, c), dtype=torch.bfloat16, device=device)
 
 
+# half-size tiles of the split-bf16 kernel (8 pixel groups): small maps and stride 2
+_TILES_S3_HALF = ((_lib.TILE_8x16, 8, 16), (_lib.TILE_16x8, 16, 8))
+_WG_SLOTS = 512  # workgroups resident on the chip at two per CU
+
+
 def choose_tile(batch, ho, wo, stride, zrows=1):
-    """Pick the workgroup tile that wastes the fewest padded output pixels."""
+    """fp32 kernel: pick the workgroup tile that wastes the fewest padded output pixels."""
     best = None
     for tid, th, tw in _TILES:
         if stride == 2:
@@ -66,6 +71,29 @@ def choose_tile(batch, ho, wo, stride, zrows=1):
         else:
             ty = -(-(batch * (ho + zrows)) // th)  # flattened rows, `zrows` shared zero rows per frame
         cost = ty * th * (-(-wo // tw)) * tw
+        if best is None or cost < best[0]:
+            best = (cost, tid)
+    return best[1]
+
+
+def choose_tile_s3(batch, ho, wo, stride, zrows, nblk, ksize=3):
+    """split-bf16 kernel: estimated time = rounds of resident workgroups x pixels per tile; the
+    half-size tiles win when the full-size grid would leave most of the chip idle (ResNet layer3/4)
+    and are the only ones whose stride-2 halo fits LDS."""
+    best = None
+    if stride == 2:
+        cands = _TILES_S3_HALF
+    else:  # stride 1: full-size tiles (half-size tiles measured no faster on ResNet layer3/4)
+        cands = _TILES
+    for tid, th, tw in cands:
+        if stride == 2:
+            ty = batch * -(-ho // th)
+        else:
+            ty = -(-(batch * (ho + zrows)) // th)
+        ntiles = ty * (-(-wo // tw))
+        rounds = -(-(ntiles * nblk) // _WG_SLOTS)
+        # equal estimates: prefer the larger tile (less per-workgroup overhead, more operand reuse)
+        cost = (rounds * th * tw, ntiles * th * tw, -th * tw)
         if best is None or cost < best[0]:
             best = (cost, tid)
     return best[1]
@@ -129,13 +157,13 @@ class PackedConv:
             self.wpacked = torch.empty((self.cout // 64) * 9 * 256, dtype=torch.float32, device=dev)
             _lib.check(lib.sfh_pack_c4_weights(_ptr(w), _ptr(self.wpacked), c0, self.cout, _stream()), "pack_c4_weights")
         elif self.s3:
-            if stem_cin or stride != 1:
-                raise ValueError("the split-bf16 kernel covers ksize 1/3, stride 1")
+            if stem_cin:
+                mode, aux = 2, stem_cin
             n = lib.sfh_packed_s3_weight_bytes(ksize, c0, c1, self.cout)
             if n <= 0:
                 raise ValueError(f"unsupported S3 conv geometry ksize={ksize} c0={c0} c1={c1} cout={self.cout}")
             self.wpacked = torch.empty(n, dtype=torch.uint8, device=dev)
-            _lib.check(lib.sfh_pack_s3_weights(_ptr(w), _ptr(self.wpacked), ksize, c0, c1, self.cout, mode,
+            _lib.check(lib.sfh_pack_s3_weights(_ptr(w), _ptr(self.wpacked), ksize, c0, c1, self.cout, mode, aux,
                                                _stream()), "pack_s3_weights")
         else:
             n = lib.sfh_packed_weight_floats(ksize, c0, c1, self.cout)
@@ -188,7 +216,12 @@ class PackedConv:
         zr = self.ksize // 2
         if self.s3:  # even rows per frame (fused 2x2 pool windows never straddle a tile edge)
             zr += (ho + zr) & 1
-        d.tile = choose_tile(batch, ho, wo, self.stride, zr) if tile is None else tile
+        if tile is not None:
+            d.tile = tile
+        elif self.s3:
+            d.tile = choose_tile_s3(batch, ho, wo, self.stride, zr, self.cout // 64, self.ksize)
+        else:
+            d.tile = choose_tile(batch, ho, wo, self.stride, zr)
         d.wpacked, d.scale, d.shift = self.wpacked.data_ptr(), self.scale.data_ptr(), self.shift.data_ptr()
         d.cout, d.relu = self.cout, 1 if self.relu else 0
         d.residual = residual.data_ptr() if residual is not None else None
@@ -365,9 +398,8 @@ class ResNetEngine:
     """ResNetSTN forward (models/resnet.py:235-254) on the HIP kernels (BasicBlock depths)."""
 
     def __init__(self, rn, in_channels, device, precision="bf16x6"):
-        """precision "bf16x6": the stride-1 3x3 convs (29 of the 36 conv launches of ResNet34) run on
-        the split-bf16 kernel with S3 activations; stem, stride-2 and 1x1-downsample convs stay on the
-        fp32 kernel (reading an fp32 copy of the stage input, writing S3)."""
+        """precision "bf16x6": the 3x3 convs (stride 1 and 2) and the 1x1 stride-2 downsample convs run
+        on the split-bf16 kernel with S3 activations; the stem stays on the fp32 kernel."""
         if precision not in ("bf16x6", "fp32"):
             raise ValueError(f"precision={precision!r}: expected 'bf16x6' or 'fp32'")
         self.s3 = precision == "bf16x6"
@@ -379,6 +411,8 @@ class ResNetEngine:
         if (4 * self.cs_in) % 16:
             self.cs_in = -(-in_channels // 8) * 8
         L = {}
+        # the stem stays on the fp32 kernel: the 16-tap split-bf16 instance spills registers and
+        # measured 1.59 ms against 0.55 ms
         L["stem"] = PackedConv(rn.conv0.weight, None, rn.bn1, 4, 4 * self.cs_in, stem_cin=in_channels, tag="resnet")
         self.blocks = []
         for li in range(1, 5):
@@ -386,13 +420,13 @@ class ResNetEngine:
                 name = f"layer{li}.{bi}"
                 cin, planes = blk.conv1.in_channels, blk.conv1.out_channels
                 L[name + ".conv1"] = PackedConv(blk.conv1.weight, None, blk.bn1, 3, cin, stride=blk.stride, tag="resnet",
-                                                s3=s3 and blk.stride == 1)
+                                                s3=s3)
                 L[name + ".conv2"] = PackedConv(blk.conv2.weight, None, blk.bn2, 3, planes, tag="resnet",
                                                 s3=s3)  # ReLU after the residual add
                 if blk.downsample is not None:
                     ds = blk.downsample
                     L[name + ".down"] = PackedConv(ds[0].weight, None, ds[1], 1, cin, relu=False, stride=blk.stride,
-                                                   tag="resnet")
+                                                   tag="resnet", s3=s3)
                 self.blocks.append((name, cin, planes, blk.stride, blk.downsample is not None))
         self.L = L
         self.reg_w = _f32c(rn.reg.weight.detach(), "reg.weight")
@@ -408,6 +442,10 @@ class ResNetEngine:
         s2d = ws.get("s2d", (B, H2, W2, 4 * self.cs_in))
         _lib.check(lib.sfh_space_to_depth2(_ptr(y_nhwc), _ptr(s2d), B, H, W, self.cs_in, st), "space_to_depth2")
         c1 = ws.get("stem", (B, H2, W2, 64))
+        if L["stem"].s3:
+            s2d3 = ws.get("s2d.s3", s3_shape(B, H2, W2, 4 * self.cs_in), torch.bfloat16)
+            _lib.check(lib.sfh_f32_to_s3(_ptr(s2d), _ptr(s2d3), B * H2, W2, 4 * self.cs_in, st), "f32_to_s3")
+            s2d = s2d3
         L["stem"].run(s2d, B, H2, W2, c1)
         h, w = (H2 - 1) // 2 + 1, (W2 - 1) // 2 + 1
         x = ws.get("pool", (B, h, w, 64))
@@ -426,9 +464,6 @@ class ResNetEngine:
         for name, cin, planes, stride, has_down in self.blocks:
             ho, wo = (h - 1) // stride + 1, (w - 1) // stride + 1
             src = x
-            if s3 and stride != 1:  # fp32 copy of the stage input for the two stride-2 fp32 launches
-                src = ws.get(name + ".xf", (B, h, w, cin))
-                _lib.check(lib.sfh_s3_to_f32(_ptr(x), _ptr(src), B * h, w, cin, st), "s3_to_f32")
             t = act(name + ".t", ho, wo, planes)
             L[name + ".conv1"].run(src, B, h, w, t)
             if has_down:
@@ -467,6 +502,19 @@ def f32_to_s3(t):
     B, H, W, C = t.shape
     out = s3_empty(B, H, W, C, t.device)
     _lib.check(lib.sfh_f32_to_s3(_ptr(t), _ptr(out), B * H, W, C, _stream()), "f32_to_s3")
+    return out
+
+
+def frames_u8_to_input(frames_u8):
+    """uint8 (B,H,W,C) decoded frames on the GPU -> float32 (B,C,H,W) in [0,1], bit-identical to the
+    reference dataset's `img.transpose((2,0,1)) / 255` (utils/dataset.py:154-159)."""
+    lib = _lib.load()
+    if frames_u8.dtype != torch.uint8 or frames_u8.dim() != 4 or not frames_u8.is_cuda:
+        raise ValueError("expected a uint8 (B,H,W,C) tensor on the GPU")
+    f = frames_u8.contiguous()
+    B, H, W, C = f.shape
+    out = torch.empty((B, C, H, W), dtype=torch.float32, device=f.device)
+    _lib.check(lib.sfh_u8hwc_to_f32nchw(_ptr(f), _ptr(out), B, C, H, W, _stream()), "u8hwc_to_f32nchw")
     return out
 
 

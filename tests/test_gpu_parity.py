@@ -83,7 +83,7 @@ def _run_double_conv_s3(E, block, x_nhwc, B, H, W, c0, src1=None, c1=0, pad1=(0,
     return out, pooled
 
 
-@pytest.mark.parametrize("tile", [None, 0, 1, 2])
+@pytest.mark.parametrize("tile", [None, 0, 1, 2, 3, 4])
 def test_double_conv_s3_golden(E, golden_blocks, tile):
     g = golden_blocks
     m, _ = _mods_to_cuda(modules.DoubleConv(64, 128, 64), 12)
@@ -156,6 +156,35 @@ def test_outconv_argmax_golden(E, golden_blocks):
     torch.cuda.synchronize()
     assert _maxerr(logits.cpu(), g["outc_64_4.y"]) < 1e-5
     assert torch.equal(am.cpu(), torch_ref.preds_to_masks(logits.cpu()))
+
+
+@pytest.mark.parametrize("hw", [(24, 40), (22, 37), (45, 80)])
+def test_conv_variants_s3_vs_oracle(E, hw):
+    """the same ResNet block shapes on the split-bf16 kernel: stride-2 3x3 and 1x1, S3 residual."""
+    H, W = hw
+    blk = modules.BasicBlock(64, 128, 2, torch.nn.Sequential(torch.nn.Conv2d(64, 128, 1, stride=2, bias=False),
+                                                             torch.nn.BatchNorm2d(128)))
+    blk, sd = _mods_to_cuda(blk, 21)
+    sd = {"b." + k: v for k, v in sd.items()}
+    x = torch.from_numpy(synth._rng(21, f"x{H}x{W}").uniform(-1, 1, (2, 64, H, W)).astype(np.float32))
+    want = torch_ref._basic_block(x, sd, "b", 2)
+    xs = E.f32_to_s3(_nhwc(x))
+    ho, wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    c1 = E.PackedConv(blk.conv1.weight, None, blk.bn1, 3, 64, stride=2, s3=True)
+    c2 = E.PackedConv(blk.conv2.weight, None, blk.bn2, 3, 128, s3=True)
+    dn = E.PackedConv(blk.downsample[0].weight, None, blk.downsample[1], 1, 64, relu=False, stride=2, s3=True)
+    t = E.s3_empty(2, ho, wo, 128, "cuda")
+    idn = E.s3_empty(2, ho, wo, 128, "cuda")
+    out = torch.empty((2, ho, wo, 128), device="cuda")
+    c1.run(xs, 2, H, W, t)
+    dn.run(xs, 2, H, W, idn)
+    c2.run(t, 2, ho, wo, out, residual=None)
+    torch.cuda.synchronize()
+    # residual add in S3 needs an S3 destination: run conv2 once more into S3 with the residual
+    out3 = E.s3_empty(2, ho, wo, 128, "cuda")
+    c2.run(t, 2, ho, wo, out3, residual=idn)
+    torch.cuda.synchronize()
+    assert _maxerr(_nchw(E.s3_to_f32(out3)), want) < 5e-5
 
 
 @pytest.mark.parametrize("hw", [(24, 40), (22, 37), (45, 80)])
@@ -418,6 +447,15 @@ def test_bilinear_unet_and_resize_paths(E, precision):
     m = torch.nn.functional.interpolate(wm.unsqueeze(1), size=(96, 128), mode="nearest").squeeze(1)
     ce = torch.nn.functional.cross_entropy(out["logits"].cpu(), m.long(), reduction="none").mean(dim=(1, 2))
     assert _maxerr(out["consist_score"].cpu(), ce) < 1e-4
+
+
+def test_u8_frame_preprocessing_matches_dataset(E):
+    fr = synth.synth_frames_u8(3, 45, 80, seed=7)
+    want = torch.from_numpy((fr.transpose(0, 3, 1, 2) / 255)).type(torch.FloatTensor)   # utils/dataset.py:154-159
+    got = E.frames_u8_to_input(torch.from_numpy(fr).cuda())
+    torch.cuda.synchronize()
+    assert torch.equal(got.cpu(), want)
+    assert torch.equal(synth.frames_to_float(fr), want)
 
 
 def test_model_api_errors(E):
