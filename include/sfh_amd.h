@@ -197,6 +197,14 @@ int64_t sfh_ce_workspace_floats(int batch, int H, int W);
 int sfh_consistency_ce_fwd(const float* logits, const int32_t* mask, int batch, int nc, int H,
                            int W, int hm, int wm, float* partial, float* score, void* stream);
 
+/* Output masks as predict.py writes them (predict.py:286-315; utils/postprocess.py:7-61):
+ * src is int32 class ids (src_kind 0, e.g. predict()'s warp_mask), uint8 ids (1) or fp32 logits
+ * NCHW (2: argmax over nc classes, first maximum wins); nearest resize (hs,ws)->(hd,wd) with
+ * OpenCV's INTER_NEAREST index rule; mode 0 gray (ids), 1 bin ((id>0)*255), 2 rgb (palette:
+ * HOST pointer to 8x3 bytes, colour of class k at palette[3k..3k+2]; out is (B,hd,wd,3)).   */
+int sfh_mask_format_fwd(const void* src, int src_kind, int nc, int batch, int hs, int ws, int hd,
+                        int wd, int mode, const uint8_t* palette, uint8_t* out, void* stream);
+
 /* ResNetSTN pieces (models/resnet.py:235-254). */
 /* MaxPool2d(kernel 3, stride 2, padding 1) on NHWC (B,H,W,C) -> (B,Ho,Wo,C). */
 int sfh_maxpool3x3s2_fwd(const float* x, float* y, int batch, int H, int W, int C, void* stream);

@@ -115,10 +115,10 @@ def _loaded(mod, seed):
 def make_block_goldens(up_mod, rn_mod):
     out = {}
     with torch.no_grad():
-        # key layouts of the three UNet variants + resnet18/34
+        # key layouts of the three UNet variants + resnet18/34/50
         layouts = {}
         for tag, kw in [("default", {}), ("bilinear", {"bilinear": True}), ("uv", {"uv": True}),
-                        ("resnet18", {"resnet": "resnet18"})]:
+                        ("resnet18", {"resnet": "resnet18"}), ("resnet50", {"resnet": "resnet50"})]:
             net = _RefNet(up_mod, rn_mod, **kw)
             layouts[tag] = [[k, list(v.shape), str(v.dtype)] for k, v in net.state_dict().items()]
         json.dump(layouts, open(os.path.join(GOLD, "state_dict_layouts.json"), "w"))
@@ -156,6 +156,12 @@ def make_block_goldens(up_mod, rn_mod):
         out["resnet34_7.x"], out["resnet34_7.theta"] = x.numpy(), m(x).numpy()
         m = _loaded(rn_mod.resnet_stn("resnet18", None, 7), 18)
         out["resnet18_7.theta"] = m(x).numpy()
+        # Bottleneck depths: resnet50 through the reference factory; the wide variant through
+        # _make_resnet (its named constructor does not accept in_channels, models/resnet.py:339-355)
+        m = _loaded(rn_mod.resnet_stn("resnet50", None, 7), 19)
+        out["resnet50_7.theta"] = m(x).numpy()
+        m = _loaded(rn_mod._make_resnet(rn_mod.Bottleneck, [3, 4, 6, 3], None, 7, width_per_group=128), 20)
+        out["wide_resnet50_2_7.theta"] = m(x).numpy()
 
         # whole UNet + STN with the real channel plan on a small odd-sized frame
         net = _loaded(_RefNet(up_mod, rn_mod), 19)

@@ -1,0 +1,46 @@
+"""CPU restatement of the reference's mask post-processing (test infrastructure only).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this package.
+Follows utils/postprocess.py:7-61 and predict.py:286-315.  OpenCV is absent in this image, so
+the INTER_NEAREST index rule is restated from OpenCV's published resizeNN
+(sx = min(floor(dx * (1/fx)), ws-1), fx = wd/ws evaluated in double): parity unpinned for that rule.
+"""
+import numpy as np
+
+_COLOURS = {1: (0, 255, 0), 2: (255, 0, 0), 3: (0, 0, 255), 4: (255, 255, 255), 5: (255, 0, 255),
+            6: (0, 255, 255), 7: (255, 255, 0)}
+
+
+def onehot_to_image(masks, n_classes=4):
+    """utils/postprocess.py:21-61."""
+    if n_classes not in (4, 7, 8):
+        raise NotImplementedError
+    if masks.ndim == 2:
+        masks = masks[None]
+    rgb = np.zeros(masks.shape + (3,), dtype=np.uint8)
+    for k in range(1, n_classes):
+        rgb[masks == k] = _COLOURS[k]
+    return rgb
+
+
+def resize_nearest(img, out_size):
+    """cv2.resize(img, (wd, hd), interpolation=cv2.INTER_NEAREST) on an (H,W[,C]) array."""
+    wd, hd = out_size
+    hs, ws = img.shape[:2]
+    ifx, ify = 1.0 / (wd / ws), 1.0 / (hd / hs)
+    sx = np.minimum(np.floor(np.arange(wd) * ifx).astype(np.int64), ws - 1)
+    sy = np.minimum(np.floor(np.arange(hd) * ify).astype(np.int64), hs - 1)
+    return img[sy][:, sx]
+
+
+def format_masks(ids, mask_type, n_classes, out_size):
+    """predict.py:286-315 on a uint8 id mask batch (B,H,W)."""
+    if mask_type == "rgb":
+        m = onehot_to_image(ids, n_classes)
+    elif mask_type == "bin":
+        m = ((ids > 0) * 255).astype(np.uint8)
+    elif mask_type == "gray":
+        m = ids
+    else:
+        raise NotImplementedError
+    return np.stack([resize_nearest(x, out_size) for x in m], axis=0)

@@ -96,6 +96,16 @@ def _basic_block(x, sd, p, stride):
     return F.relu(out + x)
 
 
+def _bottleneck(x, sd, p, stride):
+    """models/resnet.py:120-140 (stride on the 3x3 conv)."""
+    out = F.relu(_bn(F.conv2d(x, sd[p + ".conv1.weight"], None), sd, p + ".bn1"))
+    out = F.relu(_bn(F.conv2d(out, sd[p + ".conv2.weight"], None, stride=stride, padding=1), sd, p + ".bn2"))
+    out = _bn(F.conv2d(out, sd[p + ".conv3.weight"], None), sd, p + ".bn3")
+    if p + ".downsample.0.weight" in sd:
+        x = _bn(F.conv2d(x, sd[p + ".downsample.0.weight"], None, stride=stride), sd, p + ".downsample.1")
+    return F.relu(out + x)
+
+
 def resnet_stn(y, sd, p="resnet_reg", layers=(3, 4, 6, 3)):
     """models/resnet.py:235-254 - stem 7x7 s2, maxpool 3 s2 p1, 4 stages, avgpool, Linear -> (B,1,3,3)."""
     x = F.relu(_bn(F.conv2d(y, sd[p + ".conv0.weight"], None, stride=2, padding=3), sd, p + ".bn1"))
@@ -103,7 +113,8 @@ def resnet_stn(y, sd, p="resnet_reg", layers=(3, 4, 6, 3)):
     for li, n in enumerate(layers, start=1):
         for bi in range(n):
             stride = 2 if (li > 1 and bi == 0) else 1
-            x = _basic_block(x, sd, f"{p}.layer{li}.{bi}", stride)
+            bp = f"{p}.layer{li}.{bi}"
+            x = (_bottleneck if bp + ".conv3.weight" in sd else _basic_block)(x, sd, bp, stride)
     x = torch.flatten(F.adaptive_avg_pool2d(x, (1, 1)), 1)
     x = F.linear(x, sd[p + ".reg.weight"], sd[p + ".reg.bias"])
     return x.view(-1, 1, 3, 3)

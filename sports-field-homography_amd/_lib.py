@@ -60,6 +60,8 @@ SIGNATURES = {
     "sfh_ce_workspace_floats": (C.c_int64, [C.c_int, C.c_int, C.c_int]),
     "sfh_consistency_ce_fwd": (C.c_int, [_p, _p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                          _p, _p, _p]),
+    "sfh_mask_format_fwd": (C.c_int, [_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                      C.c_int, _p, _p, _p]),
     "sfh_maxpool3x3s2_fwd": (C.c_int, [_p, _p, C.c_int, C.c_int, C.c_int, C.c_int, _p]),
     "sfh_avgpool_linear_fwd": (C.c_int, [_p, _p, _p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _p, _p]),
 }

@@ -339,6 +339,64 @@ __global__ __launch_bounds__(256) void avgpool_linear_kernel(
   }
 }
 
+// ----------------------------------------------------------------- mask output formatting
+// Class-id masks -> the uint8 images predict.py writes (predict.py:286-315): source is either
+// logits NCHW (argmax = utils/postprocess.py:7-18), an int32 warp_mask or a uint8 id mask;
+// nearest resize to (hd, wd) with OpenCV's INTER_NEAREST index rule (sx = min(floor(dx * (1/fx)),
+// ws-1), fx = wd/ws in double), then mask_type gray (ids) / bin ((id>0)*255) / rgb (the colour
+// table of utils/postprocess.py:21-61, 3 bytes per pixel).  One thread = 4 output pixels of a row.
+struct MaskPalette {
+  uint8_t c[8][3];
+};
+
+template <int KIND>  // 0: int32 ids, 1: uint8 ids, 2: fp32 logits NCHW
+__device__ __forceinline__ int mask_id_at(const void* __restrict__ src, long b, int nc, int hs, int ws, int sy, int sx) {
+  if (KIND == 0) return ((const int32_t*)src)[(b * hs + sy) * ws + sx];
+  if (KIND == 1) return ((const uint8_t*)src)[(b * hs + sy) * ws + sx];
+  const float* lg = (const float*)src + (b * nc * hs + sy) * (long)ws + sx;
+  const long plane = (long)hs * ws;
+  int best = 0;
+  float bv = lg[0];
+  for (int k = 1; k < nc; ++k) {
+    const float v = lg[k * plane];
+    if (v > bv) { bv = v; best = k; }
+  }
+  return best;
+}
+
+template <int KIND>
+__global__ __launch_bounds__(256) void mask_format_kernel(const void* __restrict__ src, int nc, int hs, int ws,
+                                                          int hd, int wd, double ify, double ifx, int mode,
+                                                          MaskPalette pal, uint8_t* __restrict__ out, long total4) {
+  const long t = (long)blockIdx.x * 256 + threadIdx.x;
+  if (t >= total4) return;
+  const int wq = (wd + 3) >> 2;
+  const int xq = (int)(t % wq) * 4;
+  const long r = t / wq;
+  const int dy = (int)(r % hd);
+  const long b = r / hd;
+  const int sy = min((int)floor((double)dy * ify), hs - 1);
+  const int nb = mode == 2 ? 3 : 1;
+  uint8_t* o = out + ((b * hd + dy) * (long)wd + xq) * nb;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int dx = xq + j;
+    if (dx >= wd) break;
+    const int sx = min((int)floor((double)dx * ifx), ws - 1);
+    const int id = mask_id_at<KIND>(src, b, nc, hs, ws, sy, sx);
+    if (mode == 0) {
+      o[j] = (uint8_t)id;
+    } else if (mode == 1) {
+      o[j] = id > 0 ? 255 : 0;
+    } else {
+      const int k = (id >= 0 && id < 8) ? id : 0;
+      o[3 * j + 0] = pal.c[k][0];
+      o[3 * j + 1] = pal.c[k][1];
+      o[3 * j + 2] = pal.c[k][2];
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" int sfh_nchw_to_nhwc(const float* src, float* dst, int batch, int C, int H, int W, int cs,
@@ -476,4 +534,29 @@ extern "C" int sfh_avgpool_linear_fwd(const float* x, const float* w, const floa
   hipLaunchKernelGGL(avgpool_linear_kernel, dim3((unsigned)batch), dim3(256), (size_t)C * sizeof(float),
                      (hipStream_t)stream, x, w, bias, H * W, C, nout, out);
   return sfh_check_launch("avgpool_linear_kernel");
+}
+
+extern "C" int sfh_mask_format_fwd(const void* src, int src_kind, int nc, int batch, int hs, int ws,
+                                   int hd, int wd, int mode, const uint8_t* palette, uint8_t* out,
+                                   void* stream) {
+  SFH_REQUIRE(src && out && batch > 0 && hs > 0 && ws > 0 && hd > 0 && wd > 0, "mask_format: bad argument");
+  SFH_REQUIRE(src_kind >= 0 && src_kind <= 2, "mask_format: src_kind %d (0 int32 ids, 1 uint8 ids, 2 logits)", src_kind);
+  SFH_REQUIRE(mode >= 0 && mode <= 2, "mask_format: mode %d (0 gray, 1 bin, 2 rgb)", mode);
+  SFH_REQUIRE(src_kind != 2 || nc >= 2, "mask_format: logits need nc >= 2");
+  SFH_REQUIRE(mode != 2 || palette, "mask_format: rgb mode needs a palette of 8x3 bytes");
+  MaskPalette pal = {};
+  if (palette)
+    for (int k = 0; k < 8; ++k)
+      for (int c = 0; c < 3; ++c) pal.c[k][c] = palette[k * 3 + c];  // host pointer, copied by value
+  const double ify = 1.0 / ((double)hd / (double)hs), ifx = 1.0 / ((double)wd / (double)ws);
+  const long total4 = (long)batch * hd * ((wd + 3) / 4);
+  const dim3 grid((unsigned)((total4 + 255) / 256));
+#define SFH_MF(K)                                                                                   \
+  hipLaunchKernelGGL(mask_format_kernel<K>, grid, dim3(256), 0, (hipStream_t)stream, src, nc, hs, ws, hd, \
+                     wd, ify, ifx, mode, pal, out, total4)
+  if (src_kind == 0) SFH_MF(0);
+  else if (src_kind == 1) SFH_MF(1);
+  else SFH_MF(2);
+#undef SFH_MF
+  return sfh_check_launch("mask_format_kernel");
 }

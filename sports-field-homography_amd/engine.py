@@ -395,7 +395,7 @@ class UNetEngine:
 
 
 class ResNetEngine:
-    """ResNetSTN forward (models/resnet.py:235-254) on the HIP kernels (BasicBlock depths)."""
+    """ResNetSTN forward (models/resnet.py:235-254) on the HIP kernels (BasicBlock and Bottleneck depths)."""
 
     def __init__(self, rn, in_channels, device, precision="bf16x6"):
         """precision "bf16x6": the 3x3 convs (stride 1 and 2) and the 1x1 stride-2 downsample convs run
@@ -418,16 +418,25 @@ class ResNetEngine:
         for li in range(1, 5):
             for bi, blk in enumerate(getattr(rn, f"layer{li}")):
                 name = f"layer{li}.{bi}"
-                cin, planes = blk.conv1.in_channels, blk.conv1.out_channels
-                L[name + ".conv1"] = PackedConv(blk.conv1.weight, None, blk.bn1, 3, cin, stride=blk.stride, tag="resnet",
-                                                s3=s3)
-                L[name + ".conv2"] = PackedConv(blk.conv2.weight, None, blk.bn2, 3, planes, tag="resnet",
-                                                s3=s3)  # ReLU after the residual add
+                cin = blk.conv1.in_channels
+                if hasattr(blk, "conv3"):  # Bottleneck (models/resnet.py:120-140): 1x1, 3x3 (stride), 1x1
+                    width, cout = blk.conv1.out_channels, blk.conv3.out_channels
+                    L[name + ".conv1"] = PackedConv(blk.conv1.weight, None, blk.bn1, 1, cin, tag="resnet", s3=s3)
+                    L[name + ".conv2"] = PackedConv(blk.conv2.weight, None, blk.bn2, 3, width, stride=blk.stride,
+                                                    tag="resnet", s3=s3)
+                    L[name + ".conv3"] = PackedConv(blk.conv3.weight, None, blk.bn3, 1, width, tag="resnet",
+                                                    s3=s3)  # ReLU after the residual add
+                else:  # BasicBlock (models/resnet.py:64-82)
+                    width = cout = blk.conv1.out_channels
+                    L[name + ".conv1"] = PackedConv(blk.conv1.weight, None, blk.bn1, 3, cin, stride=blk.stride,
+                                                    tag="resnet", s3=s3)
+                    L[name + ".conv2"] = PackedConv(blk.conv2.weight, None, blk.bn2, 3, width, tag="resnet",
+                                                    s3=s3)  # ReLU after the residual add
                 if blk.downsample is not None:
                     ds = blk.downsample
                     L[name + ".down"] = PackedConv(ds[0].weight, None, ds[1], 1, cin, relu=False, stride=blk.stride,
                                                    tag="resnet", s3=s3)
-                self.blocks.append((name, cin, planes, blk.stride, blk.downsample is not None))
+                self.blocks.append((name, width, cout, blk.stride, blk.downsample is not None, hasattr(blk, "conv3")))
         self.L = L
         self.reg_w = _f32c(rn.reg.weight.detach(), "reg.weight")
         self.reg_b = _f32c(rn.reg.bias.detach(), "reg.bias")
@@ -461,18 +470,24 @@ class ResNetEngine:
             xs = act("pool.s3", h, w, 64)
             _lib.check(lib.sfh_f32_to_s3(_ptr(x), _ptr(xs), B * h, w, 64, st), "f32_to_s3")
             x = xs
-        for name, cin, planes, stride, has_down in self.blocks:
+        for name, width, cout, stride, has_down, bottleneck in self.blocks:
             ho, wo = (h - 1) // stride + 1, (w - 1) // stride + 1
-            src = x
-            t = act(name + ".t", ho, wo, planes)
-            L[name + ".conv1"].run(src, B, h, w, t)
             if has_down:
-                idn = act(name + ".idn", ho, wo, planes)
-                L[name + ".down"].run(src, B, h, w, idn)
+                idn = act(name + ".idn", ho, wo, cout)
+                L[name + ".down"].run(x, B, h, w, idn)
             else:
                 idn = x
-            out = act(name + ".out", ho, wo, planes)
-            L[name + ".conv2"].run(t, B, ho, wo, out, residual=idn)
+            out = act(name + ".out", ho, wo, cout)
+            if bottleneck:
+                t1 = act(name + ".t1", h, w, width)
+                L[name + ".conv1"].run(x, B, h, w, t1)
+                t2 = act(name + ".t2", ho, wo, width)
+                L[name + ".conv2"].run(t1, B, h, w, t2)
+                L[name + ".conv3"].run(t2, B, ho, wo, out, residual=idn)
+            else:
+                t = act(name + ".t", ho, wo, width)
+                L[name + ".conv1"].run(x, B, h, w, t)
+                L[name + ".conv2"].run(t, B, ho, wo, out, residual=idn)
             x, h, w = out, ho, wo
         if s3:
             xf = ws.get("final.f32", (B, h, w, _chan(x)))

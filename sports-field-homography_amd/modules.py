@@ -99,23 +99,58 @@ class BasicBlock(_NoForward):
         self.stride = stride
 
 
-_RESNET_LAYERS = {"resnet18": (2, 2, 2, 2), "resnet34": (3, 4, 6, 3)}
+class Bottleneck(_NoForward):
+    """1x1 -> 3x3 (carries the stride) -> 1x1 (x4 channels) + BN, residual add
+    (reference: models/resnet.py:85-140, the "ResNet V1.5" placement of the stride)."""
+
+    expansion = 4
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None, base_width=64):
+        super().__init__()
+        width = int(planes * (base_width / 64.0))
+        self.conv1 = nn.Conv2d(inplanes, width, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(width)
+        self.conv2 = nn.Conv2d(width, width, 3, stride=stride, padding=1, bias=False)
+        self.bn2 = nn.BatchNorm2d(width)
+        self.conv3 = nn.Conv2d(width, planes * self.expansion, 1, bias=False)
+        self.bn3 = nn.BatchNorm2d(planes * self.expansion)
+        self.relu = nn.ReLU(inplace=True)
+        self.downsample = downsample
+        self.stride = stride
+
+
+# name -> (block, blocks per stage, width_per_group); reference table models/resnet.py:361-371
+# ('resnet52' is the reference's key for its ResNet-152 constructor).  Through the reference's
+# factory only resnet18/34/50 are constructible with an explicit in_channels (the deeper and wide
+# constructors do not take that argument, models/resnet.py:297-355); they are accepted here.
+_RESNET_VARIANTS = {
+    "resnet18": (BasicBlock, (2, 2, 2, 2), 64),
+    "resnet34": (BasicBlock, (3, 4, 6, 3), 64),
+    "resnet50": (Bottleneck, (3, 4, 6, 3), 64),
+    "resnet101": (Bottleneck, (3, 4, 23, 3), 64),
+    "resnet52": (Bottleneck, (3, 8, 36, 3), 64),
+    "resnet152": (Bottleneck, (3, 8, 36, 3), 64),
+    "wide_resnet50_2": (Bottleneck, (3, 4, 6, 3), 128),
+    "wide_resnet101_2": (Bottleneck, (3, 4, 23, 3), 128),
+}
+_RESNET_LAYERS = {k: v[1] for k, v in _RESNET_VARIANTS.items()}
 
 
 class ResNetSTN(_NoForward):
     """ResNet regressor that emits a 3x3 homography (reference: models/resnet.py:143-257).
 
-    Only the BasicBlock depths (resnet18/34) are implemented on the HIP path; the
-    Bottleneck variants of the reference (models/resnet.py:285-371) are SURVEY.md §8 row f4.
+    BasicBlock and Bottleneck depths run on the HIP path; the grouped-convolution ResNeXt
+    variants (models/resnet.py:318-337) do not.
     """
 
     def __init__(self, name="resnet34", in_channels=4):
         super().__init__()
-        if name not in _RESNET_LAYERS:
+        if name not in _RESNET_VARIANTS:
             raise NotImplementedError(
-                f"resnet_name={name!r}: only {sorted(_RESNET_LAYERS)} run on the HIP path"
+                f"resnet_name={name!r}: only {sorted(_RESNET_VARIANTS)} run on the HIP path "
+                "(ResNeXt needs grouped convolutions)"
             )
-        layers = _RESNET_LAYERS[name]
+        self.block, layers, self.base_width = _RESNET_VARIANTS[name]
         self.inplanes = 64
         self.conv0 = nn.Conv2d(in_channels, 64, kernel_size=7, stride=2, padding=3, bias=False)
         self.bn1 = nn.BatchNorm2d(64)
@@ -126,19 +161,20 @@ class ResNetSTN(_NoForward):
         self.layer3 = self._stage(256, layers[2], 2)
         self.layer4 = self._stage(512, layers[3], 2)
         self.avgpool = nn.AdaptiveAvgPool2d((1, 1))
-        self.reg = nn.Linear(512, 9)
+        self.reg = nn.Linear(512 * self.block.expansion, 9)
         self._init_weights()
 
     def _stage(self, planes, blocks, stride):
+        block, kw = self.block, ({} if self.block is BasicBlock else {"base_width": self.base_width})
         down = None
-        if stride != 1 or self.inplanes != planes:
+        if stride != 1 or self.inplanes != planes * block.expansion:
             down = nn.Sequential(
-                nn.Conv2d(self.inplanes, planes, 1, stride=stride, bias=False),
-                nn.BatchNorm2d(planes),
+                nn.Conv2d(self.inplanes, planes * block.expansion, 1, stride=stride, bias=False),
+                nn.BatchNorm2d(planes * block.expansion),
             )
-        mods = [BasicBlock(self.inplanes, planes, stride, down)]
-        self.inplanes = planes
-        mods += [BasicBlock(planes, planes) for _ in range(1, blocks)]
+        mods = [block(self.inplanes, planes, stride, down, **kw)]
+        self.inplanes = planes * block.expansion
+        mods += [block(self.inplanes, planes, **kw) for _ in range(1, blocks)]
         return nn.Sequential(*mods)
 
     def _init_weights(self):

@@ -38,6 +38,8 @@ def _fill(seed, name, shape):
         return g.uniform(0.5, 1.5, shape).astype(np.float32)
     if len(shape) == 1:
         if leaf == "weight":  # BatchNorm gamma
+            if ("resnet_reg" in name or name.startswith("layer")) and ".bn3." in name:
+                return g.uniform(0.1, 0.3, shape).astype(np.float32)  # Bottleneck's last BN
             if "resnet_reg" in name and ".bn2." in name:
                 # small residual-branch gain keeps the 16 un-normalised residual adds bounded
                 return g.uniform(0.1, 0.3, shape).astype(np.float32)

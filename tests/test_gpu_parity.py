@@ -215,11 +215,12 @@ def test_conv_variants_vs_oracle(E, hw):
 
 # ---------------------------------------------------------------- ResNet-STN
 @pytest.mark.parametrize("precision", ["bf16x6", "fp32"])
-@pytest.mark.parametrize("name,key,layers", [("resnet34", "resnet34_7.theta", (3, 4, 6, 3)),
-                                             ("resnet18", "resnet18_7.theta", (2, 2, 2, 2))])
-def test_resnet_stn_golden(E, golden_blocks, name, key, layers, precision):
+@pytest.mark.parametrize("name,key,seed", [("resnet34", "resnet34_7.theta", 17), ("resnet18", "resnet18_7.theta", 18),
+                                           ("resnet50", "resnet50_7.theta", 19),
+                                           ("wide_resnet50_2", "wide_resnet50_2_7.theta", 20)])
+def test_resnet_stn_golden(E, golden_blocks, name, key, seed, precision):
     g = golden_blocks
-    rn, _ = _mods_to_cuda(modules.ResNetSTN(name, 7), 17 if name == "resnet34" else 18)
+    rn, _ = _mods_to_cuda(modules.ResNetSTN(name, 7), seed)
     x = torch.from_numpy(g["resnet34_7.x"])
     eng = E.ResNetEngine(rn, 7, torch.device("cuda"), precision)
     y = E.nchw_to_nhwc(x.cuda(), 8)
@@ -447,6 +448,27 @@ def test_bilinear_unet_and_resize_paths(E, precision):
     m = torch.nn.functional.interpolate(wm.unsqueeze(1), size=(96, 128), mode="nearest").squeeze(1)
     ce = torch.nn.functional.cross_entropy(out["logits"].cpu(), m.long(), reduction="none").mean(dim=(1, 2))
     assert _maxerr(out["consist_score"].cpu(), ce) < 1e-4
+
+
+def test_predict_resnet50_variant(E):
+    """resnet_name='resnet50' (Bottleneck blocks, models/resnet.py:85-140) end to end."""
+    from sfh_amd.reconstructor import Reconstructor
+    B = 2
+    court = synth.load_court_template("ncaa_nc4_640x360", 4, B)[:, :, :90, :112].contiguous()
+    poi = synth.load_court_poi("pitch", B)
+    net = Reconstructor(court.cuda(), poi.cuda(), target_size=(112, 90), unet_size=(112, 90), warp_size=(112, 90),
+                        warp_with_nearest=True, resnet_name="resnet50")
+    sd = synth.synth_state_dict(net.state_dict(), 31)
+    net.load_state_dict(sd)
+    net.cuda().eval()
+    x = synth.smooth_frames(B, 90, 112, seed=31)
+    with torch.no_grad():
+        out = net.predict(x.cuda(), consistency=False)
+        logits, _, _ = torch_ref.forward_unet(x, sd, (112, 90), (112, 90))
+        theta = torch_ref.resnet_stn(torch.cat((logits, x), 1), sd)
+    assert _maxerr(out["theta"].cpu(), theta) < 1e-4
+    wm = (warp_ref.homography_warp(out["theta"].cpu(), court, 90, 112, "nearest") * 4)
+    assert torch.equal(out["warp_mask"].cpu(), wm.to(torch.int32))
 
 
 def test_u8_frame_preprocessing_matches_dataset(E):
