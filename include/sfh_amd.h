@@ -125,7 +125,12 @@ int64_t sfh_packed_weight_floats(int ksize, int c0, int c1, int cout_virtual);
  * mode = 2: w is OIHW (cout, aux, 7, 7), the stride-2 pad-3 stem of ResNetSTN
  *           (models/resnet.py:172), re-expressed as a 4x4 conv (pad 2 before / 1 after) over
  *           the 2x2 space-to-depth input produced by sfh_space_to_depth2; ksize = 4,
- *           c0 = 4 * (padded channels of the un-shuffled tensor), aux = real cin.            */
+ *           c0 = 4 * (padded channels of the un-shuffled tensor), aux = real cin.
+ * mode = 3: backward-data of a stride-1 Conv2d: w is OIHW (c0, aux, k, k); the packed conv maps dz
+ *           (c0 = the layer's cout) to dx (cout_virtual >= aux = the layer's cin) with the taps
+ *           flipped and in/out channels swapped.
+ * mode = 4: backward-data of ConvTranspose2d k2 s2: w is IOHW (cout_virtual, aux, 2, 2); a 1x1 conv
+ *           over sfh_space_to_depth2(dY) (c0 = 4*aux channels) producing dx.                      */
 int sfh_pack_conv_weights(const float* w, float* packed, int ksize, int c0, int c1,
                           int cout_virtual, int mode, int aux, void* stream);
 
@@ -211,6 +216,81 @@ int sfh_maxpool3x3s2_fwd(const float* x, float* y, int batch, int H, int W, int 
 /* AdaptiveAvgPool2d(1) + flatten + Linear(C -> nout): x NHWC (B,H,W,C), w (nout,C), out (B,nout). */
 int sfh_avgpool_linear_fwd(const float* x, const float* w, const float* bias, int batch, int H,
                            int W, int C, int nout, float* out, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Training mode (Reconstructor.forward under net.train() + loss.backward(), train.py:170,233).
+ * Activations fp32 NHWC with channel stride == C; reductions over pixels accumulate in fp64 into
+ * caller-zeroed `acc` buffers.
+ * --------------------------------------------------------------------------------------------- */
+/* nn.BatchNorm2d(training=True) (unet/unet_parts.py:16,19; models/resnet.py:174 etc.):
+ * acc[0][c] += sum_p z[p][c], acc[1][c] += sum_p z[p][c]^2   (acc: 2*C doubles)                  */
+int sfh_bn_stats(const float* z, int64_t npix, int C, double* acc, void* stream);
+/* mean_invstd[0][c] = mean, [1][c] = 1/sqrt(biased var + eps); running stats (optional pair) updated
+ * with `momentum` and the unbiased variance like torch.                                           */
+int sfh_bn_finalize(const double* acc, int64_t npix, int C, float eps, float momentum, float* running_mean,
+                    float* running_var, float* mean_invstd, void* stream);
+/* y = [relu]((z - mean) * invstd * gamma + beta [+ residual])                                      */
+int sfh_bn_apply(const float* z, const float* mean_invstd, const float* gamma, const float* beta,
+                 const float* residual, int relu, int64_t npix, int C, float* y, void* stream);
+/* backward of bn_apply: with g = dy * (y > 0) (or dy when relu == 0), acc[0][c] += sum g,
+ * acc[1][c] += sum g * xhat  (= dbeta, dgamma);  then
+ * dz = gamma * invstd * (g - acc[0]/N - xhat * acc[1]/N), and dres = g (gradient of the residual
+ * branch, optional).                                                                              */
+int sfh_bn_bwd_reduce(const float* dy, const float* y, const float* z, const float* mean_invstd, int relu,
+                      int64_t npix, int C, double* acc, void* stream);
+int sfh_bn_bwd_apply(const float* dy, const float* y, const float* z, const float* mean_invstd,
+                     const float* gamma, const double* acc, int relu, int64_t npix, int C, float* dz,
+                     float* dres, void* stream);
+/* acc[c] += sum_p x[p][c] over a channel slice of a (npix, cs) tensor: conv / transposed-conv bias
+ * gradients.                                                                                       */
+int sfh_colsum(const float* x, int64_t npix, int C, int cs, double* acc, void* stream);
+/* nn.MaxPool2d(2) (unet/unet_parts.py:33) on NHWC, forward (floor) and backward: the gradient goes to
+ * the first maximum of each window in scan order, like ATen; accumulate != 0 adds into dx.          */
+int sfh_maxpool2_fwd(const float* x, float* y, int batch, int H, int W, int C, void* stream);
+int sfh_maxpool2_bwd(const float* x, const float* dy, float* dx, int batch, int H, int W, int C,
+                     int accumulate, void* stream);
+/* dst (B,h,w,C) (+)= src[b, y+oy, x+ox, c_off:c_off+C], src (B,Hs,Ws,cs), zero outside: the backward of
+ * torch.cat / F.pad in Up (unet/unet_parts.py:59-67).                                              */
+int sfh_slice_add(const float* src, int Hs, int Ws, int cs, int c_off, int oy, int ox, float* dst,
+                  int batch, int h, int w, int C, int accumulate, void* stream);
+/* dst (B,H,W,C): dst[2j][2i] = src[j][i], zero elsewhere - turns the backward of a stride-2 conv into
+ * a stride-1 problem (models/resnet.py:56,172 stride-2 convs).                                     */
+int sfh_zero_stuff2(const float* src, float* dst, int batch, int ho, int wo, int H, int W, int C,
+                    void* stream);
+/* Weight gradient of a stride-1 conv on the fp32 matrix cores (backward-filter):
+ *   raw[m][tap][n_off + n] += sum_{b,y,x} dz[b][y][x][m] * xin[b][y + ky - pad][x + kx - pad][n]
+ * dz (B,H,W,dz_cs) with M channels used; x (B,xh,xw,x_cs) with N channels, placed at (pad_top,pad_left)
+ * inside the HxW conv input frame (second source of a concat), zero outside; ksize 1, 3 (pad 1) or
+ * 4 (pad 2 before / 1 after: the space-to-depth stem, N <= 32); raw is (M, ksize^2, raw_n) fp32,
+ * caller-zeroed, accumulated with atomics.                                                          */
+int sfh_conv_wgrad(const float* dz, int dz_cs, int M, const float* x, int x_cs, int xh, int xw, int N,
+                   int pad_top, int pad_left, int batch, int H, int W, int ksize, float* raw, int raw_n,
+                   int n_off, void* stream);
+
+/* Backward of OutConv (unet/unet_parts.py:74-77): dlogits NCHW (B,nc,H,W), x NHWC (B,H,W,cin);
+ * dx NHWC (optional), acc_w (nc*cin doubles) += dW, acc_b (nc doubles) += db (caller-zeroed).        */
+int sfh_outconv_bwd(const float* x, int cin, const float* w, const float* dlogits_nchw, int nc, int batch,
+                    int H, int W, float* dx, double* acc_w, double* acc_b, void* stream);
+
+/* ResNetSTN backward pieces (models/resnet.py:235-254).
+ * MaxPool2d(3, stride 2, padding 1) on NHWC: dx (B,H,W,C) from dy (B,Ho,Wo,C), first maximum wins. */
+int sfh_maxpool3x3s2_bwd(const float* x, const float* dy, float* dx, int batch, int H, int W, int C,
+                         void* stream);
+/* AdaptiveAvgPool2d(1) + Linear: dx (B,H,W,C); acc_w (nout*C doubles) += dW, acc_b (nout) += db.     */
+int sfh_avgpool_linear_bwd(const float* x, const float* w, const float* dout, int batch, int H, int W, int C,
+                           int nout, float* dx, double* acc_w, double* acc_b, void* stream);
+/* Backward-data of the 7x7 s2 p3 stem for the first nc (<= 8) input channels - the logits inside
+ * torch.cat((logits, x), 1) (models/reconstructor.py:179): dlogits_nchw (B,nc,H,W) += ...;
+ * dz (B,Ho,Wo,64) NHWC, w OIHW (64,cin,7,7).                                                         */
+int sfh_stem_bwd_data(const float* dz, const float* w, int cin, int nc, int batch, int H, int W,
+                      float* dlogits_nchw, void* stream);
+/* d loss / d theta of the bilinear homography warp (sfh_homography_warp_fwd mode 1): acc (B*9 doubles,
+ * caller-zeroed) += sum over pixels; dout (B,h,w).                                                   */
+int sfh_homography_warp_bwd_theta(const float* theta, const float* tmpl, int64_t tmpl_bstride, int ht, int wt,
+                                  int batch, int h, int w, const float* dout, double* acc, void* stream);
+/* d loss / d theta of sfh_poi_project_fwd: dout (B,N,2) -> dtheta (B,9).                              */
+int sfh_poi_project_bwd_theta(const float* theta, const float* poi, int batch, int npts, int normalize,
+                              const float* dout, float* dtheta, void* stream);
 
 #ifdef __cplusplus
 }

@@ -30,9 +30,12 @@ from . import warp_ref
 BN_EPS = 1e-5  # nn.BatchNorm2d default, used unchanged by unet/unet_parts.py:16,19
 
 
+BN_TRAINING = False  # set by oracle/train_ref.py: batch statistics + in-place running-stat update
+
+
 def _bn(x, sd, p):
     return F.batch_norm(x, sd[p + ".running_mean"], sd[p + ".running_var"],
-                        sd[p + ".weight"], sd[p + ".bias"], False, 0.1, BN_EPS)
+                        sd[p + ".weight"], sd[p + ".bias"], BN_TRAINING, 0.1, BN_EPS)
 
 
 def double_conv(x, sd, p):

@@ -62,6 +62,26 @@ SIGNATURES = {
                                          _p, _p, _p]),
     "sfh_mask_format_fwd": (C.c_int, [_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                       C.c_int, _p, _p, _p]),
+    "sfh_bn_stats": (C.c_int, [_p, C.c_int64, C.c_int, _p, _p]),
+    "sfh_bn_finalize": (C.c_int, [_p, C.c_int64, C.c_int, C.c_float, C.c_float, _p, _p, _p, _p]),
+    "sfh_bn_apply": (C.c_int, [_p, _p, _p, _p, _p, C.c_int, C.c_int64, C.c_int, _p, _p]),
+    "sfh_bn_bwd_reduce": (C.c_int, [_p, _p, _p, _p, C.c_int, C.c_int64, C.c_int, _p, _p]),
+    "sfh_bn_bwd_apply": (C.c_int, [_p, _p, _p, _p, _p, _p, C.c_int, C.c_int64, C.c_int, _p, _p, _p]),
+    "sfh_colsum": (C.c_int, [_p, C.c_int64, C.c_int, C.c_int, _p, _p]),
+    "sfh_maxpool2_fwd": (C.c_int, [_p, _p, C.c_int, C.c_int, C.c_int, C.c_int, _p]),
+    "sfh_maxpool2_bwd": (C.c_int, [_p, _p, _p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _p]),
+    "sfh_slice_add": (C.c_int, [_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _p,
+                                C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _p]),
+    "sfh_zero_stuff2": (C.c_int, [_p, _p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _p]),
+    "sfh_conv_wgrad": (C.c_int, [_p, C.c_int, C.c_int, _p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                 C.c_int, C.c_int, C.c_int, C.c_int, _p, C.c_int, C.c_int, _p]),
+    "sfh_outconv_bwd": (C.c_int, [_p, C.c_int, _p, _p, C.c_int, C.c_int, C.c_int, C.c_int, _p, _p, _p, _p]),
+    "sfh_maxpool3x3s2_bwd": (C.c_int, [_p, _p, _p, C.c_int, C.c_int, C.c_int, C.c_int, _p]),
+    "sfh_avgpool_linear_bwd": (C.c_int, [_p, _p, _p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _p, _p, _p, _p]),
+    "sfh_stem_bwd_data": (C.c_int, [_p, _p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _p, _p]),
+    "sfh_homography_warp_bwd_theta": (C.c_int, [_p, _p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                                _p, _p, _p]),
+    "sfh_poi_project_bwd_theta": (C.c_int, [_p, _p, C.c_int, C.c_int, C.c_int, _p, _p, _p]),
     "sfh_maxpool3x3s2_fwd": (C.c_int, [_p, _p, C.c_int, C.c_int, C.c_int, C.c_int, _p]),
     "sfh_avgpool_linear_fwd": (C.c_int, [_p, _p, _p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _p, _p]),
 }

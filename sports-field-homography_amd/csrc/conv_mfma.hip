@@ -653,6 +653,12 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, float* __restri
       const int ky7 = 2 * ky + (par >> 1) - 1, kx7 = 2 * kx + (par & 1) - 1;
       if (c >= aux || ky7 < 0 || ky7 > 6 || kx7 < 0 || kx7 > 6) continue;
       v = w[(((size_t)cv * aux + c) * 7 + ky7) * 7 + kx7];
+    } else if (transposed == 3) {  // backward-data of Conv2d: input = dz (orig cout), output = dx (orig cin = aux)
+      if (cv >= aux) continue;
+      v = w[(((size_t)cin * aux + cv) * ks + (ks - 1 - ky)) * ks + (ks - 1 - kx)];
+    } else if (transposed == 4) {  // backward-data of ConvTranspose2d as a 1x1 conv over space-to-depth(dY)
+      const int qd = cin / aux, co = cin - qd * aux;  // aux = orig cout; input channel = (py*2+px)*cout + co
+      v = w[(((size_t)cv * aux + co) * 2 + (qd >> 1)) * 2 + (qd & 1)];
     } else if (transposed) {  // ConvTranspose2d weight (cin, cout, 2, 2); cv = (dy*2+dx)*cout + co
       const int cout = coutv >> 2;
       const int qd = cv / cout, co = cv - qd * cout;
@@ -746,7 +752,11 @@ extern "C" int sfh_pack_conv_weights(const float* w, float* packed, int ksize, i
   SFH_REQUIRE(n > 0, "pack_conv_weights: bad geometry ks=%d c0=%d c1=%d cout=%d", ksize, c0, c1,
               cout_virtual);
   SFH_REQUIRE(w && packed, "pack_conv_weights: null pointer");
-  SFH_REQUIRE(transposed >= 0 && transposed <= 2, "pack_conv_weights: bad mode %d", transposed);
+  SFH_REQUIRE(transposed >= 0 && transposed <= 4, "pack_conv_weights: bad mode %d", transposed);
+  SFH_REQUIRE(transposed != 3 || (c1 == 0 && (ksize == 1 || ksize == 3) && aux > 0 && aux <= cout_virtual),
+              "pack_conv_weights: mode 3 (backward-data) needs c0 = orig cout, c1 = 0, aux = orig cin <= cout_virtual");
+  SFH_REQUIRE(transposed != 4 || (ksize == 1 && c1 == 0 && aux > 0 && c0 == 4 * aux),
+              "pack_conv_weights: mode 4 (ConvTranspose2d backward-data) needs ksize=1, c0 = 4*orig cout, aux = orig cout");
   SFH_REQUIRE(transposed != 1 || (ksize == 1 && c1 == 0 && cout_virtual % 256 == 0),
               "pack_conv_weights: transposed needs ksize=1, c1=0, cout multiple of 64");
   SFH_REQUIRE(transposed != 2 || (ksize == 4 && c1 == 0 && c0 % 16 == 0 && aux > 0 && aux <= c0 / 4),

@@ -1,0 +1,782 @@
+// train.hip - training-mode kernels of the hot path: batch-statistics
+// BatchNorm forward/backward, ReLU/max-pool backward, the data movers of the backward pass and the
+// weight-gradient convolution on the fp32 matrix cores.
+//
+// Replaces, for Reconstructor.forward in train() mode + loss.backward() (train.py:170,233):
+//   nn.BatchNorm2d(training=True) fwd/bwd of DoubleConv / BasicBlock (unet/unet_parts.py:16,19,
+//   models/resnet.py:67-74), nn.ReLU / nn.MaxPool2d backward, and cuDNN's backward-filter.
+// Backward-data convolutions reuse sfh_conv_fwd with weights packed by sfh_pack_conv_weights
+// mode 3 / 4.  All activations fp32 NHWC with channel stride == channel count.
+//
+// Reductions over pixels accumulate in fp64 (ATen's CPU batch-norm uses a double accumulator).
+#include <hip/amd_detail/amd_hip_unsafe_atomics.h>
+
+#include "common.h"
+
+namespace {
+
+// ------------------------------------------------------------------ per-channel reductions
+// rows = pixels, C channels (multiple of 4).  A block of 256 threads = (256/cq) pixel lanes x cq
+// channel quads reduces RED_ROWS pixels and adds its partials to fp64 accumulators with atomics;
+// C > 1024 is processed in chunks of 1024 channels.
+constexpr int RED_ROWS = 2048;
+
+// acc[0][c] += sum z, acc[1][c] += sum z^2
+__global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__ z, long npix, int C,
+                                                       double* __restrict__ acc) {
+  __shared__ double sh[256];
+  for (int c0 = 0; c0 < C; c0 += 1024) {
+    const int cq = min(1024, C - c0) >> 2;
+    const int lanes = 256 / cq;
+    const int q = threadIdx.x % cq, pl = threadIdx.x / cq;
+    double s0[4] = {0, 0, 0, 0}, s1[4] = {0, 0, 0, 0};
+    const long p0 = (long)blockIdx.x * RED_ROWS, p1 = min(p0 + RED_ROWS, npix);
+    if (pl < lanes)
+      for (long p = p0 + pl; p < p1; p += lanes) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(z + p * C + c0 + 4 * q);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          s0[j] += (double)v[j];
+          s1[j] += (double)v[j] * (double)v[j];
+        }
+      }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      __syncthreads();
+      sh[threadIdx.x] = (pl < lanes) ? (j < 4 ? s0[j] : s1[j - 4]) : 0.0;
+      __syncthreads();
+      if (threadIdx.x < cq) {
+        double t = 0.0;
+        for (int l = 0; l < lanes; ++l) t += sh[l * cq + threadIdx.x];
+        unsafeAtomicAdd(&acc[(long)(j >> 2) * C + c0 + 4 * threadIdx.x + (j & 3)], t);
+      }
+    }
+  }
+}
+
+// acc[c] += sum x[:, c] over a channel slice (cs >= C)
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, long npix, int C, int cs,
+                                                     double* __restrict__ acc) {
+  // one channel quad per thread column; supports cs >= C (channel slices)
+  const int cq = C >> 2;
+  for (int q0 = 0; q0 < cq; q0 += 256) {
+    const int qn = min(256, cq - q0);
+    const int lanes = 256 / qn;
+    const int q = threadIdx.x % qn, pl = threadIdx.x / qn;
+    double s[4] = {0, 0, 0, 0};
+    const long p0 = (long)blockIdx.x * RED_ROWS, p1 = min(p0 + RED_ROWS, npix);
+    if (pl < lanes)
+      for (long p = p0 + pl; p < p1; p += lanes) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(x + p * cs + 4 * (q0 + q));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) s[j] += (double)v[j];
+      }
+    __shared__ double sh[256];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      __syncthreads();
+      sh[threadIdx.x] = (pl < lanes) ? s[j] : 0.0;
+      __syncthreads();
+      if (threadIdx.x < qn) {
+        double t = 0.0;
+        for (int l = 0; l < lanes; ++l) t += sh[l * qn + threadIdx.x];
+        unsafeAtomicAdd(&acc[4 * (q0 + threadIdx.x) + j], t);
+      }
+    }
+  }
+}
+
+__global__ void bn_finalize_kernel(const double* __restrict__ acc, long npix, int C, float eps, float momentum,
+                                   float* __restrict__ running_mean, float* __restrict__ running_var,
+                                   float* __restrict__ mean_invstd) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const double n = (double)npix;
+  const double mean = acc[c] / n;
+  double var = acc[C + c] / n - mean * mean;
+  var = var > 0.0 ? var : 0.0;
+  mean_invstd[c] = (float)mean;
+  mean_invstd[C + c] = (float)(1.0 / sqrt(var + (double)eps));
+  if (running_mean) {
+    const double unbiased = npix > 1 ? var * n / (n - 1.0) : var;
+    running_mean[c] = (float)((1.0 - (double)momentum) * (double)running_mean[c] + (double)momentum * mean);
+    running_var[c] = (float)((1.0 - (double)momentum) * (double)running_var[c] + (double)momentum * unbiased);
+  }
+}
+
+// y = [relu]( (z - mean) * invstd * gamma + beta [+ residual] )
+__global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ z, const float* __restrict__ mi,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       const float* __restrict__ residual, int relu, long total4,
+                                                       int C, float* __restrict__ y) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total4) return;
+  const int c = (int)((i * 4) % C);
+  const f32x4 v = reinterpret_cast<const f32x4*>(z)[i];
+  f32x4 o;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float xh = (v[j] - mi[c + j]) * mi[C + c + j];
+    o[j] = xh * gamma[c + j] + beta[c + j];
+  }
+  if (residual) {
+    const f32x4 r = reinterpret_cast<const f32x4*>(residual)[i];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] += r[j];
+  }
+  if (relu) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = fmaxf(o[j], 0.f);
+  }
+  reinterpret_cast<f32x4*>(y)[i] = o;
+}
+
+// g = dy * (y > 0 if relu); sums: [0] = sum g, [1] = sum g * xhat
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                                            const float* __restrict__ z, const float* __restrict__ mi,
+                                                            int relu, long npix, int C, double* __restrict__ acc) {
+  __shared__ double sh[256];
+  for (int c0 = 0; c0 < C; c0 += 1024) {
+    const int cq = min(1024, C - c0) >> 2;
+    const int lanes = 256 / cq;
+    const int q = threadIdx.x % cq, pl = threadIdx.x / cq;
+    double s0[4] = {0, 0, 0, 0}, s1[4] = {0, 0, 0, 0};
+    const long p0 = (long)blockIdx.x * RED_ROWS, p1 = min(p0 + RED_ROWS, npix);
+    if (pl < lanes)
+      for (long p = p0 + pl; p < p1; p += lanes) {
+        const long o = p * C + c0 + 4 * q;
+        const f32x4 g = *reinterpret_cast<const f32x4*>(dy + o);
+        const f32x4 zz = *reinterpret_cast<const f32x4*>(z + o);
+        f32x4 yy = {1.f, 1.f, 1.f, 1.f};
+        if (relu) yy = *reinterpret_cast<const f32x4*>(y + o);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float gj = yy[j] > 0.f ? g[j] : 0.f;
+          const float xh = (zz[j] - mi[c0 + 4 * q + j]) * mi[C + c0 + 4 * q + j];
+          s0[j] += (double)gj;
+          s1[j] += (double)gj * (double)xh;
+        }
+      }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      __syncthreads();
+      sh[threadIdx.x] = (pl < lanes) ? (j < 4 ? s0[j] : s1[j - 4]) : 0.0;
+      __syncthreads();
+      if (threadIdx.x < cq) {
+        double t = 0.0;
+        for (int l = 0; l < lanes; ++l) t += sh[l * cq + threadIdx.x];
+        unsafeAtomicAdd(&acc[(long)(j >> 2) * C + c0 + 4 * threadIdx.x + (j & 3)], t);
+      }
+    }
+  }
+}
+
+// dz = gamma * invstd * (g - sum_g / N - xhat * sum_gx / N); optionally dres = g
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                                           const float* __restrict__ z, const float* __restrict__ mi,
+                                                           const float* __restrict__ gamma, const double* __restrict__ acc,
+                                                           int relu, long npix, long total4, int C,
+                                                           float* __restrict__ dz, float* __restrict__ dres) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total4) return;
+  const int c = (int)((i * 4) % C);
+  const f32x4 g4 = reinterpret_cast<const f32x4*>(dy)[i];
+  const f32x4 zz = reinterpret_cast<const f32x4*>(z)[i];
+  f32x4 yy = {1.f, 1.f, 1.f, 1.f};
+  if (relu) yy = reinterpret_cast<const f32x4*>(y)[i];
+  const float inv_n = 1.0f / (float)npix;
+  f32x4 o, gg;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float g = yy[j] > 0.f ? g4[j] : 0.f;
+    const float invstd = mi[C + c + j];
+    const float xh = (zz[j] - mi[c + j]) * invstd;
+    const float mg = (float)acc[c + j] * inv_n, mgx = (float)acc[C + c + j] * inv_n;
+    o[j] = gamma[c + j] * invstd * (g - mg - xh * mgx);
+    gg[j] = g;
+  }
+  reinterpret_cast<f32x4*>(dz)[i] = o;
+  if (dres) reinterpret_cast<f32x4*>(dres)[i] = gg;
+}
+
+// ------------------------------------------------------------------ max-pool 2x2 (floor)
+__global__ __launch_bounds__(256) void maxpool2_fwd_kernel(const float* __restrict__ x, int H, int W, int C,
+                                                           int Ho, int Wo, long total4, float* __restrict__ y) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total4) return;
+  const int cq = C >> 2;
+  const int q = (int)(i % cq);
+  long r = i / cq;
+  const int xo = (int)(r % Wo); r /= Wo;
+  const int yo = (int)(r % Ho);
+  const long b = r / Ho;
+  const float* p = x + ((b * H + 2 * yo) * (long)W + 2 * xo) * C + 4 * q;
+  const f32x4 a = *reinterpret_cast<const f32x4*>(p), bq = *reinterpret_cast<const f32x4*>(p + C);
+  const f32x4 c = *reinterpret_cast<const f32x4*>(p + (long)W * C), d = *reinterpret_cast<const f32x4*>(p + (long)W * C + C);
+  f32x4 o;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) o[j] = fmaxf(fmaxf(a[j], bq[j]), fmaxf(c[j], d[j]));
+  reinterpret_cast<f32x4*>(y)[i] = o;
+}
+
+// dx[b,y,x,c] (+)= dy[b,y/2,x/2,c] where (y,x) is the FIRST maximum of its window in scan order
+// (ATen's max_pool2d keeps the first index), 0 elsewhere (incl. the floor-cropped border).
+__global__ __launch_bounds__(256) void maxpool2_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                           int H, int W, int C, int Ho, int Wo, long total4,
+                                                           int accumulate, float* __restrict__ dx) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;  // one thread per pooled output quad
+  if (i >= total4) return;
+  const int cq = C >> 2;
+  const int q = (int)(i % cq);
+  long r = i / cq;
+  const int xo = (int)(r % Wo); r /= Wo;
+  const int yo = (int)(r % Ho);
+  const long b = r / Ho;
+  const long base = ((b * H + 2 * yo) * (long)W + 2 * xo) * C + 4 * q;
+  const long off[4] = {0, C, (long)W * C, (long)W * C + C};
+  f32x4 v[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) v[k] = *reinterpret_cast<const f32x4*>(x + base + off[k]);
+  const f32x4 g = reinterpret_cast<const f32x4*>(dy)[i];
+  f32x4 o[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    int best = 0;
+    float bv = v[0][j];
+#pragma unroll
+    for (int k = 1; k < 4; ++k)
+      if (v[k][j] > bv) { bv = v[k][j]; best = k; }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) o[k][j] = (k == best) ? g[j] : 0.f;
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    f32x4* d = reinterpret_cast<f32x4*>(dx + base + off[k]);
+    if (accumulate) {
+      f32x4 t = *d;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) t[j] += o[k][j];
+      *d = t;
+    } else {
+      *d = o[k];
+    }
+  }
+}
+
+// ------------------------------------------------------------------ data movers
+// dst (B,h,w,C) (+)= src[b, y+oy, x+ox, c_off : c_off+C] with src (B,Hs,Ws,cs); out-of-range -> 0
+__global__ __launch_bounds__(256) void slice_add_kernel(const float* __restrict__ src, int Hs, int Ws, int cs, int c_off,
+                                                        int oy, int ox, int h, int w, int C, long total4,
+                                                        int accumulate, float* __restrict__ dst) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total4) return;
+  const int cq = C >> 2;
+  const int q = (int)(i % cq);
+  long r = i / cq;
+  const int x = (int)(r % w); r /= w;
+  const int y = (int)(r % h);
+  const long b = r / h;
+  const int sy = y + oy, sx = x + ox;
+  f32x4 v = {0.f, 0.f, 0.f, 0.f};
+  if (sy >= 0 && sy < Hs && sx >= 0 && sx < Ws)
+    v = *reinterpret_cast<const f32x4*>(src + ((b * Hs + sy) * (long)Ws + sx) * cs + c_off + 4 * q);
+  f32x4* d = reinterpret_cast<f32x4*>(dst) + i;
+  if (accumulate) {
+    f32x4 t = *d;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) t[j] += v[j];
+    *d = t;
+  } else {
+    *d = v;
+  }
+}
+
+// dst (B,H,W,C): dst[2j,2i] = src[j,i] (src (B,ho,wo,C)), zero elsewhere
+__global__ __launch_bounds__(256) void zero_stuff2_kernel(const float* __restrict__ src, int ho, int wo, int H, int W,
+                                                          int C, long total4, float* __restrict__ dst) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total4) return;
+  const int cq = C >> 2;
+  const int q = (int)(i % cq);
+  long r = i / cq;
+  const int x = (int)(r % W); r /= W;
+  const int y = (int)(r % H);
+  const long b = r / H;
+  f32x4 v = {0.f, 0.f, 0.f, 0.f};
+  if (!(y & 1) && !(x & 1) && (y >> 1) < ho && (x >> 1) < wo)
+    v = *reinterpret_cast<const f32x4*>(src + ((b * ho + (y >> 1)) * (long)wo + (x >> 1)) * C + 4 * q);
+  reinterpret_cast<f32x4*>(dst)[i] = v;
+}
+
+// ------------------------------------------------------------------ OutConv backward
+// logits = w x + b (1x1, cin -> NC): dx[p][ci] = sum_k dl[k][p] w[k][ci];
+// acc_w[k][ci] += sum_p dl[k][p] x[p][ci]; acc_b[k] += sum_p dl[k][p].   dl is NCHW, x / dx NHWC.
+template <int NC>
+__global__ __launch_bounds__(256) void outconv_bwd_kernel(const float* __restrict__ x, int cin,
+                                                          const float* __restrict__ w, const float* __restrict__ dl,
+                                                          long npix, int HW, float* __restrict__ dx,
+                                                          double* __restrict__ acc_w, double* __restrict__ acc_b) {
+  __shared__ double sh[256];
+  const int cq = cin >> 2;  // <= 64
+  const int lanes = 256 / cq;
+  const int q = threadIdx.x % cq, pl = threadIdx.x / cq;
+  f32x4 wk[NC];
+#pragma unroll
+  for (int k = 0; k < NC; ++k) wk[k] = *reinterpret_cast<const f32x4*>(w + k * cin + 4 * q);
+  float sw[NC][4], sb[NC];
+#pragma unroll
+  for (int k = 0; k < NC; ++k) {
+    sb[k] = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) sw[k][j] = 0.f;
+  }
+  const long p0 = (long)blockIdx.x * 1024, p1 = min(p0 + 1024, npix);
+  if (pl < lanes)
+    for (long p = p0 + pl; p < p1; p += lanes) {
+      const long b = p / HW, i = p - b * HW;
+      const f32x4 xv = *reinterpret_cast<const f32x4*>(x + p * cin + 4 * q);
+      f32x4 o = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int k = 0; k < NC; ++k) {
+        const float g = dl[(b * NC + k) * HW + i];
+        sb[k] += g;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          o[j] += g * wk[k][j];
+          sw[k][j] += g * xv[j];
+        }
+      }
+      if (dx) *reinterpret_cast<f32x4*>(dx + p * cin + 4 * q) = o;
+    }
+#pragma unroll
+  for (int k = 0; k < NC; ++k) {
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+      __syncthreads();
+      sh[threadIdx.x] = (pl < lanes) ? (double)(j < 4 ? sw[k][j] : sb[k]) : 0.0;
+      __syncthreads();
+      if (j < 4) {
+        if (threadIdx.x < cq) {
+          double t = 0.0;
+          for (int l = 0; l < lanes; ++l) t += sh[l * cq + threadIdx.x];
+          unsafeAtomicAdd(&acc_w[k * cin + 4 * threadIdx.x + j], t);
+        }
+      } else if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int l = 0; l < lanes; ++l) t += sh[l * cq];  // q == 0 lanes
+        unsafeAtomicAdd(&acc_b[k], t);
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------ ResNetSTN backward pieces
+// MaxPool2d(3, stride 2, padding 1) backward: every input pixel looks at the (up to 4) windows that
+// contain it and takes their gradient when it is the window's first maximum in scan order.
+__global__ __launch_bounds__(256) void maxpool3x3s2_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                               int H, int W, int C, int Ho, int Wo, long total4,
+                                                               float* __restrict__ dx) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total4) return;
+  const int cq = C >> 2;
+  const int q = (int)(idx % cq);
+  long r = idx / cq;
+  const int xi = (int)(r % W); r /= W;
+  const int yi = (int)(r % H);
+  const long b = r / H;
+  const float* xb = x + b * (long)H * W * C + 4 * q;
+  f32x4 g = {0.f, 0.f, 0.f, 0.f};
+  for (int yo = yi / 2; yo <= (yi + 1) / 2; ++yo) {   // windows with 2*yo-1 <= yi <= 2*yo+1
+    if (yo >= Ho) continue;
+    for (int xo = xi / 2; xo <= (xi + 1) / 2; ++xo) {
+      if (xo >= Wo) continue;
+      f32x4 best = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+      int by[4] = {-1, -1, -1, -1}, bx[4] = {-1, -1, -1, -1};
+      for (int ky = 0; ky < 3; ++ky) {
+        const int yy = 2 * yo - 1 + ky;
+        if (yy < 0 || yy >= H) continue;
+        for (int kx = 0; kx < 3; ++kx) {
+          const int xx = 2 * xo - 1 + kx;
+          if (xx < 0 || xx >= W) continue;
+          const f32x4 v = *reinterpret_cast<const f32x4*>(xb + ((long)yy * W + xx) * C);
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (v[j] > best[j] || by[j] < 0) { best[j] = v[j]; by[j] = yy; bx[j] = xx; }
+        }
+      }
+      const f32x4 d = *reinterpret_cast<const f32x4*>(dy + ((b * Ho + yo) * (long)Wo + xo) * C + 4 * q);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (by[j] == yi && bx[j] == xi) g[j] += d[j];
+    }
+  }
+  reinterpret_cast<f32x4*>(dx)[idx] = g;
+}
+
+// AdaptiveAvgPool2d(1) + Linear backward; one block per frame.
+// dx[b,p,c] = (sum_j dout[b][j] w[j][c]) / HW;  acc_w[j][c] += dout[b][j] * mean_p x[b,p,c];  acc_b[j] += dout[b][j]
+__global__ __launch_bounds__(256) void avgpool_linear_bwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                                 const float* __restrict__ dout, int HW, int C, int nout,
+                                                                 float* __restrict__ dx, double* __restrict__ acc_w,
+                                                                 double* __restrict__ acc_b) {
+  const int b = blockIdx.x;
+  const float* xb = x + (long)b * HW * C;
+  float* dxb = dx + (long)b * HW * C;
+  const float inv = 1.0f / (float)HW;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float s = 0.f;
+    for (int i = 0; i < HW; ++i) s += xb[(long)i * C + c];
+    const float mean = s * inv;
+    float df = 0.f;
+    for (int j = 0; j < nout; ++j) {
+      const float d = dout[b * nout + j];
+      df += d * w[j * C + c];
+      unsafeAtomicAdd(&acc_w[(long)j * C + c], (double)d * (double)mean);
+    }
+    df *= inv;
+    for (int i = 0; i < HW; ++i) dxb[(long)i * C + c] = df;
+  }
+  if (threadIdx.x < nout) unsafeAtomicAdd(&acc_b[threadIdx.x], (double)dout[b * nout + threadIdx.x]);
+}
+
+// Backward-data of the 7x7 stride-2 pad-3 stem (models/resnet.py:172) for the first `nc` input channels
+// (the logits inside cat((logits, x), 1)): dlogits[b][c][y][x] += sum_{co,ky,kx} dz[b][Y][X][co] *
+// w[co][c][ky][kx] with 2Y + ky - 3 = y, 2X + kx - 3 = x.  One thread per input pixel; the weights of
+// the nc channels sit in LDS as [ky][kx][co][4].
+template <int NC4>
+__global__ __launch_bounds__(256) void stem_bwd_data_kernel(const float* __restrict__ dz, const float* __restrict__ w,
+                                                            int cin, int nc, int H, int W, int Ho, int Wo,
+                                                            float* __restrict__ dlogits) {
+  extern __shared__ __attribute__((aligned(16))) float wl[];  // [49][64][4*NC4]
+  for (int i = threadIdx.x; i < 49 * 64 * 4 * NC4; i += 256) {
+    const int c = i % (4 * NC4), co = (i / (4 * NC4)) % 64, t = i / (4 * NC4 * 64);
+    wl[i] = c < nc ? w[((long)co * cin + c) * 49 + t] : 0.f;
+  }
+  __syncthreads();
+  const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  const int b = blockIdx.z;
+  if (x >= W || y >= H) return;
+  float acc[4 * NC4];
+#pragma unroll
+  for (int c = 0; c < 4 * NC4; ++c) acc[c] = 0.f;
+  for (int ky = (y + 3) & 1; ky < 7; ky += 2) {
+    const int Y = (y + 3 - ky) >> 1;
+    if (Y < 0 || Y >= Ho) continue;
+    for (int kx = (x + 3) & 1; kx < 7; kx += 2) {
+      const int X = (x + 3 - kx) >> 1;
+      if (X < 0 || X >= Wo) continue;
+      const float* dp = dz + (((long)b * Ho + Y) * Wo + X) * 64;
+      const float* wp = wl + (ky * 7 + kx) * 64 * 4 * NC4;
+#pragma unroll 4
+      for (int co4 = 0; co4 < 16; ++co4) {
+        const f32x4 d = *reinterpret_cast<const f32x4*>(dp + 4 * co4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+#pragma unroll
+          for (int q = 0; q < NC4; ++q) {
+            const f32x4 ww = *reinterpret_cast<const f32x4*>(wp + ((4 * co4 + j) * NC4 + q) * 4);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc[4 * q + c] += d[j] * ww[c];
+          }
+        }
+      }
+    }
+  }
+  for (int c = 0; c < nc; ++c) dlogits[(((long)b * nc + c) * H + y) * W + x] += acc[c];
+}
+
+// ------------------------------------------------------------------ weight gradient (fp32 MFMA)
+// raw[m][tap][n] += sum over pixels p of dz[p][m] * xin[p + tap][n]
+//   GEMM view: M = output channels, N = input channels of one source, K = B*H*W pixels.
+// Workgroup = 64 m x 16*NSUB n x all taps, over a strided subset of 2x32-pixel tiles (blockIdx.z =
+// split); each wave owns 16 m.  v_mfma_f32_16x16x4_f32: A[i=m][k=pixel], B[k=pixel][j=n] - in NHWC the
+// 16 channels of a pixel are contiguous, so both fragments are plain ds_read_b32 with k = lane/16.
+// LDS rows are 64 floats per pixel; bit 4 of the channel index is XORed with the pixel parity so the
+// two pixels a 32-lane group reads land in different bank halves.
+struct WgradArgs {
+  const float* dz; int dz_cs; int M;
+  const float* x; int x_cs, xh, xw, N, pad_top, pad_left;
+  int batch, H, W;
+  float* raw; int raw_n, n_off;
+  int ntx, nty, ntiles, nsplit;
+};
+
+constexpr int WG_TH = 2, WG_TW = 32;
+
+template <int KS, int NSUB>
+__global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
+  constexpr int PADB = KS == 3 ? 1 : (KS == 4 ? 2 : 0);
+  constexpr int HR = WG_TH + KS - 1, HW = WG_TW + KS - 1, HPX = HR * HW;
+  constexpr int KK = KS * KS;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* xL = lds;               // [HPX][64]
+  float* zL = lds + HPX * 64;    // [WG_TH*WG_TW][64]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l16 = lane & 15, kq = lane >> 4;
+  const int m0 = blockIdx.x * 64, n0 = blockIdx.y * (16 * NSUB);
+  f32x4 acc[KK][NSUB];
+#pragma unroll
+  for (int t = 0; t < KK; ++t)
+#pragma unroll
+    for (int s = 0; s < NSUB; ++s) acc[t][s] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  for (int tile = blockIdx.z; tile < a.ntiles; tile += a.nsplit) {
+    const int tx = tile % a.ntx;
+    const int ty = (tile / a.ntx) % a.nty;
+    const int b = tile / (a.ntx * a.nty);
+    const int y0 = ty * WG_TH, x0 = tx * WG_TW;
+    __syncthreads();  // previous tile's fragments consumed
+    // ---- stage the input halo: HPX pixels x (16*NSUB) channels
+    for (int i = tid; i < HPX * (4 * NSUB); i += 256) {
+      const int q = i % (4 * NSUB), hp = i / (4 * NSUB);
+      const int hr = hp / HW, hc = hp - hr * HW;
+      const int sy = y0 + hr - PADB - a.pad_top, sx = x0 + hc - PADB - a.pad_left;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      const int n = n0 + 4 * q;
+      if (sy >= 0 && sy < a.xh && sx >= 0 && sx < a.xw && n < a.N)
+        v = *reinterpret_cast<const f32x4*>(a.x + (((long)b * a.xh + sy) * a.xw + sx) * a.x_cs + n);
+      *reinterpret_cast<f32x4*>(xL + hp * 64 + 4 * (q ^ ((hp & 1) << 2))) = v;
+    }
+    // ---- stage dz: 64 pixels x 64 channels
+    for (int i = tid; i < WG_TH * WG_TW * 16; i += 256) {
+      const int q = i & 15, p = i >> 4;
+      const int r = p / WG_TW, c = p - r * WG_TW;
+      const int y = y0 + r, x = x0 + c, m = m0 + 4 * q;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (y < a.H && x < a.W && m < a.M)
+        v = *reinterpret_cast<const f32x4*>(a.dz + (((long)b * a.H + y) * a.W + x) * a.dz_cs + m);
+      *reinterpret_cast<f32x4*>(zL + p * 64 + 4 * (q ^ ((p & 1) << 2))) = v;
+    }
+    __syncthreads();
+    // ---- contraction over the 64 pixels of the tile, 4 per MFMA
+#pragma unroll 1
+    for (int r = 0; r < WG_TH; ++r) {
+#pragma unroll 2
+      for (int c4 = 0; c4 < WG_TW / 4; ++c4) {
+        const int pz = r * WG_TW + c4 * 4 + kq;
+        const float av = zL[pz * 64 + ((wave * 16 + l16) ^ ((pz & 1) << 4))];
+#pragma unroll
+        for (int ky = 0; ky < KS; ++ky)
+#pragma unroll
+          for (int kx = 0; kx < KS; ++kx) {
+            const int ph = (r + ky) * HW + c4 * 4 + kq + kx;
+            const float* row = xL + ph * 64;
+            const int sw = (ph & 1) << 4;
+#pragma unroll
+            for (int s = 0; s < NSUB; ++s) {
+              const float bv = row[(s * 16 + l16) ^ sw];
+              acc[ky * KS + kx][s] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[ky * KS + kx][s], 0, 0, 0);
+            }
+          }
+      }
+    }
+  }
+  // ---- D[i = 4*(lane/16) + r][j = lane%16]
+#pragma unroll
+  for (int t = 0; t < KK; ++t)
+#pragma unroll
+    for (int s = 0; s < NSUB; ++s) {
+      const int n = n0 + s * 16 + l16;
+      if (n >= a.N) continue;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = m0 + wave * 16 + 4 * kq + r;
+        if (m < a.M) unsafeAtomicAdd(a.raw + ((long)m * KK + t) * a.raw_n + a.n_off + n, acc[t][s][r]);
+      }
+    }
+}
+
+template <int KS, int NSUB>
+int launch_wgrad(const WgradArgs& a, hipStream_t stream) {
+  constexpr int HPX = (WG_TH + KS - 1) * (WG_TW + KS - 1);
+  const size_t lds = (size_t)(HPX + WG_TH * WG_TW) * 64 * sizeof(float);
+  const dim3 grid((unsigned)sfh_cdiv(a.M, 64), (unsigned)sfh_cdiv(a.N, 16 * NSUB), (unsigned)a.nsplit);
+  hipLaunchKernelGGL((wgrad_kernel<KS, NSUB>), grid, dim3(256), lds, stream, a);
+  return sfh_check_launch("wgrad_kernel");
+}
+
+}  // namespace
+
+// =============================================================================== C ABI
+extern "C" int sfh_bn_stats(const float* z, int64_t npix, int C, double* acc, void* stream) {
+  SFH_REQUIRE(z && acc && npix > 0 && C > 0 && C % 4 == 0, "bn_stats: bad argument");
+  const unsigned nb = (unsigned)((npix + RED_ROWS - 1) / RED_ROWS);
+  hipLaunchKernelGGL(bn_stats_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, z, (long)npix, C, acc);
+  return sfh_check_launch("bn_stats_kernel");
+}
+
+extern "C" int sfh_bn_finalize(const double* acc, int64_t npix, int C, float eps, float momentum,
+                               float* running_mean, float* running_var, float* mean_invstd, void* stream) {
+  SFH_REQUIRE(acc && mean_invstd && npix > 0 && C > 0, "bn_finalize: bad argument");
+  SFH_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "bn_finalize: running stats must come in pairs");
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, (hipStream_t)stream, acc,
+                     (long)npix, C, eps, momentum, running_mean, running_var, mean_invstd);
+  return sfh_check_launch("bn_finalize_kernel");
+}
+
+extern "C" int sfh_bn_apply(const float* z, const float* mean_invstd, const float* gamma, const float* beta,
+                            const float* residual, int relu, int64_t npix, int C, float* y, void* stream) {
+  SFH_REQUIRE(z && mean_invstd && gamma && beta && y && npix > 0 && C > 0 && C % 4 == 0, "bn_apply: bad argument");
+  const long total4 = (long)npix * C / 4;
+  hipLaunchKernelGGL(bn_apply_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, z,
+                     mean_invstd, gamma, beta, residual, relu, total4, C, y);
+  return sfh_check_launch("bn_apply_kernel");
+}
+
+extern "C" int sfh_bn_bwd_reduce(const float* dy, const float* y, const float* z, const float* mean_invstd,
+                                 int relu, int64_t npix, int C, double* acc, void* stream) {
+  SFH_REQUIRE(dy && z && mean_invstd && acc && (y || !relu) && npix > 0 && C > 0 && C % 4 == 0,
+              "bn_bwd_reduce: bad argument");
+  const unsigned nb = (unsigned)((npix + RED_ROWS - 1) / RED_ROWS);
+  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, dy, y, z, mean_invstd, relu,
+                     (long)npix, C, acc);
+  return sfh_check_launch("bn_bwd_reduce_kernel");
+}
+
+extern "C" int sfh_bn_bwd_apply(const float* dy, const float* y, const float* z, const float* mean_invstd,
+                                const float* gamma, const double* acc, int relu, int64_t npix, int C, float* dz,
+                                float* dres, void* stream) {
+  SFH_REQUIRE(dy && z && mean_invstd && gamma && acc && dz && (y || !relu) && npix > 0 && C > 0 && C % 4 == 0,
+              "bn_bwd_apply: bad argument");
+  const long total4 = (long)npix * C / 4;
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     dy, y, z, mean_invstd, gamma, acc, relu, (long)npix, total4, C, dz, dres);
+  return sfh_check_launch("bn_bwd_apply_kernel");
+}
+
+extern "C" int sfh_colsum(const float* x, int64_t npix, int C, int cs, double* acc, void* stream) {
+  SFH_REQUIRE(x && acc && npix > 0 && C > 0 && C % 4 == 0 && cs >= C && cs % 4 == 0, "colsum: bad argument");
+  const unsigned nb = (unsigned)((npix + RED_ROWS - 1) / RED_ROWS);
+  hipLaunchKernelGGL(colsum_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, x, (long)npix, C, cs, acc);
+  return sfh_check_launch("colsum_kernel");
+}
+
+extern "C" int sfh_maxpool2_fwd(const float* x, float* y, int batch, int H, int W, int C, void* stream) {
+  SFH_REQUIRE(x && y && batch > 0 && H >= 2 && W >= 2 && C > 0 && C % 4 == 0, "maxpool2_fwd: bad argument");
+  const int Ho = H / 2, Wo = W / 2;
+  const long total4 = (long)batch * Ho * Wo * (C / 4);
+  hipLaunchKernelGGL(maxpool2_fwd_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x,
+                     H, W, C, Ho, Wo, total4, y);
+  return sfh_check_launch("maxpool2_fwd_kernel");
+}
+
+extern "C" int sfh_maxpool2_bwd(const float* x, const float* dy, float* dx, int batch, int H, int W, int C,
+                                int accumulate, void* stream) {
+  SFH_REQUIRE(x && dy && dx && batch > 0 && H >= 2 && W >= 2 && C > 0 && C % 4 == 0, "maxpool2_bwd: bad argument");
+  SFH_REQUIRE(accumulate || (H % 2 == 0 && W % 2 == 0),
+              "maxpool2_bwd: odd sizes leave a border the kernel does not write; zero dx and pass accumulate=1");
+  const int Ho = H / 2, Wo = W / 2;
+  const long total4 = (long)batch * Ho * Wo * (C / 4);
+  hipLaunchKernelGGL(maxpool2_bwd_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x,
+                     dy, H, W, C, Ho, Wo, total4, accumulate, dx);
+  return sfh_check_launch("maxpool2_bwd_kernel");
+}
+
+extern "C" int sfh_slice_add(const float* src, int Hs, int Ws, int cs, int c_off, int oy, int ox, float* dst,
+                             int batch, int h, int w, int C, int accumulate, void* stream) {
+  SFH_REQUIRE(src && dst && batch > 0 && h > 0 && w > 0 && C > 0 && C % 4 == 0 && cs % 4 == 0 && c_off % 4 == 0 &&
+                  c_off >= 0 && c_off + C <= cs && Hs > 0 && Ws > 0,
+              "slice_add: bad argument");
+  const long total4 = (long)batch * h * w * (C / 4);
+  hipLaunchKernelGGL(slice_add_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src,
+                     Hs, Ws, cs, c_off, oy, ox, h, w, C, total4, accumulate, dst);
+  return sfh_check_launch("slice_add_kernel");
+}
+
+extern "C" int sfh_zero_stuff2(const float* src, float* dst, int batch, int ho, int wo, int H, int W, int C,
+                               void* stream) {
+  SFH_REQUIRE(src && dst && batch > 0 && ho > 0 && wo > 0 && C > 0 && C % 4 == 0, "zero_stuff2: bad argument");
+  SFH_REQUIRE(H >= 2 * ho - 1 && W >= 2 * wo - 1, "zero_stuff2: destination %dx%d too small for %dx%d", H, W, ho, wo);
+  const long total4 = (long)batch * H * W * (C / 4);
+  hipLaunchKernelGGL(zero_stuff2_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src,
+                     ho, wo, H, W, C, total4, dst);
+  return sfh_check_launch("zero_stuff2_kernel");
+}
+
+extern "C" int sfh_conv_wgrad(const float* dz, int dz_cs, int M, const float* x, int x_cs, int xh, int xw, int N,
+                              int pad_top, int pad_left, int batch, int H, int W, int ksize, float* raw, int raw_n,
+                              int n_off, void* stream) {
+  SFH_REQUIRE(dz && x && raw, "conv_wgrad: null pointer");
+  SFH_REQUIRE(batch > 0 && H > 0 && W > 0 && xh > 0 && xw > 0, "conv_wgrad: bad geometry");
+  SFH_REQUIRE(M > 0 && M % 4 == 0 && dz_cs % 4 == 0 && dz_cs >= M, "conv_wgrad: M=%d dz_cs=%d", M, dz_cs);
+  SFH_REQUIRE(N > 0 && N % 4 == 0 && x_cs % 4 == 0 && x_cs >= N, "conv_wgrad: N=%d x_cs=%d", N, x_cs);
+  SFH_REQUIRE(n_off >= 0 && n_off + N <= raw_n, "conv_wgrad: n_off=%d N=%d raw_n=%d", n_off, N, raw_n);
+  SFH_REQUIRE(ksize == 1 || ksize == 3 || ksize == 4, "conv_wgrad: ksize %d", ksize);
+  SFH_REQUIRE(ksize != 4 || N <= 32, "conv_wgrad: the 4x4 (stem) case supports N <= 32");
+  WgradArgs a;
+  a.dz = dz; a.dz_cs = dz_cs; a.M = M;
+  a.x = x; a.x_cs = x_cs; a.xh = xh; a.xw = xw; a.N = N; a.pad_top = pad_top; a.pad_left = pad_left;
+  a.batch = batch; a.H = H; a.W = W;
+  a.raw = raw; a.raw_n = raw_n; a.n_off = n_off;
+  a.ntx = sfh_cdiv(W, WG_TW); a.nty = sfh_cdiv(H, WG_TH); a.ntiles = batch * a.ntx * a.nty;
+  const int nsub = ksize == 4 ? 2 : 4;
+  const int mn = sfh_cdiv(M, 64) * sfh_cdiv(N, 16 * nsub);
+  int ns = sfh_cdiv(1024, mn);
+  if (ns > a.ntiles) ns = a.ntiles;
+  if (ns < 1) ns = 1;
+  if (ns > 65535) ns = 65535;
+  a.nsplit = ns;
+  hipStream_t st = (hipStream_t)stream;
+  if (ksize == 3) return launch_wgrad<3, 4>(a, st);
+  if (ksize == 1) return launch_wgrad<1, 4>(a, st);
+  return launch_wgrad<4, 2>(a, st);
+}
+
+extern "C" int sfh_outconv_bwd(const float* x, int cin, const float* w, const float* dlogits_nchw, int nc,
+                               int batch, int H, int W, float* dx, double* acc_w, double* acc_b, void* stream) {
+  SFH_REQUIRE(x && w && dlogits_nchw && acc_w && acc_b && batch > 0 && H > 0 && W > 0, "outconv_bwd: bad argument");
+  SFH_REQUIRE(cin % 4 == 0 && cin >= 4 && cin <= 256, "outconv_bwd: cin=%d (multiple of 4, <= 256)", cin);
+  SFH_REQUIRE(nc >= 1 && nc <= 8, "outconv_bwd: nc=%d unsupported (1..8)", nc);
+  const long npix = (long)batch * H * W;
+  const unsigned grid = (unsigned)((npix + 1023) / 1024);
+#define SFH_OB(N)                                                                                      \
+  case N:                                                                                              \
+    hipLaunchKernelGGL(outconv_bwd_kernel<N>, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, cin, w, \
+                       dlogits_nchw, npix, H * W, dx, acc_w, acc_b);                                   \
+    break;
+  switch (nc) { SFH_OB(1) SFH_OB(2) SFH_OB(3) SFH_OB(4) SFH_OB(5) SFH_OB(6) SFH_OB(7) SFH_OB(8) }
+#undef SFH_OB
+  return sfh_check_launch("outconv_bwd_kernel");
+}
+
+extern "C" int sfh_maxpool3x3s2_bwd(const float* x, const float* dy, float* dx, int batch, int H, int W, int C,
+                                    void* stream) {
+  SFH_REQUIRE(x && dy && dx && batch > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, "maxpool3x3s2_bwd: bad argument");
+  const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+  const long total4 = (long)batch * H * W * (C / 4);
+  hipLaunchKernelGGL(maxpool3x3s2_bwd_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0,
+                     (hipStream_t)stream, x, dy, H, W, C, Ho, Wo, total4, dx);
+  return sfh_check_launch("maxpool3x3s2_bwd_kernel");
+}
+
+extern "C" int sfh_avgpool_linear_bwd(const float* x, const float* w, const float* dout, int batch, int H, int W,
+                                      int C, int nout, float* dx, double* acc_w, double* acc_b, void* stream) {
+  SFH_REQUIRE(x && w && dout && dx && acc_w && acc_b && batch > 0 && H > 0 && W > 0 && C > 0 && nout > 0 && nout <= 256,
+              "avgpool_linear_bwd: bad argument");
+  hipLaunchKernelGGL(avgpool_linear_bwd_kernel, dim3((unsigned)batch), dim3(256), 0, (hipStream_t)stream, x, w, dout,
+                     H * W, C, nout, dx, acc_w, acc_b);
+  return sfh_check_launch("avgpool_linear_bwd_kernel");
+}
+
+extern "C" int sfh_stem_bwd_data(const float* dz, const float* w, int cin, int nc, int batch, int H, int W,
+                                 float* dlogits_nchw, void* stream) {
+  SFH_REQUIRE(dz && w && dlogits_nchw && batch > 0 && batch <= 65535 && H > 0 && W > 0, "stem_bwd_data: bad argument");
+  SFH_REQUIRE(nc >= 1 && nc <= 8 && nc <= cin, "stem_bwd_data: nc=%d cin=%d", nc, cin);
+  const int Ho = (H + 6 - 7) / 2 + 1, Wo = (W + 6 - 7) / 2 + 1;
+  const dim3 grid((unsigned)sfh_cdiv(W, 64), (unsigned)sfh_cdiv(H, 4), (unsigned)batch);
+  if (nc <= 4) {
+    hipLaunchKernelGGL(stem_bwd_data_kernel<1>, grid, dim3(256), 49 * 64 * 4 * sizeof(float), (hipStream_t)stream, dz, w,
+                       cin, nc, H, W, Ho, Wo, dlogits_nchw);
+  } else {
+    static bool attr = false;
+    if (!attr) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&stem_bwd_data_kernel<2>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 49 * 64 * 8 * (int)sizeof(float));
+      attr = true;
+    }
+    hipLaunchKernelGGL(stem_bwd_data_kernel<2>, grid, dim3(256), 49 * 64 * 8 * sizeof(float), (hipStream_t)stream, dz, w,
+                       cin, nc, H, W, Ho, Wo, dlogits_nchw);
+  }
+  return sfh_check_launch("stem_bwd_data_kernel");
+}

@@ -5,8 +5,8 @@ Same constructor keywords, attributes, method names, returned dict keys, dtypes 
 (see engine.py).  There is no fallback: calling the model on CPU tensors, or without
 the built library, raises.
 
-Not yet on the HIP path (raise ``NotImplementedError``):
-training-mode forward/backward and Bottleneck ResNets.
+Training (``net.train(); net(x); loss.backward()``) runs on the HIP kernels of
+``training.py`` for the default configuration; ``predict`` stays eval-only like a BatchNorm model should.
 """
 import os
 from enum import Enum
@@ -240,9 +240,12 @@ class Reconstructor(nn.Module):
         return {k: torch.cat([o[k] for o in outs], 0) for k in outs[0]}
 
     def forward(self, x):
-        """Inference-mode forward (reference: :160-194): logits, [uv], theta, poi, bilinear
-        (or nearest) warp_mask as float."""
-        self._require_eval("forward")
+        """Reference: :160-194 - logits, [uv], theta, poi, bilinear (or nearest) warp_mask as float.
+        Under ``train()`` the batch-statistics training kernels run and the outputs carry an
+        autograd node whose backward produces the parameter gradients (training.py)."""
+        if self.training:
+            from . import training
+            return training.train_forward(self, x)
         return self._chunked(self._forward_one, x)
 
     def _forward_one(self, x, off):

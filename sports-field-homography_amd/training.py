@@ -1,0 +1,488 @@
+"""Training-mode forward and backward of the hot path on the HIP kernels.
+
+What ``net.train(); preds = net(imgs); loss.backward()`` does in the reference (train.py:151,170,
+233): batch-statistics BatchNorm (running stats updated with momentum 0.1), activations kept for
+the backward pass, and gradients for every parameter.  The losses, ``clip_grad_value_`` and the
+optimizer stay with the caller (train.py:181-237), exactly as in the reference.
+
+fp32 NHWC activations and the fp32 MFMA kernels throughout (``sfh_conv_fwd`` for forward and
+backward-data, ``sfh_conv_wgrad`` for backward-filter).  A tape of closures records the backward
+of each layer; gradients of activations are keyed by tensor identity and accumulated with
+``sfh_slice_add``.  PyTorch provides memory, streams and the autograd hook
+(``torch.autograd.Function``) only.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from . import engine as E
+from .engine import PackedConv, _ptr, _stream
+
+BN_MOMENTUM = 0.1  # nn.BatchNorm2d default, unchanged by the reference
+
+
+def _empty(shape, like, dtype=torch.float32):
+    return torch.empty(shape, dtype=dtype, device=like.device)
+
+
+def _zeros(shape, like, dtype=torch.float32):
+    return torch.zeros(shape, dtype=dtype, device=like.device)
+
+
+class Tape:
+    """Backward closures in forward order + gradients of activations by tensor identity."""
+
+    def __init__(self):
+        self.ops = []
+        self.grads = {}
+        self.param_grads = {}
+        self.lib = _lib.load()
+
+    def push(self, fn):
+        self.ops.append(fn)
+
+    def add_grad(self, t, g):
+        """grad[t] += g (g has t's shape; ownership of g passes to the tape)."""
+        cur = self.grads.get(id(t))
+        if cur is None:
+            self.grads[id(t)] = g
+            return
+        B, H, W, C = g.shape
+        _lib.check(self.lib.sfh_slice_add(_ptr(g), H, W, C, 0, 0, 0, _ptr(cur), B, H, W, C, 1, _stream()), "slice_add")
+
+    def pop_grad(self, t):
+        return self.grads.pop(id(t), None)
+
+    def peek_grad(self, t):
+        return self.grads.get(id(t))
+
+    def backward(self):
+        for fn in reversed(self.ops):
+            fn()
+        self.ops = []
+
+
+# --------------------------------------------------------------------------------------- layers
+def _bn_forward(lib, z, bn, relu, residual=None):
+    """Batch-statistics BatchNorm (+residual) (+ReLU); updates the running stats in place."""
+    B, H, W, C = z.shape
+    npix = B * H * W
+    acc = _zeros((2 * C,), z, torch.float64)
+    _lib.check(lib.sfh_bn_stats(_ptr(z), npix, C, _ptr(acc), _stream()), "bn_stats")
+    mi = _empty((2 * C,), z)
+    _lib.check(lib.sfh_bn_finalize(_ptr(acc), npix, C, float(bn.eps), BN_MOMENTUM, _ptr(bn.running_mean),
+                                   _ptr(bn.running_var), _ptr(mi), _stream()), "bn_finalize")
+    bn.num_batches_tracked += 1
+    y = _empty(z.shape, z)
+    _lib.check(lib.sfh_bn_apply(_ptr(z), _ptr(mi), _ptr(bn.weight.detach()), _ptr(bn.bias.detach()),
+                                _ptr(residual), 1 if relu else 0, npix, C, _ptr(y), _stream()), "bn_apply")
+    return y, mi
+
+
+def _bn_backward(lib, dy, y, z, mi, bn, relu, want_dres):
+    B, H, W, C = z.shape
+    npix = B * H * W
+    acc = _zeros((2 * C,), z, torch.float64)
+    _lib.check(lib.sfh_bn_bwd_reduce(_ptr(dy), _ptr(y), _ptr(z), _ptr(mi), 1 if relu else 0, npix, C, _ptr(acc),
+                                     _stream()), "bn_bwd_reduce")
+    dz = _empty(z.shape, z)
+    dres = _empty(z.shape, z) if want_dres else None
+    _lib.check(lib.sfh_bn_bwd_apply(_ptr(dy), _ptr(y), _ptr(z), _ptr(mi), _ptr(bn.weight.detach()), _ptr(acc),
+                                    1 if relu else 0, npix, C, _ptr(dz), _ptr(dres), _stream()), "bn_bwd_apply")
+    a = acc.to(torch.float32)
+    return dz, a[C:], a[:C], dres   # dz, dgamma, dbeta, dresidual
+
+
+def _colsum(lib, t, C=None, cs=None):
+    C = C or t.shape[-1]
+    cs = cs or t.shape[-1]
+    npix = t.numel() // cs
+    acc = _zeros((C,), t, torch.float64)
+    _lib.check(lib.sfh_colsum(_ptr(t), npix, C, cs, _ptr(acc), _stream()), "colsum")
+    return acc.to(torch.float32)
+
+
+def _wgrad(lib, dz, srcs, B, H, W, ksize, cin_store):
+    """raw (M, k*k, cin_store) = sum_p dz[p] (x) xin[p + tap]; srcs = [(tensor, channels, n_off, pad_top, pad_left)]."""
+    M = dz.shape[3]
+    raw = _zeros((M, ksize * ksize, cin_store), dz)
+    for (t, n, n_off, pt, pl) in srcs:
+        _lib.check(lib.sfh_conv_wgrad(_ptr(dz), dz.shape[3], M, _ptr(t), t.shape[3], t.shape[1], t.shape[2], n,
+                                      pt, pl, B, H, W, ksize, _ptr(raw), cin_store, n_off, _stream()), "conv_wgrad")
+    return raw
+
+
+class _Names:
+    """parameter tensor -> state_dict key, for the gradient dictionary."""
+
+    def __init__(self, module):
+        self.by_id = {id(p): k for k, p in module.named_parameters()}
+
+    def __call__(self, p):
+        return self.by_id[id(p)]
+
+
+def conv_bn_act(tape, names, conv, bn, srcs, B, H, W, relu=True, residual=None, need_dx=True):
+    """z = conv(cat(srcs)) + bias; y = [relu](bn_train(z) [+ residual]).
+
+    srcs: [(tensor NHWC, channels used, pad_top, pad_left)], one or two (skip first, like torch.cat
+    in unet/unet_parts.py:67).  Stride-1 3x3 / 1x1 convs, and stride-2 ones via zero-stuffing in the
+    backward."""
+    lib = tape.lib
+    ks, stride = conv.kernel_size[0], conv.stride[0]
+    w = conv.weight.detach()
+    cout = w.shape[0]
+    t0, c0 = srcs[0][0], srcs[0][1]
+    t1, c1 = (srcs[1][0], srcs[1][1]) if len(srcs) > 1 else (None, 0)
+    pc = PackedConv(w, conv.bias, None, ks, c0, c1, relu=False, stride=stride, tag="train_fwd")
+    ho, wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    z = _empty((B, ho, wo, cout), t0)
+    pc.run(t0, B, H, W, z, src1=t1, pad1=(srcs[1][2], srcs[1][3]) if t1 is not None else (0, 0))
+    y, mi = _bn_forward(lib, z, bn, relu, residual)
+
+    def backward():
+        dy = tape.pop_grad(y)
+        if dy is None:
+            raise RuntimeError("conv_bn_act: no gradient reached this layer")
+        dz, dgamma, dbeta, dres = _bn_backward(lib, dy, y, z, mi, bn, relu, residual is not None)
+        g = tape.param_grads
+        g[names(bn.weight)], g[names(bn.bias)] = dgamma, dbeta
+        if conv.bias is not None:
+            g[names(conv.bias)] = _colsum(lib, dz)
+        if residual is not None:
+            tape.add_grad(residual, dres)
+        if stride == 2:  # zero-stuff dz to the input resolution: stride-1 backward from here on
+            u = _empty((B, H, W, cout), dz)
+            _lib.check(lib.sfh_zero_stuff2(_ptr(dz), _ptr(u), B, ho, wo, H, W, cout, _stream()), "zero_stuff2")
+            dz = u
+        cin_store = t0.shape[3] if t1 is None else c0 + c1
+        wsrc = [(t0, min(c0 + 3 & ~3, t0.shape[3]), 0, 0, 0)]
+        if t1 is not None:
+            wsrc.append((t1, c1, c0, srcs[1][2], srcs[1][3]))
+        raw = _wgrad(lib, dz, wsrc, B, H, W, ks, cin_store)
+        g[names(conv.weight)] = raw.view(cout, ks, ks, cin_store)[..., :c0 + c1].permute(0, 3, 1, 2).contiguous()
+        if not need_dx:
+            return
+        bd = PackedConv.backward_data(w, ks)
+        dx = _empty((B, H, W, bd.cout), dz)
+        bd.run(dz, B, H, W, dx)
+        if t1 is None:
+            tape.add_grad(t0, dx)
+            return
+        d0 = _empty(t0.shape, dz)
+        _lib.check(lib.sfh_slice_add(_ptr(dx), H, W, bd.cout, 0, 0, 0, _ptr(d0), B, H, W, c0, 0, _stream()), "slice_add")
+        tape.add_grad(t0, d0)
+        d1 = _empty(t1.shape, dz)
+        _lib.check(lib.sfh_slice_add(_ptr(dx), H, W, bd.cout, c0, srcs[1][2], srcs[1][3], _ptr(d1), B, t1.shape[1],
+                                     t1.shape[2], c1, 0, _stream()), "slice_add")
+        tape.add_grad(t1, d1)
+
+    tape.push(backward)
+    return y
+
+
+def maxpool2(tape, x):
+    """nn.MaxPool2d(2) (unet/unet_parts.py:33)."""
+    lib = tape.lib
+    B, H, W, C = x.shape
+    p = _empty((B, H // 2, W // 2, C), x)
+    _lib.check(lib.sfh_maxpool2_fwd(_ptr(x), _ptr(p), B, H, W, C, _stream()), "maxpool2_fwd")
+
+    def backward():
+        dp = tape.pop_grad(p)
+        cur = tape.peek_grad(x)
+        if cur is None:
+            even = H % 2 == 0 and W % 2 == 0
+            cur = _empty(x.shape, x) if even else _zeros(x.shape, x)
+            _lib.check(lib.sfh_maxpool2_bwd(_ptr(x), _ptr(dp), _ptr(cur), B, H, W, C, 0 if even else 1, _stream()),
+                       "maxpool2_bwd")
+            tape.add_grad(x, cur)
+        else:
+            _lib.check(lib.sfh_maxpool2_bwd(_ptr(x), _ptr(dp), _ptr(cur), B, H, W, C, 1, _stream()), "maxpool2_bwd")
+
+    tape.push(backward)
+    return p
+
+
+def conv_transpose2x2(tape, names, up, x):
+    """nn.ConvTranspose2d(cin, cin/2, 2, stride=2) (unet/unet_parts.py:52)."""
+    lib = tape.lib
+    B, h, w, cin = x.shape
+    wt = up.weight.detach()
+    cout = wt.shape[1]
+    pc = PackedConv(wt, up.bias, None, 1, cin, relu=False, transposed=True, tag="train_fwd")
+    u = _empty((B, 2 * h, 2 * w, cout), x)
+    pc.run(x, B, h, w, u)
+
+    def backward():
+        du = tape.pop_grad(u)
+        g = tape.param_grads
+        g[names(up.bias)] = _colsum(lib, du)
+        s = _empty((B, h, w, 4 * cout), x)  # s[(py*2+px)*cout + co] = du[2y+py][2x+px][co]
+        _lib.check(lib.sfh_space_to_depth2(_ptr(du), _ptr(s), B, 2 * h, 2 * w, cout, _stream()), "space_to_depth2")
+        raw = _wgrad(lib, s, [(x, cin, 0, 0, 0)], B, h, w, 1, cin)      # (4*cout, 1, cin)
+        g[names(up.weight)] = raw.view(2, 2, cout, cin).permute(3, 2, 0, 1).contiguous()
+        bd = PackedConv.backward_data(wt, 1, transposed=True)
+        dx = _empty((B, h, w, bd.cout), x)
+        bd.run(s, B, h, w, dx)
+        tape.add_grad(x, dx)
+
+    tape.push(backward)
+    return u
+
+
+def out_conv(tape, names, oc, y, B, H, W, frame_nhwc=None, stn_cs=0):
+    """OutConv (unet/unet_parts.py:74-77) -> logits NCHW (+ the STN input cat((logits, x), 1) in NHWC)."""
+    lib = tape.lib
+    wt, bias = oc.conv.weight.detach(), oc.conv.bias.detach()
+    nc, cin = wt.shape[0], wt.shape[1]
+    logits = _empty((B, nc, H, W), y)
+    stn_in = _empty((B, H, W, stn_cs), y) if frame_nhwc is not None else None
+    _lib.check(lib.sfh_outconv_fwd(_ptr(y), cin, _ptr(wt), _ptr(bias), nc, B, H, W, _ptr(logits), None, _ptr(stn_in),
+                                   stn_cs, _ptr(frame_nhwc), frame_nhwc.shape[3] if frame_nhwc is not None else 0,
+                                   _stream()), "outconv")
+
+    def backward(dlogits):
+        """dlogits: (B,nc,H,W) contiguous - total gradient wrt the logits."""
+        acc_w = _zeros((nc * cin,), y, torch.float64)
+        acc_b = _zeros((nc,), y, torch.float64)
+        dy = _empty(y.shape, y)
+        _lib.check(lib.sfh_outconv_bwd(_ptr(y), cin, _ptr(wt), _ptr(dlogits), nc, B, H, W, _ptr(dy), _ptr(acc_w),
+                                       _ptr(acc_b), _stream()), "outconv_bwd")
+        g = tape.param_grads
+        g[names(oc.conv.weight)] = acc_w.to(torch.float32).view(nc, cin, 1, 1)
+        g[names(oc.conv.bias)] = acc_b.to(torch.float32)
+        tape.add_grad(y, dy)
+
+    return logits, stn_in, backward
+
+
+# ----------------------------------------------------------------------------------------- UNet
+class UNetTrainer:
+    """forward_unet (models/reconstructor.py:132-158) in training mode, deconv Up variant, no resize."""
+
+    def __init__(self, net):
+        if net.unet_bilinear:
+            raise NotImplementedError("training the bilinear Up variant is not on the HIP path yet")
+        self.net = net
+        self.names = _Names(net)
+
+    def forward(self, tape, x_nchw, want_stn_in=False, stn_cs=8):
+        net, names = self.net, self.names
+        lib = tape.lib
+        B, _, H, W = x_nchw.shape
+        x = E.nchw_to_nhwc(x_nchw, 4)
+
+        def dconv(block, srcs, h, w, need_dx=True):
+            (cv1, bn1), (cv2, bn2) = block.convs()
+            y1 = conv_bn_act(tape, names, cv1, bn1, srcs, B, h, w, need_dx=need_dx)
+            return conv_bn_act(tape, names, cv2, bn2, [(y1, y1.shape[3], 0, 0)], B, h, w)
+
+        x1 = dconv(net.inc, [(x, 3, 0, 0)], H, W, need_dx=False)
+        feats = [x1]
+        h, w = H, W
+        for i in range(1, 5):
+            p = maxpool2(tape, feats[-1])
+            h, w = h // 2, w // 2
+            feats.append(dconv(getattr(net, f"down{i}").block, [(p, p.shape[3], 0, 0)], h, w))
+        y = feats[4]
+        for i in range(1, 5):
+            up = getattr(net, f"up{i}")
+            skip = feats[4 - i]
+            u = conv_transpose2x2(tape, names, up.up, y)
+            hs, ws = skip.shape[1], skip.shape[2]
+            dy_, dx_ = hs - u.shape[1], ws - u.shape[2]
+            y = dconv(up.conv, [(skip, skip.shape[3], 0, 0), (u, u.shape[3], dy_ // 2, dx_ // 2)], hs, ws)
+        frame = x if want_stn_in else None
+        logits, stn_in, oc_bwd = out_conv(tape, names, net.outc, y, B, H, W, frame, stn_cs)
+        return logits, feats[4], stn_in, oc_bwd
+
+
+# --------------------------------------------------------------------------------------- ResNetSTN
+class ResNetTrainer:
+    """ResNetSTN (models/resnet.py:235-254) in training mode; BasicBlock and Bottleneck depths."""
+
+    def __init__(self, net):
+        self.net = net
+        self.rn = net.resnet_reg
+        self.names = _Names(net)
+
+    def forward(self, tape, stn_in, logits, nc, cin):
+        """stn_in: (B,H,W,cs) NHWC = cat((logits, frame)) zero-padded to cs channels; `logits` is the NCHW
+        tensor whose gradient slot receives the stem's backward-data.  Returns theta (B,1,3,3)."""
+        lib, rn, names = tape.lib, self.rn, self.names
+        B, H, W, cs = stn_in.shape
+        st = _stream
+        H2, W2 = (H + 1) // 2, (W + 1) // 2
+        s2d = _empty((B, H2, W2, 4 * cs), stn_in)
+        _lib.check(lib.sfh_space_to_depth2(_ptr(stn_in), _ptr(s2d), B, H, W, cs, st()), "space_to_depth2")
+        w0 = rn.conv0.weight.detach()
+        pc = PackedConv(w0, None, None, 4, 4 * cs, relu=False, stem_cin=cin, tag="train_fwd")
+        z0 = _empty((B, H2, W2, 64), stn_in)
+        pc.run(s2d, B, H2, W2, z0)
+        c1, mi0 = _bn_forward(lib, z0, rn.bn1, True)
+        h, w = (H2 - 1) // 2 + 1, (W2 - 1) // 2 + 1
+        x = _empty((B, h, w, 64), stn_in)
+        _lib.check(lib.sfh_maxpool3x3s2_fwd(_ptr(c1), _ptr(x), B, H2, W2, 64, st()), "maxpool3x3s2")
+        x_pool = x
+
+        def stem_backward():
+            dx = tape.pop_grad(x_pool)
+            dc1 = _empty(c1.shape, c1)
+            _lib.check(lib.sfh_maxpool3x3s2_bwd(_ptr(c1), _ptr(dx), _ptr(dc1), B, H2, W2, 64, st()), "maxpool3x3s2_bwd")
+            dz, dgamma, dbeta, _ = _bn_backward(lib, dc1, c1, z0, mi0, rn.bn1, True, False)
+            g = tape.param_grads
+            g[names(rn.bn1.weight)], g[names(rn.bn1.bias)] = dgamma, dbeta
+            raw = _wgrad(lib, dz, [(s2d, 4 * cs, 0, 0, 0)], B, H2, W2, 4, 4 * cs)     # (64, 16, 4*cs)
+            # 4x4 taps over the space-to-depth input -> 7x7: ky = 2*ty + py - 1 (sfh_pack_conv_weights mode 2)
+            r = raw.view(64, 4, 4, 2, 2, cs).permute(0, 5, 1, 3, 2, 4).reshape(64, cs, 8, 8)
+            g[names(rn.conv0.weight)] = r[:, :cin, 1:, 1:].contiguous()
+            dl = tape.peek_grad(logits)
+            if dl is not None:  # the logits are the first nc channels of the STN input
+                _lib.check(lib.sfh_stem_bwd_data(_ptr(dz), _ptr(w0), cin, nc, B, H, W, _ptr(dl), st()), "stem_bwd_data")
+
+        tape.push(stem_backward)
+
+        def cba(conv, bn, src, hh, ww, relu=True, residual=None):
+            return conv_bn_act(tape, names, conv, bn, [(src, src.shape[3], 0, 0)], B, hh, ww, relu=relu,
+                               residual=residual)
+
+        for li in range(1, 5):
+            for blk in getattr(rn, f"layer{li}"):
+                s = blk.stride
+                ho, wo = (h - 1) // s + 1, (w - 1) // s + 1
+                idn = cba(blk.downsample[0], blk.downsample[1], x, h, w, relu=False) if blk.downsample is not None else x
+                if hasattr(blk, "conv3"):
+                    t = cba(blk.conv1, blk.bn1, x, h, w)
+                    t = cba(blk.conv2, blk.bn2, t, h, w)
+                    x = cba(blk.conv3, blk.bn3, t, ho, wo, residual=idn)
+                else:
+                    t = cba(blk.conv1, blk.bn1, x, h, w)
+                    x = cba(blk.conv2, blk.bn2, t, ho, wo, residual=idn)
+                h, w = ho, wo
+        feat = x
+        C = feat.shape[3]
+        wr, br = rn.reg.weight.detach(), rn.reg.bias.detach()
+        theta = _empty((B, 9), stn_in)
+        _lib.check(lib.sfh_avgpool_linear_fwd(_ptr(feat), _ptr(wr), _ptr(br), B, h, w, C, 9, _ptr(theta), st()),
+                   "avgpool_linear")
+        fh, fw = h, w
+
+        def head_backward():
+            dth = tape.pop_grad(theta)
+            acc_w = _zeros((9 * C,), feat, torch.float64)
+            acc_b = _zeros((9,), feat, torch.float64)
+            dfeat = _empty(feat.shape, feat)
+            _lib.check(lib.sfh_avgpool_linear_bwd(_ptr(feat), _ptr(wr), _ptr(dth), B, fh, fw, C, 9, _ptr(dfeat),
+                                                  _ptr(acc_w), _ptr(acc_b), st()), "avgpool_linear_bwd")
+            g = tape.param_grads
+            g[names(rn.reg.weight)] = acc_w.to(torch.float32).view(9, C)
+            g[names(rn.reg.bias)] = acc_b.to(torch.float32)
+            tape.add_grad(feat, dfeat)
+
+        tape.push(head_backward)
+        return theta
+
+
+# ------------------------------------------------------------------------------- whole model
+def warp_backward_theta(theta, court_img, h, w, dout, shared_template):
+    """d loss / d theta of the bilinear warp (models/reconstructor.py:109-118,185-190)."""
+    lib = _lib.load()
+    B = theta.shape[0]
+    ht, wt = court_img.shape[2], court_img.shape[3]
+    acc = _zeros((B * 9,), theta, torch.float64)
+    _lib.check(lib.sfh_homography_warp_bwd_theta(_ptr(theta), _ptr(court_img), 0 if shared_template else ht * wt, ht, wt,
+                                                 B, h, w, _ptr(dout), _ptr(acc), _stream()), "homography_warp_bwd")
+    return acc.to(torch.float32).view(B, 9)
+
+
+def poi_backward_theta(theta, court_poi, dout, normalize=True):
+    lib = _lib.load()
+    B = theta.shape[0]
+    p = court_poi[:B].contiguous()
+    dth = _empty((B, 9), theta)
+    _lib.check(lib.sfh_poi_project_bwd_theta(_ptr(theta), _ptr(p), B, p.shape[1], 1 if normalize else 0, _ptr(dout),
+                                             _ptr(dth), _stream()), "poi_project_bwd")
+    return dth
+
+
+class _TrainForward(torch.autograd.Function):
+    """Reconstructor.forward under net.train() as one autograd node: the forward runs the HIP
+    training kernels and keeps the tape; backward() turns the output gradients into parameter
+    gradients (returned in the order of net.parameters())."""
+
+    @staticmethod
+    def forward(ctx, net, x, *params):
+        tape = Tape()
+        B, _, H, W = x.shape
+        x = E._f32c(x.detach(), "input frames")
+        ut = UNetTrainer(net)
+        cin = net.mask_classes + 3
+        cs = -(-cin // 4) * 4
+        if (4 * cs) % 16:
+            cs = -(-cin // 8) * 8
+        logits, _, stn_in, oc_bwd = ut.forward(tape, x, want_stn_in=True, stn_cs=cs)
+        theta = ResNetTrainer(net).forward(tape, stn_in, logits, net.mask_classes, cin)
+        theta4 = theta.view(B, 1, 3, 3)
+        shared = net._template_is_shared(net.court_img, B)
+        poi = E.poi_project(theta4, net.court_poi)
+        outs = [logits, theta4, poi]
+        ctx.warp = bool(net.warper)
+        if net.warper:
+            ww, wh = net.warp_size
+            wm, _ = E.homography_warp(theta4, net.court_img, wh, ww, net.warp_with_nearest, shared_template=shared)
+            outs.append(wm)
+        ctx.tape, ctx.oc_bwd, ctx.net, ctx.theta, ctx.logits, ctx.shared = tape, oc_bwd, net, theta, logits, shared
+        ctx.nparams = len(params)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, dlogits, dtheta, dpoi, *rest):
+        net, tape, theta = ctx.net, ctx.tape, ctx.theta
+        B = theta.shape[0]
+        dth = torch.zeros_like(theta) if dtheta is None else dtheta.reshape(B, 9).to(torch.float32).clone()
+        if dpoi is not None:
+            dth += poi_backward_theta(theta, net.court_poi, dpoi.contiguous())
+        if ctx.warp and rest and rest[0] is not None and not net.warp_with_nearest:
+            ww, wh = net.warp_size
+            dth += warp_backward_theta(theta, net.court_img, wh, ww, rest[0].contiguous(), ctx.shared)
+        dl = torch.zeros_like(ctx.logits) if dlogits is None else dlogits.contiguous().clone()
+        tape.grads[id(theta)] = dth
+        tape.grads[id(ctx.logits)] = dl
+        # ResNet closures run first (pushed last) and add the stem's gradient into dl; then the UNet
+        ops, tape.ops = tape.ops, []
+        unet_ops = ops[:ctx_split(ops)]
+        for fn in reversed(ops[len(unet_ops):]):
+            fn()
+        ctx.oc_bwd(tape.pop_grad(ctx.logits))
+        for fn in reversed(unet_ops):
+            fn()
+        g = tape.param_grads
+        names = _Names(net)
+        grads = tuple(g.get(names(p)) for p in net.parameters())
+        ctx.tape = None
+        return (None, None) + grads
+
+
+def ctx_split(ops):
+    """index of the first ResNet closure on the tape (the stem's)."""
+    for i, fn in enumerate(ops):
+        if fn.__name__ == "stem_backward":
+            return i
+    return len(ops)
+
+
+def train_forward(net, x):
+    """models/reconstructor.py:160-194 under net.train(): dict with logits, theta, poi[, warp_mask]."""
+    if net.unet_uv or net.resnet_input.name != "IMG_AND_MASK" or not (net.use_unet and net.use_resnet):
+        raise NotImplementedError("the HIP training path covers the default configuration "
+                                  "(resnet_input='img+mask', no uv head)")
+    if net._needs_resize(x):
+        raise NotImplementedError("training with unet_size/target_size different from the frame size is not on the HIP path")
+    params = tuple(net.parameters())
+    outs = _TrainForward.apply(net, x, *params)
+    ret = {"logits": outs[0], "theta": outs[1], "poi": outs[2]}
+    if net.warper:
+        ret["warp_mask"] = outs[3]
+    return ret
