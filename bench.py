@@ -60,6 +60,64 @@ def pmc_traffic(tag):
         return None
 
 
+def train_bench(args):
+    """Config 3 (train.py:155-237): forward under net.train(), CE + SmoothL1 + RRMSE + consistency CE,
+    backward, clip_grad_value_(0.1), RMSprop(momentum 0.9).  The model's forward/backward run on the HIP
+    training kernels; losses and optimizer are the caller's torch ops, as in the reference."""
+    import torch
+    import torch.nn.functional as F
+    from sfh_amd import synth
+    from sfh_amd.reconstructor import Reconstructor
+
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    B, W, H = args.batch, args.width, args.height
+    court = synth.load_court_template("ncaa_nc4_640x360" if (W, H) == (640, 360) else "pitch_v3_nc4_1280x720", 4, B).to(dev)
+    poi = synth.load_court_poi("pitch", B).to(dev)
+    net = Reconstructor(court, poi, target_size=(W, H), unet_size=(W, H), warp_size=(W, H))
+    net.load_state_dict(synth.synth_state_dict(net.state_dict(), 0))
+    net.to(dev).train()
+    opt = torch.optim.RMSprop(net.parameters(), lr=1e-5, weight_decay=1e-8, momentum=0.9)
+    g = torch.Generator().manual_seed(0)
+    x = synth.frames_to_float(synth.synth_frames_u8(B, H, W, seed=0)).to(dev)
+    mask = torch.randint(0, 4, (B, H, W), generator=g).to(dev)
+    weight = torch.ones(B, device=dev)
+    gt_poi = torch.rand(B, poi.shape[1], 2, generator=g).to(dev)
+    nonzeros = torch.ones(B, poi.shape[1], device=dev)
+    num_nonzero = nonzeros.sum(1)
+
+    def step():
+        preds = net(x)
+        seg = (F.cross_entropy(preds["logits"], mask, reduction="none").mean(dim=(1, 2)) * weight).mean()
+        rec = (F.smooth_l1_loss(preds["warp_mask"], mask.float() / 4.0, reduction="none").mean(dim=(1, 2)) * weight).mean()
+        dist = torch.sqrt(torch.sum((gt_poi - preds["poi"]) ** 2, dim=2))
+        reproj = torch.mean(torch.sum(dist * nonzeros, dim=1) / num_nonzero)
+        cons = F.cross_entropy(preds["logits"], (preds["warp_mask"] * 4).to(torch.long))
+        loss = seg + rec + reproj + cons
+        opt.zero_grad()
+        loss.backward()
+        torch.nn.utils.clip_grad_value_(net.parameters(), 0.1)
+        opt.step()
+        return loss
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    print(json.dumps({
+        "metric": "training steps: frames/sec at %dx%d batch=%d (forward + losses + backward + clip + RMSprop)" % (W, H, B),
+        "value": round(B * args.steps / el, 2), "unit": "frames/s", "n_gpus": 1, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(el / args.steps * 1e3, 2), "higher_is_better": True,
+        "dtype": "f32", "data": "synthetic", "final_loss": float(loss),
+        "peak_mem_gib": round(torch.cuda.max_memory_allocated() / 2**30, 2),
+        "config": {"workload": "BASELINE config 3: Reconstructor training step, CE + SmoothL1 + RRMSE + consistency CE"}}),
+        flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -71,7 +129,12 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=2)
     ap.add_argument("--consistency", action="store_true", help="also compute consist_score + poi")
+    ap.add_argument("--train", action="store_true",
+                    help="BASELINE config 3 instead of the headline: one training step (forward, losses, "
+                         "backward, clip, RMSprop) per batch; prints its own JSON line")
     args = ap.parse_args()
+    if args.train:
+        return train_bench(args)
 
     import torch
     import torch.distributed as dist

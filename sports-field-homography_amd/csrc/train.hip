@@ -17,9 +17,16 @@ namespace {
 
 // ------------------------------------------------------------------ per-channel reductions
 // rows = pixels, C channels (multiple of 4).  A block of 256 threads = (256/cq) pixel lanes x cq
-// channel quads reduces RED_ROWS pixels and adds its partials to fp64 accumulators with atomics;
+// channel quads strides over the pixels (grid-stride, at most RED_BLOCKS blocks so that the fp64
+// atomics on the few accumulator addresses stay cheap) and adds its partials to fp64 accumulators;
 // C > 1024 is processed in chunks of 1024 channels.
-constexpr int RED_ROWS = 2048;
+constexpr int RED_ROWS = 256;     // pixels per block below which no further blocks are launched
+constexpr int RED_BLOCKS = 1024;  // 4 per CU
+
+static inline unsigned red_grid(long npix) {
+  long nb = (npix + RED_ROWS - 1) / RED_ROWS;
+  return (unsigned)(nb < 1 ? 1 : (nb > RED_BLOCKS ? RED_BLOCKS : nb));
+}
 
 // acc[0][c] += sum z, acc[1][c] += sum z^2
 __global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__ z, long npix, int C,
@@ -30,9 +37,8 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__
     const int lanes = 256 / cq;
     const int q = threadIdx.x % cq, pl = threadIdx.x / cq;
     double s0[4] = {0, 0, 0, 0}, s1[4] = {0, 0, 0, 0};
-    const long p0 = (long)blockIdx.x * RED_ROWS, p1 = min(p0 + RED_ROWS, npix);
     if (pl < lanes)
-      for (long p = p0 + pl; p < p1; p += lanes) {
+      for (long p = (long)blockIdx.x * lanes + pl; p < npix; p += (long)gridDim.x * lanes) {
         const f32x4 v = *reinterpret_cast<const f32x4*>(z + p * C + c0 + 4 * q);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -64,9 +70,8 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x
     const int lanes = 256 / qn;
     const int q = threadIdx.x % qn, pl = threadIdx.x / qn;
     double s[4] = {0, 0, 0, 0};
-    const long p0 = (long)blockIdx.x * RED_ROWS, p1 = min(p0 + RED_ROWS, npix);
     if (pl < lanes)
-      for (long p = p0 + pl; p < p1; p += lanes) {
+      for (long p = (long)blockIdx.x * lanes + pl; p < npix; p += (long)gridDim.x * lanes) {
         const f32x4 v = *reinterpret_cast<const f32x4*>(x + p * cs + 4 * (q0 + q));
 #pragma unroll
         for (int j = 0; j < 4; ++j) s[j] += (double)v[j];
@@ -141,9 +146,8 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
     const int lanes = 256 / cq;
     const int q = threadIdx.x % cq, pl = threadIdx.x / cq;
     double s0[4] = {0, 0, 0, 0}, s1[4] = {0, 0, 0, 0};
-    const long p0 = (long)blockIdx.x * RED_ROWS, p1 = min(p0 + RED_ROWS, npix);
     if (pl < lanes)
-      for (long p = p0 + pl; p < p1; p += lanes) {
+      for (long p = (long)blockIdx.x * lanes + pl; p < npix; p += (long)gridDim.x * lanes) {
         const long o = p * C + c0 + 4 * q;
         const f32x4 g = *reinterpret_cast<const f32x4*>(dy + o);
         const f32x4 zz = *reinterpret_cast<const f32x4*>(z + o);
@@ -601,7 +605,7 @@ int launch_wgrad(const WgradArgs& a, hipStream_t stream) {
 // =============================================================================== C ABI
 extern "C" int sfh_bn_stats(const float* z, int64_t npix, int C, double* acc, void* stream) {
   SFH_REQUIRE(z && acc && npix > 0 && C > 0 && C % 4 == 0, "bn_stats: bad argument");
-  const unsigned nb = (unsigned)((npix + RED_ROWS - 1) / RED_ROWS);
+  const unsigned nb = red_grid((long)npix);
   hipLaunchKernelGGL(bn_stats_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, z, (long)npix, C, acc);
   return sfh_check_launch("bn_stats_kernel");
 }
@@ -628,7 +632,7 @@ extern "C" int sfh_bn_bwd_reduce(const float* dy, const float* y, const float* z
                                  int relu, int64_t npix, int C, double* acc, void* stream) {
   SFH_REQUIRE(dy && z && mean_invstd && acc && (y || !relu) && npix > 0 && C > 0 && C % 4 == 0,
               "bn_bwd_reduce: bad argument");
-  const unsigned nb = (unsigned)((npix + RED_ROWS - 1) / RED_ROWS);
+  const unsigned nb = red_grid((long)npix);
   hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, dy, y, z, mean_invstd, relu,
                      (long)npix, C, acc);
   return sfh_check_launch("bn_bwd_reduce_kernel");
@@ -647,7 +651,7 @@ extern "C" int sfh_bn_bwd_apply(const float* dy, const float* y, const float* z,
 
 extern "C" int sfh_colsum(const float* x, int64_t npix, int C, int cs, double* acc, void* stream) {
   SFH_REQUIRE(x && acc && npix > 0 && C > 0 && C % 4 == 0 && cs >= C && cs % 4 == 0, "colsum: bad argument");
-  const unsigned nb = (unsigned)((npix + RED_ROWS - 1) / RED_ROWS);
+  const unsigned nb = red_grid((long)npix);
   hipLaunchKernelGGL(colsum_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, x, (long)npix, C, cs, acc);
   return sfh_check_launch("colsum_kernel");
 }

@@ -149,7 +149,9 @@ def conv_bn_act(tape, names, conv, bn, srcs, B, H, W, relu=True, residual=None, 
         g = tape.param_grads
         g[names(bn.weight)], g[names(bn.bias)] = dgamma, dbeta
         if conv.bias is not None:
-            g[names(conv.bias)] = _colsum(lib, dz)
+            # a bias in front of a batch-statistics BatchNorm has exactly zero gradient (the batch mean
+            # absorbs it); autograd's value is rounding noise around 0
+            g[names(conv.bias)] = _zeros((cout,), dz)
         if residual is not None:
             tape.add_grad(residual, dres)
         if stride == 2:  # zero-stuff dz to the input resolution: stride-1 backward from here on
