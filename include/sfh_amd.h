@@ -102,7 +102,7 @@ int sfh_conv_s3_fwd(const sfh_conv_desc* d, void* stream);
 int64_t sfh_packed_s3_weight_bytes(int ksize, int c0, int c1, int cout_virtual);
 /* mode 0: OIHW conv weight; mode 1: IOHW ConvTranspose2d weight (ksize 1, cout_virtual = 4*cout);
  * mode 2: the 7x7 s2 stem as a 4x4 conv over the space-to-depth input (ksize 4, aux = real cin),
- * as in sfh_pack_conv_weights. */
+ * mode 3 / 4: backward-data of Conv2d / ConvTranspose2d; all as in sfh_pack_conv_weights. */
 int sfh_pack_s3_weights(const float* w, void* packed, int ksize, int c0, int c1, int cout_virtual,
                         int mode, int aux, void* stream);
 /* fp32 NHWC (rows = B*H, W, cs) <-> S3 (rows, cs/32, 3, 4, W, 8) conversion */

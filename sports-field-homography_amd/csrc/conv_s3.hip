@@ -362,6 +362,11 @@ __global__ void pack_s3_weights_kernel(const float* __restrict__ w, unsigned sho
       const int ky7 = 2 * ky + (par >> 1) - 1, kx7 = 2 * kx + (par & 1) - 1;
       v = (c < aux && ky7 >= 0 && ky7 <= 6 && kx7 >= 0 && kx7 <= 6)
               ? w[(((size_t)cv * aux + c) * 7 + ky7) * 7 + kx7] : 0.f;
+    } else if (transposed == 3) {  // backward-data of Conv2d (see sfh_pack_conv_weights mode 3)
+      v = cv < aux ? w[(((size_t)cin * aux + cv) * ks + (ks - 1 - ky)) * ks + (ks - 1 - kx)] : 0.f;
+    } else if (transposed == 4) {  // backward-data of ConvTranspose2d (mode 4): aux = orig cout
+      const int qd = cin / aux, co = cin - qd * aux;
+      v = w[(((size_t)cv * aux + co) * 2 + (qd >> 1)) * 2 + (qd & 1)];
     } else if (transposed) {
       const int cout = coutv >> 2;
       const int qd = cv / cout, co = cv - qd * cout;
@@ -385,22 +390,39 @@ __device__ __forceinline__ long s3_elem(long row, int x, int c, int plane, int W
   return ((((row * (cs >> 5) + (c >> 5)) * 3 + plane) * 4 + ((c & 31) >> 3)) * W + x) * 8 + (c & 7);
 }
 
-__global__ void f32_to_s3_kernel(const float* __restrict__ src, unsigned short* __restrict__ dst, int W, int cs,
-                                 long total) {
-  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+// one thread = 8 channels (one group) of one pixel; a wave covers 16 pixels x the 4 groups of one
+// 32-channel block: reads are whole 128-byte lines, writes 256 contiguous bytes per (plane, group)
+__global__ __launch_bounds__(256) void f32_to_s3_kernel(const float* __restrict__ src, unsigned short* __restrict__ dst,
+                                                        int W, int cs, int xchunks, long total) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
   if (i >= total) return;
-  const long pix = i / cs;
-  const int c = i - pix * cs;
-  const long row = pix / W;
-  const int x = pix - row * W;
-  const float v = src[i];
-  const __bf16 v0 = (__bf16)v;
-  const float r1 = v - (float)v0;
-  const __bf16 v1 = (__bf16)r1;
-  const __bf16 v2 = (__bf16)(r1 - (float)v1);
-  dst[s3_elem(row, x, c, 0, W, cs)] = __builtin_bit_cast(unsigned short, v0);
-  dst[s3_elem(row, x, c, 1, W, cs)] = __builtin_bit_cast(unsigned short, v1);
-  dst[s3_elem(row, x, c, 2, W, cs)] = __builtin_bit_cast(unsigned short, v2);
+  const int g = (int)(i & 3), px = (int)((i >> 2) & 15);
+  long r = i >> 6;
+  const int xc = (int)(r % xchunks); r /= xchunks;
+  const int cb = (int)(r % (cs >> 5));
+  const long row = r / (cs >> 5);
+  const int x = xc * 16 + px;
+  if (x >= W) return;
+  const float* sp = src + (row * W + x) * cs + cb * 32 + g * 8;
+  const f32x4 a = *reinterpret_cast<const f32x4*>(sp), b = *reinterpret_cast<const f32x4*>(sp + 4);
+  const float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+  typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
+  u16x8 p0, p1, p2;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const __bf16 v0 = (__bf16)v[j];
+    const float r1 = v[j] - (float)v0;
+    const __bf16 v1 = (__bf16)r1;
+    const __bf16 v2 = (__bf16)(r1 - (float)v1);
+    p0[j] = __builtin_bit_cast(unsigned short, v0);
+    p1[j] = __builtin_bit_cast(unsigned short, v1);
+    p2[j] = __builtin_bit_cast(unsigned short, v2);
+  }
+  const long e = s3_elem(row, x, cb * 32 + g * 8, 0, W, cs);
+  const long ps = 4L * W * 8;  // plane stride in elements
+  *reinterpret_cast<u16x8*>(dst + e) = p0;
+  *reinterpret_cast<u16x8*>(dst + e + ps) = p1;
+  *reinterpret_cast<u16x8*>(dst + e + 2 * ps) = p2;
 }
 
 __global__ void s3_to_f32_kernel(const unsigned short* __restrict__ src, float* __restrict__ dst, int W, int cs,
@@ -486,7 +508,9 @@ extern "C" int sfh_pack_s3_weights(const float* w, void* packed, int ksize, int 
   SFH_REQUIRE(n > 0, "pack_s3_weights: bad geometry ks=%d c0=%d c1=%d cout=%d", ksize, c0, c1, cout_virtual);
   SFH_REQUIRE(w && packed, "pack_s3_weights: null pointer");
   SFH_REQUIRE((mode == 0 && ksize != 4) || (mode == 1 && ksize == 1 && c1 == 0 && cout_virtual % 256 == 0) ||
-                  (mode == 2 && ksize == 4 && c1 == 0 && aux > 0 && aux <= c0 / 4),
+                  (mode == 2 && ksize == 4 && c1 == 0 && aux > 0 && aux <= c0 / 4) ||
+                  (mode == 3 && c1 == 0 && (ksize == 1 || ksize == 3) && aux > 0 && aux <= cout_virtual) ||
+                  (mode == 4 && ksize == 1 && c1 == 0 && aux > 0 && c0 == 4 * aux),
               "pack_s3_weights: bad mode/geometry (mode %d, ksize %d)", mode, ksize);
   const long total = n / 48;  // one thread per (lane, 8 channels) of all three planes
   hipLaunchKernelGGL(pack_s3_weights_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
@@ -496,9 +520,10 @@ extern "C" int sfh_pack_s3_weights(const float* w, void* packed, int ksize, int 
 
 extern "C" int sfh_f32_to_s3(const float* src, void* dst, int64_t rows, int W, int cs, void* stream) {
   SFH_REQUIRE(src && dst && rows > 0 && W > 0 && cs > 0 && cs % 32 == 0, "f32_to_s3: cs must be a multiple of 32");
-  const long total = rows * W * cs;
+  const int xchunks = (W + 15) / 16;
+  const long total = rows * (cs / 32) * xchunks * 64;
   hipLaunchKernelGGL(f32_to_s3_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                     src, (unsigned short*)dst, W, cs, total);
+                     src, (unsigned short*)dst, W, cs, xchunks, total);
   return sfh_check_launch("f32_to_s3_kernel");
 }
 

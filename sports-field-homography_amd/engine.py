@@ -184,7 +184,7 @@ class PackedConv:
                                    _ptr(self.scale), _ptr(self.shift), _stream()), "fold_bn")
 
     @classmethod
-    def backward_data(cls, weight, ksize, transposed=False, tag="bwd_data"):
+    def backward_data(cls, weight, ksize, transposed=False, tag="bwd_data", s3=False):
         """The conv that maps dz -> dx for a stride-1 nn.Conv2d (OIHW weight; taps flipped, channels
         swapped: pack mode 3) or for nn.ConvTranspose2d k2 s2 (IOHW weight; a 1x1 conv over
         space_to_depth2(dY): pack mode 4).  fp32 kernel; output channels padded to a multiple of 64."""
@@ -200,16 +200,25 @@ class PackedConv:
             cout, cin = w.shape[0], w.shape[1]
             assert tuple(w.shape[2:]) == (ksize, ksize) and ksize in (1, 3)
             c0, mode, aux = cout, 3, cin
-        self.tag, self.s3, self.c4, self.stem_cin = tag, False, False, 0
+        self.tag, self.s3, self.c4, self.stem_cin = tag, bool(s3), False, 0
         self.ksize, self.c0, self.c1, self.relu, self.stride, self.transposed = ksize, c0, 0, False, 1, False
-        self.cout = -(-cin // 64) * 64
-        self.cout_real = cin
-        n = lib.sfh_packed_weight_floats(ksize, c0, 0, self.cout)
-        if n <= 0:
-            raise ValueError(f"unsupported backward-data geometry ksize={ksize} c0={c0} cout={self.cout}")
-        self.wpacked = torch.empty(n, dtype=torch.float32, device=dev)
-        _lib.check(lib.sfh_pack_conv_weights(_ptr(w), _ptr(self.wpacked), ksize, c0, 0, self.cout, mode, aux,
-                                             _stream()), "pack_conv_weights")
+        if cin % 64:
+            raise ValueError(f"backward-data conv needs a multiple of 64 input channels, got {cin}")
+        self.cout = self.cout_real = cin
+        if s3:
+            n = lib.sfh_packed_s3_weight_bytes(ksize, c0, 0, self.cout)
+            if n <= 0:
+                raise ValueError(f"unsupported S3 backward-data geometry ksize={ksize} c0={c0} cout={self.cout}")
+            self.wpacked = torch.empty(n, dtype=torch.uint8, device=dev)
+            _lib.check(lib.sfh_pack_s3_weights(_ptr(w), _ptr(self.wpacked), ksize, c0, 0, self.cout, mode, aux,
+                                               _stream()), "pack_s3_weights")
+        else:
+            n = lib.sfh_packed_weight_floats(ksize, c0, 0, self.cout)
+            if n <= 0:
+                raise ValueError(f"unsupported backward-data geometry ksize={ksize} c0={c0} cout={self.cout}")
+            self.wpacked = torch.empty(n, dtype=torch.float32, device=dev)
+            _lib.check(lib.sfh_pack_conv_weights(_ptr(w), _ptr(self.wpacked), ksize, c0, 0, self.cout, mode, aux,
+                                                 _stream()), "pack_conv_weights")
         self.scale = torch.ones(self.cout, dtype=torch.float32, device=dev)
         self.shift = torch.zeros(self.cout, dtype=torch.float32, device=dev)
         return self

@@ -5,13 +5,16 @@ What ``net.train(); preds = net(imgs); loss.backward()`` does in the reference (
 the backward pass, and gradients for every parameter.  The losses, ``clip_grad_value_`` and the
 optimizer stay with the caller (train.py:181-237), exactly as in the reference.
 
-fp32 NHWC activations and the fp32 MFMA kernels throughout (``sfh_conv_fwd`` for forward and
-backward-data, ``sfh_conv_wgrad`` for backward-filter).  A tape of closures records the backward
+Activations are kept in fp32 NHWC.  Forward and backward-data convolutions run on the split-bf16
+kernel (``sfh_conv_s3_fwd``: fp32-equivalent, the sources are converted to the S3 format once per
+tensor) unless ``SFH_TRAIN_PRECISION=fp32`` selects the fp32 MFMA kernel; the first layer, the stem
+and the backward-filter (``sfh_conv_wgrad``) are fp32 MFMA.  A tape of closures records the backward
 of each layer; gradients of activations are keyed by tensor identity and accumulated with
 ``sfh_slice_add``.  PyTorch provides memory, streams and the autograd hook
 (``torch.autograd.Function``) only.
 """
 import ctypes
+import os
 
 import torch
 
@@ -20,6 +23,13 @@ from . import engine as E
 from .engine import PackedConv, _ptr, _stream
 
 BN_MOMENTUM = 0.1  # nn.BatchNorm2d default, unchanged by the reference
+
+
+def _use_s3():
+    p = os.environ.get("SFH_TRAIN_PRECISION", "bf16x6")
+    if p not in ("bf16x6", "fp32"):
+        raise ValueError(f"SFH_TRAIN_PRECISION={p!r}: expected 'bf16x6' or 'fp32'")
+    return p == "bf16x6"
 
 
 def _empty(shape, like, dtype=torch.float32):
@@ -38,6 +48,15 @@ class Tape:
         self.grads = {}
         self.param_grads = {}
         self.lib = _lib.load()
+        self.use_s3 = _use_s3()
+        self._s3 = {}
+
+    def s3(self, t):
+        """split-bf16 copy of an NHWC activation (converted once, kept while the tape lives)"""
+        v = self._s3.get(id(t))
+        if v is None:
+            v = self._s3[id(t)] = (t, E.f32_to_s3(t))
+        return v[1]
 
     def push(self, fn):
         self.ops.append(fn)
@@ -135,10 +154,12 @@ def conv_bn_act(tape, names, conv, bn, srcs, B, H, W, relu=True, residual=None, 
     cout = w.shape[0]
     t0, c0 = srcs[0][0], srcs[0][1]
     t1, c1 = (srcs[1][0], srcs[1][1]) if len(srcs) > 1 else (None, 0)
-    pc = PackedConv(w, conv.bias, None, ks, c0, c1, relu=False, stride=stride, tag="train_fwd")
+    s3 = tape.use_s3 and c0 % 32 == 0 and c1 % 32 == 0 and c0 == t0.shape[3] and (t1 is None or c1 == t1.shape[3])
+    pc = PackedConv(w, conv.bias, None, ks, c0, c1, relu=False, stride=stride, tag="train_fwd", s3=s3)
     ho, wo = (H - 1) // stride + 1, (W - 1) // stride + 1
     z = _empty((B, ho, wo, cout), t0)
-    pc.run(t0, B, H, W, z, src1=t1, pad1=(srcs[1][2], srcs[1][3]) if t1 is not None else (0, 0))
+    pc.run(tape.s3(t0) if s3 else t0, B, H, W, z, src1=(tape.s3(t1) if s3 else t1) if t1 is not None else None,
+           pad1=(srcs[1][2], srcs[1][3]) if t1 is not None else (0, 0))
     y, mi = _bn_forward(lib, z, bn, relu, residual)
 
     def backward():
@@ -166,9 +187,9 @@ def conv_bn_act(tape, names, conv, bn, srcs, B, H, W, relu=True, residual=None, 
         g[names(conv.weight)] = raw.view(cout, ks, ks, cin_store)[..., :c0 + c1].permute(0, 3, 1, 2).contiguous()
         if not need_dx:
             return
-        bd = PackedConv.backward_data(w, ks)
+        bd = PackedConv.backward_data(w, ks, s3=s3)
         dx = _empty((B, H, W, bd.cout), dz)
-        bd.run(dz, B, H, W, dx)
+        bd.run(E.f32_to_s3(dz) if s3 else dz, B, H, W, dx)
         if t1 is None:
             tape.add_grad(t0, dx)
             return
@@ -213,9 +234,10 @@ def conv_transpose2x2(tape, names, up, x):
     B, h, w, cin = x.shape
     wt = up.weight.detach()
     cout = wt.shape[1]
-    pc = PackedConv(wt, up.bias, None, 1, cin, relu=False, transposed=True, tag="train_fwd")
+    s3 = tape.use_s3 and cin % 32 == 0
+    pc = PackedConv(wt, up.bias, None, 1, cin, relu=False, transposed=True, tag="train_fwd", s3=s3)
     u = _empty((B, 2 * h, 2 * w, cout), x)
-    pc.run(x, B, h, w, u)
+    pc.run(tape.s3(x) if s3 else x, B, h, w, u)
 
     def backward():
         du = tape.pop_grad(u)
@@ -225,9 +247,9 @@ def conv_transpose2x2(tape, names, up, x):
         _lib.check(lib.sfh_space_to_depth2(_ptr(du), _ptr(s), B, 2 * h, 2 * w, cout, _stream()), "space_to_depth2")
         raw = _wgrad(lib, s, [(x, cin, 0, 0, 0)], B, h, w, 1, cin)      # (4*cout, 1, cin)
         g[names(up.weight)] = raw.view(2, 2, cout, cin).permute(3, 2, 0, 1).contiguous()
-        bd = PackedConv.backward_data(wt, 1, transposed=True)
+        bd = PackedConv.backward_data(wt, 1, transposed=True, s3=s3)
         dx = _empty((B, h, w, bd.cout), x)
-        bd.run(s, B, h, w, dx)
+        bd.run(E.f32_to_s3(s) if s3 else s, B, h, w, dx)
         tape.add_grad(x, dx)
 
     tape.push(backward)
@@ -435,6 +457,7 @@ class _TrainForward(torch.autograd.Function):
             ww, wh = net.warp_size
             wm, _ = E.homography_warp(theta4, net.court_img, wh, ww, net.warp_with_nearest, shared_template=shared)
             outs.append(wm)
+        tape._s3.clear()   # the split-bf16 copies only feed forward convolutions
         ctx.tape, ctx.oc_bwd, ctx.net, ctx.theta, ctx.logits, ctx.shared = tape, oc_bwd, net, theta, logits, shared
         ctx.nparams = len(params)
         return tuple(outs)
@@ -463,7 +486,12 @@ class _TrainForward(torch.autograd.Function):
         g = tape.param_grads
         names = _Names(net)
         grads = tuple(g.get(names(p)) for p in net.parameters())
-        ctx.tape = None
+        # the closures reference the tape and the tape the closures: break the cycle so the activations
+        # are released now rather than at the next garbage collection
+        tape.ops, tape.param_grads = [], {}
+        tape.grads.clear()
+        tape._s3.clear()
+        ctx.tape = ctx.oc_bwd = ctx.theta = ctx.logits = None
         return (None, None) + grads
 
 
