@@ -304,6 +304,10 @@ __global__ __launch_bounds__(256, 2) void conv_s3_kernel(const sfh_conv_desc d, 
         stage(st + 1, 1, std::integral_constant<bool, SWAPS>{});
       }
     }
+    // the last stage re-issues its own DMA into the other buffer (branch-free MFMA block): it must
+    // have landed before the wave ends, or it would write into the LDS of the workgroup that
+    // inherits this allocation
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   } else {
     // single buffer: [DMA stage st] [drain + barrier] [compute] [barrier: buffer free again]
     for (int st = 0; st < nst; st += 2) {

@@ -506,16 +506,16 @@ struct WgradArgs {
   int ntx, nty, ntiles, nsplit;
 };
 
-constexpr int WG_TH = 2, WG_TW = 32;
-
-template <int KS, int NSUB>
+template <int KS, int NSUB, int TH, int TW>
 __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
+  static_assert(TH * TW == 64 && TW % 4 == 0, "64-pixel tiles");
   constexpr int PADB = KS == 3 ? 1 : (KS == 4 ? 2 : 0);
-  constexpr int HR = WG_TH + KS - 1, HW = WG_TW + KS - 1, HPX = HR * HW;
+  constexpr int HR = TH + KS - 1, HW = TW + KS - 1, HPX = HR * HW;
   constexpr int KK = KS * KS;
+  constexpr int NHV = (HPX * 4 * NSUB + 255) / 256;  // halo float4 loads per thread
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* xL = lds;               // [HPX][64]
-  float* zL = lds + HPX * 64;    // [WG_TH*WG_TW][64]
+  float* zL = lds + HPX * 64;    // [64][64]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l16 = lane & 15, kq = lane >> 4;
   const int m0 = blockIdx.x * 64, n0 = blockIdx.y * (16 * NSUB);
@@ -529,36 +529,50 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
     const int tx = tile % a.ntx;
     const int ty = (tile / a.ntx) % a.nty;
     const int b = tile / (a.ntx * a.nty);
-    const int y0 = ty * WG_TH, x0 = tx * WG_TW;
-    __syncthreads();  // previous tile's fragments consumed
-    // ---- stage the input halo: HPX pixels x (16*NSUB) channels
-    for (int i = tid; i < HPX * (4 * NSUB); i += 256) {
+    const int y0 = ty * TH, x0 = tx * TW;
+    // ---- issue every global load of the tile first (one latency, not one per iteration)
+    f32x4 hv[NHV], zv[4];
+#pragma unroll
+    for (int k = 0; k < NHV; ++k) {
+      const int i = tid + k * 256;
       const int q = i % (4 * NSUB), hp = i / (4 * NSUB);
       const int hr = hp / HW, hc = hp - hr * HW;
       const int sy = y0 + hr - PADB - a.pad_top, sx = x0 + hc - PADB - a.pad_left;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
       const int n = n0 + 4 * q;
-      if (sy >= 0 && sy < a.xh && sx >= 0 && sx < a.xw && n < a.N)
-        v = *reinterpret_cast<const f32x4*>(a.x + (((long)b * a.xh + sy) * a.xw + sx) * a.x_cs + n);
-      *reinterpret_cast<f32x4*>(xL + hp * 64 + 4 * (q ^ ((hp & 1) << 2))) = v;
+      hv[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (hp < HPX && sy >= 0 && sy < a.xh && sx >= 0 && sx < a.xw && n < a.N)
+        hv[k] = *reinterpret_cast<const f32x4*>(a.x + (((long)b * a.xh + sy) * a.xw + sx) * a.x_cs + n);
     }
-    // ---- stage dz: 64 pixels x 64 channels
-    for (int i = tid; i < WG_TH * WG_TW * 16; i += 256) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int i = tid + k * 256;
       const int q = i & 15, p = i >> 4;
-      const int r = p / WG_TW, c = p - r * WG_TW;
+      const int r = p / TW, c = p - r * TW;
       const int y = y0 + r, x = x0 + c, m = m0 + 4 * q;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      zv[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
       if (y < a.H && x < a.W && m < a.M)
-        v = *reinterpret_cast<const f32x4*>(a.dz + (((long)b * a.H + y) * a.W + x) * a.dz_cs + m);
-      *reinterpret_cast<f32x4*>(zL + p * 64 + 4 * (q ^ ((p & 1) << 2))) = v;
+        zv[k] = *reinterpret_cast<const f32x4*>(a.dz + (((long)b * a.H + y) * a.W + x) * a.dz_cs + m);
+    }
+    __syncthreads();  // previous tile's fragments consumed
+#pragma unroll
+    for (int k = 0; k < NHV; ++k) {
+      const int i = tid + k * 256;
+      const int q = i % (4 * NSUB), hp = i / (4 * NSUB);
+      if (hp < HPX) *reinterpret_cast<f32x4*>(xL + hp * 64 + 4 * (q ^ ((hp & 1) << 2))) = hv[k];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int i = tid + k * 256;
+      const int q = i & 15, p = i >> 4;
+      *reinterpret_cast<f32x4*>(zL + p * 64 + 4 * (q ^ ((p & 1) << 2))) = zv[k];
     }
     __syncthreads();
     // ---- contraction over the 64 pixels of the tile, 4 per MFMA
 #pragma unroll 1
-    for (int r = 0; r < WG_TH; ++r) {
+    for (int r = 0; r < TH; ++r) {
 #pragma unroll 2
-      for (int c4 = 0; c4 < WG_TW / 4; ++c4) {
-        const int pz = r * WG_TW + c4 * 4 + kq;
+      for (int c4 = 0; c4 < TW / 4; ++c4) {
+        const int pz = r * TW + c4 * 4 + kq;
         const float av = zL[pz * 64 + ((wave * 16 + l16) ^ ((pz & 1) << 4))];
 #pragma unroll
         for (int ky = 0; ky < KS; ++ky)
@@ -591,13 +605,34 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
     }
 }
 
-template <int KS, int NSUB>
-int launch_wgrad(const WgradArgs& a, hipStream_t stream) {
-  constexpr int HPX = (WG_TH + KS - 1) * (WG_TW + KS - 1);
-  const size_t lds = (size_t)(HPX + WG_TH * WG_TW) * 64 * sizeof(float);
+template <int KS, int NSUB, int TH, int TW>
+int launch_wgrad(WgradArgs a, hipStream_t stream) {
+  constexpr int HPX = (TH + KS - 1) * (TW + KS - 1);
+  const size_t lds = (size_t)(HPX + 64) * 64 * sizeof(float);
+  a.ntx = sfh_cdiv(a.W, TW);
+  a.nty = sfh_cdiv(a.H, TH);
+  a.ntiles = a.batch * a.ntx * a.nty;
+  const int mn = sfh_cdiv(a.M, 64) * sfh_cdiv(a.N, 16 * NSUB);
+  int ns = sfh_cdiv(1024, mn);
+  if (ns > a.ntiles) ns = a.ntiles;
+  if (ns < 1) ns = 1;
+  if (ns > 65535) ns = 65535;
+  a.nsplit = ns;
   const dim3 grid((unsigned)sfh_cdiv(a.M, 64), (unsigned)sfh_cdiv(a.N, 16 * NSUB), (unsigned)a.nsplit);
-  hipLaunchKernelGGL((wgrad_kernel<KS, NSUB>), grid, dim3(256), lds, stream, a);
+  hipLaunchKernelGGL((wgrad_kernel<KS, NSUB, TH, TW>), grid, dim3(256), lds, stream, a);
   return sfh_check_launch("wgrad_kernel");
+}
+
+// tile shape (rows x cols, 64 pixels) with the fewest padded pixels; ties go to the widest
+static int wgrad_tile(int H, int W) {
+  const int th[3] = {2, 4, 8}, tw[3] = {32, 16, 8};
+  int best = 0;
+  long bc = -1;
+  for (int i = 0; i < 3; ++i) {
+    const long c = (long)sfh_cdiv(H, th[i]) * sfh_cdiv(W, tw[i]);
+    if (bc < 0 || c < bc) { bc = c; best = i; }
+  }
+  return best;
 }
 
 }  // namespace
@@ -713,18 +748,16 @@ extern "C" int sfh_conv_wgrad(const float* dz, int dz_cs, int M, const float* x,
   a.x = x; a.x_cs = x_cs; a.xh = xh; a.xw = xw; a.N = N; a.pad_top = pad_top; a.pad_left = pad_left;
   a.batch = batch; a.H = H; a.W = W;
   a.raw = raw; a.raw_n = raw_n; a.n_off = n_off;
-  a.ntx = sfh_cdiv(W, WG_TW); a.nty = sfh_cdiv(H, WG_TH); a.ntiles = batch * a.ntx * a.nty;
-  const int nsub = ksize == 4 ? 2 : 4;
-  const int mn = sfh_cdiv(M, 64) * sfh_cdiv(N, 16 * nsub);
-  int ns = sfh_cdiv(1024, mn);
-  if (ns > a.ntiles) ns = a.ntiles;
-  if (ns < 1) ns = 1;
-  if (ns > 65535) ns = 65535;
-  a.nsplit = ns;
+  a.ntx = a.nty = a.ntiles = a.nsplit = 0;
   hipStream_t st = (hipStream_t)stream;
-  if (ksize == 3) return launch_wgrad<3, 4>(a, st);
-  if (ksize == 1) return launch_wgrad<1, 4>(a, st);
-  return launch_wgrad<4, 2>(a, st);
+  const int t = wgrad_tile(H, W);
+#define SFH_WG(KS_, NS_)                                         \
+  (t == 0 ? launch_wgrad<KS_, NS_, 2, 32>(a, st)                  \
+          : (t == 1 ? launch_wgrad<KS_, NS_, 4, 16>(a, st) : launch_wgrad<KS_, NS_, 8, 8>(a, st)))
+  if (ksize == 3) return SFH_WG(3, 4);
+  if (ksize == 1) return SFH_WG(1, 4);
+  return SFH_WG(4, 2);
+#undef SFH_WG
 }
 
 extern "C" int sfh_outconv_bwd(const float* x, int cin, const float* w, const float* dlogits_nchw, int nc,
