@@ -175,6 +175,38 @@ def make_block_goldens(up_mod, rn_mod):
     print("blocks.npz:", {k: v.shape for k, v in out.items()})
 
 
+def make_train_goldens(up_mod, rn_mod):
+    """Training-mode vectors from the reference's own classes: ``module.train()``, forward, then
+    ``out.backward(dy)`` with torch autograd - outputs, input/parameter gradients and the running
+    statistics after the step (unet/unet_parts.py:7-68, models/resnet.py:36-82)."""
+    out = {}
+
+    def run(tag, mod, seed, inputs, only=None):
+        m = _loaded(mod, seed).train()
+        xs = [t.clone().requires_grad_(True) for t in inputs]
+        y = m(*xs)
+        dy = _rand(tuple(y.shape), seed, "dy", -1, 1)
+        y.backward(dy)
+        out[tag + ".y"], out[tag + ".dy"] = y.detach().numpy(), dy.numpy()
+        for i, t in enumerate(xs):
+            out[f"{tag}.x{i}"], out[f"{tag}.dx{i}"] = inputs[i].numpy(), t.grad.numpy()
+        for k, p in m.named_parameters():
+            if only is None or k in only:
+                out[f"{tag}.grad.{k}"] = p.grad.numpy()
+        for k, b in m.named_buffers():
+            if k.endswith("running_var") and (only is None or k.replace("running_var", "weight") in only):
+                out[f"{tag}.buf.{k}"] = b.numpy().copy()
+
+    run("t_dc_64_128", up_mod.DoubleConv(64, 128), 31, [_rand((2, 64, 13, 18), 31, "x", -1, 1)])
+    run("t_down_64_128", up_mod.Down(64, 128), 32, [_rand((2, 64, 14, 19), 32, "x", -1, 1)])
+    run("t_up_128_64", up_mod.Up(128, 64, False), 33,
+        [_rand((2, 128, 6, 9), 33, "x1", -1, 1), _rand((2, 64, 13, 19), 33, "x2", -1, 1)])
+    blk = rn_mod.BasicBlock(64, 128, 2, torch.nn.Sequential(rn_mod.conv1x1(64, 128, 2), torch.nn.BatchNorm2d(128)))
+    run("t_basic_64_128_s2", blk, 34, [_rand((2, 64, 13, 18), 34, "x", -1, 1)])
+    np.savez_compressed(os.path.join(GOLD, "train_blocks.npz"), **out)
+    print("train_blocks.npz:", len(out), "arrays,", sum(v.nbytes for v in out.values()) // 1024, "KiB raw")
+
+
 def make_full_golden(up_mod, rn_mod):
     """640x360 end-to-end vector: reference classes for UNet/ResNet + oracle warp/CE/POI."""
     torch.set_num_threads(os.cpu_count())
@@ -206,12 +238,17 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--full", action="store_true")
     ap.add_argument("--data-only", action="store_true")
+    ap.add_argument("--train-only", action="store_true", help="only tests/golden/train_blocks.npz")
     a = ap.parse_args()
     os.makedirs(GOLD, exist_ok=True)
     make_data()
     if not a.data_only:
         up_mod = _load("ref_unet_parts", "unet/unet_parts.py")
         rn_mod = _load("ref_resnet", "models/resnet.py")
+        if a.train_only:
+            make_train_goldens(up_mod, rn_mod)
+            raise SystemExit(0)
         make_block_goldens(up_mod, rn_mod)
+        make_train_goldens(up_mod, rn_mod)
         if a.full:
             make_full_golden(up_mod, rn_mod)

@@ -285,3 +285,76 @@ def test_full_training_forward_backward(T):
     for k, v in ref.items():
         if k.endswith("running_mean") or k.endswith("running_var"):
             assert _relerr(new[k], v) < 1e-4, k
+
+
+# ----------------------------------------------- vectors produced by the reference's own classes
+@pytest.fixture(scope="module")
+def golden_train():
+    import os
+    return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "train_blocks.npz"))
+
+
+def _golden_case(T, g, tag, mod, seed, build):
+    """build(tape, names, mod, xs) -> y on the HIP training kernels; compare with the reference's
+    train-mode outputs / gradients (oracle/make_fixtures.py:make_train_goldens)."""
+    sd = synth.synth_state_dict(mod.state_dict(), seed)
+    mod.load_state_dict(sd)
+    mod.cuda().train()
+    xs = [_nhwc(torch.from_numpy(g[f"{tag}.x{i}"])) for i in range(2) if f"{tag}.x{i}" in g]
+    tape = T.Tape()
+    y = build(tape, T._Names(mod), mod, xs)
+    tape.add_grad(y, _nhwc(torch.from_numpy(g[f"{tag}.dy"])))
+    tape.backward()
+    torch.cuda.synchronize()
+    assert _relerr(_nchw(y), torch.from_numpy(g[f"{tag}.y"])) < 1e-5
+    for i, t in enumerate(xs):
+        assert _relerr(_nchw(tape.pop_grad(t)), torch.from_numpy(g[f"{tag}.dx{i}"])) < 5e-5, (tag, i)
+    for k in g.files:
+        if k.startswith(tag + ".grad."):
+            name = k[len(tag) + 6:]
+            want = torch.from_numpy(g[k])
+            if name.endswith("double_conv.0.bias") or name.endswith("double_conv.3.bias"):
+                # conv bias in front of BatchNorm: zero up to rounding (the reference's value is noise)
+                assert want.abs().max() < 1e-3 and tape.param_grads[name].abs().max().item() < 1e-3
+            else:
+                assert _relerr(tape.param_grads[name], want) < 5e-5, (tag, name)
+        if k.startswith(tag + ".buf."):
+            assert _relerr(mod.state_dict()[k[len(tag) + 5:]], torch.from_numpy(g[k])) < 1e-6
+
+
+def _dconv(T, tape, names, block, srcs, B, h, w):
+    (cv1, bn1), (cv2, bn2) = block.convs()
+    y1 = T.conv_bn_act(tape, names, cv1, bn1, srcs, B, h, w)
+    return T.conv_bn_act(tape, names, cv2, bn2, [(y1, y1.shape[3], 0, 0)], B, h, w)
+
+
+def test_training_blocks_vs_reference_golden(T, golden_train):
+    g = golden_train
+
+    def dc(tape, names, m, xs):
+        B, H, W, C = xs[0].shape
+        return _dconv(T, tape, names, m, [(xs[0], C, 0, 0)], B, H, W)
+
+    def down(tape, names, m, xs):
+        p = T.maxpool2(tape, xs[0])
+        B, H, W, C = p.shape
+        return _dconv(T, tape, names, m.block, [(p, C, 0, 0)], B, H, W)
+
+    def up(tape, names, m, xs):
+        u = T.conv_transpose2x2(tape, names, m.up, xs[0])
+        B, H, W, C = xs[1].shape
+        dy, dx = H - u.shape[1], W - u.shape[2]
+        return _dconv(T, tape, names, m.conv, [(xs[1], C, 0, 0), (u, u.shape[3], dy // 2, dx // 2)], B, H, W)
+
+    def basic(tape, names, m, xs):
+        B, H, W, C = xs[0].shape
+        one = lambda t: [(t, t.shape[3], 0, 0)]
+        idn = T.conv_bn_act(tape, names, m.downsample[0], m.downsample[1], one(xs[0]), B, H, W, relu=False)
+        t = T.conv_bn_act(tape, names, m.conv1, m.bn1, one(xs[0]), B, H, W)
+        return T.conv_bn_act(tape, names, m.conv2, m.bn2, one(t), B, t.shape[1], t.shape[2], residual=idn)
+
+    _golden_case(T, g, "t_dc_64_128", modules.DoubleConv(64, 128), 31, dc)
+    _golden_case(T, g, "t_down_64_128", modules.Down(64, 128), 32, down)
+    _golden_case(T, g, "t_up_128_64", modules.Up(128, 64, False), 33, up)
+    ds = torch.nn.Sequential(torch.nn.Conv2d(64, 128, 1, stride=2, bias=False), torch.nn.BatchNorm2d(128))
+    _golden_case(T, g, "t_basic_64_128_s2", modules.BasicBlock(64, 128, 2, ds), 34, basic)
