@@ -86,7 +86,17 @@ def train_bench(args):
     nonzeros = torch.ones(B, poi.shape[1], device=dev)
     num_nonzero = nonzeros.sum(1)
 
+    from sfh_amd import training
+    ts = None if args.train_autograd else training.TrainStep(net, lr=1e-5, weight_decay=1e-8, seg_lambda=1.0,
+                                                             rec_lambda=1.0, reproj_lambda=1.0, consist_lambda=1.0)
+    batch = {"mask": mask, "weight": weight, "poi": gt_poi, "nonzeros": nonzeros, "num_nonzero": num_nonzero}
+
+    def step_hip():
+        return ts.step(x, batch).sum()
+
     def step():
+        if ts is not None:
+            return step_hip()
         preds = net(x)
         seg = (F.cross_entropy(preds["logits"], mask, reduction="none").mean(dim=(1, 2)) * weight).mean()
         rec = (F.smooth_l1_loss(preds["warp_mask"], mask.float() / 4.0, reduction="none").mean(dim=(1, 2)) * weight).mean()
@@ -112,7 +122,8 @@ def train_bench(args):
         "metric": "training steps: frames/sec at %dx%d batch=%d (forward + losses + backward + clip + RMSprop)" % (W, H, B),
         "value": round(B * args.steps / el, 2), "unit": "frames/s", "n_gpus": 1, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(el / args.steps * 1e3, 2), "higher_is_better": True,
-        "dtype": "f32", "data": "synthetic", "final_loss": float(loss),
+        "dtype": "bf16x6->f32 convs (fp32 MFMA backward-filter)", "data": "synthetic", "final_loss": float(loss.detach()),
+        "losses_and_optimizer": "torch ops (caller side)" if args.train_autograd else "HIP kernels (training.TrainStep)",
         "peak_mem_gib": round(torch.cuda.max_memory_allocated() / 2**30, 2),
         "config": {"workload": "BASELINE config 3: Reconstructor training step, CE + SmoothL1 + RRMSE + consistency CE"}}),
         flush=True)
@@ -132,8 +143,11 @@ def main():
     ap.add_argument("--train", action="store_true",
                     help="BASELINE config 3 instead of the headline: one training step (forward, losses, "
                          "backward, clip, RMSprop) per batch; prints its own JSON line")
+    ap.add_argument("--train-autograd", action="store_true",
+                    help="with --train: losses, clip and RMSprop as the caller's torch ops around the model's "
+                         "autograd node (the reference's train.py structure) instead of the all-HIP TrainStep")
     args = ap.parse_args()
-    if args.train:
+    if args.train or args.train_autograd:
         return train_bench(args)
 
     import torch

@@ -292,6 +292,25 @@ int sfh_homography_warp_bwd_theta(const float* theta, const float* tmpl, int64_t
 int sfh_poi_project_bwd_theta(const float* theta, const float* poi, int batch, int npts, int normalize,
                               const float* dout, float* dtheta, void* stream);
 
+/* Losses of the training step (train.py:181-224, models/losses.py:33-41) in one pass: segmentation
+ * CE(logits, gt) and SmoothL1 (rec_mse = 0) or MSE (rec_mse = 1) of (warp, gt/nc), both averaged per frame, weighted by weight[b] and averaged
+ * over the batch, and the consistency CE(logits, trunc(warp*nc)) averaged over all pixels; each times its
+ * lambda (0 disables).  gt_mask int64 (B,H,W); outputs d/dlogits (NCHW), d/dwarp (B,H,W, optional) and
+ * loss3[0..2] += seg, rec, consistency (fp64, caller-zeroed).                                           */
+int sfh_train_losses(const float* logits_nchw, const int64_t* gt_mask, const float* weight,
+                     const float* warp_mask, int nc, int batch, int H, int W, float lambda_seg,
+                     float lambda_rec, int rec_mse, float lambda_cons, float* dlogits_nchw, float* dwarp,
+                     double* loss3, void* stream);
+/* ReprojectionLoss (models/losses.py:6-31), reduction 'mean', times lambda: *loss += value; dpoi (B,N,2). */
+int sfh_reproj_loss(const float* poi, const float* gt_poi, const float* nonzeros, const float* num_nonzero,
+                    int batch, int npts, float lambda, float* dpoi, double* loss, void* stream);
+/* nn.utils.clip_grad_value_(clip) + torch.optim.RMSprop step (train.py:88,234-237) over many tensors in
+ * one launch.  tensor_table: device array of {float* param; const float* grad; float* square_avg;
+ * float* momentum_buf;}; chunk_table: device array of {int32 tensor; int32 count; int64 offset;}, one
+ * workgroup per chunk.  clip_value <= 0 disables clipping, momentum == 0 skips the buffer.              */
+int sfh_rmsprop_step(const void* tensor_table, const void* chunk_table, int nchunks, float lr, float alpha,
+                     float eps, float weight_decay, float momentum, float clip_value, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -82,6 +82,11 @@ SIGNATURES = {
     "sfh_homography_warp_bwd_theta": (C.c_int, [_p, _p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                                 _p, _p, _p]),
     "sfh_poi_project_bwd_theta": (C.c_int, [_p, _p, C.c_int, C.c_int, C.c_int, _p, _p, _p]),
+    "sfh_train_losses": (C.c_int, [_p, _p, _p, _p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float,
+                                   C.c_int, C.c_float, _p, _p, _p, _p]),
+    "sfh_reproj_loss": (C.c_int, [_p, _p, _p, _p, C.c_int, C.c_int, C.c_float, _p, _p, _p]),
+    "sfh_rmsprop_step": (C.c_int, [_p, _p, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
+                                   C.c_float, _p]),
     "sfh_maxpool3x3s2_fwd": (C.c_int, [_p, _p, C.c_int, C.c_int, C.c_int, C.c_int, _p]),
     "sfh_avgpool_linear_fwd": (C.c_int, [_p, _p, _p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _p, _p]),
 }

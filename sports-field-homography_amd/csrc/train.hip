@@ -490,6 +490,125 @@ __global__ __launch_bounds__(256) void stem_bwd_data_kernel(const float* __restr
   for (int c = 0; c < nc; ++c) dlogits[(((long)b * nc + c) * H + y) * W + x] += acc[c];
 }
 
+// ------------------------------------------------------------------ losses of the training step
+// train.py:181-224 + models/losses.py in one pass over the pixels: segmentation CE (per-sample
+// weighted), SmoothL1 between the bilinear warp and gt/nc (per-sample weighted), consistency CE against
+// trunc(warp * nc).  Writes d loss / d logits (NCHW) and d loss / d warp, accumulates the three loss
+// values in fp64.  loss[0] = seg, [1] = rec, [2] = consistency (already scaled by their lambdas).
+struct LossArgs {
+  const float* logits; const long* gt; const float* weight; const float* warp;
+  int nc, HW; long npix; int batch;
+  float l_seg, l_rec, l_cons;   // lambda (0 = loss disabled)
+  int rec_mse;                  // 1: nn.MSELoss, 0: nn.SmoothL1Loss (train.py:113-118)
+  float* dlogits; float* dwarp; double* loss;
+};
+
+template <int NC>
+__global__ __launch_bounds__(256) void train_losses_kernel(const LossArgs a) {
+  __shared__ double sh[256];
+  double s_seg = 0.0, s_rec = 0.0, s_cons = 0.0;
+  const float inv = 1.0f / ((float)a.HW * (float)a.batch);
+  for (long p = (long)blockIdx.x * 256 + threadIdx.x; p < a.npix; p += (long)gridDim.x * 256) {
+    const long b = p / a.HW, i = p - b * a.HW;
+    float l[NC], mx = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < NC; ++k) { l[k] = a.logits[(b * NC + k) * a.HW + i]; mx = fmaxf(mx, l[k]); }
+    float se = 0.f, e[NC];
+#pragma unroll
+    for (int k = 0; k < NC; ++k) { e[k] = expf(l[k] - mx); se += e[k]; }
+    const float lse = logf(se) + mx, rs = 1.0f / se;
+    const int gt = (int)a.gt[p];
+    const float wb = a.weight[b];
+    const float wv = a.warp ? a.warp[p] : 0.f;
+    const int tc = min(max((int)(wv * (float)NC), 0), NC - 1);   // (warp_mask * nc).to(long)
+    const float cs = a.l_seg * wb * inv, cc = a.l_cons * inv;
+    float lgt = 0.f, ltc = 0.f;
+#pragma unroll
+    for (int k = 0; k < NC; ++k) {
+      const float pk = e[k] * rs;
+      if (k == gt) lgt = l[k];
+      if (k == tc) ltc = l[k];
+      a.dlogits[(b * NC + k) * a.HW + i] = cs * (pk - (k == gt ? 1.f : 0.f)) + cc * (pk - (k == tc ? 1.f : 0.f));
+    }
+    s_seg += (double)(wb * (lse - lgt));
+    s_cons += (double)(lse - ltc);
+    if (a.warp) {
+      const float d = wv - (float)gt / (float)NC;
+      const float ad = fabsf(d);
+      if (a.rec_mse) {
+        s_rec += (double)(wb * d * d);
+        if (a.dwarp) a.dwarp[p] = a.l_rec * wb * inv * 2.f * d;
+      } else {
+        s_rec += (double)(wb * (ad < 1.f ? 0.5f * d * d : ad - 0.5f));
+        if (a.dwarp) a.dwarp[p] = a.l_rec * wb * inv * (ad < 1.f ? d : (d > 0.f ? 1.f : -1.f));
+      }
+    }
+  }
+  double v[3] = {s_seg * a.l_seg, s_rec * a.l_rec, s_cons * a.l_cons};
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    __syncthreads();
+    sh[threadIdx.x] = v[k];
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+      if (threadIdx.x < off) sh[threadIdx.x] += sh[threadIdx.x + off];
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) unsafeAtomicAdd(&a.loss[k], sh[0] * (double)inv);
+  }
+}
+
+// models/losses.py:6-19 (reduction 'mean') and its gradient wrt the projected points; one thread per frame.
+__global__ void reproj_loss_kernel(const float* __restrict__ poi, const float* __restrict__ gt,
+                                   const float* __restrict__ nonzeros, const float* __restrict__ num_nonzero,
+                                   int batch, int npts, float lambda, float* __restrict__ dpoi, double* __restrict__ loss) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= batch) return;
+  double s = 0.0;
+  const float sc = lambda / (num_nonzero[b] * (float)batch);
+  for (int n = 0; n < npts; ++n) {
+    const long o = ((long)b * npts + n) * 2;
+    const float dx = gt[o] - poi[o], dy = gt[o + 1] - poi[o + 1];
+    const float dist = sqrtf(dx * dx + dy * dy);
+    const float nz = nonzeros[(long)b * npts + n];
+    s += (double)(dist * nz);
+    const float g = dist > 0.f ? nz * sc / dist : 0.f;   // torch propagates NaN at dist == 0; 0 here
+    dpoi[o] = -g * dx;
+    dpoi[o + 1] = -g * dy;
+  }
+  unsafeAtomicAdd(loss, s * (double)sc);
+}
+
+// ------------------------------------------------------------------ clip_grad_value_ + RMSprop
+// train.py:88,234-237: g = clamp(grad, -clip, clip); g += wd * p; sq = alpha*sq + (1-alpha)*g*g;
+// buf = mu*buf + g / (sqrt(sq) + eps); p -= lr * buf   (torch.optim.RMSprop, centered=False).
+// Multi-tensor: `table` holds per tensor {param, grad, square_avg, momentum_buf} pointers and `chunks`
+// {tensor index, element offset, count}; one block per chunk.
+struct OptTensor { float* p; const float* g; float* sq; float* buf; };
+struct OptChunk { int tensor; int count; long offset; };
+
+__global__ __launch_bounds__(256) void rmsprop_kernel(const OptTensor* __restrict__ table, const OptChunk* __restrict__ chunks,
+                                                      float lr, float alpha, float eps, float wd, float mu, float clip) {
+  const OptChunk c = chunks[blockIdx.x];
+  const OptTensor t = table[c.tensor];
+  for (int i = threadIdx.x; i < c.count; i += 256) {
+    const long o = c.offset + i;
+    float g = t.g[o];
+    if (clip > 0.f) g = fminf(fmaxf(g, -clip), clip);
+    const float p = t.p[o];
+    g = g + wd * p;
+    const float sq = alpha * t.sq[o] + (1.0f - alpha) * g * g;
+    t.sq[o] = sq;
+    const float avg = sqrtf(sq) + eps;
+    float step = g / avg;
+    if (mu > 0.f) {
+      step = mu * t.buf[o] + step;
+      t.buf[o] = step;
+    }
+    t.p[o] = p - lr * step;
+  }
+}
+
 // ------------------------------------------------------------------ weight gradient (fp32 MFMA)
 // raw[m][tap][n] += sum over pixels p of dz[p][m] * xin[p + tap][n]
 //   GEMM view: M = output channels, N = input channels of one source, K = B*H*W pixels.
@@ -816,4 +935,48 @@ extern "C" int sfh_stem_bwd_data(const float* dz, const float* w, int cin, int n
                        cin, nc, H, W, Ho, Wo, dlogits_nchw);
   }
   return sfh_check_launch("stem_bwd_data_kernel");
+}
+
+extern "C" int sfh_train_losses(const float* logits_nchw, const int64_t* gt_mask, const float* weight,
+                                const float* warp_mask, int nc, int batch, int H, int W, float lambda_seg,
+                                float lambda_rec, int rec_mse, float lambda_cons, float* dlogits_nchw,
+                                float* dwarp, double* loss3, void* stream) {
+  SFH_REQUIRE(logits_nchw && gt_mask && weight && dlogits_nchw && loss3 && batch > 0 && H > 0 && W > 0,
+              "train_losses: bad argument");
+  SFH_REQUIRE(nc >= 2 && nc <= 8, "train_losses: nc=%d unsupported (2..8)", nc);
+  SFH_REQUIRE(warp_mask || (lambda_rec == 0.f && lambda_cons == 0.f), "train_losses: rec/consistency need the warp mask");
+  LossArgs a;
+  a.logits = logits_nchw; a.gt = (const long*)gt_mask; a.weight = weight; a.warp = warp_mask;
+  a.nc = nc; a.HW = H * W; a.npix = (long)batch * H * W; a.batch = batch;
+  a.l_seg = lambda_seg; a.l_rec = lambda_rec; a.l_cons = lambda_cons; a.rec_mse = rec_mse;
+  a.dlogits = dlogits_nchw; a.dwarp = dwarp; a.loss = loss3;
+  long nb = (a.npix + 255) / 256;
+  if (nb > 2048) nb = 2048;
+#define SFH_TL(N)                                                                                         \
+  case N:                                                                                                 \
+    hipLaunchKernelGGL(train_losses_kernel<N>, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, a); \
+    break;
+  switch (nc) { SFH_TL(2) SFH_TL(3) SFH_TL(4) SFH_TL(5) SFH_TL(6) SFH_TL(7) SFH_TL(8) }
+#undef SFH_TL
+  return sfh_check_launch("train_losses_kernel");
+}
+
+extern "C" int sfh_reproj_loss(const float* poi, const float* gt_poi, const float* nonzeros,
+                               const float* num_nonzero, int batch, int npts, float lambda, float* dpoi,
+                               double* loss, void* stream) {
+  SFH_REQUIRE(poi && gt_poi && nonzeros && num_nonzero && dpoi && loss && batch > 0 && npts > 0,
+              "reproj_loss: bad argument");
+  hipLaunchKernelGGL(reproj_loss_kernel, dim3((unsigned)sfh_cdiv(batch, 64)), dim3(64), 0, (hipStream_t)stream, poi,
+                     gt_poi, nonzeros, num_nonzero, batch, npts, lambda, dpoi, loss);
+  return sfh_check_launch("reproj_loss_kernel");
+}
+
+extern "C" int sfh_rmsprop_step(const void* tensor_table, const void* chunk_table, int nchunks, float lr,
+                                float alpha, float eps, float weight_decay, float momentum, float clip_value,
+                                void* stream) {
+  SFH_REQUIRE(tensor_table && chunk_table && nchunks > 0, "rmsprop_step: bad argument");
+  hipLaunchKernelGGL(rmsprop_kernel, dim3((unsigned)nchunks), dim3(256), 0, (hipStream_t)stream,
+                     (const OptTensor*)tensor_table, (const OptChunk*)chunk_table, lr, alpha, eps, weight_decay,
+                     momentum, clip_value);
+  return sfh_check_launch("rmsprop_kernel");
 }

@@ -516,3 +516,137 @@ def train_forward(net, x):
     if net.warper:
         ret["warp_mask"] = outs[3]
     return ret
+
+
+# ------------------------------------------------------------------- the whole step on HIP kernels
+class TrainStep:
+    """One iteration of the reference's training loop (train.py:155-237) without torch autograd:
+    forward under batch-statistics BatchNorm, the four losses with their lambdas, backward,
+    ``clip_grad_value_`` and the RMSprop update - every arithmetic step a HIP kernel of libsfh_amd.so.
+
+    Hyper-parameter defaults are the reference's (utils/config.py:106-139, train.py:88)."""
+
+    def __init__(self, net, lr=1e-4, weight_decay=1e-8, momentum=0.9, alpha=0.99, eps=1e-8, clip_value=0.1,
+                 seg_lambda=2.0, rec_lambda=2.0, reproj_lambda=8.0, consist_lambda=1.0, rec_loss="SmoothL1",
+                 consist_start_iter=0):
+        if rec_loss not in ("SmoothL1", "MSE"):
+            raise NotImplementedError(f"rec_loss={rec_loss!r}")
+        self.net = net
+        self.hp = dict(lr=lr, wd=weight_decay, mu=momentum, alpha=alpha, eps=eps, clip=clip_value)
+        self.lam = dict(seg=seg_lambda, rec=rec_lambda, reproj=reproj_lambda, consist=consist_lambda)
+        self.rec_mse = 1 if rec_loss == "MSE" else 0
+        self.consist_start_iter = consist_start_iter
+        self.global_step = 0
+        self._init_optimizer([p for p in net.parameters()])
+
+    def _init_optimizer(self, params):
+        """gradient / state tensors and the device tables of the multi-tensor optimizer kernel"""
+        import numpy as np
+        self.params = params
+        dev = self.params[0].device
+        if dev.type != "cuda":
+            raise RuntimeError("TrainStep needs the model on the GPU (there is no CPU fallback)")
+        self.names = _Names(self.net)
+        self.grads = [torch.zeros_like(p) for p in self.params]
+        self.sq = [torch.zeros_like(p) for p in self.params]
+        self.buf = [torch.zeros_like(p) for p in self.params]
+        CH = 65536
+        tab = np.zeros((len(self.params), 4), dtype=np.int64)
+        chunks = []
+        for i, (p, g, s, b) in enumerate(zip(self.params, self.grads, self.sq, self.buf)):
+            tab[i] = (p.data_ptr(), g.data_ptr(), s.data_ptr(), b.data_ptr())
+            n = p.numel()
+            for off in range(0, n, CH):
+                chunks.append((i, min(CH, n - off), off))
+        ch = np.zeros(len(chunks), dtype=np.dtype([("t", "<i4"), ("c", "<i4"), ("o", "<i8")]))
+        for j, (t, c, o) in enumerate(chunks):
+            ch[j] = (t, c, o)
+        self.table = torch.from_numpy(tab.view(np.uint8).reshape(-1).copy()).to(dev)
+        self.chunks = torch.from_numpy(ch.view(np.uint8).reshape(-1).copy()).to(dev)
+        self.nchunks = len(chunks)
+
+    def loss_and_grads(self, x, batch):
+        """forward + losses + backward; fills self.grads, returns {'seg','rec','reproj','consist'} as a
+        float64 device tensor of 4 values.  batch: mask (B,H,W) int64, weight (B), poi (B,N,2),
+        nonzeros (B,N), num_nonzero (B)."""
+        net, lib = self.net, _lib.load()
+        if not net.training:
+            raise RuntimeError("TrainStep: call net.train() first")
+        tape = Tape()
+        B, _, H, W = x.shape
+        x = E._f32c(x, "input frames")
+        cin = net.mask_classes + 3
+        cs = -(-cin // 4) * 4
+        if (4 * cs) % 16:
+            cs = -(-cin // 8) * 8
+        logits, _, stn_in, oc_bwd = UNetTrainer(net).forward(tape, x, want_stn_in=True, stn_cs=cs)
+        theta = ResNetTrainer(net).forward(tape, stn_in, logits, net.mask_classes, cin)
+        tape._s3.clear()
+        theta4 = theta.view(B, 1, 3, 3)
+        shared = net._template_is_shared(net.court_img, B)
+        poi = E.poi_project(theta4, net.court_poi)
+        ww, wh = net.warp_size
+        if (wh, ww) != (H, W):
+            raise NotImplementedError("TrainStep needs warp_size == frame size (the losses compare per pixel)")
+        warp, _ = E.homography_warp(theta4, net.court_img, wh, ww, net.warp_with_nearest, shared_template=shared)
+        st = _stream()
+        losses = _zeros((4,), x, torch.float64)   # seg, rec, consist, reproj
+        mask = batch["mask"]
+        if mask.dtype != torch.int64 or not mask.is_contiguous():
+            raise ValueError("batch['mask'] must be a contiguous int64 tensor (B,H,W)")
+        dlogits = _empty(logits.shape, x)
+        dwarp = _empty(warp.shape, x)
+        l_cons = self.lam["consist"] if self.global_step * B >= self.consist_start_iter else 0.0
+        _lib.check(lib.sfh_train_losses(_ptr(logits), _ptr(mask), _ptr(E._f32c(batch["weight"], "weight")), _ptr(warp),
+                                        net.mask_classes, B, H, W, self.lam["seg"], self.lam["rec"], self.rec_mse,
+                                        l_cons, _ptr(dlogits), _ptr(dwarp), _ptr(losses), st), "train_losses")
+        gt_poi = E._f32c(batch["poi"], "gt poi")
+        dpoi = _empty(poi.shape, x)
+        _lib.check(lib.sfh_reproj_loss(_ptr(poi), _ptr(gt_poi), _ptr(E._f32c(batch["nonzeros"], "nonzeros")),
+                                       _ptr(E._f32c(batch["num_nonzero"], "num_nonzero")), B, poi.shape[1],
+                                       self.lam["reproj"], _ptr(dpoi), ctypes.c_void_p(losses.data_ptr() + 24), st),
+                   "reproj_loss")
+        # backward: theta first (POI + warp), ResNet (adds the stem's gradient into dlogits), then the UNet
+        dth = poi_backward_theta(theta, net.court_poi, dpoi)
+        if not net.warp_with_nearest:
+            wt = warp_backward_theta(theta, net.court_img, wh, ww, dwarp, shared)
+            dth = _add_small(lib, dth, wt)
+        tape.grads[id(theta)] = dth
+        tape.grads[id(logits)] = dlogits
+        ops, tape.ops = tape.ops, []
+        k = ctx_split(ops)
+        for fn in reversed(ops[k:]):
+            fn()
+        oc_bwd(tape.pop_grad(logits))
+        for fn in reversed(ops[:k]):
+            fn()
+        g = tape.param_grads
+        for p, dst in zip(self.params, self.grads):
+            dst.copy_(g[self.names(p)].reshape(dst.shape))
+        tape.ops, tape.param_grads = [], {}
+        tape.grads.clear()
+        return losses
+
+    def step(self, x, batch):
+        """-> float64 device tensor [seg, rec, consist, reproj] (each already times its lambda)."""
+        losses = self.loss_and_grads(x, batch)
+        lib, hp = _lib.load(), self.hp
+        _lib.check(lib.sfh_rmsprop_step(_ptr(self.table), _ptr(self.chunks), self.nchunks, hp["lr"], hp["alpha"],
+                                        hp["eps"], hp["wd"], hp["mu"], hp["clip"], _stream()), "rmsprop_step")
+        self.global_step += 1
+        return losses
+
+
+def _add_small(lib, a, b):
+    """a += b for two small (B,9) fp32 tensors (theta gradients), on the HIP mover kernel."""
+    n = a.numel()
+    pad = (-n) % 4
+    if pad:   # slice_add works on channel quads
+        a4 = torch.zeros(n + pad, dtype=a.dtype, device=a.device)
+        b4 = torch.zeros(n + pad, dtype=a.dtype, device=a.device)
+        a4[:n].copy_(a.reshape(-1))
+        b4[:n].copy_(b.reshape(-1))
+        _lib.check(lib.sfh_slice_add(_ptr(b4), 1, 1, n + pad, 0, 0, 0, _ptr(a4), 1, 1, 1, n + pad, 1, _stream()), "slice_add")
+        return a4[:n].reshape(a.shape).contiguous()
+    _lib.check(lib.sfh_slice_add(_ptr(b), 1, 1, n, 0, 0, 0, _ptr(a), 1, 1, 1, n, 1, _stream()), "slice_add")
+    return a
