@@ -295,12 +295,14 @@ int sfh_poi_project_bwd_theta(const float* theta, const float* poi, int batch, i
 /* Losses of the training step (train.py:181-224, models/losses.py:33-41) in one pass: segmentation
  * CE(logits, gt) and SmoothL1 (rec_mse = 0) or MSE (rec_mse = 1) of (warp, gt/nc), both averaged per frame, weighted by weight[b] and averaged
  * over the batch, and the consistency CE(logits, trunc(warp*nc)) averaged over all pixels; each times its
- * lambda (0 disables).  gt_mask int64 (B,H,W); outputs d/dlogits (NCHW), d/dwarp (B,H,W, optional) and
+ * lambda (0 disables).  focal_flags bit 0 / bit 1: the segmentation / consistency term is
+ * kornia.losses.FocalLoss(alpha=1, gamma=2) instead of CE (train.py:101,126; Kornia 0.5/0.6 formula:
+ * sum_k (onehot_k + 1e-6) * -(1 - q_k)^2 log q_k with q = softmax + 1e-8).  gt_mask int64 (B,H,W); outputs d/dlogits (NCHW), d/dwarp (B,H,W, optional) and
  * loss3[0..2] += seg, rec, consistency (fp64, caller-zeroed).                                           */
 int sfh_train_losses(const float* logits_nchw, const int64_t* gt_mask, const float* weight,
                      const float* warp_mask, int nc, int batch, int H, int W, float lambda_seg,
-                     float lambda_rec, int rec_mse, float lambda_cons, float* dlogits_nchw, float* dwarp,
-                     double* loss3, void* stream);
+                     float lambda_rec, int rec_mse, float lambda_cons, int focal_flags, float* dlogits_nchw,
+                     float* dwarp, double* loss3, void* stream);
 /* ReprojectionLoss (models/losses.py:6-31), reduction 'mean', times lambda: *loss += value; dpoi (B,N,2). */
 int sfh_reproj_loss(const float* poi, const float* gt_poi, const float* nonzeros, const float* num_nonzero,
                     int batch, int npts, float lambda, float* dpoi, double* loss, void* stream);

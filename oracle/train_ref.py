@@ -73,3 +73,14 @@ def losses(preds, batch, mask_classes=4, lambdas=(1.0, 1.0, 1.0, 1.0), consisten
         out["consist"] = F.cross_entropy(preds["logits"], rec_int) * cons_l
     out["total"] = sum(out.values())
     return out
+
+
+def focal_loss(logits, target, alpha=1.0, gamma=2.0, eps=1e-8):
+    """kornia.losses.FocalLoss(alpha=1.0, gamma=2.0, reduction='none') as train.py:101,126 builds it.
+    Kornia is not in this image (parity unpinned, see oracle/torch_ref.py); this follows the published
+    0.5/0.6 implementation: softmax + eps, a one-hot target that carries +1e-6 on every class,
+    focal = -alpha * (1 - p)^gamma * log(p), summed over the class axis."""
+    p = F.softmax(logits, dim=1) + eps
+    onehot = F.one_hot(target, logits.shape[1]).permute(0, 3, 1, 2).to(logits.dtype) + 1e-6
+    focal = -alpha * torch.pow(1.0 - p, gamma) * torch.log(p)
+    return torch.sum(onehot * focal, dim=1)

@@ -83,7 +83,7 @@ SIGNATURES = {
                                                 _p, _p, _p]),
     "sfh_poi_project_bwd_theta": (C.c_int, [_p, _p, C.c_int, C.c_int, C.c_int, _p, _p, _p]),
     "sfh_train_losses": (C.c_int, [_p, _p, _p, _p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float,
-                                   C.c_int, C.c_float, _p, _p, _p, _p]),
+                                   C.c_int, C.c_float, C.c_int, _p, _p, _p, _p]),
     "sfh_reproj_loss": (C.c_int, [_p, _p, _p, _p, C.c_int, C.c_int, C.c_float, _p, _p, _p]),
     "sfh_rmsprop_step": (C.c_int, [_p, _p, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
                                    C.c_float, _p]),

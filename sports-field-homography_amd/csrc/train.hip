@@ -500,8 +500,37 @@ struct LossArgs {
   int nc, HW; long npix; int batch;
   float l_seg, l_rec, l_cons;   // lambda (0 = loss disabled)
   int rec_mse;                  // 1: nn.MSELoss, 0: nn.SmoothL1Loss (train.py:113-118)
+  int seg_focal, cons_focal;    // 1: kornia FocalLoss(alpha=1, gamma=2) instead of CE (train.py:101,126)
   float* dlogits; float* dwarp; double* loss;
 };
+
+// one classification loss term at a pixel: CE (lse - l[tgt]) or Kornia's focal loss with alpha 1, gamma 2
+// (train.py:101,126): sum_k (onehot_k + 1e-6) * -(1 - q_k)^2 log q_k, q = softmax + 1e-8; adds coef * dL/dl to dl
+template <int NC>
+__device__ __forceinline__ float cls_loss(const float (&l)[NC], const float (&pr)[NC], float lse, int tgt, bool focal,
+                                          float coef, float (&dl)[NC]) {
+  if (!focal) {
+    float lt = 0.f;
+#pragma unroll
+    for (int k = 0; k < NC; ++k) {
+      if (k == tgt) lt = l[k];
+      dl[k] += coef * (pr[k] - (k == tgt ? 1.f : 0.f));
+    }
+    return lse - lt;
+  }
+  float dLdp[NC], dot = 0.f, loss = 0.f;
+#pragma unroll
+  for (int k = 0; k < NC; ++k) {
+    const float q = pr[k] + 1e-8f, t = (k == tgt ? 1.f : 0.f) + 1e-6f;
+    const float om = 1.f - q, lg = logf(q);
+    loss += t * (-om * om * lg);
+    dLdp[k] = t * (2.f * om * lg - om * om / q);
+    dot += dLdp[k] * pr[k];
+  }
+#pragma unroll
+  for (int k = 0; k < NC; ++k) dl[k] += coef * pr[k] * (dLdp[k] - dot);
+  return loss;
+}
 
 template <int NC>
 __global__ __launch_bounds__(256) void train_losses_kernel(const LossArgs a) {
@@ -513,25 +542,20 @@ __global__ __launch_bounds__(256) void train_losses_kernel(const LossArgs a) {
     float l[NC], mx = -INFINITY;
 #pragma unroll
     for (int k = 0; k < NC; ++k) { l[k] = a.logits[(b * NC + k) * a.HW + i]; mx = fmaxf(mx, l[k]); }
-    float se = 0.f, e[NC];
+    float se = 0.f, pr[NC], dl[NC];
 #pragma unroll
-    for (int k = 0; k < NC; ++k) { e[k] = expf(l[k] - mx); se += e[k]; }
+    for (int k = 0; k < NC; ++k) { pr[k] = expf(l[k] - mx); se += pr[k]; dl[k] = 0.f; }
     const float lse = logf(se) + mx, rs = 1.0f / se;
+#pragma unroll
+    for (int k = 0; k < NC; ++k) pr[k] *= rs;
     const int gt = (int)a.gt[p];
     const float wb = a.weight[b];
     const float wv = a.warp ? a.warp[p] : 0.f;
     const int tc = min(max((int)(wv * (float)NC), 0), NC - 1);   // (warp_mask * nc).to(long)
-    const float cs = a.l_seg * wb * inv, cc = a.l_cons * inv;
-    float lgt = 0.f, ltc = 0.f;
+    if (a.l_seg != 0.f) s_seg += (double)(wb * cls_loss<NC>(l, pr, lse, gt, a.seg_focal != 0, a.l_seg * wb * inv, dl));
+    if (a.l_cons != 0.f) s_cons += (double)cls_loss<NC>(l, pr, lse, tc, a.cons_focal != 0, a.l_cons * inv, dl);
 #pragma unroll
-    for (int k = 0; k < NC; ++k) {
-      const float pk = e[k] * rs;
-      if (k == gt) lgt = l[k];
-      if (k == tc) ltc = l[k];
-      a.dlogits[(b * NC + k) * a.HW + i] = cs * (pk - (k == gt ? 1.f : 0.f)) + cc * (pk - (k == tc ? 1.f : 0.f));
-    }
-    s_seg += (double)(wb * (lse - lgt));
-    s_cons += (double)(lse - ltc);
+    for (int k = 0; k < NC; ++k) a.dlogits[(b * NC + k) * a.HW + i] = dl[k];
     if (a.warp) {
       const float d = wv - (float)gt / (float)NC;
       const float ad = fabsf(d);
@@ -939,8 +963,8 @@ extern "C" int sfh_stem_bwd_data(const float* dz, const float* w, int cin, int n
 
 extern "C" int sfh_train_losses(const float* logits_nchw, const int64_t* gt_mask, const float* weight,
                                 const float* warp_mask, int nc, int batch, int H, int W, float lambda_seg,
-                                float lambda_rec, int rec_mse, float lambda_cons, float* dlogits_nchw,
-                                float* dwarp, double* loss3, void* stream) {
+                                float lambda_rec, int rec_mse, float lambda_cons, int focal_flags,
+                                float* dlogits_nchw, float* dwarp, double* loss3, void* stream) {
   SFH_REQUIRE(logits_nchw && gt_mask && weight && dlogits_nchw && loss3 && batch > 0 && H > 0 && W > 0,
               "train_losses: bad argument");
   SFH_REQUIRE(nc >= 2 && nc <= 8, "train_losses: nc=%d unsupported (2..8)", nc);
@@ -949,6 +973,7 @@ extern "C" int sfh_train_losses(const float* logits_nchw, const int64_t* gt_mask
   a.logits = logits_nchw; a.gt = (const long*)gt_mask; a.weight = weight; a.warp = warp_mask;
   a.nc = nc; a.HW = H * W; a.npix = (long)batch * H * W; a.batch = batch;
   a.l_seg = lambda_seg; a.l_rec = lambda_rec; a.l_cons = lambda_cons; a.rec_mse = rec_mse;
+  a.seg_focal = focal_flags & 1; a.cons_focal = (focal_flags >> 1) & 1;
   a.dlogits = dlogits_nchw; a.dwarp = dwarp; a.loss = loss3;
   long nb = (a.npix + 255) / 256;
   if (nb > 2048) nb = 2048;

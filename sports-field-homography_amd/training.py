@@ -528,9 +528,12 @@ class TrainStep:
 
     def __init__(self, net, lr=1e-4, weight_decay=1e-8, momentum=0.9, alpha=0.99, eps=1e-8, clip_value=0.1,
                  seg_lambda=2.0, rec_lambda=2.0, reproj_lambda=8.0, consist_lambda=1.0, rec_loss="SmoothL1",
-                 consist_start_iter=0):
+                 seg_loss="CE", consist_loss="CE", consist_start_iter=0):
         if rec_loss not in ("SmoothL1", "MSE"):
             raise NotImplementedError(f"rec_loss={rec_loss!r}")
+        if seg_loss not in ("CE", "focal") or consist_loss not in ("CE", "focal"):
+            raise NotImplementedError(f"seg_loss={seg_loss!r} consist_loss={consist_loss!r}")
+        self.focal_flags = (1 if seg_loss == "focal" else 0) | (2 if consist_loss == "focal" else 0)
         self.net = net
         self.hp = dict(lr=lr, wd=weight_decay, mu=momentum, alpha=alpha, eps=eps, clip=clip_value)
         self.lam = dict(seg=seg_lambda, rec=rec_lambda, reproj=reproj_lambda, consist=consist_lambda)
@@ -599,7 +602,7 @@ class TrainStep:
         l_cons = self.lam["consist"] if self.global_step * B >= self.consist_start_iter else 0.0
         _lib.check(lib.sfh_train_losses(_ptr(logits), _ptr(mask), _ptr(E._f32c(batch["weight"], "weight")), _ptr(warp),
                                         net.mask_classes, B, H, W, self.lam["seg"], self.lam["rec"], self.rec_mse,
-                                        l_cons, _ptr(dlogits), _ptr(dwarp), _ptr(losses), st), "train_losses")
+                                        l_cons, self.focal_flags, _ptr(dlogits), _ptr(dwarp), _ptr(losses), st), "train_losses")
         gt_poi = E._f32c(batch["poi"], "gt poi")
         dpoi = _empty(poi.shape, x)
         _lib.check(lib.sfh_reproj_loss(_ptr(poi), _ptr(gt_poi), _ptr(E._f32c(batch["nonzeros"], "nonzeros")),

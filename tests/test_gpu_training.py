@@ -369,8 +369,8 @@ def _batch(B, H, W, npts, seed):
     return b
 
 
-@pytest.mark.parametrize("rec", ["SmoothL1", "MSE"])
-def test_loss_kernels_vs_torch(T, rec):
+@pytest.mark.parametrize("rec,cls", [("SmoothL1", "CE"), ("MSE", "focal")])
+def test_loss_kernels_vs_torch(T, rec, cls):
     from sfh_amd import _lib
     from sfh_amd.engine import _ptr, _stream
     import torch.nn.functional as F
@@ -382,12 +382,13 @@ def test_loss_kernels_vs_torch(T, rec):
     poi = torch.rand(B, N, 2, generator=g).requires_grad_(True)
     b = _batch(B, H, W, N, 78)
     lam = (2.0, 2.0, 8.0, 1.0)
-    seg = train_ref.per_sample_weighted(F.cross_entropy(logits, b["mask"], reduction="none"), b["weight"]) * lam[0]
+    ce = (lambda lg, t: F.cross_entropy(lg, t, reduction="none")) if cls == "CE" else train_ref.focal_loss
+    seg = train_ref.per_sample_weighted(ce(logits, b["mask"]), b["weight"]) * lam[0]
     gt_f = b["mask"].float() / 4.0
     rl = F.smooth_l1_loss(warp, gt_f, reduction="none") if rec == "SmoothL1" else F.mse_loss(warp, gt_f, reduction="none")
     recl = train_ref.per_sample_weighted(rl, b["weight"]) * lam[1]
     rep = train_ref.reprojection_loss(poi, b["poi"], b["nonzeros"], b["num_nonzero"]) * lam[2]
-    cons = F.cross_entropy(logits, (warp * 4).to(torch.long)) * lam[3]
+    cons = ce(logits, (warp * 4).to(torch.long)).mean() * lam[3]
     (seg + recl + rep + cons).backward()
 
     lc, wc, pc = logits.detach().cuda(), warp.detach().cuda(), poi.detach().cuda()
@@ -395,7 +396,8 @@ def test_loss_kernels_vs_torch(T, rec):
     losses = torch.zeros(4, dtype=torch.float64, device="cuda")
     dl, dw, dp = torch.empty_like(lc), torch.empty_like(wc), torch.empty_like(pc)
     _lib.check(lib.sfh_train_losses(_ptr(lc), _ptr(bc["mask"]), _ptr(bc["weight"]), _ptr(wc), 4, B, H, W, lam[0], lam[1],
-                                    1 if rec == "MSE" else 0, lam[3], _ptr(dl), _ptr(dw), _ptr(losses), _stream()), "losses")
+                                    1 if rec == "MSE" else 0, lam[3], 3 if cls == "focal" else 0, _ptr(dl), _ptr(dw),
+                                    _ptr(losses), _stream()), "losses")
     import ctypes
     _lib.check(lib.sfh_reproj_loss(_ptr(pc), _ptr(bc["poi"]), _ptr(bc["nonzeros"]), _ptr(bc["num_nonzero"]), B, N, lam[2],
                                    _ptr(dp), ctypes.c_void_p(losses.data_ptr() + 24), _stream()), "reproj")
