@@ -309,9 +309,11 @@ int sfh_reproj_loss(const float* poi, const float* gt_poi, const float* nonzeros
 /* nn.utils.clip_grad_value_(clip) + torch.optim.RMSprop step (train.py:88,234-237) over many tensors in
  * one launch.  tensor_table: device array of {float* param; const float* grad; float* square_avg;
  * float* momentum_buf;}; chunk_table: device array of {int32 tensor; int32 count; int64 offset;}, one
- * workgroup per chunk.  clip_value <= 0 disables clipping, momentum == 0 skips the buffer.              */
+ * workgroup per chunk.  clip_value <= 0 disables clipping, momentum == 0 skips the buffer; the gradient
+ * is multiplied by grad_scale first (1/world after a data-parallel all-reduce sum, else 1).            */
 int sfh_rmsprop_step(const void* tensor_table, const void* chunk_table, int nchunks, float lr, float alpha,
-                     float eps, float weight_decay, float momentum, float clip_value, void* stream);
+                     float eps, float weight_decay, float momentum, float clip_value, float grad_scale,
+                     void* stream);
 
 #ifdef __cplusplus
 }

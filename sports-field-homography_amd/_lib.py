@@ -86,7 +86,7 @@ SIGNATURES = {
                                    C.c_int, C.c_float, C.c_int, _p, _p, _p, _p]),
     "sfh_reproj_loss": (C.c_int, [_p, _p, _p, _p, C.c_int, C.c_int, C.c_float, _p, _p, _p]),
     "sfh_rmsprop_step": (C.c_int, [_p, _p, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
-                                   C.c_float, _p]),
+                                   C.c_float, C.c_float, _p]),
     "sfh_maxpool3x3s2_fwd": (C.c_int, [_p, _p, C.c_int, C.c_int, C.c_int, C.c_int, _p]),
     "sfh_avgpool_linear_fwd": (C.c_int, [_p, _p, _p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _p, _p]),
 }

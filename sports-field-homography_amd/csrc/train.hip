@@ -612,12 +612,13 @@ struct OptTensor { float* p; const float* g; float* sq; float* buf; };
 struct OptChunk { int tensor; int count; long offset; };
 
 __global__ __launch_bounds__(256) void rmsprop_kernel(const OptTensor* __restrict__ table, const OptChunk* __restrict__ chunks,
-                                                      float lr, float alpha, float eps, float wd, float mu, float clip) {
+                                                      float lr, float alpha, float eps, float wd, float mu, float clip,
+                                                      float gscale) {
   const OptChunk c = chunks[blockIdx.x];
   const OptTensor t = table[c.tensor];
   for (int i = threadIdx.x; i < c.count; i += 256) {
     const long o = c.offset + i;
-    float g = t.g[o];
+    float g = t.g[o] * gscale;   // 1/world: data-parallel mean of the all-reduced sum
     if (clip > 0.f) g = fminf(fmaxf(g, -clip), clip);
     const float p = t.p[o];
     g = g + wd * p;
@@ -998,10 +999,10 @@ extern "C" int sfh_reproj_loss(const float* poi, const float* gt_poi, const floa
 
 extern "C" int sfh_rmsprop_step(const void* tensor_table, const void* chunk_table, int nchunks, float lr,
                                 float alpha, float eps, float weight_decay, float momentum, float clip_value,
-                                void* stream) {
+                                float grad_scale, void* stream) {
   SFH_REQUIRE(tensor_table && chunk_table && nchunks > 0, "rmsprop_step: bad argument");
   hipLaunchKernelGGL(rmsprop_kernel, dim3((unsigned)nchunks), dim3(256), 0, (hipStream_t)stream,
                      (const OptTensor*)tensor_table, (const OptChunk*)chunk_table, lr, alpha, eps, weight_decay,
-                     momentum, clip_value);
+                     momentum, clip_value, grad_scale);
   return sfh_check_launch("rmsprop_kernel");
 }

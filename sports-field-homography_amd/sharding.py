@@ -76,3 +76,32 @@ def predict_sharded(net, frames, consistency=True, group=None):
     out["theta_all"], out["consist_score_all"] = theta_all, score_all
     out["shard"] = (s, e)
     return out
+
+
+# ------------------------------------------------------------------------ data-parallel training
+def flat_views(shapes, device, dtype=torch.float32):
+    """One flat buffer + one view per shape (gradients of all parameters back to back): the whole
+    gradient exchange of a step is then a single collective over 4*sum(numel) bytes (209 MB for the
+    default model) instead of 182 small ones - on xGMI's point-to-point links the ring all-reduce is
+    per-link bandwidth bound, so one large message is the efficient shape."""
+    sizes = [int(torch.Size(s).numel()) for s in shapes]
+    flat = torch.zeros(sum(sizes), dtype=dtype, device=device)
+    views, off = [], 0
+    for s, n in zip(shapes, sizes):
+        views.append(flat[off:off + n].view(s))
+        off += n
+    return flat, views
+
+
+def allreduce_gradients(flat, group=None):
+    """Sum the flat gradient buffer over the ranks (RCCL all-reduce over xGMI on GPUs, gloo in the CPU
+    tests); returns the factor 1/world that turns the sum into the data-parallel mean - the optimizer
+    kernel applies it while reading the gradient (before clip_grad_value_, like DistributedDataParallel's
+    averaged gradients)."""
+    if not dist.is_initialized():
+        return 1.0
+    world = dist.get_world_size(group)
+    if world == 1:
+        return 1.0
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    return 1.0 / world

@@ -550,7 +550,9 @@ class TrainStep:
         if dev.type != "cuda":
             raise RuntimeError("TrainStep needs the model on the GPU (there is no CPU fallback)")
         self.names = _Names(self.net)
-        self.grads = [torch.zeros_like(p) for p in self.params]
+        from . import sharding
+        # all gradients live in one flat buffer: a data-parallel step is a single all-reduce
+        self.gflat, self.grads = sharding.flat_views([tuple(p.shape) for p in self.params], dev)
         self.sq = [torch.zeros_like(p) for p in self.params]
         self.buf = [torch.zeros_like(p) for p in self.params]
         CH = 65536
@@ -634,8 +636,12 @@ class TrainStep:
         """-> float64 device tensor [seg, rec, consist, reproj] (each already times its lambda)."""
         losses = self.loss_and_grads(x, batch)
         lib, hp = _lib.load(), self.hp
+        from . import sharding
+        # one process per GPU: frames shard by batch, gradients are summed over RCCL and averaged in the
+        # optimizer kernel (BatchNorm statistics stay per rank, like DistributedDataParallel's default)
+        gscale = sharding.allreduce_gradients(self.gflat)
         _lib.check(lib.sfh_rmsprop_step(_ptr(self.table), _ptr(self.chunks), self.nchunks, hp["lr"], hp["alpha"],
-                                        hp["eps"], hp["wd"], hp["mu"], hp["clip"], _stream()), "rmsprop_step")
+                                        hp["eps"], hp["wd"], hp["mu"], hp["clip"], gscale, _stream()), "rmsprop_step")
         self.global_step += 1
         return losses
 

@@ -436,7 +436,7 @@ def test_rmsprop_kernel_vs_torch(T):
             dst.copy_(gr)
         hp = ts.hp
         _lib.check(lib.sfh_rmsprop_step(_ptr(ts.table), _ptr(ts.chunks), ts.nchunks, hp["lr"], hp["alpha"], hp["eps"],
-                                        hp["wd"], hp["mu"], hp["clip"], _stream()), "rmsprop")
+                                        hp["wd"], hp["mu"], hp["clip"], 1.0, _stream()), "rmsprop")
     torch.cuda.synchronize()
     for p, r in zip(net, ref):
         assert (p.detach().cpu() - r.detach()).abs().max().item() < 2e-6

@@ -65,3 +65,42 @@ def test_predict_sharded_gloo_world2(n_frames):
     for _, _, theta_all, score_all in res:
         assert torch.equal(torch.tensor(theta_all), want_theta)
         assert torch.equal(torch.tensor(score_all), torch.arange(float(n_frames)) * 0.5)
+
+
+def _grad_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        shapes = [(4, 3, 3, 3), (4,), (9, 8), (1,)]
+        flat, views = sharding.flat_views(shapes, "cpu")
+        for i, v in enumerate(views):
+            v.copy_(torch.full(shapes[i], float((rank + 1) * (i + 1))))
+        scale = sharding.allreduce_gradients(flat)
+        q.put((rank, scale, [float(v.flatten()[0]) for v in views], flat.numel(),
+               all(v.data_ptr() >= flat.data_ptr() for v in views)))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gradient_allreduce_gloo_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000) + 77
+    procs = [ctx.Process(target=_grad_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for _, scale, firsts, n, inside in res:
+        assert scale == 0.5 and n == 4 * 27 + 4 + 72 + 1 and inside
+        # rank r filled tensor i with (r+1)*(i+1): the sum over both ranks is 3*(i+1), the mean 1.5*(i+1)
+        assert firsts == [3.0 * (i + 1) for i in range(4)]
+
+
+def test_allreduce_without_process_group_is_identity():
+    flat, views = sharding.flat_views([(2, 2), (3,)], "cpu")
+    views[0].fill_(2.0)
+    assert sharding.allreduce_gradients(flat) == 1.0 and float(flat.sum()) == 8.0
