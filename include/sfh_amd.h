@@ -279,10 +279,10 @@ int sfh_maxpool3x3s2_bwd(const float* x, const float* dy, float* dx, int batch, 
 /* AdaptiveAvgPool2d(1) + Linear: dx (B,H,W,C); acc_w (nout*C doubles) += dW, acc_b (nout) += db.     */
 int sfh_avgpool_linear_bwd(const float* x, const float* w, const float* dout, int batch, int H, int W, int C,
                            int nout, float* dx, double* acc_w, double* acc_b, void* stream);
-/* Backward-data of the 7x7 s2 p3 stem for the first nc (<= 8) input channels - the logits inside
- * torch.cat((logits, x), 1) (models/reconstructor.py:179): dlogits_nchw (B,nc,H,W) += ...;
- * dz (B,Ho,Wo,64) NHWC, w OIHW (64,cin,7,7).                                                         */
-int sfh_stem_bwd_data(const float* dz, const float* w, int cin, int nc, int batch, int H, int W,
+/* Backward-data of the 7x7 s2 p3 stem for input channels [c_off, c_off+nc), nc <= 8 - the logits
+ * (or the uv map) inside torch.cat((logits, x[, uv]), 1) (models/reconstructor.py:174-183):
+ * dlogits_nchw (B,nc,H,W) += ...; dz (B,Ho,Wo,64) NHWC, w OIHW (64,cin,7,7).                          */
+int sfh_stem_bwd_data(const float* dz, const float* w, int cin, int c_off, int nc, int batch, int H, int W,
                       float* dlogits_nchw, void* stream);
 /* d loss / d theta of the bilinear homography warp (sfh_homography_warp_fwd mode 1): acc (B*9 doubles,
  * caller-zeroed) += sum over pixels; dout (B,h,w).                                                   */

@@ -160,14 +160,30 @@ def predict(x, sd, court_img, court_poi, mask_classes=4, warp_size=(640, 360),
     return ret
 
 
+def stn_input(x, logits, uv, resnet_input="img+mask"):
+    """models/reconstructor.py:173-183."""
+    if resnet_input == "img":
+        return x
+    if resnet_input == "mask":
+        return logits
+    if resnet_input == "img+mask":
+        return torch.cat((logits, x), 1)
+    if resnet_input == "img+mask+uv":
+        return torch.cat((logits, x, uv), 1)
+    raise NotImplementedError(resnet_input)
+
+
 def forward(x, sd, court_img, court_poi, warp_size=(640, 360), unet_size=(640, 360),
-            target_size=(640, 360), use_warper=True, warp_with_nearest=False, layers=(3, 4, 6, 3)):
-    """models/reconstructor.py:160-194 (eval-mode BatchNorm) for resnet_input='img+mask'."""
+            target_size=(640, 360), use_warper=True, warp_with_nearest=False, layers=(3, 4, 6, 3),
+            resnet_input="img+mask", use_resnet=True):
+    """models/reconstructor.py:160-194 (BatchNorm mode per BN_TRAINING)."""
     ret = {}
     ret["logits"], _, uv = forward_unet(x, sd, unet_size, target_size)
     if uv is not None:
         ret["uv"] = uv
-    theta = resnet_stn(torch.cat((ret["logits"], x), 1), sd, layers=layers)
+    if not use_resnet:
+        return ret
+    theta = resnet_stn(stn_input(x, ret["logits"], uv, resnet_input), sd, layers=layers)
     ret["theta"] = theta
     ret["poi"] = transform_poi(theta, court_poi)
     if use_warper:

@@ -27,8 +27,9 @@ lg64, g64 = run(torch.float64)
 lg32, g32 = run(torch.float32)
 net.cuda().train()
 tape = T.Tape()
-lg, _, _, ocb = T.UNetTrainer(net).forward(tape, x.cuda())
-ocb(dl.cuda()); tape.backward(); torch.cuda.synchronize()
+u = T.UNetTrainer(net).forward(tape, x.cuda())
+lg = u["logits"]
+u["heads"][0][1](dl.cuda()); tape.backward(); torch.cuda.synchronize()
 rel = lambda a, b: ((a.double().cpu() - b).abs().max() / (b.abs().max() + 1e-30)).item()
 print("logits: gpu %.2e cpu32 %.2e" % (rel(lg, lg64), rel(lg32, lg64)))
 rows = [(k, rel(tape.param_grads[k], g64[k]), rel(g32[k], g64[k]), g64[k].abs().max().item()) for k in g64]

@@ -78,7 +78,7 @@ SIGNATURES = {
     "sfh_outconv_bwd": (C.c_int, [_p, C.c_int, _p, _p, C.c_int, C.c_int, C.c_int, C.c_int, _p, _p, _p, _p]),
     "sfh_maxpool3x3s2_bwd": (C.c_int, [_p, _p, _p, C.c_int, C.c_int, C.c_int, C.c_int, _p]),
     "sfh_avgpool_linear_bwd": (C.c_int, [_p, _p, _p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _p, _p, _p, _p]),
-    "sfh_stem_bwd_data": (C.c_int, [_p, _p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _p, _p]),
+    "sfh_stem_bwd_data": (C.c_int, [_p, _p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _p, _p]),
     "sfh_homography_warp_bwd_theta": (C.c_int, [_p, _p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                                 _p, _p, _p]),
     "sfh_poi_project_bwd_theta": (C.c_int, [_p, _p, C.c_int, C.c_int, C.c_int, _p, _p, _p]),

@@ -449,12 +449,12 @@ __global__ __launch_bounds__(256) void avgpool_linear_bwd_kernel(const float* __
 // the nc channels sit in LDS as [ky][kx][co][4].
 template <int NC4>
 __global__ __launch_bounds__(256) void stem_bwd_data_kernel(const float* __restrict__ dz, const float* __restrict__ w,
-                                                            int cin, int nc, int H, int W, int Ho, int Wo,
+                                                            int cin, int c_off, int nc, int H, int W, int Ho, int Wo,
                                                             float* __restrict__ dlogits) {
   extern __shared__ __attribute__((aligned(16))) float wl[];  // [49][64][4*NC4]
   for (int i = threadIdx.x; i < 49 * 64 * 4 * NC4; i += 256) {
     const int c = i % (4 * NC4), co = (i / (4 * NC4)) % 64, t = i / (4 * NC4 * 64);
-    wl[i] = c < nc ? w[((long)co * cin + c) * 49 + t] : 0.f;
+    wl[i] = c < nc ? w[((long)co * cin + c_off + c) * 49 + t] : 0.f;
   }
   __syncthreads();
   const int x = blockIdx.x * 64 + (threadIdx.x & 63);
@@ -940,15 +940,15 @@ extern "C" int sfh_avgpool_linear_bwd(const float* x, const float* w, const floa
   return sfh_check_launch("avgpool_linear_bwd_kernel");
 }
 
-extern "C" int sfh_stem_bwd_data(const float* dz, const float* w, int cin, int nc, int batch, int H, int W,
-                                 float* dlogits_nchw, void* stream) {
+extern "C" int sfh_stem_bwd_data(const float* dz, const float* w, int cin, int c_off, int nc, int batch, int H,
+                                 int W, float* dlogits_nchw, void* stream) {
   SFH_REQUIRE(dz && w && dlogits_nchw && batch > 0 && batch <= 65535 && H > 0 && W > 0, "stem_bwd_data: bad argument");
-  SFH_REQUIRE(nc >= 1 && nc <= 8 && nc <= cin, "stem_bwd_data: nc=%d cin=%d", nc, cin);
+  SFH_REQUIRE(nc >= 1 && nc <= 8 && c_off >= 0 && c_off + nc <= cin, "stem_bwd_data: c_off=%d nc=%d cin=%d", c_off, nc, cin);
   const int Ho = (H + 6 - 7) / 2 + 1, Wo = (W + 6 - 7) / 2 + 1;
   const dim3 grid((unsigned)sfh_cdiv(W, 64), (unsigned)sfh_cdiv(H, 4), (unsigned)batch);
   if (nc <= 4) {
     hipLaunchKernelGGL(stem_bwd_data_kernel<1>, grid, dim3(256), 49 * 64 * 4 * sizeof(float), (hipStream_t)stream, dz, w,
-                       cin, nc, H, W, Ho, Wo, dlogits_nchw);
+                       cin, c_off, nc, H, W, Ho, Wo, dlogits_nchw);
   } else {
     static bool attr = false;
     if (!attr) {
@@ -957,7 +957,7 @@ extern "C" int sfh_stem_bwd_data(const float* dz, const float* w, int cin, int n
       attr = true;
     }
     hipLaunchKernelGGL(stem_bwd_data_kernel<2>, grid, dim3(256), 49 * 64 * 8 * sizeof(float), (hipStream_t)stream, dz, w,
-                       cin, nc, H, W, Ho, Wo, dlogits_nchw);
+                       cin, c_off, nc, H, W, Ho, Wo, dlogits_nchw);
   }
   return sfh_check_launch("stem_bwd_data_kernel");
 }

@@ -127,7 +127,8 @@ def _wgrad(lib, dz, srcs, B, H, W, ksize, cin_store):
     M = dz.shape[3]
     raw = _zeros((M, ksize * ksize, cin_store), dz)
     for (t, n, n_off, pt, pl) in srcs:
-        _lib.check(lib.sfh_conv_wgrad(_ptr(dz), dz.shape[3], M, _ptr(t), t.shape[3], t.shape[1], t.shape[2], n,
+        # t may be a channel slice of an NHWC tensor: the pixel stride is stride(2), not shape[3]
+        _lib.check(lib.sfh_conv_wgrad(_ptr(dz), dz.shape[3], M, _ptr(t), t.stride(2), t.shape[1], t.shape[2], n,
                                       pt, pl, B, H, W, ksize, _ptr(raw), cin_store, n_off, _stream()), "conv_wgrad")
     return raw
 
@@ -320,7 +321,12 @@ class UNetTrainer:
             y = dconv(up.conv, [(skip, skip.shape[3], 0, 0), (u, u.shape[3], dy_ // 2, dx_ // 2)], hs, ws)
         frame = x if want_stn_in else None
         logits, stn_in, oc_bwd = out_conv(tape, names, net.outc, y, B, H, W, frame, stn_cs)
-        return logits, feats[4], stn_in, oc_bwd
+        heads = [(logits, oc_bwd)]
+        uv = None
+        if net.unet_uv:  # second 1x1 head on the same features (models/reconstructor.py:79,148)
+            uv, _, uv_bwd = out_conv(tape, names, net.outuv, y, B, H, W)
+            heads.append((uv, uv_bwd))
+        return {"logits": logits, "uv": uv, "x_top": feats[4], "stn_in": stn_in, "heads": heads}
 
 
 # --------------------------------------------------------------------------------------- ResNetSTN
@@ -332,9 +338,10 @@ class ResNetTrainer:
         self.rn = net.resnet_reg
         self.names = _Names(net)
 
-    def forward(self, tape, stn_in, logits, nc, cin):
-        """stn_in: (B,H,W,cs) NHWC = cat((logits, frame)) zero-padded to cs channels; `logits` is the NCHW
-        tensor whose gradient slot receives the stem's backward-data.  Returns theta (B,1,3,3)."""
+    def forward(self, tape, stn_in, targets, cin):
+        """stn_in: (B,H,W,cs) NHWC = the STN input (models/reconstructor.py:174-183) zero-padded to cs
+        channels; targets: [(NCHW tensor, first channel, channels)] - the pieces of the input that come
+        from the UNet heads and whose gradient slots receive the stem's backward-data.  Returns theta (B,9)."""
         lib, rn, names = tape.lib, self.rn, self.names
         B, H, W, cs = stn_in.shape
         st = _stream
@@ -358,13 +365,17 @@ class ResNetTrainer:
             dz, dgamma, dbeta, _ = _bn_backward(lib, dc1, c1, z0, mi0, rn.bn1, True, False)
             g = tape.param_grads
             g[names(rn.bn1.weight)], g[names(rn.bn1.bias)] = dgamma, dbeta
-            raw = _wgrad(lib, dz, [(s2d, 4 * cs, 0, 0, 0)], B, H2, W2, 4, 4 * cs)     # (64, 16, 4*cs)
+            # the 4x4 backward-filter instance holds 32 input channels: wider inputs go in slices
+            raw = _wgrad(lib, dz, [(s2d[..., c:], min(32, 4 * cs - c), c, 0, 0) for c in range(0, 4 * cs, 32)],
+                         B, H2, W2, 4, 4 * cs)                                         # (64, 16, 4*cs)
             # 4x4 taps over the space-to-depth input -> 7x7: ky = 2*ty + py - 1 (sfh_pack_conv_weights mode 2)
             r = raw.view(64, 4, 4, 2, 2, cs).permute(0, 5, 1, 3, 2, 4).reshape(64, cs, 8, 8)
             g[names(rn.conv0.weight)] = r[:, :cin, 1:, 1:].contiguous()
-            dl = tape.peek_grad(logits)
-            if dl is not None:  # the logits are the first nc channels of the STN input
-                _lib.check(lib.sfh_stem_bwd_data(_ptr(dz), _ptr(w0), cin, nc, B, H, W, _ptr(dl), st()), "stem_bwd_data")
+            for (t, c_off, nct) in targets:   # e.g. the logits = the first nc channels of the STN input
+                dl = tape.peek_grad(t)
+                if dl is not None:
+                    _lib.check(lib.sfh_stem_bwd_data(_ptr(dz), _ptr(w0), cin, c_off, nct, B, H, W, _ptr(dl), st()),
+                               "stem_bwd_data")
 
         tape.push(stem_backward)
 
@@ -431,6 +442,92 @@ def poi_backward_theta(theta, court_poi, dout, normalize=True):
     return dth
 
 
+def stn_channels(net):
+    """(real channels, stored channels) of the STN input for net.resnet_input (models/reconstructor.py:84-97)."""
+    nc = net.mask_classes
+    cin = {"IMG": 3, "MASK": nc, "IMG_AND_MASK": nc + 3, "IMG_AND_MASK_AND_UV": nc + 5}[net.resnet_input.name]
+    return cin, -(-cin // 4) * 4
+
+
+def run_forward(net, tape, x):
+    """Reconstructor.forward (models/reconstructor.py:160-194) on the training kernels.
+    -> dict: logits / uv / theta (B,9) / poi / warp_mask tensors, `heads` [(NCHW output, backward fn)]."""
+    B, _, H, W = x.shape
+    mode = net.resnet_input.name
+    nc = net.mask_classes
+    f = {"logits": None, "uv": None, "theta": None, "poi": None, "warp_mask": None, "heads": [], "shared": False}
+    cin, cs = stn_channels(net) if net.use_resnet else (0, 0)
+    if net.use_unet:
+        fused = net.use_resnet and mode == "IMG_AND_MASK"   # OutConv writes cat((logits, x)) itself
+        u = UNetTrainer(net).forward(tape, x, want_stn_in=fused, stn_cs=cs)
+        f.update(logits=u["logits"], uv=u["uv"], heads=u["heads"])
+    if net.use_resnet:
+        targets = []
+        if mode == "IMG":
+            stn_in = E.nchw_to_nhwc(x, cs)
+        elif mode == "MASK":
+            stn_in, targets = E.nchw_to_nhwc(f["logits"], cs), [(f["logits"], 0, nc)]
+        elif mode == "IMG_AND_MASK":
+            stn_in, targets = u["stn_in"], [(f["logits"], 0, nc)]
+        else:  # IMG_AND_MASK_AND_UV
+            stn_in = E.nchw_to_nhwc(torch.cat((f["logits"], x, f["uv"]), 1).contiguous(), cs)
+            targets = [(f["logits"], 0, nc), (f["uv"], nc + 3, 2)]
+        theta = ResNetTrainer(net).forward(tape, stn_in, targets, cin)
+        theta4 = theta.view(B, 1, 3, 3)
+        f["theta"] = theta
+        f["poi"] = E.poi_project(theta4, net.court_poi)
+        if net.warper:
+            f["shared"] = net._template_is_shared(net.court_img, B)
+            ww, wh = net.warp_size
+            f["warp_mask"], _ = E.homography_warp(theta4, net.court_img, wh, ww, net.warp_with_nearest,
+                                                  shared_template=f["shared"])
+    tape._s3.clear()   # the split-bf16 copies only feed forward convolutions
+    return f
+
+
+def run_backward(net, tape, f, dheads, dtheta):
+    """dheads: gradients of the head outputs in the order of f['heads'] (None = zero); dtheta (B,9) or None.
+    -> {state_dict key: gradient}.  ResNet closures run first (pushed last) and add the stem's gradient
+    into the head gradients; then the heads; then the UNet."""
+    if f["theta"] is not None:
+        tape.grads[id(f["theta"])] = dtheta if dtheta is not None else torch.zeros_like(f["theta"])
+    for (t, _), d in zip(f["heads"], dheads):
+        tape.grads[id(t)] = torch.zeros_like(t) if d is None else d
+    ops, tape.ops = tape.ops, []
+    k = ctx_split(ops)
+    for fn in reversed(ops[k:]):
+        fn()
+    for t, bwd in f["heads"]:
+        bwd(tape.pop_grad(t))
+    for fn in reversed(ops[:k]):
+        fn()
+    g = tape.param_grads
+    # the closures reference the tape and the tape the closures: break the cycle so the activations
+    # are released now rather than at the next garbage collection
+    tape.param_grads = {}
+    tape.grads.clear()
+    tape._s3.clear()
+    f["heads"] = []
+    return g
+
+
+def theta_gradient(net, f, dtheta, dpoi, dwarp):
+    """total d loss / d theta (B,9): direct + through transform_poi + through the bilinear warp"""
+    theta = f["theta"]
+    B = theta.shape[0]
+    lib = _lib.load()
+    dth = torch.zeros_like(theta) if dtheta is None else dtheta.reshape(B, 9).to(torch.float32).clone()
+    if dpoi is not None:
+        dth = _add_small(lib, dth, poi_backward_theta(theta, net.court_poi, dpoi.contiguous()))
+    if dwarp is not None and net.warper and not net.warp_with_nearest:
+        ww, wh = net.warp_size
+        dth = _add_small(lib, dth, warp_backward_theta(theta, net.court_img, wh, ww, dwarp.contiguous(), f["shared"]))
+    return dth
+
+
+_OUT_KEYS = ("logits", "uv", "theta", "poi", "warp_mask")
+
+
 class _TrainForward(torch.autograd.Function):
     """Reconstructor.forward under net.train() as one autograd node: the forward runs the HIP
     training kernels and keeps the tape; backward() turns the output gradients into parameter
@@ -439,59 +536,25 @@ class _TrainForward(torch.autograd.Function):
     @staticmethod
     def forward(ctx, net, x, *params):
         tape = Tape()
-        B, _, H, W = x.shape
         x = E._f32c(x.detach(), "input frames")
-        ut = UNetTrainer(net)
-        cin = net.mask_classes + 3
-        cs = -(-cin // 4) * 4
-        if (4 * cs) % 16:
-            cs = -(-cin // 8) * 8
-        logits, _, stn_in, oc_bwd = ut.forward(tape, x, want_stn_in=True, stn_cs=cs)
-        theta = ResNetTrainer(net).forward(tape, stn_in, logits, net.mask_classes, cin)
-        theta4 = theta.view(B, 1, 3, 3)
-        shared = net._template_is_shared(net.court_img, B)
-        poi = E.poi_project(theta4, net.court_poi)
-        outs = [logits, theta4, poi]
-        ctx.warp = bool(net.warper)
-        if net.warper:
-            ww, wh = net.warp_size
-            wm, _ = E.homography_warp(theta4, net.court_img, wh, ww, net.warp_with_nearest, shared_template=shared)
-            outs.append(wm)
-        tape._s3.clear()   # the split-bf16 copies only feed forward convolutions
-        ctx.tape, ctx.oc_bwd, ctx.net, ctx.theta, ctx.logits, ctx.shared = tape, oc_bwd, net, theta, logits, shared
-        ctx.nparams = len(params)
+        f = run_forward(net, tape, x)
+        B = x.shape[0]
+        keys = [k for k in _OUT_KEYS if f[k] is not None]
+        outs = [f[k].view(B, 1, 3, 3) if k == "theta" else f[k] for k in keys]
+        ctx.tape, ctx.f, ctx.net, ctx.keys = tape, f, net, keys
         return tuple(outs)
 
     @staticmethod
-    def backward(ctx, dlogits, dtheta, dpoi, *rest):
-        net, tape, theta = ctx.net, ctx.tape, ctx.theta
-        B = theta.shape[0]
-        dth = torch.zeros_like(theta) if dtheta is None else dtheta.reshape(B, 9).to(torch.float32).clone()
-        if dpoi is not None:
-            dth += poi_backward_theta(theta, net.court_poi, dpoi.contiguous())
-        if ctx.warp and rest and rest[0] is not None and not net.warp_with_nearest:
-            ww, wh = net.warp_size
-            dth += warp_backward_theta(theta, net.court_img, wh, ww, rest[0].contiguous(), ctx.shared)
-        dl = torch.zeros_like(ctx.logits) if dlogits is None else dlogits.contiguous().clone()
-        tape.grads[id(theta)] = dth
-        tape.grads[id(ctx.logits)] = dl
-        # ResNet closures run first (pushed last) and add the stem's gradient into dl; then the UNet
-        ops, tape.ops = tape.ops, []
-        unet_ops = ops[:ctx_split(ops)]
-        for fn in reversed(ops[len(unet_ops):]):
-            fn()
-        ctx.oc_bwd(tape.pop_grad(ctx.logits))
-        for fn in reversed(unet_ops):
-            fn()
-        g = tape.param_grads
+    def backward(ctx, *douts):
+        net, tape, f = ctx.net, ctx.tape, ctx.f
+        d = dict(zip(ctx.keys, douts))
+        dth = theta_gradient(net, f, d.get("theta"), d.get("poi"), d.get("warp_mask")) if f["theta"] is not None else None
+        head_keys = ["logits"] + (["uv"] if f["uv"] is not None else []) if f["logits"] is not None else []
+        dheads = [None if d.get(k) is None else d[k].contiguous().clone() for k in head_keys]
+        g = run_backward(net, tape, f, dheads, dth)
         names = _Names(net)
         grads = tuple(g.get(names(p)) for p in net.parameters())
-        # the closures reference the tape and the tape the closures: break the cycle so the activations
-        # are released now rather than at the next garbage collection
-        tape.ops, tape.param_grads = [], {}
-        tape.grads.clear()
-        tape._s3.clear()
-        ctx.tape = ctx.oc_bwd = ctx.theta = ctx.logits = None
+        ctx.tape = ctx.f = None
         return (None, None) + grads
 
 
@@ -504,18 +567,18 @@ def ctx_split(ops):
 
 
 def train_forward(net, x):
-    """models/reconstructor.py:160-194 under net.train(): dict with logits, theta, poi[, warp_mask]."""
-    if net.unet_uv or net.resnet_input.name != "IMG_AND_MASK" or not (net.use_unet and net.use_resnet):
-        raise NotImplementedError("the HIP training path covers the default configuration "
-                                  "(resnet_input='img+mask', no uv head)")
-    if net._needs_resize(x):
+    """models/reconstructor.py:160-194 under net.train(): dict with logits[, uv], theta, poi[, warp_mask]."""
+    if net.use_unet and net.unet_bilinear:
+        raise NotImplementedError("training the bilinear Up variant is not on the HIP path")
+    if net.use_unet and net._needs_resize(x):
         raise NotImplementedError("training with unet_size/target_size different from the frame size is not on the HIP path")
+    if not net.use_unet and net.resnet_input.name != "IMG":
+        raise NotImplementedError  # like the reference: without the UNet only the frame can feed the STN
     params = tuple(net.parameters())
     outs = _TrainForward.apply(net, x, *params)
-    ret = {"logits": outs[0], "theta": outs[1], "poi": outs[2]}
-    if net.warper:
-        ret["warp_mask"] = outs[3]
-    return ret
+    keys = [k for k in _OUT_KEYS if (k in ("logits",) and net.use_unet) or (k == "uv" and net.use_unet and net.unet_uv)
+            or (k in ("theta", "poi") and net.use_resnet) or (k == "warp_mask" and net.use_resnet and net.warper)]
+    return dict(zip(keys, outs))
 
 
 # ------------------------------------------------------------------- the whole step on HIP kernels
@@ -577,23 +640,17 @@ class TrainStep:
         net, lib = self.net, _lib.load()
         if not net.training:
             raise RuntimeError("TrainStep: call net.train() first")
+        if net.unet_uv or net.resnet_input.name != "IMG_AND_MASK" or not (net.use_unet and net.use_resnet and net.warper):
+            raise NotImplementedError("TrainStep covers the reference's training configuration "
+                                      "(UNet + ResNetSTN + warper, resnet_input='img+mask', no uv head)")
         tape = Tape()
         B, _, H, W = x.shape
         x = E._f32c(x, "input frames")
-        cin = net.mask_classes + 3
-        cs = -(-cin // 4) * 4
-        if (4 * cs) % 16:
-            cs = -(-cin // 8) * 8
-        logits, _, stn_in, oc_bwd = UNetTrainer(net).forward(tape, x, want_stn_in=True, stn_cs=cs)
-        theta = ResNetTrainer(net).forward(tape, stn_in, logits, net.mask_classes, cin)
-        tape._s3.clear()
-        theta4 = theta.view(B, 1, 3, 3)
-        shared = net._template_is_shared(net.court_img, B)
-        poi = E.poi_project(theta4, net.court_poi)
+        f = run_forward(net, tape, x)
+        logits, theta, poi, warp = f["logits"], f["theta"], f["poi"], f["warp_mask"]
         ww, wh = net.warp_size
         if (wh, ww) != (H, W):
             raise NotImplementedError("TrainStep needs warp_size == frame size (the losses compare per pixel)")
-        warp, _ = E.homography_warp(theta4, net.court_img, wh, ww, net.warp_with_nearest, shared_template=shared)
         st = _stream()
         losses = _zeros((4,), x, torch.float64)   # seg, rec, consist, reproj
         mask = batch["mask"]
@@ -611,25 +668,9 @@ class TrainStep:
                                        _ptr(E._f32c(batch["num_nonzero"], "num_nonzero")), B, poi.shape[1],
                                        self.lam["reproj"], _ptr(dpoi), ctypes.c_void_p(losses.data_ptr() + 24), st),
                    "reproj_loss")
-        # backward: theta first (POI + warp), ResNet (adds the stem's gradient into dlogits), then the UNet
-        dth = poi_backward_theta(theta, net.court_poi, dpoi)
-        if not net.warp_with_nearest:
-            wt = warp_backward_theta(theta, net.court_img, wh, ww, dwarp, shared)
-            dth = _add_small(lib, dth, wt)
-        tape.grads[id(theta)] = dth
-        tape.grads[id(logits)] = dlogits
-        ops, tape.ops = tape.ops, []
-        k = ctx_split(ops)
-        for fn in reversed(ops[k:]):
-            fn()
-        oc_bwd(tape.pop_grad(logits))
-        for fn in reversed(ops[:k]):
-            fn()
-        g = tape.param_grads
+        g = run_backward(net, tape, f, [dlogits], theta_gradient(net, f, None, dpoi, dwarp))
         for p, dst in zip(self.params, self.grads):
             dst.copy_(g[self.names(p)].reshape(dst.shape))
-        tape.ops, tape.param_grads = [], {}
-        tape.grads.clear()
         return losses
 
     def step(self, x, batch):

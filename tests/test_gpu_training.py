@@ -80,8 +80,9 @@ def test_unet_train_forward_backward(T):
 
     net.cuda().train()
     tape = T.Tape()
-    logits, xtop, _, oc_bwd = T.UNetTrainer(net).forward(tape, x.cuda())
-    oc_bwd(dlogits.cuda())
+    u = T.UNetTrainer(net).forward(tape, x.cuda())
+    logits, xtop = u["logits"], u["x_top"]
+    u["heads"][0][1](dlogits.cuda())
     tape.backward()
     torch.cuda.synchronize()
 
@@ -481,3 +482,44 @@ def test_train_step_on_hip_matches_autograd_path(T):
         assert np.isfinite(tot)
         first = tot if first is None else first
     assert tot < first, (first, tot)
+
+
+@pytest.mark.parametrize("kw,mode", [
+    ({"unet_uv": True, "resnet_input": "img+mask+uv"}, "img+mask+uv"),
+    ({"resnet_input": "mask"}, "mask"),
+    ({"resnet_input": "img"}, "img"),
+    ({"use_resnet": False, "use_warper": False}, None),
+])
+def test_training_variants(T, kw, mode):
+    """uv head, the other resnet_input modes (models/reconstructor.py:84-97,173-183) and UNet-only training."""
+    from sfh_amd.reconstructor import Reconstructor
+    B, H, W = 4, 64, 96
+    court = synth.load_court_template("ncaa_nc4_640x360", 4, B)[:, :, :H, :W].contiguous()
+    poi = synth.load_court_poi("pitch", B)
+    net = Reconstructor(court, poi, target_size=(W, H), unet_size=(W, H), warp_size=(W, H), **kw)
+    sd = synth.synth_state_dict(net.state_dict(), 53)
+    net.load_state_dict(sd)
+    x = synth.frames_to_float(synth.synth_frames_u8(B, H, W, seed=53))
+    g = torch.Generator().manual_seed(53)
+
+    ref = train_ref.leaf_state(sd)
+    with train_ref.bn_training():
+        pr = torch_ref.forward(x, ref, court, poi, warp_size=(W, H), unet_size=(W, H), target_size=(W, H),
+                               resnet_input=mode or "img+mask", use_resnet=mode is not None)
+    douts = {k: torch.randn(v.shape, generator=g) / v.numel() ** 0.5 for k, v in pr.items()}
+    sum((pr[k] * douts[k]).sum() for k in pr).backward()
+    want = {k: v.grad for k, v in ref.items() if v.requires_grad and v.grad is not None}
+
+    net.court_img, net.court_poi = court.cuda(), poi.cuda()
+    net.cuda().train()
+    preds = net(x.cuda())
+    assert sorted(preds) == sorted(pr)
+    sum((preds[k] * douts[k].cuda()).sum() for k in preds).backward()
+    torch.cuda.synchronize()
+    for k in pr:
+        tol = 2e-3 if k == "warp_mask" else 2e-4
+        assert (preds[k].detach().cpu() - pr[k].detach()).abs().max().item() < tol * max(1.0, pr[k].abs().max().item()), k
+    got = {k: p.grad for k, p in net.named_parameters() if p.grad is not None}
+    assert sorted(got) == sorted(want)
+    errs = np.sort(np.array(list(_grad_stats(got, want).values())))
+    assert np.median(errs) < 2e-2 and errs[int(0.8 * len(errs))] < 1e-1, (np.median(errs), errs[-5:])
