@@ -315,6 +315,14 @@ int sfh_rmsprop_step(const void* tensor_table, const void* chunk_table, int nchu
                      float eps, float weight_decay, float momentum, float clip_value, float grad_scale,
                      void* stream);
 
+/* Backward of sfh_upsample2x_bilinear_nhwc (the bilinear Up variant, unet/unet_parts.py:49): dy (B,2H,2W,C)
+ * -> dx (B,H,W,C).                                                                                        */
+int sfh_upsample2x_bilinear_nhwc_bwd(const float* dy, float* dx, int batch, int H, int W, int C, void* stream);
+/* Backward of sfh_resize_nchw mode 0 ('nearest': the logits / uv resize, models/reconstructor.py:153,156):
+ * dy (planes,hd,wd) -> dx (planes,hs,ws).                                                                */
+int sfh_resize_nearest_nchw_bwd(const float* dy, float* dx, int64_t planes, int hs, int ws, int hd, int wd,
+                                void* stream);
+
 #ifdef __cplusplus
 }
 #endif

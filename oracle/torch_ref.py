@@ -175,10 +175,10 @@ def stn_input(x, logits, uv, resnet_input="img+mask"):
 
 def forward(x, sd, court_img, court_poi, warp_size=(640, 360), unet_size=(640, 360),
             target_size=(640, 360), use_warper=True, warp_with_nearest=False, layers=(3, 4, 6, 3),
-            resnet_input="img+mask", use_resnet=True):
+            resnet_input="img+mask", use_resnet=True, bilinear=False):
     """models/reconstructor.py:160-194 (BatchNorm mode per BN_TRAINING)."""
     ret = {}
-    ret["logits"], _, uv = forward_unet(x, sd, unet_size, target_size)
+    ret["logits"], _, uv = forward_unet(x, sd, unet_size, target_size, bilinear=bilinear)
     if uv is not None:
         ret["uv"] = uv
     if not use_resnet:

@@ -149,6 +149,72 @@ __global__ void upsample2x_nhwc_kernel(const float* __restrict__ src, float* __r
   reinterpret_cast<f32x4*>(dst)[i] = o;
 }
 
+// Backward of upsample2x_nhwc_kernel: every input pixel gathers from the output pixels whose two
+// taps include it (same index arithmetic as the forward, so the weights are identical).
+__device__ __forceinline__ void up2_range(int i, int in, int& lo, int& hi) {
+  // outputs o with tap index i have src = o*(in-1)/(2in-1) in (i-1, i+1)
+  if (in <= 1) { lo = 0; hi = 2 * in - 1; return; }
+  lo = max(0, (int)(((long)(i - 1) * (2 * in - 1)) / (in - 1)) - 1);
+  hi = min(2 * in - 1, (int)(((long)(i + 1) * (2 * in - 1) + in - 2) / (in - 1)) + 1);
+}
+
+__global__ void upsample2x_nhwc_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int H, int W, int C,
+                                           long total4) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;  // one float4 of the input gradient
+  if (i >= total4) return;
+  const int c4n = C >> 2;
+  const int c4 = i % c4n;
+  long r = i / c4n;
+  const int x = r % W; r /= W;
+  const int y = r % H;
+  const long b = r / H;
+  int ylo, yhi, xlo, xhi;
+  up2_range(y, H, ylo, yhi);
+  up2_range(x, W, xlo, xhi);
+  const float* p = dy + b * (long)(2 * H) * (2 * W) * C + 4 * c4;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  for (int oy = ylo; oy <= yhi; ++oy) {
+    int y0, y1;
+    float ly;
+    bilinear_taps(oy, H, 2 * H, 1, y0, y1, ly);
+    const float wy = (y0 == y ? 1.f - ly : 0.f) + (y1 == y ? ly : 0.f);
+    if (wy == 0.f) continue;
+    for (int ox = xlo; ox <= xhi; ++ox) {
+      int x0, x1;
+      float lx;
+      bilinear_taps(ox, W, 2 * W, 1, x0, x1, lx);
+      const float wx = (x0 == x ? 1.f - lx : 0.f) + (x1 == x ? lx : 0.f);
+      if (wx == 0.f) continue;
+      const f32x4 g = *reinterpret_cast<const f32x4*>(p + ((long)oy * (2 * W) + ox) * C);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[j] += wy * wx * g[j];
+    }
+  }
+  reinterpret_cast<f32x4*>(dx)[i] = acc;
+}
+
+// Backward of resize_nearest_nchw_kernel: dx[src] = sum of dy over the destination pixels that read src.
+__global__ void resize_nearest_nchw_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int hs, int ws,
+                                               int hd, int wd, long total) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;  // one source pixel
+  if (i >= total) return;
+  const int xs = i % ws;
+  const long r = i / ws;
+  const int ys = r % hs;
+  const long pl = r / hs;
+  const float fy = (float)hs / hd, fx = (float)ws / wd;
+  // candidates: dst in [floor(src/f) - 1, ceil((src+1)/f) + 1]; keep those whose forward index is src
+  const int ylo = max(0, (int)floorf(ys / fy) - 1), yhi = min(hd - 1, (int)ceilf((ys + 1) / fy) + 1);
+  const int xlo = max(0, (int)floorf(xs / fx) - 1), xhi = min(wd - 1, (int)ceilf((xs + 1) / fx) + 1);
+  float acc = 0.f;
+  for (int y = ylo; y <= yhi; ++y) {
+    if (min((int)floorf(y * fy), hs - 1) != ys) continue;
+    for (int x = xlo; x <= xhi; ++x)
+      if (min((int)floorf(x * fx), ws - 1) == xs) acc += dy[(pl * hd + y) * (long)wd + x];
+  }
+  dx[i] = acc;
+}
+
 // ----------------------------------------------------------------- BatchNorm folding
 __global__ void fold_bn_kernel(const float* conv_bias, const float* gamma, const float* beta,
                                const float* mean, const float* var, float eps, int n, int repeat,
@@ -559,4 +625,22 @@ extern "C" int sfh_mask_format_fwd(const void* src, int src_kind, int nc, int ba
   else SFH_MF(2);
 #undef SFH_MF
   return sfh_check_launch("mask_format_kernel");
+}
+
+extern "C" int sfh_upsample2x_bilinear_nhwc_bwd(const float* dy, float* dx, int batch, int H, int W, int C,
+                                                void* stream) {
+  SFH_REQUIRE(dy && dx && batch > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, "upsample2x_bwd: bad argument");
+  const long total4 = (long)batch * H * W * (C / 4);
+  hipLaunchKernelGGL(upsample2x_nhwc_bwd_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0,
+                     (hipStream_t)stream, dy, dx, H, W, C, total4);
+  return sfh_check_launch("upsample2x_nhwc_bwd_kernel");
+}
+
+extern "C" int sfh_resize_nearest_nchw_bwd(const float* dy, float* dx, int64_t planes, int hs, int ws, int hd,
+                                           int wd, void* stream) {
+  SFH_REQUIRE(dy && dx && planes > 0 && hs > 0 && ws > 0 && hd > 0 && wd > 0, "resize_nearest_bwd: bad argument");
+  const long total = planes * hs * ws;
+  hipLaunchKernelGGL(resize_nearest_nchw_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                     (hipStream_t)stream, dy, dx, hs, ws, hd, wd, total);
+  return sfh_check_launch("resize_nearest_nchw_bwd_kernel");
 }

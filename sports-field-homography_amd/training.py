@@ -257,6 +257,23 @@ def conv_transpose2x2(tape, names, up, x):
     return u
 
 
+def upsample2x(tape, x):
+    """nn.Upsample(scale_factor=2, mode='bilinear', align_corners=True) (unet/unet_parts.py:49)."""
+    lib = tape.lib
+    B, h, w, C = x.shape
+    u = _empty((B, 2 * h, 2 * w, C), x)
+    _lib.check(lib.sfh_upsample2x_bilinear_nhwc(_ptr(x), _ptr(u), B, h, w, C, _stream()), "upsample2x")
+
+    def backward():
+        du = tape.pop_grad(u)
+        dx = _empty(x.shape, x)
+        _lib.check(lib.sfh_upsample2x_bilinear_nhwc_bwd(_ptr(du), _ptr(dx), B, h, w, C, _stream()), "upsample2x_bwd")
+        tape.add_grad(x, dx)
+
+    tape.push(backward)
+    return u
+
+
 def out_conv(tape, names, oc, y, B, H, W, frame_nhwc=None, stn_cs=0):
     """OutConv (unet/unet_parts.py:74-77) -> logits NCHW (+ the STN input cat((logits, x), 1) in NHWC)."""
     lib = tape.lib
@@ -285,11 +302,10 @@ def out_conv(tape, names, oc, y, B, H, W, frame_nhwc=None, stn_cs=0):
 
 # ----------------------------------------------------------------------------------------- UNet
 class UNetTrainer:
-    """forward_unet (models/reconstructor.py:132-158) in training mode, deconv Up variant, no resize."""
+    """forward_unet (models/reconstructor.py:132-158) in training mode at the UNet's own resolution
+    (both Up variants; the resizes around it live in run_forward)."""
 
     def __init__(self, net):
-        if net.unet_bilinear:
-            raise NotImplementedError("training the bilinear Up variant is not on the HIP path yet")
         self.net = net
         self.names = _Names(net)
 
@@ -315,7 +331,7 @@ class UNetTrainer:
         for i in range(1, 5):
             up = getattr(net, f"up{i}")
             skip = feats[4 - i]
-            u = conv_transpose2x2(tape, names, up.up, y)
+            u = upsample2x(tape, y) if net.unet_bilinear else conv_transpose2x2(tape, names, up.up, y)
             hs, ws = skip.shape[1], skip.shape[2]
             dy_, dx_ = hs - u.shape[1], ws - u.shape[2]
             y = dconv(up.conv, [(skip, skip.shape[3], 0, 0), (u, u.shape[3], dy_ // 2, dx_ // 2)], hs, ws)
@@ -457,10 +473,32 @@ def run_forward(net, tape, x):
     nc = net.mask_classes
     f = {"logits": None, "uv": None, "theta": None, "poi": None, "warp_mask": None, "heads": [], "shared": False}
     cin, cs = stn_channels(net) if net.use_resnet else (0, 0)
+    fused = False
     if net.use_unet:
-        fused = net.use_resnet and mode == "IMG_AND_MASK"   # OutConv writes cat((logits, x)) itself
-        u = UNetTrainer(net).forward(tape, x, want_stn_in=fused, stn_cs=cs)
-        f.update(logits=u["logits"], uv=u["uv"], heads=u["heads"])
+        uw, uh = net.unet_size
+        tw, th = net.target_size
+        resized_in, resized_out = (H, W) != (uh, uw), (tw, th) != (uw, uh)
+        # OutConv writes cat((logits, x)) itself when nothing is resized around the UNet
+        fused = net.use_resnet and mode == "IMG_AND_MASK" and not (resized_in or resized_out)
+        xin = E.resize_nchw(x, (uh, uw), "bilinear", align_corners=False) if resized_in else x   # :134-136
+        u = UNetTrainer(net).forward(tape, xin, want_stn_in=fused, stn_cs=cs)
+        heads = u["heads"]
+        if resized_out:   # nearest resize of logits / uv to target_size (:151-156) and its backward
+            lib = tape.lib
+
+            def resized(t, bwd):
+                Bc, C = t.shape[0], t.shape[1]
+                r = E.resize_nchw(t, (th, tw), "nearest")
+
+                def back(d):
+                    dt = _empty(t.shape, t)
+                    _lib.check(lib.sfh_resize_nearest_nchw_bwd(_ptr(d), _ptr(dt), Bc * C, uh, uw, th, tw, _stream()),
+                               "resize_nearest_bwd")
+                    bwd(dt)
+                return r, back
+
+            heads = [resized(t, bwd) for t, bwd in heads]
+        f.update(logits=heads[0][0], uv=heads[1][0] if len(heads) > 1 else None, heads=heads)
     if net.use_resnet:
         targets = []
         if mode == "IMG":
@@ -468,7 +506,8 @@ def run_forward(net, tape, x):
         elif mode == "MASK":
             stn_in, targets = E.nchw_to_nhwc(f["logits"], cs), [(f["logits"], 0, nc)]
         elif mode == "IMG_AND_MASK":
-            stn_in, targets = u["stn_in"], [(f["logits"], 0, nc)]
+            stn_in = u["stn_in"] if fused else E.nchw_to_nhwc(torch.cat((f["logits"], x), 1).contiguous(), cs)
+            targets = [(f["logits"], 0, nc)]
         else:  # IMG_AND_MASK_AND_UV
             stn_in = E.nchw_to_nhwc(torch.cat((f["logits"], x, f["uv"]), 1).contiguous(), cs)
             targets = [(f["logits"], 0, nc), (f["uv"], nc + 3, 2)]
@@ -568,10 +607,6 @@ def ctx_split(ops):
 
 def train_forward(net, x):
     """models/reconstructor.py:160-194 under net.train(): dict with logits[, uv], theta, poi[, warp_mask]."""
-    if net.use_unet and net.unet_bilinear:
-        raise NotImplementedError("training the bilinear Up variant is not on the HIP path")
-    if net.use_unet and net._needs_resize(x):
-        raise NotImplementedError("training with unet_size/target_size different from the frame size is not on the HIP path")
     if not net.use_unet and net.resnet_input.name != "IMG":
         raise NotImplementedError  # like the reference: without the UNet only the frame can feed the STN
     params = tuple(net.parameters())

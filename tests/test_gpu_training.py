@@ -489,14 +489,19 @@ def test_train_step_on_hip_matches_autograd_path(T):
     ({"resnet_input": "mask"}, "mask"),
     ({"resnet_input": "img"}, "img"),
     ({"use_resnet": False, "use_warper": False}, None),
+    ({"unet_bilinear": True}, "img+mask"),
+    ({"unet_size": (80, 48), "unet_uv": True}, "img+mask"),     # bilinear input resize + nearest logits / uv resize
 ])
 def test_training_variants(T, kw, mode):
-    """uv head, the other resnet_input modes (models/reconstructor.py:84-97,173-183) and UNet-only training."""
+    """uv head, the other resnet_input modes (models/reconstructor.py:84-97,173-183), UNet-only training,
+    the bilinear Up variant and the resize paths around the UNet (:134-156)."""
     from sfh_amd.reconstructor import Reconstructor
     B, H, W = 4, 64, 96
     court = synth.load_court_template("ncaa_nc4_640x360", 4, B)[:, :, :H, :W].contiguous()
     poi = synth.load_court_poi("pitch", B)
-    net = Reconstructor(court, poi, target_size=(W, H), unet_size=(W, H), warp_size=(W, H), **kw)
+    kw = dict(kw)
+    usize = kw.pop("unet_size", (W, H))
+    net = Reconstructor(court, poi, target_size=(W, H), unet_size=usize, warp_size=(W, H), **kw)
     sd = synth.synth_state_dict(net.state_dict(), 53)
     net.load_state_dict(sd)
     x = synth.frames_to_float(synth.synth_frames_u8(B, H, W, seed=53))
@@ -504,8 +509,9 @@ def test_training_variants(T, kw, mode):
 
     ref = train_ref.leaf_state(sd)
     with train_ref.bn_training():
-        pr = torch_ref.forward(x, ref, court, poi, warp_size=(W, H), unet_size=(W, H), target_size=(W, H),
-                               resnet_input=mode or "img+mask", use_resnet=mode is not None)
+        pr = torch_ref.forward(x, ref, court, poi, warp_size=(W, H), unet_size=usize, target_size=(W, H),
+                               resnet_input=mode or "img+mask", use_resnet=mode is not None,
+                               bilinear=bool(kw.get("unet_bilinear")))
     douts = {k: torch.randn(v.shape, generator=g) / v.numel() ** 0.5 for k, v in pr.items()}
     sum((pr[k] * douts[k]).sum() for k in pr).backward()
     want = {k: v.grad for k, v in ref.items() if v.requires_grad and v.grad is not None}
@@ -523,3 +529,29 @@ def test_training_variants(T, kw, mode):
     assert sorted(got) == sorted(want)
     errs = np.sort(np.array(list(_grad_stats(got, want).values())))
     assert np.median(errs) < 2e-2 and errs[int(0.8 * len(errs))] < 1e-1, (np.median(errs), errs[-5:])
+
+
+def test_upsample_and_nearest_resize_backward(T):
+    """backward of nn.Upsample(2x, bilinear, align_corners=True) and of F.interpolate(mode='nearest')"""
+    from sfh_amd import _lib
+    from sfh_amd.engine import _ptr, _stream
+    import torch.nn.functional as F
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(3)
+    for (B, C, H, W) in [(2, 8, 5, 7), (1, 4, 1, 3), (2, 4, 2, 2), (1, 8, 11, 20)]:
+        x = torch.randn(B, C, H, W, generator=g, dtype=torch.float64, requires_grad=True)
+        dy = torch.randn(B, C, 2 * H, 2 * W, generator=g)
+        F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=True).backward(dy.double())
+        dyc = _nhwc(dy)
+        dx = torch.empty((B, H, W, C), device="cuda")
+        _lib.check(lib.sfh_upsample2x_bilinear_nhwc_bwd(_ptr(dyc), _ptr(dx), B, H, W, C, _stream()), "up_bwd")
+        assert _relerr(_nchw(dx), x.grad) < 1e-5, (B, C, H, W)
+    for (hs, ws, hd, wd) in [(48, 80, 64, 96), (64, 96, 48, 80), (7, 9, 23, 31), (5, 5, 5, 5), (30, 17, 11, 40)]:
+        x = torch.randn(2, 3, hs, ws, generator=g, dtype=torch.float64, requires_grad=True)
+        dy = torch.randn(2, 3, hd, wd, generator=g)
+        xf = x.detach().float().requires_grad_(True)
+        F.interpolate(xf, size=(hd, wd), mode="nearest").backward(dy)
+        dx = torch.empty((2, 3, hs, ws), device="cuda")
+        dyc = dy.cuda()
+        _lib.check(lib.sfh_resize_nearest_nchw_bwd(_ptr(dyc), _ptr(dx), 6, hs, ws, hd, wd, _stream()), "nearest_bwd")
+        assert _relerr(dx, xf.grad) < 1e-6, (hs, ws, hd, wd)
