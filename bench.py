@@ -138,7 +138,8 @@ def main():
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--height", type=int, default=360)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-frames", type=int, default=2)
+    ap.add_argument("--cpu-frames", type=int, default=16,
+                    help="frames of the same workload timed on the host cores for cpu_baseline (about 10 s)")
     ap.add_argument("--consistency", action="store_true", help="also compute consist_score + poi")
     ap.add_argument("--train", action="store_true",
                     help="BASELINE config 3 instead of the headline: one training step (forward, losses, "
@@ -240,7 +241,7 @@ def main():
         from oracle import torch_ref
         ncpu = min(usable_cores(), int(os.environ.get("SFH_CPU_THREADS", "64")))
         torch.set_num_threads(ncpu)
-        nf = args.cpu_frames
+        nf = min(args.cpu_frames, B)
         xc = frames[0][:nf].cpu()
         sd_cpu = {k: v.cpu() for k, v in sd.items()}
         court_c, poi_c = court.cpu(), poi.cpu()
