@@ -20,16 +20,29 @@ here = os.path.dirname(os.path.abspath(__file__))
 
 
 def rows(kind):
+    """counter rows in dispatch order, each tagged with `_resnet` = launched after the step's
+    space_to_depth2 (the ResNetSTN part of predict) and before the next step's nchw_to_nhwc"""
     f = sorted(glob.glob(os.path.join(src, f"{tag}_{kind}", "*", "*_counter_collection.csv")), key=os.path.getmtime)
-    return list(csv.DictReader(open(f[-1]))) if f else []
+    rr = list(csv.DictReader(open(f[-1]))) if f else []
+    rr.sort(key=lambda r: int(r["Start_Timestamp"]))
+    in_resnet = False
+    for r in rr:
+        if "nchw_to_nhwc" in r["Kernel_Name"]:
+            in_resnet = False
+        elif "space_to_depth" in r["Kernel_Name"]:
+            in_resnet = True
+        r["_resnet"] = in_resnet
+    return rr
 
 
-def group(name):
+def group(name, resnet=False):
     m = re.search(r"ConvCfg<(\d+), (\d+)", name)
     if "conv_mfma" in name and m:
         return {("3", "1"): "fp32_conv3x3", ("1", "1"): "fp32_conv1x1"}.get((m.group(1), m.group(2)), "fp32_other_conv")
     m = re.search(r"S3Cfg<(\d+), (\d+)", name)
     if "conv_s3" in name and m:
+        if resnet:
+            return "s3_resnet"
         return "s3_conv3x3" if m.group(1) == "3" else "s3_conv1x1"
     for k in ("warp_kernel", "outconv", "maxpool", "avgpool", "space_to_depth", "nchw_to_nhwc", "pack_weights", "fold_bn", "ce_"):
         if k in name:
@@ -42,7 +55,7 @@ def per_group(kind, counter):
     for r in rows(kind):
         if r["Counter_Name"] != counter:
             continue
-        g = group(r["Kernel_Name"])
+        g = group(r["Kernel_Name"], r["_resnet"])
         if g is None:
             continue
         n, v, t = acc.get(g, (0, 0.0, 0.0))
@@ -74,7 +87,7 @@ print("\n".join(lines))
 # MFMA busy
 mf = {}
 for r in rows("mfma"):
-    g = group(r["Kernel_Name"])
+    g = group(r["Kernel_Name"], r["_resnet"])
     if g is None:
         continue
     d = mf.setdefault(g, {})

@@ -67,7 +67,7 @@ struct S3Geom {
   int Ho, Wo, rows_total, rows_per_img;
   unsigned rows_magic;
   unsigned bytes0, bytes1;
-  int nb_fast;  // 1: the cout blocks of one pixel tile run back to back on one XCD (scatter output)
+  int nb_group;  // cout blocks of one pixel tile that run back to back on one XCD (1 .. nblk_n)
 };
 
 __device__ __forceinline__ bf16x8 as_bf(const u32x4& v) { return __builtin_bit_cast(bf16x8, v); }
@@ -137,10 +137,14 @@ __global__ __launch_bounds__(256, 2) void conv_s3_kernel(const sfh_conv_desc d, 
   // on the XCD stream the same weight fragments, which then stay in its 4 MB L2 (weights are the
   // dominant L2->CU stream of this kernel: 12 KB per tap per workgroup)
   const int tpx = (g.ntiles + 7) >> 3;  // tiles per XCD
-  // transposed conv (nb_fast): all quadrants / couts of one pixel tile back to back instead, so the
-  // interleaved output rows are completed in the XCD's L2 before they are written back
-  const int nb = g.nb_fast ? kk_ % g.nblk_n : kk_ / tpx;
-  const int tile = (g.nb_fast ? kk_ / g.nblk_n : kk_ - nb * tpx) * 8 + xcd;
+  // nb_group = G cout blocks of one pixel tile run back to back: their input tile is fetched into the
+  // XCD's L2 once instead of G times.  G is chosen on the host so that the G weight sets still fit L2
+  // next to it (transposed conv: G = all quadrants / couts, so the interleaved output rows are
+  // completed in L2 before they are written back).
+  const int per = tpx * g.nb_group;
+  const int gi = kk_ / per, rr = kk_ - gi * per;
+  const int nb = gi * g.nb_group + rr % g.nb_group;
+  const int tile = (rr / g.nb_group) * 8 + xcd;
   if (tile >= g.ntiles) return;
   const int ty = tile / g.tiles_x, tx = tile - ty * g.tiles_x;
   const int x0 = tx * C::TW;
@@ -475,7 +479,23 @@ int launch_s3(const sfh_conv_desc& d, hipStream_t stream) {
   g.bytes0 = (unsigned)b0;
   g.bytes1 = (unsigned)b1;
   g.nblk_n = d.cout / 64;
-  g.nb_fast = d.out_mode == SFH_OUT_UPSCATTER2;
+  {
+    // weights of one cout block: (cin/32) stages x taps x 12 KB.  Measured on the UNet (B=16, 640x360,
+    // DoubleConv ms per batch vs budget for the group's weights): 0.5 MB 22.41, 2 MB 22.10, 16 MB 21.92,
+    // 64 MB 21.61, unbounded 21.74 - re-reading the input tile once per cout block costs more than
+    // streaming weights that no longer fit the 4 MB L2 (they hit the 256 MB Infinity Cache), so the budget
+    // is 64 MB: every layer of this model is fully grouped (SFH_DEBUG_S3_L2KB / _NBGROUP override).
+    const long wblock = (long)((d.c0 + (d.src1 ? d.c1 : 0)) / 32) * C::NTAP * 12288;
+    static const char* l2kb = getenv("SFH_DEBUG_S3_L2KB");
+    const long budget = l2kb ? (long)atoi(l2kb) << 10 : (64L << 20);
+    int G = d.out_mode == SFH_OUT_UPSCATTER2 ? g.nblk_n : (int)(budget / (wblock > 0 ? wblock : 1));
+    static const char* ov = getenv("SFH_DEBUG_S3_NBGROUP");
+    if (ov) G = atoi(ov);
+    if (G < 1) G = 1;
+    if (G > g.nblk_n) G = g.nblk_n;
+    while (g.nblk_n % G) --G;  // groups must tile the cout blocks
+    g.nb_group = G;
+  }
   const long nblocks = (long)sfh_cdiv(g.ntiles, 8) * 8 * g.nblk_n;
   SFH_REQUIRE(nblocks < (1L << 31), "conv_s3: grid too large");
   // (measured: switching small grids - ResNet layer3/4, <= 320 workgroups - to the double-buffered
