@@ -68,6 +68,7 @@ struct S3Geom {
   unsigned rows_magic;
   unsigned bytes0, bytes1;
   int nb_group;  // cout blocks of one pixel tile that run back to back on one XCD (1 .. nblk_n)
+  int xcd_interleave;
 };
 
 __device__ __forceinline__ bf16x8 as_bf(const u32x4& v) { return __builtin_bit_cast(bf16x8, v); }
@@ -144,7 +145,9 @@ __global__ __launch_bounds__(256, 2) void conv_s3_kernel(const sfh_conv_desc d, 
   const int per = tpx * g.nb_group;
   const int gi = kk_ / per, rr = kk_ - gi * per;
   const int nb = gi * g.nb_group + rr % g.nb_group;
-  const int tile = (rr / g.nb_group) * 8 + xcd;
+  // each XCD owns a contiguous range of pixel tiles (whole tile rows), so vertically adjacent tiles
+  // share their halo rows in that XCD's L2 (xcd_interleave: the old round-robin order, for A/B runs)
+  const int tile = g.xcd_interleave ? (rr / g.nb_group) * 8 + xcd : xcd * tpx + rr / g.nb_group;
   if (tile >= g.ntiles) return;
   const int ty = tile / g.tiles_x, tx = tile - ty * g.tiles_x;
   const int x0 = tx * C::TW;
@@ -495,6 +498,8 @@ int launch_s3(const sfh_conv_desc& d, hipStream_t stream) {
     if (G > g.nblk_n) G = g.nblk_n;
     while (g.nblk_n % G) --G;  // groups must tile the cout blocks
     g.nb_group = G;
+    static const char* il = getenv("SFH_DEBUG_S3_XCD_INTERLEAVE");
+    g.xcd_interleave = il ? atoi(il) : 0;
   }
   const long nblocks = (long)sfh_cdiv(g.ntiles, 8) * 8 * g.nblk_n;
   SFH_REQUIRE(nblocks < (1L << 31), "conv_s3: grid too large");
