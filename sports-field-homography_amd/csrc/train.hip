@@ -647,7 +647,7 @@ struct WgradArgs {
   const float* x; int x_cs, xh, xw, N, pad_top, pad_left;
   int batch, H, W;
   float* raw; int raw_n, n_off;
-  int ntx, nty, ntiles, nsplit;
+  int ntx, nty, ntiles, nsplit, mt, mn;
 };
 
 template <int KS, int NSUB, int TH, int TW>
@@ -662,14 +662,20 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
   float* zL = lds + HPX * 64;    // [64][64]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l16 = lane & 15, kq = lane >> 4;
-  const int m0 = blockIdx.x * 64, n0 = blockIdx.y * (16 * NSUB);
+  // XCD-aware order (workgroups go round-robin to the 8 XCDs): the mn = (m tiles) x (n tiles) workgroups
+  // of one pixel split run back to back on ONE XCD, so the split's dz / x tiles are fetched into that
+  // L2 once instead of once per (m, n) block
+  const int xcd = blockIdx.x & 7, kk_ = blockIdx.x >> 3;
+  const int split = (kk_ / a.mn) * 8 + xcd, mni = kk_ % a.mn;
+  if (split >= a.nsplit) return;
+  const int m0 = (mni % a.mt) * 64, n0 = (mni / a.mt) * (16 * NSUB);
   f32x4 acc[KK][NSUB];
 #pragma unroll
   for (int t = 0; t < KK; ++t)
 #pragma unroll
     for (int s = 0; s < NSUB; ++s) acc[t][s] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  for (int tile = blockIdx.z; tile < a.ntiles; tile += a.nsplit) {
+  for (int tile = split; tile < a.ntiles; tile += a.nsplit) {
     const int tx = tile % a.ntx;
     const int ty = (tile / a.ntx) % a.nty;
     const int b = tile / (a.ntx * a.nty);
@@ -761,8 +767,11 @@ int launch_wgrad(WgradArgs a, hipStream_t stream) {
   if (ns > a.ntiles) ns = a.ntiles;
   if (ns < 1) ns = 1;
   if (ns > 65535) ns = 65535;
+  if (ns < 8 && a.ntiles >= 8) ns = 8;  // one split per XCD at least
   a.nsplit = ns;
-  const dim3 grid((unsigned)sfh_cdiv(a.M, 64), (unsigned)sfh_cdiv(a.N, 16 * NSUB), (unsigned)a.nsplit);
+  a.mt = sfh_cdiv(a.M, 64);
+  a.mn = mn;
+  const dim3 grid((unsigned)(sfh_cdiv(ns, 8) * 8 * mn));
   hipLaunchKernelGGL((wgrad_kernel<KS, NSUB, TH, TW>), grid, dim3(256), lds, stream, a);
   return sfh_check_launch("wgrad_kernel");
 }
@@ -892,7 +901,7 @@ extern "C" int sfh_conv_wgrad(const float* dz, int dz_cs, int M, const float* x,
   a.x = x; a.x_cs = x_cs; a.xh = xh; a.xw = xw; a.N = N; a.pad_top = pad_top; a.pad_left = pad_left;
   a.batch = batch; a.H = H; a.W = W;
   a.raw = raw; a.raw_n = raw_n; a.n_off = n_off;
-  a.ntx = a.nty = a.ntiles = a.nsplit = 0;
+  a.ntx = a.nty = a.ntiles = a.nsplit = a.mt = a.mn = 0;
   hipStream_t st = (hipStream_t)stream;
   const int t = wgrad_tile(H, W);
 #define SFH_WG(KS_, NS_)                                         \
