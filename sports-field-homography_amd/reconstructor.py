@@ -141,6 +141,13 @@ class Reconstructor(nn.Module):
             self._engine_stamp = stamp
         return self._engines
 
+    def __getstate__(self):
+        """The model is pickled into spawned worker processes (predict.py:130,252): ship parameters and
+        configuration only - packed weights and workspaces are rebuilt in the worker on first use."""
+        st = self.__dict__.copy()
+        st["_engines"] = st["_engine_stamp"] = st["_tmpl_shared"] = None
+        return st
+
     def _require_eval(self, what):
         if self.training:
             raise NotImplementedError(

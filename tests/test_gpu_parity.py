@@ -497,3 +497,33 @@ def test_model_api_errors(E):
     bad = dict(sd); bad.pop("outc.conv.bias")
     with pytest.raises(RuntimeError):
         net.load_state_dict(bad)                                  # strict key check like the reference
+
+
+def _spawned_predict(net, x, q):
+    net.court_img, net.court_poi = net.court_img.cuda(), net.court_poi.cuda()
+    with torch.no_grad():
+        out = net.to("cuda").eval().predict(x.cuda(), consistency=True)
+    q.put({k: v.cpu().numpy() for k, v in out.items() if k in ("theta", "consist_score", "warp_mask")})
+
+
+def test_predict_in_spawned_worker_process(E):
+    """predict.py runs the model in a spawned worker per device (predict.py:130,252): the pickled model
+    (no kernel-side state) gives the same result there as in this process."""
+    import torch.multiprocessing as mp
+    net, sd, court, poi = _model((112, 90))
+    net.load_state_dict(sd)
+    x = synth.smooth_frames(2, 90, 112, seed=3)
+    with torch.no_grad():
+        here = net.cuda().eval().predict(x.cuda(), consistency=True)
+    net.cpu()
+    net.court_img, net.court_poi = court.cpu(), poi.cpu()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_spawned_predict, args=(net, x, q))
+    p.start()
+    there = q.get(timeout=300)
+    p.join(timeout=60)
+    assert p.exitcode == 0
+    assert np.array_equal(there["theta"], here["theta"].cpu().numpy())
+    assert np.array_equal(there["warp_mask"], here["warp_mask"].cpu().numpy())
+    assert np.allclose(there["consist_score"], here["consist_score"].cpu().numpy(), atol=1e-6)
