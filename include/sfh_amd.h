@@ -150,6 +150,11 @@ int sfh_fold_bn(const float* conv_bias, const float* gamma, const float* beta,
  * (utils/dataset.py:154-159, :323-330: `img.transpose((2,0,1)) / 255` -> FloatTensor) on the GPU. */
 int sfh_u8hwc_to_f32nchw(const uint8_t* src, float* dst, int batch, int C, int H, int W, void* stream);
 
+/* Same with the video path's 2x downscale in front (utils/dataset.py:312-316: frames wider than the target
+ * go through cv2.resize(..., INTER_AREA)): src uint8 (B,2H,2W,C) -> dst (B,C,H,W) = ((a+b+c+d+2)>>2)/255,
+ * OpenCV's 2x2 area fast path.  Other scale factors are not covered. */
+int sfh_u8hwc_area2_to_f32nchw(const uint8_t* src, float* dst, int batch, int C, int H, int W, void* stream);
+
 /* (B, C, H, W) fp32 -> (B, H, W, cs) fp32, channels >= C zero-filled. */
 int sfh_nchw_to_nhwc(const float* src, float* dst, int batch, int C, int H, int W, int cs,
                      void* stream);

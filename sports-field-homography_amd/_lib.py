@@ -48,6 +48,7 @@ SIGNATURES = {
     "sfh_space_to_depth2": (C.c_int, [_p, _p, C.c_int, C.c_int, C.c_int, C.c_int, _p]),
     "sfh_fold_bn": (C.c_int, [_p, _p, _p, _p, _p, C.c_float, C.c_int, C.c_int, _p, _p, _p]),
     "sfh_u8hwc_to_f32nchw": (C.c_int, [_p, _p, C.c_int, C.c_int, C.c_int, C.c_int, _p]),
+    "sfh_u8hwc_area2_to_f32nchw": (C.c_int, [_p, _p, C.c_int, C.c_int, C.c_int, C.c_int, _p]),
     "sfh_nchw_to_nhwc": (C.c_int, [_p, _p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _p]),
     "sfh_nhwc_to_nchw": (C.c_int, [_p, _p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _p]),
     "sfh_resize_nchw": (C.c_int, [_p, _p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _p]),

@@ -35,6 +35,25 @@ __global__ void u8hwc_to_f32nchw_kernel(const uint8_t* __restrict__ src, float* 
   for (int c = 0; c < C; ++c) d[(long)c * HW] = (float)s[c] / 255.0f;
 }
 
+// cv2.resize(frame, (W, H), interpolation=cv2.INTER_AREA) for an exact 2x downscale of uint8 frames
+// (utils/dataset.py:312-316: frames wider than the target use INTER_AREA) followed by the same /255:
+// OpenCV's 2x2 area fast path is (a + b + c + d + 2) >> 2 per channel.
+__global__ void u8hwc_area2_to_f32nchw_kernel(const uint8_t* __restrict__ src, float* __restrict__ dst, int C, int H,
+                                              int W, long npix) {
+  const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;   // one output pixel
+  if (p >= npix) return;
+  const int HW = H * W;
+  const long b = p / HW;
+  const int i = (int)(p - b * HW), y = i / W, x = i - y * W;
+  const long rs = 2L * W * C;  // source row stride in bytes
+  const uint8_t* s = src + (b * 2 * H + 2 * y) * rs + 2L * x * C;
+  float* d = dst + b * (long)C * HW + i;
+  for (int c = 0; c < C; ++c) {
+    const int v = ((int)s[c] + (int)s[C + c] + (int)s[rs + c] + (int)s[rs + C + c] + 2) >> 2;
+    d[(long)c * HW] = (float)v / 255.0f;
+  }
+}
+
 __global__ void nhwc_to_nchw_kernel(const float* __restrict__ src, float* __restrict__ dst,
                                     int C, int HW, int cs, long npix) {
   const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -481,6 +500,15 @@ extern "C" int sfh_u8hwc_to_f32nchw(const uint8_t* src, float* dst, int batch, i
   hipLaunchKernelGGL(u8hwc_to_f32nchw_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0,
                      (hipStream_t)stream, src, dst, C, H * W, npix);
   return sfh_check_launch("u8hwc_to_f32nchw_kernel");
+}
+
+extern "C" int sfh_u8hwc_area2_to_f32nchw(const uint8_t* src, float* dst, int batch, int C, int H, int W,
+                                          void* stream) {
+  SFH_REQUIRE(src && dst && batch > 0 && C > 0 && C <= 4 && H > 0 && W > 0, "u8hwc_area2_to_f32nchw: bad argument");
+  const long npix = (long)batch * H * W;
+  hipLaunchKernelGGL(u8hwc_area2_to_f32nchw_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0,
+                     (hipStream_t)stream, src, dst, C, H, W, npix);
+  return sfh_check_launch("u8hwc_area2_to_f32nchw_kernel");
 }
 
 extern "C" int sfh_nhwc_to_nchw(const float* src, float* dst, int batch, int C, int H, int W, int cs,

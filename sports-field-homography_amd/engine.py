@@ -560,14 +560,24 @@ def f32_to_s3(t):
     return out
 
 
-def frames_u8_to_input(frames_u8):
+def frames_u8_to_input(frames_u8, target_size=None):
     """uint8 (B,H,W,C) decoded frames on the GPU -> float32 (B,C,H,W) in [0,1], bit-identical to the
-    reference dataset's `img.transpose((2,0,1)) / 255` (utils/dataset.py:154-159)."""
+    reference dataset's `img.transpose((2,0,1)) / 255` (utils/dataset.py:154-159).  target_size = (W, H):
+    like VideoDataset.preprocess_img (utils/dataset.py:310-330) the frames are resized first; on the GPU
+    only the exact 2x downscale (cv2.INTER_AREA's 2x2 fast path, e.g. 1280x720 -> 640x360) is covered."""
     lib = _lib.load()
     if frames_u8.dtype != torch.uint8 or frames_u8.dim() != 4 or not frames_u8.is_cuda:
         raise ValueError("expected a uint8 (B,H,W,C) tensor on the GPU")
     f = frames_u8.contiguous()
     B, H, W, C = f.shape
+    if target_size is not None and (int(target_size[0]), int(target_size[1])) != (W, H):
+        tw, th = int(target_size[0]), int(target_size[1])
+        if (2 * tw, 2 * th) != (W, H):
+            raise NotImplementedError(f"GPU frame resize {W}x{H} -> {tw}x{th}: only the exact 2x downscale is on the "
+                                      "HIP path; resize on the host as utils/dataset.py does")
+        out = torch.empty((B, C, th, tw), dtype=torch.float32, device=f.device)
+        _lib.check(lib.sfh_u8hwc_area2_to_f32nchw(_ptr(f), _ptr(out), B, C, th, tw, _stream()), "u8hwc_area2_to_f32nchw")
+        return out
     out = torch.empty((B, C, H, W), dtype=torch.float32, device=f.device)
     _lib.check(lib.sfh_u8hwc_to_f32nchw(_ptr(f), _ptr(out), B, C, H, W, _stream()), "u8hwc_to_f32nchw")
     return out

@@ -480,6 +480,19 @@ def test_u8_frame_preprocessing_matches_dataset(E):
     assert torch.equal(synth.frames_to_float(fr), want)
 
 
+def test_u8_frame_area2_downscale(E):
+    """1280x720-style frames -> half size with OpenCV's 2x2 INTER_AREA rule, then /255 (utils/dataset.py:310-330)."""
+    fr = synth.synth_frames_u8(2, 44, 72, seed=9)
+    f = fr.astype(np.int32)
+    area = ((f[:, 0::2, 0::2] + f[:, 0::2, 1::2] + f[:, 1::2, 0::2] + f[:, 1::2, 1::2] + 2) >> 2).astype(np.uint8)
+    want = torch.from_numpy((area.transpose(0, 3, 1, 2) / 255)).type(torch.FloatTensor)
+    got = E.frames_u8_to_input(torch.from_numpy(fr).cuda(), target_size=(36, 22))
+    torch.cuda.synchronize()
+    assert torch.equal(got.cpu(), want)
+    with pytest.raises(NotImplementedError):
+        E.frames_u8_to_input(torch.from_numpy(fr).cuda(), target_size=(30, 20))
+
+
 def test_model_api_errors(E):
     from sfh_amd.reconstructor import Reconstructor
     net, sd, court, poi = _model((112, 90))
