@@ -218,9 +218,10 @@ int sfh_mask_format_fwd(const void* src, int src_kind, int nc, int batch, int hs
 /* ResNetSTN pieces (models/resnet.py:235-254). */
 /* MaxPool2d(kernel 3, stride 2, padding 1) on NHWC (B,H,W,C) -> (B,Ho,Wo,C). */
 int sfh_maxpool3x3s2_fwd(const float* x, float* y, int batch, int H, int W, int C, void* stream);
-/* AdaptiveAvgPool2d(1) + flatten + Linear(C -> nout): x NHWC (B,H,W,C), w (nout,C), out (B,nout). */
+/* AdaptiveAvgPool2d(1) + flatten + Linear(C -> nout): x NHWC (B,H,W,C), w (nout,C), feat (B,C) = the
+ * pooled features (workspace / second output), out (B,nout). */
 int sfh_avgpool_linear_fwd(const float* x, const float* w, const float* bias, int batch, int H,
-                           int W, int C, int nout, float* out, void* stream);
+                           int W, int C, int nout, float* feat, float* out, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Training mode (Reconstructor.forward under net.train() + loss.backward(), train.py:170,233).

@@ -401,23 +401,28 @@ __global__ void maxpool3x3s2_kernel(const float* __restrict__ x, float* __restri
   *reinterpret_cast<f32x4*>(y + idx * 4) = m;
 }
 
-// one block per frame: channel means (coalesced over channels), then nout dot products.
+// AdaptiveAvgPool2d(1) + Linear in two small launches: channel means with one thread per (frame, channel)
+// (coalesced over channels, 64 channels per block so that a 16-frame batch fills 128 CUs instead of 16),
+// then nout dot products per frame.
+__global__ __launch_bounds__(64) void avgpool_mean_kernel(const float* __restrict__ x, int HW, int C,
+                                                          float* __restrict__ mean) {
+  const int b = blockIdx.y, c = blockIdx.x * 64 + threadIdx.x;
+  if (c >= C) return;
+  const float* xb = x + (long)b * HW * C + c;
+  float s = 0.f;
+  for (int i = 0; i < HW; ++i) s += xb[(long)i * C];
+  mean[(long)b * C + c] = s / (float)HW;
+}
+
 __global__ __launch_bounds__(256) void avgpool_linear_kernel(
-    const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias, int HW,
-    int C, int nout, float* __restrict__ out) {
-  extern __shared__ float mean[];  // [C]
+    const float* __restrict__ mean, const float* __restrict__ w, const float* __restrict__ bias, int C, int nout,
+    float* __restrict__ out) {
   const int b = blockIdx.x;
-  const float* xb = x + (long)b * HW * C;
-  for (int c = threadIdx.x; c < C; c += 256) {
-    float s = 0.f;
-    for (int i = 0; i < HW; ++i) s += xb[(long)i * C + c];
-    mean[c] = s / (float)HW;
-  }
-  __syncthreads();
+  const float* mb = mean + (long)b * C;
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
   for (int o = wv; o < nout; o += 4) {
     float s = 0.f;
-    for (int c = lane; c < C; c += 64) s += mean[c] * w[o * C + c];
+    for (int c = lane; c < C; c += 64) s += mb[c] * w[o * C + c];
 #pragma unroll
     for (int k = 32; k > 0; k >>= 1) s += __shfl_down(s, k);
     if (lane == 0) out[b * nout + o] = s + bias[o];
@@ -621,12 +626,15 @@ extern "C" int sfh_maxpool3x3s2_fwd(const float* x, float* y, int batch, int H, 
 }
 
 extern "C" int sfh_avgpool_linear_fwd(const float* x, const float* w, const float* bias, int batch,
-                                      int H, int W, int C, int nout, float* out, void* stream) {
-  SFH_REQUIRE(x && w && bias && out && batch > 0 && H > 0 && W > 0 && C > 0 && nout > 0,
+                                      int H, int W, int C, int nout, float* feat, float* out, void* stream) {
+  SFH_REQUIRE(x && w && bias && feat && out && batch > 0 && batch <= 65535 && H > 0 && W > 0 && C > 0 && nout > 0,
               "avgpool_linear: bad argument");
-  SFH_REQUIRE(C <= 8192, "avgpool_linear: C too large");
-  hipLaunchKernelGGL(avgpool_linear_kernel, dim3((unsigned)batch), dim3(256), (size_t)C * sizeof(float),
-                     (hipStream_t)stream, x, w, bias, H * W, C, nout, out);
+  hipLaunchKernelGGL(avgpool_mean_kernel, dim3((unsigned)sfh_cdiv(C, 64), (unsigned)batch), dim3(64), 0,
+                     (hipStream_t)stream, x, H * W, C, feat);
+  int rc = sfh_check_launch("avgpool_mean_kernel");
+  if (rc) return rc;
+  hipLaunchKernelGGL(avgpool_linear_kernel, dim3((unsigned)batch), dim3(256), 0, (hipStream_t)stream, feat, w, bias, C,
+                     nout, out);
   return sfh_check_launch("avgpool_linear_kernel");
 }
 

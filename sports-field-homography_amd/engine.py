@@ -534,8 +534,9 @@ class ResNetEngine:
             _lib.check(lib.sfh_s3_to_f32(_ptr(x), _ptr(xf), B * h, w, _chan(x), st), "s3_to_f32")
             x = xf
         theta = torch.empty((B, 9), dtype=torch.float32, device=x.device)
+        pooled = ws.get("pooled", (B, x.shape[3]))
         _lib.check(lib.sfh_avgpool_linear_fwd(_ptr(x), _ptr(self.reg_w), _ptr(self.reg_b), B, h, w,
-                                              x.shape[3], 9, _ptr(theta), st), "avgpool_linear")
+                                              x.shape[3], 9, _ptr(pooled), _ptr(theta), st), "avgpool_linear")
         return theta.view(B, 1, 3, 3)
 
 

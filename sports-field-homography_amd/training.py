@@ -416,8 +416,9 @@ class ResNetTrainer:
         C = feat.shape[3]
         wr, br = rn.reg.weight.detach(), rn.reg.bias.detach()
         theta = _empty((B, 9), stn_in)
-        _lib.check(lib.sfh_avgpool_linear_fwd(_ptr(feat), _ptr(wr), _ptr(br), B, h, w, C, 9, _ptr(theta), st()),
-                   "avgpool_linear")
+        pooled = _empty((B, C), stn_in)
+        _lib.check(lib.sfh_avgpool_linear_fwd(_ptr(feat), _ptr(wr), _ptr(br), B, h, w, C, 9, _ptr(pooled), _ptr(theta),
+                                              st()), "avgpool_linear")
         fh, fw = h, w
 
         def head_backward():
