@@ -49,7 +49,10 @@ extern "C" {
 
 /* Output modes of sfh_conv_fwd. */
 #define SFH_OUT_NHWC 0        /* dst[b][y][x][co]                                        */
-#define SFH_OUT_UPSCATTER2 1  /* transposed conv k2 s2: virtual cout = (dy*2+dx)*Cout+co  */
+#define SFH_OUT_UPSCATTER2 1  /* transposed conv k2 s2: virtual cout = (dy*2+dx)*Cout+co; with ksize 2
+                                 (sfh_conv_s3_fwd only): the 2x2 window of quadrant (dy,dx) starts at
+                                 (y + dy - 1, x + dx - 1) - the composed ConvTranspose2d + conv3x3 of
+                                 sfh_compose_up_weights */
 
 typedef struct sfh_conv_desc {
   /* source 0: channels [0, c0) of the conv input; physical NHWC tensor (B, h0, w0, cs0). */
@@ -82,6 +85,11 @@ typedef struct sfh_conv_desc {
   /* optional second output: MaxPool2d(2) (floor) of dst, (B, Ho/2, Wo/2, pool_cs) */
   float* dst_pool;
   int32_t pool_cs;
+  /* 1: `residual` is fp32 NHWC (channel stride dst_cs) even though dst is S3 (sfh_conv_s3_fwd) */
+  int32_t residual_f32;
+  /* optional [9][cout] shift table replacing `shift`, indexed by the border class of the OUTPUT pixel
+   * (3*(row: 0 first, 2 last, 1 other) + (col: same)): the up-sampling fusion below needs it */
+  const float* shift_border;
 } sfh_conv_desc;
 
 const char* sfh_last_error(void);
@@ -328,6 +336,18 @@ int sfh_upsample2x_bilinear_nhwc_bwd(const float* dy, float* dx, int batch, int 
  * dy (planes,hd,wd) -> dx (planes,hs,ws).                                                                */
 int sfh_resize_nearest_nchw_bwd(const float* dy, float* dx, int64_t planes, int hs, int ws, int hd, int wd,
                                 void* stream);
+
+/* Up block fusion (unet/unet_parts.py:52,59-67 + the first conv of DoubleConv): the u-half of
+ *   conv3x3(cat([skip, ConvTranspose2d(x)]))  =  a 2x2 conv over the LOW-resolution x per output parity.
+ * wconv OIHW (cout, c0+c1, 3, 3), wt IOHW (cx, c1, 2, 2), bt (c1); scale4 / shift4 (4*cout) = the folded
+ * BatchNorm epilogue of the conv repeated per quadrant:
+ *   w2 (4*cout, cx, 2, 2): virtual cout (py*2+px)*cout + co, tap (a,b) reads x[Y + py - 1 + a][X + px - 1 + b];
+ *   shift_border (9, 4*cout): shift4 + scale4 * (what the transposed conv's bias contributes through the conv
+ *   taps that fall inside the image), per border class of the output pixel (sfh_conv_desc.shift_border).
+ * Valid when the up-sampled tensor needs no F.pad (2h == H, 2w == W).                                    */
+int sfh_compose_up_weights(const float* wconv, int cout, int c0, int c1, const float* wt, int cx,
+                           const float* bt, const float* scale4, const float* shift4, float* w2,
+                           float* shift_border, void* stream);
 
 #ifdef __cplusplus
 }

@@ -28,6 +28,7 @@ class ConvDesc(C.Structure):
         ("residual", _p),
         ("dst", _p), ("dst_cs", _i), ("out_mode", _i),
         ("src_fmt", _i), ("dst_fmt", _i), ("dst_pool", _p), ("pool_cs", _i),
+        ("residual_f32", _i), ("shift_border", _p),
     ]
 
 
@@ -90,6 +91,7 @@ SIGNATURES = {
                                    C.c_float, C.c_float, _p]),
     "sfh_upsample2x_bilinear_nhwc_bwd": (C.c_int, [_p, _p, C.c_int, C.c_int, C.c_int, C.c_int, _p]),
     "sfh_resize_nearest_nchw_bwd": (C.c_int, [_p, _p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, _p]),
+    "sfh_compose_up_weights": (C.c_int, [_p, C.c_int, C.c_int, C.c_int, _p, C.c_int, _p, _p, _p, _p, _p, _p]),
     "sfh_maxpool3x3s2_fwd": (C.c_int, [_p, _p, C.c_int, C.c_int, C.c_int, C.c_int, _p]),
     "sfh_avgpool_linear_fwd": (C.c_int, [_p, _p, _p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _p, _p, _p]),
 }

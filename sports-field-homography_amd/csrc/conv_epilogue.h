@@ -81,7 +81,11 @@ __device__ __forceinline__ void sfh_conv_epilogue(const sfh_conv_desc& d, const 
   };
   const unsigned xb = s3 ? 16u : cs * 4u;  // bytes per pixel step along x
   int pb[MT], py[MT], px[MT];
-  unsigned voff[MT];
+  // the fp32 residual beside an S3 destination and the border-class shift table exist only for the
+  // 2x2 up-scatter conv (fused Up block); every other instance compiles them out
+  constexpr bool UPF = CFG::KS == 2;
+  unsigned voff[MT], rvoff[UPF ? MT : 1], cls[UPF ? MT : 1];
+  const bool res_s3 = s3 && !(UPF && d.residual_f32);
 #pragma unroll
   for (int mi = 0; mi < MT; ++mi) {
     const int s = msub0 + mi;
@@ -110,6 +114,14 @@ __device__ __forceinline__ void sfh_conv_epilogue(const sfh_conv_desc& d, const 
       xo = (unsigned)x;
     }
     voff[mi] = ok ? rowi * rowb + xo * xb + lane_co : kSfhOOB;
+    if constexpr (UPF) {
+      // fp32 NHWC residual beside an S3 destination (same pixel, channel stride cs)
+      rvoff[mi] = ok ? ((rowi * wdst + xo) * cs + c_lane) * 4u : kSfhOOB;
+      // border class of the output pixel for the optional per-class shift table
+      const unsigned hdst = (unsigned)(d.out_mode == SFH_OUT_UPSCATTER2 ? 2 * g.Ho : g.Ho);
+      const unsigned yo = rowi - (unsigned)b * hdst;
+      cls[mi] = (yo == 0u ? 0u : (yo == hdst - 1u ? 2u : 1u)) * 3u + (xo == 0u ? 0u : (xo == wdst - 1u ? 2u : 1u));
+    }
   }
   // ---- pass 1: finish the values in place and store them
 #pragma unroll
@@ -118,10 +130,15 @@ __device__ __forceinline__ void sfh_conv_epilogue(const sfh_conv_desc& d, const 
     for (int ni = 0; ni < NI; ++ni) {
       const unsigned nioff = ni_off(ni);
       f32x4 v = acc[ni][mi];
+      f32x4 shv = sh[ni];
+      if constexpr (UPF) {
+        if (d.shift_border)
+          shv = *reinterpret_cast<const f32x4*>(d.shift_border + cls[mi] * (unsigned)d.cout + n0 + ni * 16 + 4 * lg);
+      }
 #pragma unroll
-      for (int j = 0; j < 4; ++j) v[j] = v[j] * sc[ni][j] + sh[ni][j];
+      for (int j = 0; j < 4; ++j) v[j] = v[j] * sc[ni][j] + shv[j];
       if (d.residual) {
-        if (s3) {
+        if (res_s3) {
 #pragma unroll
           for (int p = 2; p >= 0; --p) {
             const sfh_u32x2 w = __builtin_bit_cast(
@@ -132,8 +149,10 @@ __device__ __forceinline__ void sfh_conv_epilogue(const sfh_conv_desc& d, const 
             v[3] += __builtin_bit_cast(float, w[1] & 0xFFFF0000u);
           }
         } else {
+          const bool rf = UPF && s3;   // fp32 residual addressed independently of the S3 destination
           const f32x4 q = __builtin_bit_cast(
-              f32x4, __builtin_amdgcn_raw_buffer_load_b128(rr_, (int)voff[mi], (int)nioff, 0));
+              f32x4, __builtin_amdgcn_raw_buffer_load_b128(rr_, (int)(rf ? rvoff[UPF ? mi : 0] : voff[mi]),
+                                                           (int)(rf ? (unsigned)ni * 64u : nioff), 0));
 #pragma unroll
           for (int j = 0; j < 4; ++j) v[j] += q[j];
         }

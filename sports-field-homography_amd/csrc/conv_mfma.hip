@@ -538,7 +538,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_v2_kernel(const sfh_conv_des
 // one tap: k index = channel (r, g, b, 0), nine k-steps in total.  All weights of the 64 couts
 // (9 taps x 4 cout groups, one float per lane each) stay in registers; the halo is 5.4 KB of LDS.
 struct C4Cfg {  // tile geometry seen by the shared epilogue: 8 rows x 32 cols, 1x16 pixel groups
-  static constexpr int SUBX = 2, SH = 1, SW = 16, TH = 8, TW = 32;
+  static constexpr int SUBX = 2, SH = 1, SW = 16, TH = 8, TW = 32, KS = 3;
   static constexpr bool FLATROWS = true;
   static constexpr int HW = 34, HPIX = 10 * 34;
 };

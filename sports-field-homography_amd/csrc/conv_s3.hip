@@ -73,26 +73,28 @@ struct S3Geom {
 
 __device__ __forceinline__ bf16x8 as_bf(const u32x4& v) { return __builtin_bit_cast(bf16x8, v); }
 
+// pad_y / pad_x: rows / columns before the output pixel covered by the window (C::PAD except for the
+// 2x2 up-scatter conv, whose window position depends on the output quadrant)
 template <class C>
 __device__ __forceinline__ unsigned s3_halo_voffset(const sfh_conv_desc& d, const S3Geom& g, int which,
-                                                    int slot, int r0, int x0) {
+                                                    int slot, int r0, int x0, int pad_y, int pad_x) {
   if (slot >= C::HSLOTS) return kOOB;
   const int pl = slot / C::HPIXP, p = slot - pl * C::HPIXP;  // pl = plane*4 + channel group
   if (p >= C::HPIX) return kOOB;
   const int hy = p / C::HW, hx = p - hy * C::HW;
   int b, y;
   if (C::FLATROWS) {
-    const int r = r0 - C::PAD + hy;
+    const int r = r0 - pad_y + hy;
     if (r < 0) return kOOB;
     b = (int)__umulhi((unsigned)r, g.rows_magic);
     y = r - b * g.rows_per_img;
     if (b >= d.batch || y >= d.H) return kOOB;
   } else {
     b = r0 >> 16;
-    y = (r0 & 0xFFFF) * C::STRIDE - C::PAD + hy;
+    y = (r0 & 0xFFFF) * C::STRIDE - pad_y + hy;
     if (y < 0 || y >= d.H) return kOOB;
   }
-  const int x = x0 * C::STRIDE - C::PAD + hx;
+  const int x = x0 * C::STRIDE - pad_x + hx;
   if (x < 0 || x >= d.W) return kOOB;
   // S3 layout (B, H, cs/32, 3, 4, W, 8) bf16: byte offset of (row, channel block 0, plane/group pl, x)
   unsigned rowi, xs_, ws_, nblk;
@@ -178,9 +180,16 @@ __global__ __launch_bounds__(256, 2) void conv_s3_kernel(const sfh_conv_desc d, 
 
   // byte offsets of this thread's halo slots in the CURRENT source (recomputed once when the
   // stage loop crosses from source 0 to source 1)
+  // 2x2 up-scatter conv: quadrant (dy,dx) of this cout block reads rows y + dy - 1 .. y + dy
+  int pad_y = C::PAD, pad_x = C::PAD;
+  if (C::KS == 2) {
+    const int qd = n0 / (d.cout >> 2);
+    pad_y = 1 - (qd >> 1);
+    pad_x = 1 - (qd & 1);
+  }
   unsigned hoff[C::NSL];
 #pragma unroll
-  for (int i = 0; i < C::NSL; ++i) hoff[i] = s3_halo_voffset<C>(d, g, 0, tid + 256 * i, r0, x0);
+  for (int i = 0; i < C::NSL; ++i) hoff[i] = s3_halo_voffset<C>(d, g, 0, tid + 256 * i, r0, x0, pad_y, pad_x);
 
   // LDS-DMA piece i (64 slots of this wave) of stage st into buffer b
   auto dma_piece = [&](int st, int b, int i) {
@@ -290,7 +299,7 @@ __global__ __launch_bounds__(256, 2) void conv_s3_kernel(const sfh_conv_desc d, 
   auto maybe_switch = [&](int st) {  // the DMA issued during stage st targets stage st+1
     if (d.src1 && st + 1 == nst0) {
 #pragma unroll
-      for (int i = 0; i < C::NSL; ++i) hoff[i] = s3_halo_voffset<C>(d, g, 1, tid + 256 * i, r0, x0);
+      for (int i = 0; i < C::NSL; ++i) hoff[i] = s3_halo_voffset<C>(d, g, 1, tid + 256 * i, r0, x0, pad_y, pad_x);
     }
   };
   // hipcc's own wait before the barrier covers only part of the outstanding LDS-DMA (observed:
@@ -323,7 +332,7 @@ __global__ __launch_bounds__(256, 2) void conv_s3_kernel(const sfh_conv_desc d, 
       if (st + 1 < nst) {
         if (d.src1 && st + 1 == nst0) {
 #pragma unroll
-          for (int i = 0; i < C::NSL; ++i) hoff[i] = s3_halo_voffset<C>(d, g, 1, tid + 256 * i, r0, x0);
+          for (int i = 0; i < C::NSL; ++i) hoff[i] = s3_halo_voffset<C>(d, g, 1, tid + 256 * i, r0, x0, pad_y, pad_x);
         }
         __syncthreads();
         dma_stage(st + 1, 0);
@@ -333,7 +342,7 @@ __global__ __launch_bounds__(256, 2) void conv_s3_kernel(const sfh_conv_desc d, 
       if (st + 2 < nst) {
         if (d.src1 && st + 2 == nst0) {
 #pragma unroll
-          for (int i = 0; i < C::NSL; ++i) hoff[i] = s3_halo_voffset<C>(d, g, 1, tid + 256 * i, r0, x0);
+          for (int i = 0; i < C::NSL; ++i) hoff[i] = s3_halo_voffset<C>(d, g, 1, tid + 256 * i, r0, x0, pad_y, pad_x);
         }
         __syncthreads();
         dma_stage(st + 2, 0);
@@ -521,7 +530,7 @@ int launch_s3(const sfh_conv_desc& d, hipStream_t stream) {
 }  // namespace
 
 extern "C" int64_t sfh_packed_s3_weight_bytes(int ksize, int c0, int c1, int cout_virtual) {
-  if ((ksize != 1 && ksize != 3 && ksize != 4) || c0 <= 0 || c0 % 32 || c1 < 0 || c1 % 32 || cout_virtual <= 0 ||
+  if ((ksize != 1 && ksize != 2 && ksize != 3 && ksize != 4) || c0 <= 0 || c0 % 32 || c1 < 0 || c1 % 32 || cout_virtual <= 0 ||
       cout_virtual % 64)
     return -1;
   return (int64_t)(cout_virtual / 64) * ((c0 + c1) / 32) * (ksize * ksize) * 3 * 4096;
@@ -578,8 +587,11 @@ extern "C" int sfh_conv_s3_fwd(const sfh_conv_desc* dp, void* stream_) {
                     d.pad_left1 + d.w1 <= d.W, "conv_s3_fwd: source 1 does not fit the frame");
   }
   if (d.out_mode == SFH_OUT_UPSCATTER2)
-    SFH_REQUIRE(d.ksize == 1 && d.stride == 1 && (d.cout / 4) % 64 == 0 && !d.residual && !d.dst_pool,
-                "conv_s3_fwd: up-scatter needs ksize=1, stride=1, cout/4 multiple of 64");
+    SFH_REQUIRE((d.ksize == 1 || d.ksize == 2) && d.stride == 1 && (d.cout / 4) % 64 == 0 && !d.dst_pool &&
+                    (d.ksize == 2 || !d.residual) && !d.src1,
+                "conv_s3_fwd: up-scatter needs ksize 1 or 2, stride=1, cout/4 multiple of 64, one source");
+  SFH_REQUIRE(d.ksize != 2 || d.out_mode == SFH_OUT_UPSCATTER2, "conv_s3_fwd: ksize 2 exists only as the up-scatter conv");
+  SFH_REQUIRE(!d.residual_f32 || (d.residual && d.dst_fmt == SFH_FMT_S3), "conv_s3_fwd: residual_f32 needs a residual and an S3 dst");
   // buffering policy: short K -> two single-buffered workgroups per CU; long K -> one
   // double-buffered workgroup.  SFH_DEBUG_S3_DB=0/1 forces one variant (experiments).
   const int nstages = (d.c0 + (d.src1 ? d.c1 : 0)) / 32;
@@ -597,6 +609,9 @@ extern "C" int sfh_conv_s3_fwd(const sfh_conv_desc* dp, void* stream_) {
   SFH_S3CASE(1, 1, SFH_TILE_8x32, 1, 16, 8, 32)
   SFH_S3CASE(1, 1, SFH_TILE_16x16, 1, 16, 16, 16)
   SFH_S3CASE(1, 1, SFH_TILE_32x8, 2, 8, 32, 8)
+  SFH_S3CASE(2, 1, SFH_TILE_8x32, 1, 16, 8, 32)
+  SFH_S3CASE(2, 1, SFH_TILE_16x16, 1, 16, 16, 16)
+  SFH_S3CASE(2, 1, SFH_TILE_32x8, 2, 8, 32, 8)
   // half-size tiles (8 pixel groups) for small feature maps: twice the workgroups
   SFH_S3CASE(3, 1, SFH_TILE_8x16, 1, 16, 8, 16)
   SFH_S3CASE(3, 1, SFH_TILE_16x8, 2, 8, 16, 8)

@@ -234,6 +234,75 @@ __global__ void resize_nearest_nchw_bwd_kernel(const float* __restrict__ dy, flo
   dx[i] = acc;
 }
 
+// ----------------------------------------------------------------- Up block weight composition
+// conv3x3 tap k (0..2) at output parity p (0/1) reads the up-sampled row 2Y + p + k - 1 = 2(Y + s) + d:
+//   s = floor((p + k - 1) / 2), d = (p + k - 1) mod 2;   window slot a = s + (1 - p) in {0, 1}
+__device__ __forceinline__ void up_tap(int p, int k, int& a, int& d) {
+  const int t = p + k - 1;             // -1 .. 2
+  const int s = t < 0 ? -1 : t >> 1;
+  d = t & 1;
+  a = s + 1 - p;
+}
+
+// w2[(q*cout + co)][cx][a][b] = sum over the conv taps that land in window slot (a,b) and over the
+// intermediate channels cu of wconv[co][c0+cu][ky][kx] * wt[cx][cu][dy][dx]
+__global__ void compose_up_weights_kernel(const float* __restrict__ wc, int cout, int c0, int c1,
+                                          const float* __restrict__ wt, int cx, float* __restrict__ w2, long total) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int b = idx & 1, a = (idx >> 1) & 1;
+  long r = idx >> 2;
+  const int x = (int)(r % cx); r /= cx;
+  const int co = (int)(r % cout);
+  const int q = (int)(r / cout);
+  const int py = q >> 1, px = q & 1;
+  const int cin = c0 + c1;
+  float acc = 0.f;
+  for (int ky = 0; ky < 3; ++ky) {
+    int ay, dy;
+    up_tap(py, ky, ay, dy);
+    if (ay != a) continue;
+    for (int kx = 0; kx < 3; ++kx) {
+      int ax, dx;
+      up_tap(px, kx, ax, dx);
+      if (ax != b) continue;
+      const float* wcp = wc + (((long)co * cin + c0) * 3 + ky) * 3 + kx;   // + cu*9
+      const float* wtp = wt + ((long)x * c1 * 2 + dy) * 2 + dx;             // + cu*4
+      float s = 0.f;
+      for (int cu = 0; cu < c1; ++cu) s += wcp[(long)cu * 9] * wtp[(long)cu * 4];
+      acc += s;
+    }
+  }
+  w2[idx] = acc;
+}
+
+// shift_border[cls][cv] = shift[cv] + scale[cv] * (sum over the conv taps inside the image for border class
+// cls (3*row class + col class; 0: first row/col - tap 0 outside, 2: last - tap 2 outside, 1: interior) of
+// sum_cu wconv[co][c0+cu][ky][kx] * bt[cu]),  cv = q*cout + co: the transposed conv's bias seen through the
+// zero-padded 3x3 conv, folded behind the BatchNorm scale
+__global__ void compose_up_bias_kernel(const float* __restrict__ wc, int cout, int c0, int c1,
+                                       const float* __restrict__ bt, const float* __restrict__ scale,
+                                       const float* __restrict__ shift, float* __restrict__ out) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= 9 * 4 * cout) return;
+  const int cv = idx % (4 * cout), cls = idx / (4 * cout);
+  const int co = cv % cout;
+  const int cy = cls / 3, cxx = cls % 3;
+  const int cin = c0 + c1;
+  float acc = 0.f;
+  for (int ky = 0; ky < 3; ++ky) {
+    if ((cy == 0 && ky == 0) || (cy == 2 && ky == 2)) continue;
+    for (int kx = 0; kx < 3; ++kx) {
+      if ((cxx == 0 && kx == 0) || (cxx == 2 && kx == 2)) continue;
+      const float* wcp = wc + (((long)co * cin + c0) * 3 + ky) * 3 + kx;
+      float s = 0.f;
+      for (int cu = 0; cu < c1; ++cu) s += wcp[(long)cu * 9] * bt[cu];
+      acc += s;
+    }
+  }
+  out[idx] = shift[cv] + scale[cv] * acc;
+}
+
 // ----------------------------------------------------------------- BatchNorm folding
 __global__ void fold_bn_kernel(const float* conv_bias, const float* gamma, const float* beta,
                                const float* mean, const float* var, float eps, int n, int repeat,
@@ -679,4 +748,19 @@ extern "C" int sfh_resize_nearest_nchw_bwd(const float* dy, float* dx, int64_t p
   hipLaunchKernelGGL(resize_nearest_nchw_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
                      (hipStream_t)stream, dy, dx, hs, ws, hd, wd, total);
   return sfh_check_launch("resize_nearest_nchw_bwd_kernel");
+}
+
+extern "C" int sfh_compose_up_weights(const float* wconv, int cout, int c0, int c1, const float* wt, int cx,
+                                      const float* bt, const float* scale4, const float* shift4, float* w2,
+                                      float* shift_border, void* stream) {
+  SFH_REQUIRE(wconv && wt && bt && scale4 && shift4 && w2 && shift_border && cout > 0 && c0 >= 0 && c1 > 0 && cx > 0,
+              "compose_up_weights: bad argument");
+  const long total = 4L * cout * cx * 4;
+  hipLaunchKernelGGL(compose_up_weights_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     wconv, cout, c0, c1, wt, cx, w2, total);
+  int rc = sfh_check_launch("compose_up_weights_kernel");
+  if (rc) return rc;
+  hipLaunchKernelGGL(compose_up_bias_kernel, dim3((unsigned)((36 * cout + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     wconv, cout, c0, c1, bt, scale4, shift4, shift_border);
+  return sfh_check_launch("compose_up_bias_kernel");
 }

@@ -5,6 +5,7 @@ PyTorch is used here for device memory (``torch.empty``), the current HIP stream
 parameter storage only; every arithmetic step is a call into ``libsfh_amd.so``.
 """
 import ctypes
+import os
 
 import torch
 
@@ -184,6 +185,45 @@ class PackedConv:
                                    _ptr(self.scale), _ptr(self.shift), _stream()), "fold_bn")
 
     @classmethod
+    def fused_up(cls, conv, bn, up, c0, tag="doubleconv3x3"):
+        """The u-half of conv3x3(cat([skip, ConvTranspose2d(x)])) (+bias, BN, ReLU) as ONE 2x2 conv over the
+        low-resolution x with quadrant scatter (sfh_compose_up_weights): takes x (S3), adds the fp32
+        partial of the skip-half conv as residual and writes the activated S3 output.  Split-bf16 kernel only."""
+        lib = _lib.load()
+        self = cls.__new__(cls)
+        wc = _f32c(conv.weight.detach(), "conv weight")
+        wt = _f32c(up.weight.detach(), "up weight")
+        bt = _f32c(up.bias.detach(), "up bias")
+        dev = wc.device
+        cout, cin = wc.shape[0], wc.shape[1]
+        cx, c1 = wt.shape[0], wt.shape[1]
+        assert cin == c0 + c1 and tuple(wc.shape[2:]) == (3, 3) and tuple(wt.shape[2:]) == (2, 2)
+        if cout % 64 or cx % 32:
+            raise ValueError("fused Up conv needs cout % 64 == 0 and a multiple of 32 low-resolution channels")
+        self.tag, self.s3, self.c4, self.stem_cin = tag, True, False, 0
+        self.ksize, self.c0, self.c1, self.relu, self.stride, self.transposed = 2, cx, 0, True, 1, True
+        self.cout, self.cout_real = 4 * cout, cout
+        self.flops_per_out_pixel = 2.0 * cout * 9 * c1   # the part of the reference conv this launch stands for
+        self.scale = torch.empty(self.cout, dtype=torch.float32, device=dev)
+        self.shift = torch.empty(self.cout, dtype=torch.float32, device=dev)
+        args = [_f32c(t.detach(), "bn tensor") for t in (bn.weight, bn.bias, bn.running_mean, bn.running_var)]
+        b = _f32c(conv.bias.detach(), "conv bias") if conv.bias is not None else None
+        _lib.check(lib.sfh_fold_bn(_ptr(b), *[_ptr(a) for a in args], float(bn.eps), cout, 4, _ptr(self.scale),
+                                   _ptr(self.shift), _stream()), "fold_bn")
+        w2 = torch.empty((4 * cout, cx, 2, 2), dtype=torch.float32, device=dev)
+        self.shift_border = torch.empty((9, 4 * cout), dtype=torch.float32, device=dev)
+        _lib.check(lib.sfh_compose_up_weights(_ptr(wc), cout, c0, c1, _ptr(wt), cx, _ptr(bt), _ptr(self.scale),
+                                              _ptr(self.shift), _ptr(w2), _ptr(self.shift_border), _stream()),
+                   "compose_up_weights")
+        n = lib.sfh_packed_s3_weight_bytes(2, cx, 0, self.cout)
+        if n <= 0:
+            raise ValueError(f"unsupported fused Up geometry cx={cx} cout={cout}")
+        self.wpacked = torch.empty(n, dtype=torch.uint8, device=dev)
+        _lib.check(lib.sfh_pack_s3_weights(_ptr(w2), _ptr(self.wpacked), 2, cx, 0, self.cout, 0, 0, _stream()),
+                   "pack_s3_weights")
+        return self
+
+    @classmethod
     def backward_data(cls, weight, ksize, transposed=False, tag="bwd_data", s3=False):
         """The conv that maps dz -> dx for a stride-1 nn.Conv2d (OIHW weight; taps flipped, channels
         swapped: pack mode 3) or for nn.ConvTranspose2d k2 s2 (IOHW weight; a 1x1 conv over
@@ -265,6 +305,10 @@ class PackedConv:
         d.wpacked, d.scale, d.shift = self.wpacked.data_ptr(), self.scale.data_ptr(), self.shift.data_ptr()
         d.cout, d.relu = self.cout, 1 if self.relu else 0
         d.residual = residual.data_ptr() if residual is not None else None
+        d.residual_f32 = 1 if (residual is not None and residual.dtype == torch.float32
+                               and dst.dtype == torch.bfloat16) else 0
+        sb = getattr(self, "shift_border", None)
+        d.shift_border = sb.data_ptr() if sb is not None else None
         d.dst, d.dst_cs = dst.data_ptr(), _chan(dst)
         d.out_mode = _lib.OUT_UPSCATTER2 if self.transposed else _lib.OUT_NHWC
         exp = (batch, 2 * ho, 2 * wo) if self.transposed else (batch, ho, wo)
@@ -289,7 +333,11 @@ class PackedConv:
             # algorithmic work: 2 * MACs of the reference op (real cin, real taps)
             kk = 49 if self.ksize == 4 else (4 if self.transposed else self.ksize * self.ksize)
             cin = self.stem_cin if self.ksize == 4 else self.c0 + self.c1
-            tm.records.append((self.tag, 2.0 * batch * ho * wo * self.cout_real * kk * cin, e0, e1))
+            flops = 2.0 * batch * ho * wo * self.cout_real * kk * cin
+            fpp = getattr(self, "flops_per_out_pixel", None)
+            if fpp is not None:   # fused Up conv: credited with the u-half of the reference's 3x3 conv only
+                flops = fpp * batch * (2 * ho) * (2 * wo)
+            tm.records.append((self.tag, flops, e0, e1))
         return dst
 
 
@@ -336,6 +384,18 @@ class UNetEngine:
             dc(f"down{i}", getattr(net, f"down{i}").block, cin)
         for i, cin in enumerate((1024, 512, 256, 128), start=1):
             up = getattr(net, f"up{i}")
+            if not self.bilinear and s3 and os.environ.get("SFH_FUSE_UP", "1") != "0":
+                # ConvTranspose2d folded into the consumer conv (used when no F.pad is needed): the
+                # skip-half 3x3 conv leaves an fp32 partial, the composed 2x2 conv over the low-resolution
+                # tensor finishes it - the up-sampled tensor is never written
+                (cv1, bn1), _ = up.conv.convs()
+                c0s = cin // 2
+                L[f"up{i}.skip"] = PackedConv(cv1.weight.detach()[:, :c0s].contiguous(), None, None, 3, c0s, relu=False,
+                                              tag="doubleconv3x3", s3=True)
+                L[f"up{i}.fused"] = PackedConv.fused_up(cv1, bn1, up.up, c0s)
+                # the partial enters the fused conv's epilogue as a residual, i.e. after the BatchNorm scale:
+                # the skip-half carries that scale itself (shift stays 0)
+                L[f"up{i}.skip"].scale.copy_(L[f"up{i}.fused"].scale[:cv1.out_channels])
             if not self.bilinear:  # bilinear variant (A3b): parameter-free 2x upsampling kernel instead
                 L[f"up{i}.up"] = PackedConv(up.up.weight, up.up.bias, None, 1, cin, relu=False, transposed=True,
                                             tag="convT2x2", s3=s3)
@@ -397,6 +457,14 @@ class UNetEngine:
             hs, ws_ = _hw(skip)
             hy, wy = _hw(y)
             cout = L[f"up{i}.conv.3"].cout_real
+            if f"up{i}.fused" in L and (2 * hy, 2 * wy) == (hs, ws_):
+                part = ws.get(f"up{i}.part", (B, hs, ws_, L[f"up{i}.skip"].cout_real))     # fp32 partial
+                L[f"up{i}.skip"].run(skip, B, hs, ws_, part)
+                mid = act(f"up{i}.conv.mid", (B, hs, ws_), L[f"up{i}.fused"].cout_real)
+                L[f"up{i}.fused"].run(y, B, hy, wy, mid, residual=part)
+                y = act(f"up{i}.conv.out", (B, hs, ws_), cout, f32=(i == 4))
+                L[f"up{i}.conv.3"].run(mid, B, hs, ws_, y)
+                continue
             cup = _chan(y) if self.bilinear else L[f"up{i}.up"].cout_real
             upb = act(f"up{i}.up", (B, 2 * hy, 2 * wy), cup)
             if self.bilinear:  # nn.Upsample(2x, bilinear, align_corners=True) on an fp32 view of y
