@@ -43,7 +43,7 @@ def group(name, resnet=False):
     if "conv_s3" in name and m:
         if resnet:
             return "s3_resnet"
-        return "s3_conv3x3" if m.group(1) == "3" else "s3_conv1x1"
+        return {"3": "s3_conv3x3", "2": "s3_up2x2"}.get(m.group(1), "s3_conv1x1")
     for k in ("warp_kernel", "outconv", "maxpool", "avgpool", "space_to_depth", "nchw_to_nhwc", "pack_weights", "fold_bn", "ce_"):
         if k in name:
             return k

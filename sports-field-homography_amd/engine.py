@@ -185,7 +185,7 @@ class PackedConv:
                                    _ptr(self.scale), _ptr(self.shift), _stream()), "fold_bn")
 
     @classmethod
-    def fused_up(cls, conv, bn, up, c0, tag="doubleconv3x3"):
+    def fused_up(cls, conv, bn, up, c0, tag="fusedup2x2"):
         """The u-half of conv3x3(cat([skip, ConvTranspose2d(x)])) (+bias, BN, ReLU) as ONE 2x2 conv over the
         low-resolution x with quadrant scatter (sfh_compose_up_weights): takes x (S3), adds the fp32
         partial of the skip-half conv as residual and writes the activated S3 output.  Split-bf16 kernel only."""

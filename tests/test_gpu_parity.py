@@ -471,6 +471,38 @@ def test_predict_resnet50_variant(E):
     assert torch.equal(out["warp_mask"].cpu(), wm.to(torch.int32))
 
 
+def test_fused_up_block_vs_unfused_and_oracle(E, monkeypatch):
+    """Up blocks without F.pad run as skip-half conv + composed 2x2 quadrant conv over the low-resolution
+    tensor (ConvTranspose2d folded into the consumer conv); with SFH_FUSE_UP=0 as ConvTranspose2d + conv over
+    the concatenation.  Both against the oracle, and against each other, incl. the image borders."""
+    from sfh_amd.reconstructor import Reconstructor
+    B, H, W = 2, 96, 128           # 96 -> 48 -> 24 -> 12 -> 6: every level is fused
+    court = synth.load_court_template("ncaa_nc4_640x360", 4, B)[:, :, :H, :W].contiguous()
+    poi = synth.load_court_poi("pitch", B)
+    x = synth.smooth_frames(B, H, W, seed=37)
+    outs = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("SFH_FUSE_UP", flag)
+        net = Reconstructor(court.cuda(), poi.cuda(), target_size=(W, H), unet_size=(W, H), warp_size=(W, H),
+                            warp_with_nearest=True)
+        sd = synth.synth_state_dict(net.state_dict(), 37)
+        net.load_state_dict(sd)
+        net.cuda().eval()
+        with torch.no_grad():
+            outs[flag] = net.predict(x.cuda(), consistency=False)
+        un, _ = net._get_engines()
+        assert ("up4.fused" in un.L) == (flag == "1")
+    with torch.no_grad():
+        logits, _, _ = torch_ref.forward_unet(x, sd, (W, H), (W, H))
+    for flag in ("1", "0"):
+        assert _maxerr(outs[flag]["logits"].cpu(), logits) < 3e-4, flag
+    d = (outs["1"]["logits"] - outs["0"]["logits"]).abs()
+    assert d.max().item() < 1e-4
+    # borders are where the transposed conv's bias reaches the conv through fewer taps
+    assert max(d[:, :, 0].max().item(), d[:, :, -1].max().item(), d[:, :, :, 0].max().item(), d[:, :, :, -1].max().item()) < 1e-4
+    assert _maxerr(outs["1"]["theta"].cpu(), outs["0"]["theta"].cpu()) < 1e-5
+
+
 def test_u8_frame_preprocessing_matches_dataset(E):
     fr = synth.synth_frames_u8(3, 45, 80, seed=7)
     want = torch.from_numpy((fr.transpose(0, 3, 1, 2) / 255)).type(torch.FloatTensor)   # utils/dataset.py:154-159
