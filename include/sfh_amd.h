@@ -87,9 +87,13 @@ typedef struct sfh_conv_desc {
   int32_t pool_cs;
   /* 1: `residual` is fp32 NHWC (channel stride dst_cs) even though dst is S3 (sfh_conv_s3_fwd) */
   int32_t residual_f32;
-  /* optional [9][cout] shift table replacing `shift`, indexed by the border class of the OUTPUT pixel
-   * (3*(row: 0 first, 2 last, 1 other) + (col: same)): the up-sampling fusion below needs it */
+  /* optional [16][cout] shift table replacing `shift`, indexed by the border class of the OUTPUT pixel
+   * (4*(row class) + (col class), see sfh_compose_up_weights): the up-sampling fusion below needs it */
   const float* shift_border;
+  /* 2x2 up-scatter conv only: size of the destination frame when the up-sampled tensor is one row /
+   * column short of it (F.pad in Up, unet/unet_parts.py:59-63, with diff 1: pad 0 before, 1 after);
+   * 0 = 2*Ho x 2*Wo.  The conv frame (H, W) is then source rows/cols + 1, the extra source row reads 0. */
+  int32_t up_dst_h, up_dst_w;
 } sfh_conv_desc;
 
 const char* sfh_last_error(void);
@@ -342,9 +346,10 @@ int sfh_resize_nearest_nchw_bwd(const float* dy, float* dx, int64_t planes, int 
  * wconv OIHW (cout, c0+c1, 3, 3), wt IOHW (cx, c1, 2, 2), bt (c1); scale4 / shift4 (4*cout) = the folded
  * BatchNorm epilogue of the conv repeated per quadrant:
  *   w2 (4*cout, cx, 2, 2): virtual cout (py*2+px)*cout + co, tap (a,b) reads x[Y + py - 1 + a][X + px - 1 + b];
- *   shift_border (9, 4*cout): shift4 + scale4 * (what the transposed conv's bias contributes through the conv
- *   taps that fall inside the image), per border class of the output pixel (sfh_conv_desc.shift_border).
- * Valid when the up-sampled tensor needs no F.pad (2h == H, 2w == W).                                    */
+ *   shift_border (16, 4*cout): shift4 + scale4 * (what the transposed conv's bias contributes through the conv
+ *   taps that fall inside the up-sampled tensor), per class of the output pixel: 4*(row class) + (col class),
+ *   class 0: first row/col of the up-sampled tensor, 2: its last, 3: the padded row/col after it (F.pad with
+ *   diff 1), 1: everything else (sfh_conv_desc.shift_border).                                             */
 int sfh_compose_up_weights(const float* wconv, int cout, int c0, int c1, const float* wt, int cx,
                            const float* bt, const float* scale4, const float* shift4, float* w2,
                            float* shift_border, void* stream);

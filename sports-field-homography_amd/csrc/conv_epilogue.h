@@ -50,7 +50,13 @@ __device__ __forceinline__ void sfh_conv_epilogue(const sfh_conv_desc& d, const 
   // of a lane group are 256 contiguous bytes (lane groups lg and lg^1 hold the two 8-byte halves of
   // each 16-byte element) and the consumers' LDS-DMA pieces are contiguous along x.
   const unsigned cs = (unsigned)d.dst_cs;
-  const unsigned wdst = (unsigned)(d.out_mode == SFH_OUT_UPSCATTER2 ? 2 * g.Wo : g.Wo);
+  constexpr bool UPF = CFG::KS == 2;  // the 2x2 up-scatter conv of the fused Up block
+  unsigned wdst = (unsigned)(d.out_mode == SFH_OUT_UPSCATTER2 ? 2 * g.Wo : g.Wo);
+  unsigned hdst = (unsigned)(d.out_mode == SFH_OUT_UPSCATTER2 ? 2 * g.Ho : g.Ho);
+  if constexpr (UPF) {
+    if (d.up_dst_w) wdst = (unsigned)d.up_dst_w;
+    if (d.up_dst_h) hdst = (unsigned)d.up_dst_h;
+  }
   const unsigned run = wdst * 16u;                            // bytes of one (block, plane, group) run
   const unsigned rowb = s3 ? (cs >> 5) * 12u * run : wdst * cs * 4u;  // bytes per image row
   const unsigned planeb = 4u * run;                           // S3: next plane
@@ -83,7 +89,6 @@ __device__ __forceinline__ void sfh_conv_epilogue(const sfh_conv_desc& d, const 
   int pb[MT], py[MT], px[MT];
   // the fp32 residual beside an S3 destination and the border-class shift table exist only for the
   // 2x2 up-scatter conv (fused Up block); every other instance compiles them out
-  constexpr bool UPF = CFG::KS == 2;
   unsigned voff[MT], rvoff[UPF ? MT : 1], cls[UPF ? MT : 1];
   const bool res_s3 = s3 && !(UPF && d.residual_f32);
 #pragma unroll
@@ -107,8 +112,9 @@ __device__ __forceinline__ void sfh_conv_epilogue(const sfh_conv_desc& d, const 
     pb[mi] = b; py[mi] = y; px[mi] = x;
     unsigned rowi, xo;
     if (d.out_mode == SFH_OUT_UPSCATTER2) {
-      rowi = (unsigned)(b * 2 * g.Ho + 2 * y + (qd >> 1));
+      rowi = (unsigned)b * hdst + (unsigned)(2 * y + (qd >> 1));
       xo = (unsigned)(2 * x + (qd & 1));
+      if constexpr (UPF) ok = ok && (unsigned)(2 * y + (qd >> 1)) < hdst && xo < wdst;
     } else {
       rowi = (unsigned)(b * g.Ho + y);
       xo = (unsigned)x;
@@ -117,10 +123,10 @@ __device__ __forceinline__ void sfh_conv_epilogue(const sfh_conv_desc& d, const 
     if constexpr (UPF) {
       // fp32 NHWC residual beside an S3 destination (same pixel, channel stride cs)
       rvoff[mi] = ok ? ((rowi * wdst + xo) * cs + c_lane) * 4u : kSfhOOB;
-      // border class of the output pixel for the optional per-class shift table
-      const unsigned hdst = (unsigned)(d.out_mode == SFH_OUT_UPSCATTER2 ? 2 * g.Ho : g.Ho);
-      const unsigned yo = rowi - (unsigned)b * hdst;
-      cls[mi] = (yo == 0u ? 0u : (yo == hdst - 1u ? 2u : 1u)) * 3u + (xo == 0u ? 0u : (xo == wdst - 1u ? 2u : 1u));
+      // class of the output pixel relative to the up-sampled tensor (2*h0 x 2*w0 inside the destination)
+      const unsigned yo = rowi - (unsigned)b * hdst, uh = 2u * (unsigned)d.h0, uw = 2u * (unsigned)d.w0;
+      cls[mi] = (yo == 0u ? 0u : (yo == uh - 1u ? 2u : (yo >= uh ? 3u : 1u))) * 4u +
+                (xo == 0u ? 0u : (xo == uw - 1u ? 2u : (xo >= uw ? 3u : 1u)));
     }
   }
   // ---- pass 1: finish the values in place and store them

@@ -99,6 +99,7 @@ __device__ __forceinline__ unsigned s3_halo_voffset(const sfh_conv_desc& d, cons
   // S3 layout (B, H, cs/32, 3, 4, W, 8) bf16: byte offset of (row, channel block 0, plane/group pl, x)
   unsigned rowi, xs_, ws_, nblk;
   if (which == 0) {
+    if (C::KS == 2 && (y >= d.h0 || x >= d.w0)) return kOOB;  // fused Up with F.pad: the extra row / column reads 0
     rowi = (unsigned)(b * d.h0 + y);
     xs_ = (unsigned)x;
     ws_ = (unsigned)d.w0;
@@ -578,7 +579,14 @@ extern "C" int sfh_conv_s3_fwd(const sfh_conv_desc* dp, void* stream_) {
   SFH_REQUIRE(d.cout > 0 && d.cout % 64 == 0, "conv_s3_fwd: cout=%d must be a multiple of 64", d.cout);
   SFH_REQUIRE(d.c0 > 0 && d.c0 % 32 == 0 && d.cs0 >= d.c0, "conv_s3_fwd: c0=%d must be a multiple of 32 (cs0=%d)", d.c0, d.cs0);
   SFH_REQUIRE(!d.pool0, "conv_s3_fwd: pool-on-load is not available for S3 sources (use the producer's dst_pool)");
-  SFH_REQUIRE(d.h0 == d.H && d.w0 == d.W, "conv_s3_fwd: source 0 is %dx%d, frame is %dx%d", d.h0, d.w0, d.H, d.W);
+  SFH_REQUIRE((d.h0 == d.H && d.w0 == d.W) ||
+                  (d.ksize == 2 && (d.H == d.h0 || d.H == d.h0 + 1) && (d.W == d.w0 || d.W == d.w0 + 1)),
+              "conv_s3_fwd: source 0 is %dx%d, frame is %dx%d", d.h0, d.w0, d.H, d.W);
+  SFH_REQUIRE((!d.up_dst_h && !d.up_dst_w) || d.ksize == 2, "conv_s3_fwd: up_dst_h/w exist only for the 2x2 up-scatter conv");
+  if (d.ksize == 2)
+    SFH_REQUIRE((d.up_dst_h == 0 || (d.up_dst_h >= 2 * d.h0 && d.up_dst_h <= 2 * d.H)) &&
+                    (d.up_dst_w == 0 || (d.up_dst_w >= 2 * d.w0 && d.up_dst_w <= 2 * d.W)),
+                "conv_s3_fwd: up_dst %dx%d does not match the source %dx%d", d.up_dst_h, d.up_dst_w, d.h0, d.w0);
   SFH_REQUIRE(d.stride == 1 || (d.stride == 2 && !d.src1 && !d.dst_pool && d.out_mode == SFH_OUT_NHWC),
               "conv_s3_fwd: stride 2 supports a single source, plain output");
   if (d.src1) {

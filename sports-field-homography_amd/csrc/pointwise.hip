@@ -276,24 +276,29 @@ __global__ void compose_up_weights_kernel(const float* __restrict__ wc, int cout
   w2[idx] = acc;
 }
 
-// shift_border[cls][cv] = shift[cv] + scale[cv] * (sum over the conv taps inside the image for border class
-// cls (3*row class + col class; 0: first row/col - tap 0 outside, 2: last - tap 2 outside, 1: interior) of
-// sum_cu wconv[co][c0+cu][ky][kx] * bt[cu]),  cv = q*cout + co: the transposed conv's bias seen through the
-// zero-padded 3x3 conv, folded behind the BatchNorm scale
+// shift_border[cls][cv] = shift[cv] + scale[cv] * (sum over the conv taps that fall inside the up-sampled tensor
+// of sum_cu wconv[co][c0+cu][ky][kx] * bt[cu]),  cv = q*cout + co, cls = 4*(row class) + (col class):
+// class 0: first row/col of the up-sampled tensor (tap 0 outside), 2: its last (tap 2 outside), 3: the padded
+// row/col after it (only tap 0 inside), 1: interior.  The transposed conv's bias seen through the zero-padded
+// 3x3 conv, folded behind the BatchNorm scale.
+__device__ __forceinline__ bool up_tap_inside(int cls, int k) {
+  return cls == 1 || (cls == 0 && k != 0) || (cls == 2 && k != 2) || (cls == 3 && k == 0);
+}
+
 __global__ void compose_up_bias_kernel(const float* __restrict__ wc, int cout, int c0, int c1,
                                        const float* __restrict__ bt, const float* __restrict__ scale,
                                        const float* __restrict__ shift, float* __restrict__ out) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= 9 * 4 * cout) return;
+  if (idx >= 16 * 4 * cout) return;
   const int cv = idx % (4 * cout), cls = idx / (4 * cout);
   const int co = cv % cout;
-  const int cy = cls / 3, cxx = cls % 3;
+  const int cy = cls >> 2, cxx = cls & 3;
   const int cin = c0 + c1;
   float acc = 0.f;
   for (int ky = 0; ky < 3; ++ky) {
-    if ((cy == 0 && ky == 0) || (cy == 2 && ky == 2)) continue;
+    if (!up_tap_inside(cy, ky)) continue;
     for (int kx = 0; kx < 3; ++kx) {
-      if ((cxx == 0 && kx == 0) || (cxx == 2 && kx == 2)) continue;
+      if (!up_tap_inside(cxx, kx)) continue;
       const float* wcp = wc + (((long)co * cin + c0) * 3 + ky) * 3 + kx;
       float s = 0.f;
       for (int cu = 0; cu < c1; ++cu) s += wcp[(long)cu * 9] * bt[cu];
@@ -760,7 +765,7 @@ extern "C" int sfh_compose_up_weights(const float* wconv, int cout, int c0, int 
                      wconv, cout, c0, c1, wt, cx, w2, total);
   int rc = sfh_check_launch("compose_up_weights_kernel");
   if (rc) return rc;
-  hipLaunchKernelGGL(compose_up_bias_kernel, dim3((unsigned)((36 * cout + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+  hipLaunchKernelGGL(compose_up_bias_kernel, dim3((unsigned)((64 * cout + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                      wconv, cout, c0, c1, bt, scale4, shift4, shift_border);
   return sfh_check_launch("compose_up_bias_kernel");
 }

@@ -211,7 +211,7 @@ class PackedConv:
         _lib.check(lib.sfh_fold_bn(_ptr(b), *[_ptr(a) for a in args], float(bn.eps), cout, 4, _ptr(self.scale),
                                    _ptr(self.shift), _stream()), "fold_bn")
         w2 = torch.empty((4 * cout, cx, 2, 2), dtype=torch.float32, device=dev)
-        self.shift_border = torch.empty((9, 4 * cout), dtype=torch.float32, device=dev)
+        self.shift_border = torch.empty((16, 4 * cout), dtype=torch.float32, device=dev)
         _lib.check(lib.sfh_compose_up_weights(_ptr(wc), cout, c0, c1, _ptr(wt), cx, _ptr(bt), _ptr(self.scale),
                                               _ptr(self.shift), _ptr(w2), _ptr(self.shift_border), _stream()),
                    "compose_up_weights")
@@ -264,7 +264,7 @@ class PackedConv:
         return self
 
     def run(self, src0, batch, H, W, dst, src1=None, pool0=False, pad1=(0, 0), residual=None, tile=None,
-            dst_pool=None):
+            dst_pool=None, up_dst=None):
         """src0/src1: NHWC float32 tensors (or S3 tensors (B,H,W,3,C) bf16 when the layer is s3);
         dst/residual/dst_pool: float32 NHWC, or S3 when their dtype is bfloat16.  H, W: conv input frame."""
         lib = _lib.load()
@@ -312,6 +312,9 @@ class PackedConv:
         d.dst, d.dst_cs = dst.data_ptr(), _chan(dst)
         d.out_mode = _lib.OUT_UPSCATTER2 if self.transposed else _lib.OUT_NHWC
         exp = (batch, 2 * ho, 2 * wo) if self.transposed else (batch, ho, wo)
+        if up_dst is not None:   # fused Up block with F.pad: the destination is one row / column short of 2*H x 2*W
+            d.up_dst_h, d.up_dst_w = up_dst
+            exp = (batch,) + tuple(up_dst)
         if (dst.shape[0],) + _hw(dst) != exp or _chan(dst) < self.cout_real:
             raise ValueError(f"conv dst shape {tuple(dst.shape)} does not match {exp + (self.cout_real,)}")
         for t in (dst, dst_pool, residual, src0, src1):
@@ -457,11 +460,13 @@ class UNetEngine:
             hs, ws_ = _hw(skip)
             hy, wy = _hw(y)
             cout = L[f"up{i}.conv.3"].cout_real
-            if f"up{i}.fused" in L and (2 * hy, 2 * wy) == (hs, ws_):
+            ey, ex = hs - 2 * hy, ws_ - 2 * wy   # F.pad of Up: diff 1 pads one row / column AFTER the tensor
+            if f"up{i}.fused" in L and ey in (0, 1) and ex in (0, 1):
                 part = ws.get(f"up{i}.part", (B, hs, ws_, L[f"up{i}.skip"].cout_real))     # fp32 partial
                 L[f"up{i}.skip"].run(skip, B, hs, ws_, part)
                 mid = act(f"up{i}.conv.mid", (B, hs, ws_), L[f"up{i}.fused"].cout_real)
-                L[f"up{i}.fused"].run(y, B, hy, wy, mid, residual=part)
+                L[f"up{i}.fused"].run(y, B, hy + ey, wy + ex, mid, residual=part,
+                                      up_dst=(hs, ws_) if (ey or ex) else None)
                 y = act(f"up{i}.conv.out", (B, hs, ws_), cout, f32=(i == 4))
                 L[f"up{i}.conv.3"].run(mid, B, hs, ws_, y)
                 continue

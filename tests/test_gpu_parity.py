@@ -471,12 +471,14 @@ def test_predict_resnet50_variant(E):
     assert torch.equal(out["warp_mask"].cpu(), wm.to(torch.int32))
 
 
-def test_fused_up_block_vs_unfused_and_oracle(E, monkeypatch):
+@pytest.mark.parametrize("size", [(96, 128), (90, 112), (54, 72)])
+def test_fused_up_block_vs_unfused_and_oracle(E, monkeypatch, size):
     """Up blocks without F.pad run as skip-half conv + composed 2x2 quadrant conv over the low-resolution
     tensor (ConvTranspose2d folded into the consumer conv); with SFH_FUSE_UP=0 as ConvTranspose2d + conv over
     the concatenation.  Both against the oracle, and against each other, incl. the image borders."""
     from sfh_amd.reconstructor import Reconstructor
-    B, H, W = 2, 96, 128           # 96 -> 48 -> 24 -> 12 -> 6: every level is fused
+    # 96x128: no level needs F.pad; 90x112: 5->10 vs 11 and 22->44 vs 45 (one padded row); 54x72: 27 rows, 9 cols
+    B, (H, W) = 2, size
     court = synth.load_court_template("ncaa_nc4_640x360", 4, B)[:, :, :H, :W].contiguous()
     poi = synth.load_court_poi("pitch", B)
     x = synth.smooth_frames(B, H, W, seed=37)
