@@ -19,7 +19,8 @@ L = [("inc.0", gm(3, 64, 360, 640)), ("inc.3", gm(64, 64, 360, 640)),
 if any('S3Cfg<2,' in r['Kernel_Name'] for r in step):
     # fused Up blocks (no F.pad at that level): skip-half 3x3 conv + composed 2x2 quadrant conv over the
     # low-resolution tensor, credited with the u-half of the reference's 3x3 conv; no ConvTranspose launch
-    L = L[:13] + [("u2.skip", gm(256, 256, 90, 160)), ("u2.fuse", gm(256, 256, 90, 160)), ("u2.3", gm(256, 256, 90, 160)),
+    L = L[:10] + [("u1.skip", gm(512, 512, 45, 80)), ("u1.fuse", gm(512, 512, 45, 80)), ("u1.3", gm(512, 512, 45, 80)),
+                  ("u2.skip", gm(256, 256, 90, 160)), ("u2.fuse", gm(256, 256, 90, 160)), ("u2.3", gm(256, 256, 90, 160)),
                   ("u3.skip", gm(128, 128, 180, 320)), ("u3.fuse", gm(128, 128, 180, 320)), ("u3.3", gm(128, 128, 180, 320)),
                   ("u4.skip", gm(64, 64, 360, 640)), ("u4.fuse", gm(64, 64, 360, 640)), ("u4.3", gm(64, 64, 360, 640))]
 dur = lambda r: (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e6
