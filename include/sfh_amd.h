@@ -247,9 +247,11 @@ int sfh_bn_stats(const float* z, int64_t npix, int C, double* acc, void* stream)
  * with `momentum` and the unbiased variance like torch.                                           */
 int sfh_bn_finalize(const double* acc, int64_t npix, int C, float eps, float momentum, float* running_mean,
                     float* running_var, float* mean_invstd, void* stream);
-/* y = [relu]((z - mean) * invstd * gamma + beta [+ residual])                                      */
+/* y = [relu]((z - mean) * invstd * gamma + beta [+ residual]); y_s3 (optional, C % 32 == 0, W = row
+ * length of the (rows, W, C) tensor): the same values again in the S3 layout for the next convolution. */
 int sfh_bn_apply(const float* z, const float* mean_invstd, const float* gamma, const float* beta,
-                 const float* residual, int relu, int64_t npix, int C, float* y, void* stream);
+                 const float* residual, int relu, int64_t npix, int C, float* y, void* y_s3, int W,
+                 void* stream);
 /* backward of bn_apply: with g = dy * (y > 0) (or dy when relu == 0), acc[0][c] += sum g,
  * acc[1][c] += sum g * xhat  (= dbeta, dgamma);  then
  * dz = gamma * invstd * (g - acc[0]/N - xhat * acc[1]/N), and dres = g (gradient of the residual
@@ -258,7 +260,7 @@ int sfh_bn_bwd_reduce(const float* dy, const float* y, const float* z, const flo
                       int64_t npix, int C, double* acc, void* stream);
 int sfh_bn_bwd_apply(const float* dy, const float* y, const float* z, const float* mean_invstd,
                      const float* gamma, const double* acc, int relu, int64_t npix, int C, float* dz,
-                     float* dres, void* stream);
+                     float* dres, void* dz_s3, int W, void* stream);   /* dz_s3: optional S3 copy of dz */
 /* acc[c] += sum_p x[p][c] over a channel slice of a (npix, cs) tensor: conv / transposed-conv bias
  * gradients.                                                                                       */
 int sfh_colsum(const float* x, int64_t npix, int C, int cs, double* acc, void* stream);

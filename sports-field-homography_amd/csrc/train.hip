@@ -203,6 +203,119 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
   if (dres) reinterpret_cast<f32x4*>(dres)[i] = gg;
 }
 
+// ------------------------------------------------------------------ BatchNorm kernels with an S3 copy
+// Same arithmetic as bn_apply / bn_bwd_apply, with the thread mapping of f32_to_s3 (one thread = 8
+// channels of one pixel, a wave = 16 pixels x the 4 groups of a 32-channel block) so that the result is
+// written twice in one pass: fp32 NHWC (for BatchNorm backward and the backward-filter kernel) and the
+// split-bf16 S3 layout (B*H, C/32, 3, 4, W, 8) that the next convolution reads.  C % 32 == 0.
+typedef unsigned short tr_u16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ void tr_split8(const float (&v)[8], unsigned short* __restrict__ dst, long e, long ps) {
+  tr_u16x8 p0, p1, p2;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const __bf16 v0 = (__bf16)v[j];
+    const float r1 = v[j] - (float)v0;
+    const __bf16 v1 = (__bf16)r1;
+    const __bf16 v2 = (__bf16)(r1 - (float)v1);
+    p0[j] = __builtin_bit_cast(unsigned short, v0);
+    p1[j] = __builtin_bit_cast(unsigned short, v1);
+    p2[j] = __builtin_bit_cast(unsigned short, v2);
+  }
+  *reinterpret_cast<tr_u16x8*>(dst + e) = p0;
+  *reinterpret_cast<tr_u16x8*>(dst + e + ps) = p1;
+  *reinterpret_cast<tr_u16x8*>(dst + e + 2 * ps) = p2;
+}
+
+// decode thread index -> (row, x, first channel); returns false outside the tensor
+__device__ __forceinline__ bool tr_s3_thread(long i, int W, int C, int xchunks, long& row, int& x, int& c0) {
+  const int g = (int)(i & 3), px = (int)((i >> 2) & 15);
+  long r = i >> 6;
+  const int xc = (int)(r % xchunks); r /= xchunks;
+  const int cb = (int)(r % (C >> 5));
+  row = r / (C >> 5);
+  x = xc * 16 + px;
+  c0 = cb * 32 + g * 8;
+  return x < W;
+}
+
+__device__ __forceinline__ long tr_s3_elem(long row, int x, int c, int W, int C) {
+  return ((((row * (C >> 5) + (c >> 5)) * 3) * 4 + ((c & 31) >> 3)) * W + x) * 8;
+}
+
+__global__ __launch_bounds__(256) void bn_apply_s3_kernel(const float* __restrict__ z, const float* __restrict__ mi,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                          const float* __restrict__ residual, int relu, int W, int C,
+                                                          int xchunks, long total, float* __restrict__ y,
+                                                          unsigned short* __restrict__ y_s3) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  long row; int x, c0;
+  if (!tr_s3_thread(i, W, C, xchunks, row, x, c0)) return;
+  const long o = (row * W + x) * C + c0;
+  float v[8];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const f32x4 zz = *reinterpret_cast<const f32x4*>(z + o + 4 * h);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int c = c0 + 4 * h + j;
+      v[4 * h + j] = (zz[j] - mi[c]) * mi[C + c] * gamma[c] + beta[c];
+    }
+    if (residual) {
+      const f32x4 r = *reinterpret_cast<const f32x4*>(residual + o + 4 * h);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[4 * h + j] += r[j];
+    }
+  }
+  if (relu) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
+  }
+  *reinterpret_cast<f32x4*>(y + o) = (f32x4){v[0], v[1], v[2], v[3]};
+  *reinterpret_cast<f32x4*>(y + o + 4) = (f32x4){v[4], v[5], v[6], v[7]};
+  tr_split8(v, y_s3, tr_s3_elem(row, x, c0, W, C), 4L * W * 8);
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_apply_s3_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                                              const float* __restrict__ z, const float* __restrict__ mi,
+                                                              const float* __restrict__ gamma, const double* __restrict__ acc,
+                                                              int relu, long npix, int W, int C, int xchunks, long total,
+                                                              float* __restrict__ dz, float* __restrict__ dres,
+                                                              unsigned short* __restrict__ dz_s3) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  long row; int x, c0;
+  if (!tr_s3_thread(i, W, C, xchunks, row, x, c0)) return;
+  const long o = (row * W + x) * C + c0;
+  const float inv_n = 1.0f / (float)npix;
+  float v[8], gg[8];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const f32x4 g4 = *reinterpret_cast<const f32x4*>(dy + o + 4 * h);
+    const f32x4 zz = *reinterpret_cast<const f32x4*>(z + o + 4 * h);
+    f32x4 yy = {1.f, 1.f, 1.f, 1.f};
+    if (relu) yy = *reinterpret_cast<const f32x4*>(y + o + 4 * h);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int c = c0 + 4 * h + j;
+      const float g = yy[j] > 0.f ? g4[j] : 0.f;
+      const float invstd = mi[C + c];
+      const float xh = (zz[j] - mi[c]) * invstd;
+      const float mg = (float)acc[c] * inv_n, mgx = (float)acc[C + c] * inv_n;
+      v[4 * h + j] = gamma[c] * invstd * (g - mg - xh * mgx);
+      gg[4 * h + j] = g;
+    }
+  }
+  *reinterpret_cast<f32x4*>(dz + o) = (f32x4){v[0], v[1], v[2], v[3]};
+  *reinterpret_cast<f32x4*>(dz + o + 4) = (f32x4){v[4], v[5], v[6], v[7]};
+  if (dres) {
+    *reinterpret_cast<f32x4*>(dres + o) = (f32x4){gg[0], gg[1], gg[2], gg[3]};
+    *reinterpret_cast<f32x4*>(dres + o + 4) = (f32x4){gg[4], gg[5], gg[6], gg[7]};
+  }
+  tr_split8(v, dz_s3, tr_s3_elem(row, x, c0, W, C), 4L * W * 8);
+}
+
 // ------------------------------------------------------------------ max-pool 2x2 (floor)
 __global__ __launch_bounds__(256) void maxpool2_fwd_kernel(const float* __restrict__ x, int H, int W, int C,
                                                            int Ho, int Wo, long total4, float* __restrict__ y) {
@@ -808,8 +921,17 @@ extern "C" int sfh_bn_finalize(const double* acc, int64_t npix, int C, float eps
 }
 
 extern "C" int sfh_bn_apply(const float* z, const float* mean_invstd, const float* gamma, const float* beta,
-                            const float* residual, int relu, int64_t npix, int C, float* y, void* stream) {
+                            const float* residual, int relu, int64_t npix, int C, float* y, void* y_s3, int W,
+                            void* stream) {
   SFH_REQUIRE(z && mean_invstd && gamma && beta && y && npix > 0 && C > 0 && C % 4 == 0, "bn_apply: bad argument");
+  if (y_s3) {
+    SFH_REQUIRE(C % 32 == 0 && W > 0 && npix % W == 0, "bn_apply: the S3 copy needs C %% 32 == 0 and npix = rows * W");
+    const int xchunks = (W + 15) / 16;
+    const long total = (npix / W) * (C / 32) * xchunks * 64;
+    hipLaunchKernelGGL(bn_apply_s3_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, z,
+                       mean_invstd, gamma, beta, residual, relu, W, C, xchunks, total, y, (unsigned short*)y_s3);
+    return sfh_check_launch("bn_apply_s3_kernel");
+  }
   const long total4 = (long)npix * C / 4;
   hipLaunchKernelGGL(bn_apply_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, z,
                      mean_invstd, gamma, beta, residual, relu, total4, C, y);
@@ -828,9 +950,18 @@ extern "C" int sfh_bn_bwd_reduce(const float* dy, const float* y, const float* z
 
 extern "C" int sfh_bn_bwd_apply(const float* dy, const float* y, const float* z, const float* mean_invstd,
                                 const float* gamma, const double* acc, int relu, int64_t npix, int C, float* dz,
-                                float* dres, void* stream) {
+                                float* dres, void* dz_s3, int W, void* stream) {
   SFH_REQUIRE(dy && z && mean_invstd && gamma && acc && dz && (y || !relu) && npix > 0 && C > 0 && C % 4 == 0,
               "bn_bwd_apply: bad argument");
+  if (dz_s3) {
+    SFH_REQUIRE(C % 32 == 0 && W > 0 && npix % W == 0, "bn_bwd_apply: the S3 copy needs C %% 32 == 0 and npix = rows * W");
+    const int xchunks = (W + 15) / 16;
+    const long total = (npix / W) * (C / 32) * xchunks * 64;
+    hipLaunchKernelGGL(bn_bwd_apply_s3_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       dy, y, z, mean_invstd, gamma, acc, relu, (long)npix, W, C, xchunks, total, dz, dres,
+                       (unsigned short*)dz_s3);
+    return sfh_check_launch("bn_bwd_apply_s3_kernel");
+  }
   const long total4 = (long)npix * C / 4;
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                      dy, y, z, mean_invstd, gamma, acc, relu, (long)npix, total4, C, dz, dres);

@@ -83,8 +83,9 @@ class Tape:
 
 
 # --------------------------------------------------------------------------------------- layers
-def _bn_forward(lib, z, bn, relu, residual=None):
-    """Batch-statistics BatchNorm (+residual) (+ReLU); updates the running stats in place."""
+def _bn_forward(lib, z, bn, relu, residual=None, tape=None):
+    """Batch-statistics BatchNorm (+residual) (+ReLU); updates the running stats in place.  With a tape in
+    split-bf16 mode the S3 copy the next convolution needs is written by the same kernel."""
     B, H, W, C = z.shape
     npix = B * H * W
     acc = _zeros((2 * C,), z, torch.float64)
@@ -94,12 +95,15 @@ def _bn_forward(lib, z, bn, relu, residual=None):
                                    _ptr(bn.running_var), _ptr(mi), _stream()), "bn_finalize")
     bn.num_batches_tracked += 1
     y = _empty(z.shape, z)
+    y_s3 = E.s3_empty(B, H, W, C, z.device) if (tape is not None and tape.use_s3 and C % 32 == 0) else None
     _lib.check(lib.sfh_bn_apply(_ptr(z), _ptr(mi), _ptr(bn.weight.detach()), _ptr(bn.bias.detach()),
-                                _ptr(residual), 1 if relu else 0, npix, C, _ptr(y), _stream()), "bn_apply")
+                                _ptr(residual), 1 if relu else 0, npix, C, _ptr(y), _ptr(y_s3), W, _stream()), "bn_apply")
+    if y_s3 is not None:
+        tape._s3[id(y)] = (y, y_s3)
     return y, mi
 
 
-def _bn_backward(lib, dy, y, z, mi, bn, relu, want_dres):
+def _bn_backward(lib, dy, y, z, mi, bn, relu, want_dres, want_s3=False):
     B, H, W, C = z.shape
     npix = B * H * W
     acc = _zeros((2 * C,), z, torch.float64)
@@ -107,10 +111,12 @@ def _bn_backward(lib, dy, y, z, mi, bn, relu, want_dres):
                                      _stream()), "bn_bwd_reduce")
     dz = _empty(z.shape, z)
     dres = _empty(z.shape, z) if want_dres else None
+    dz_s3 = E.s3_empty(B, H, W, C, z.device) if (want_s3 and C % 32 == 0) else None
     _lib.check(lib.sfh_bn_bwd_apply(_ptr(dy), _ptr(y), _ptr(z), _ptr(mi), _ptr(bn.weight.detach()), _ptr(acc),
-                                    1 if relu else 0, npix, C, _ptr(dz), _ptr(dres), _stream()), "bn_bwd_apply")
+                                    1 if relu else 0, npix, C, _ptr(dz), _ptr(dres), _ptr(dz_s3), W, _stream()),
+               "bn_bwd_apply")
     a = acc.to(torch.float32)
-    return dz, a[C:], a[:C], dres   # dz, dgamma, dbeta, dresidual
+    return dz, a[C:], a[:C], dres, dz_s3   # dz, dgamma, dbeta, dresidual, S3 copy of dz
 
 
 def _colsum(lib, t, C=None, cs=None):
@@ -143,7 +149,7 @@ class _Names:
         return self.by_id[id(p)]
 
 
-def conv_bn_act(tape, names, conv, bn, srcs, B, H, W, relu=True, residual=None, need_dx=True):
+def conv_bn_act(tape, names, conv, bn, srcs, B, H, W, relu=True, residual=None, need_dx=True, s3_out=True):
     """z = conv(cat(srcs)) + bias; y = [relu](bn_train(z) [+ residual]).
 
     srcs: [(tensor NHWC, channels used, pad_top, pad_left)], one or two (skip first, like torch.cat
@@ -161,13 +167,14 @@ def conv_bn_act(tape, names, conv, bn, srcs, B, H, W, relu=True, residual=None, 
     z = _empty((B, ho, wo, cout), t0)
     pc.run(tape.s3(t0) if s3 else t0, B, H, W, z, src1=(tape.s3(t1) if s3 else t1) if t1 is not None else None,
            pad1=(srcs[1][2], srcs[1][3]) if t1 is not None else (0, 0))
-    y, mi = _bn_forward(lib, z, bn, relu, residual)
+    y, mi = _bn_forward(lib, z, bn, relu, residual, tape if s3_out else None)   # s3_out: a conv consumes y
 
     def backward():
         dy = tape.pop_grad(y)
         if dy is None:
             raise RuntimeError("conv_bn_act: no gradient reached this layer")
-        dz, dgamma, dbeta, dres = _bn_backward(lib, dy, y, z, mi, bn, relu, residual is not None)
+        dz, dgamma, dbeta, dres, dz_s3 = _bn_backward(lib, dy, y, z, mi, bn, relu, residual is not None,
+                                                      want_s3=s3 and need_dx and stride == 1)
         g = tape.param_grads
         g[names(bn.weight)], g[names(bn.bias)] = dgamma, dbeta
         if conv.bias is not None:
@@ -190,7 +197,7 @@ def conv_bn_act(tape, names, conv, bn, srcs, B, H, W, relu=True, residual=None, 
             return
         bd = PackedConv.backward_data(w, ks, s3=s3)
         dx = _empty((B, H, W, bd.cout), dz)
-        bd.run(E.f32_to_s3(dz) if s3 else dz, B, H, W, dx)
+        bd.run((dz_s3 if dz_s3 is not None else E.f32_to_s3(dz)) if s3 else dz, B, H, W, dx)
         if t1 is None:
             tape.add_grad(t0, dx)
             return
@@ -315,10 +322,10 @@ class UNetTrainer:
         B, _, H, W = x_nchw.shape
         x = E.nchw_to_nhwc(x_nchw, 4)
 
-        def dconv(block, srcs, h, w, need_dx=True):
+        def dconv(block, srcs, h, w, need_dx=True, s3_out=True):
             (cv1, bn1), (cv2, bn2) = block.convs()
             y1 = conv_bn_act(tape, names, cv1, bn1, srcs, B, h, w, need_dx=need_dx)
-            return conv_bn_act(tape, names, cv2, bn2, [(y1, y1.shape[3], 0, 0)], B, h, w)
+            return conv_bn_act(tape, names, cv2, bn2, [(y1, y1.shape[3], 0, 0)], B, h, w, s3_out=s3_out)
 
         x1 = dconv(net.inc, [(x, 3, 0, 0)], H, W, need_dx=False)
         feats = [x1]
@@ -334,7 +341,8 @@ class UNetTrainer:
             u = upsample2x(tape, y) if net.unet_bilinear else conv_transpose2x2(tape, names, up.up, y)
             hs, ws = skip.shape[1], skip.shape[2]
             dy_, dx_ = hs - u.shape[1], ws - u.shape[2]
-            y = dconv(up.conv, [(skip, skip.shape[3], 0, 0), (u, u.shape[3], dy_ // 2, dx_ // 2)], hs, ws)
+            # the last block feeds the 1x1 heads (fp32) only: no S3 copy of it
+            y = dconv(up.conv, [(skip, skip.shape[3], 0, 0), (u, u.shape[3], dy_ // 2, dx_ // 2)], hs, ws, s3_out=i < 4)
         frame = x if want_stn_in else None
         logits, stn_in, oc_bwd = out_conv(tape, names, net.outc, y, B, H, W, frame, stn_cs)
         heads = [(logits, oc_bwd)]
@@ -378,7 +386,7 @@ class ResNetTrainer:
             dx = tape.pop_grad(x_pool)
             dc1 = _empty(c1.shape, c1)
             _lib.check(lib.sfh_maxpool3x3s2_bwd(_ptr(c1), _ptr(dx), _ptr(dc1), B, H2, W2, 64, st()), "maxpool3x3s2_bwd")
-            dz, dgamma, dbeta, _ = _bn_backward(lib, dc1, c1, z0, mi0, rn.bn1, True, False)
+            dz, dgamma, dbeta, _, _ = _bn_backward(lib, dc1, c1, z0, mi0, rn.bn1, True, False)
             g = tape.param_grads
             g[names(rn.bn1.weight)], g[names(rn.bn1.bias)] = dgamma, dbeta
             # the 4x4 backward-filter instance holds 32 input channels: wider inputs go in slices

@@ -23,3 +23,12 @@ def golden_blocks():
 def golden_full():
     import numpy as np
     return np.load(os.path.join(GOLDEN, "full_640x360.npz"))
+
+
+@pytest.fixture(autouse=True)
+def _seed_global_rng():
+    """Modules built inside tests (nn.Conv2d defaults etc.) draw their initial weights from torch's global
+    generator: seed it so that every run of a test sees the same numbers."""
+    import torch
+    torch.manual_seed(20240917)
+    yield
