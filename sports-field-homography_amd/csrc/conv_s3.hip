@@ -513,8 +513,14 @@ int launch_s3(const sfh_conv_desc& d, hipStream_t stream) {
   }
   const long nblocks = (long)sfh_cdiv(g.ntiles, 8) * 8 * g.nblk_n;
   SFH_REQUIRE(nblocks < (1L << 31), "conv_s3: grid too large");
-  // (measured: switching small grids - ResNet layer3/4, <= 320 workgroups - to the double-buffered
-  // variant changes nothing, 137 vs 134 us, so DB stays a debug switch: SFH_DEBUG_S3_DB=1)
+  // small grids (at most ~one workgroup per CU anyway, e.g. ResNet layer3/4): the double-buffered
+  // variant overlaps each stage's DMA latency with the previous stage's MFMAs (SFH_DEBUG_S3_DBLIM
+  // overrides the threshold, 0 = never)
+  if constexpr (!DB && C::LDS_BYTES <= 160 * 1024) {
+    static const char* force = getenv("SFH_DEBUG_S3_DB");
+    static const char* lim = getenv("SFH_DEBUG_S3_DBLIM");
+    if (!force && nblocks <= (lim ? atol(lim) : 320)) return launch_s3<C, true>(d, stream);
+  }
   // (an LDS-free variant for 1x1 / transposed convs that streams both operands straight into
   // registers was measured slower: 3.69 ms vs 2.96 ms per step for the four ConvTranspose launches)
   static bool attr_set = false;
