@@ -94,6 +94,10 @@ typedef struct sfh_conv_desc {
    * column short of it (F.pad in Up, unet/unet_parts.py:59-63, with diff 1: pad 0 before, 1 after);
    * 0 = 2*Ho x 2*Wo.  The conv frame (H, W) is then source rows/cols + 1, the extra source row reads 0. */
   int32_t up_dst_h, up_dst_w;
+  /* 1: walk the pixel tiles from the last to the first (sfh_conv_s3_fwd).  Alternating the direction from
+   * one layer to the next makes a layer start on the part of its input that the previous launch wrote
+   * last, i.e. the part still resident in L2 / Infinity Cache. */
+  int32_t reverse_tiles;
 } sfh_conv_desc;
 
 const char* sfh_last_error(void);

@@ -29,6 +29,7 @@ class ConvDesc(C.Structure):
         ("dst", _p), ("dst_cs", _i), ("out_mode", _i),
         ("src_fmt", _i), ("dst_fmt", _i), ("dst_pool", _p), ("pool_cs", _i),
         ("residual_f32", _i), ("shift_border", _p), ("up_dst_h", _i), ("up_dst_w", _i),
+        ("reverse_tiles", _i),
     ]
 
 

@@ -150,7 +150,9 @@ __global__ __launch_bounds__(256, 2) void conv_s3_kernel(const sfh_conv_desc d, 
   const int nb = gi * g.nb_group + rr % g.nb_group;
   // each XCD owns a contiguous range of pixel tiles (whole tile rows), so vertically adjacent tiles
   // share their halo rows in that XCD's L2 (xcd_interleave: the old round-robin order, for A/B runs)
-  const int tile = g.xcd_interleave ? (rr / g.nb_group) * 8 + xcd : xcd * tpx + rr / g.nb_group;
+  // reverse_tiles: every XCD walks its range backwards, i.e. starts on what it wrote last in the previous launch
+  const int tl = d.reverse_tiles ? tpx - 1 - rr / g.nb_group : rr / g.nb_group;
+  const int tile = g.xcd_interleave ? tl * 8 + xcd : xcd * tpx + tl;
   if (tile >= g.ntiles) return;
   const int ty = tile / g.tiles_x, tx = tile - ty * g.tiles_x;
   const int x0 = tx * C::TW;

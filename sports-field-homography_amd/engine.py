@@ -120,6 +120,9 @@ class PackedConv:
     """One conv-shaped layer: fragment-ordered weights + folded per-channel epilogue."""
 
     timer = None   # set to a ConvTimer to time every launch (class-wide)
+    # consecutive launches walk their pixel tiles in opposite directions (see sfh_conv_desc.reverse_tiles)
+    snake = os.environ.get("SFH_SNAKE", "1") != "0"
+    _flip = False
 
     def __init__(self, weight, bias, bn, ksize, c0, c1=0, relu=True, transposed=False, stride=1,
                  stem_cin=0, tag="conv", s3=False):
@@ -304,6 +307,8 @@ class PackedConv:
             d.tile = choose_tile(batch, ho, wo, self.stride, zr)
         d.wpacked, d.scale, d.shift = self.wpacked.data_ptr(), self.scale.data_ptr(), self.shift.data_ptr()
         d.cout, d.relu = self.cout, 1 if self.relu else 0
+        d.reverse_tiles = 1 if (self.s3 and PackedConv.snake and PackedConv._flip) else 0
+        PackedConv._flip = not PackedConv._flip
         d.residual = residual.data_ptr() if residual is not None else None
         d.residual_f32 = 1 if (residual is not None and residual.dtype == torch.float32
                                and dst.dtype == torch.bfloat16) else 0
