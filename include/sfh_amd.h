@@ -360,6 +360,15 @@ int sfh_compose_up_weights(const float* wconv, int cout, int c0, int c1, const f
                            const float* bt, const float* scale4, const float* shift4, float* w2,
                            float* shift_border, void* stream);
 
+/* The ResNetSTN stem (models/resnet.py:172,241-243: 7x7 stride-2 pad-3 conv + BatchNorm + ReLU, <= 8 input
+ * channels -> 64) with the split-bf16 arithmetic, K packed by tap (4 taps x 8 channels per MFMA): d->src0 fp32
+ * NHWC (B,H,W,8) = cat((logits, frame)) zero-padded, d->wpacked from sfh_pack_stem_weights (w OIHW
+ * (64,cin,7,7)), d->dst fp32 NHWC (B,Ho,Wo,64), scale/shift/relu as in sfh_conv_fwd; the other descriptor
+ * fields must describe a plain single-source launch.                                                    */
+int sfh_stem7x7_fwd(const sfh_conv_desc* d, void* stream);
+int64_t sfh_packed_stem_weight_bytes(void);
+int sfh_pack_stem_weights(const float* w, void* packed, int cin, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -93,6 +93,9 @@ SIGNATURES = {
     "sfh_upsample2x_bilinear_nhwc_bwd": (C.c_int, [_p, _p, C.c_int, C.c_int, C.c_int, C.c_int, _p]),
     "sfh_resize_nearest_nchw_bwd": (C.c_int, [_p, _p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, _p]),
     "sfh_compose_up_weights": (C.c_int, [_p, C.c_int, C.c_int, C.c_int, _p, C.c_int, _p, _p, _p, _p, _p, _p]),
+    "sfh_stem7x7_fwd": (C.c_int, [C.POINTER(ConvDesc), _p]),
+    "sfh_packed_stem_weight_bytes": (C.c_int64, []),
+    "sfh_pack_stem_weights": (C.c_int, [_p, _p, C.c_int, _p]),
     "sfh_maxpool3x3s2_fwd": (C.c_int, [_p, _p, C.c_int, C.c_int, C.c_int, C.c_int, _p]),
     "sfh_avgpool_linear_fwd": (C.c_int, [_p, _p, _p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _p, _p, _p]),
 }

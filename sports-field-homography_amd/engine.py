@@ -512,6 +512,48 @@ class UNetEngine:
         return out
 
 
+class StemConv:
+    """ResNetSTN stem (7x7 s2 conv + BatchNorm + ReLU) on the tap-packed split-bf16 kernel (csrc/stem.hip):
+    reads the fp32 NHWC STN input (8 stored channels) directly, no space-to-depth copy."""
+
+    def __init__(self, conv, bn, cin, tag="resnet"):
+        lib = _lib.load()
+        w = _f32c(conv.weight.detach(), "stem weight")
+        if tuple(w.shape) != (64, cin, 7, 7) or cin > 8:
+            raise ValueError(f"stem kernel needs a (64, <=8, 7, 7) weight, got {tuple(w.shape)}")
+        dev = w.device
+        self.tag, self.cin = tag, cin
+        self.wpacked = torch.empty(lib.sfh_packed_stem_weight_bytes(), dtype=torch.uint8, device=dev)
+        _lib.check(lib.sfh_pack_stem_weights(_ptr(w), _ptr(self.wpacked), cin, _stream()), "pack_stem_weights")
+        self.scale = torch.empty(64, dtype=torch.float32, device=dev)
+        self.shift = torch.empty(64, dtype=torch.float32, device=dev)
+        args = [_f32c(t.detach(), "bn tensor") for t in (bn.weight, bn.bias, bn.running_mean, bn.running_var)]
+        _lib.check(lib.sfh_fold_bn(None, *[_ptr(a) for a in args], float(bn.eps), 64, 1, _ptr(self.scale),
+                                   _ptr(self.shift), _stream()), "fold_bn")
+
+    def run(self, x_nhwc8, B, H, W, dst):
+        lib = _lib.load()
+        d = ConvDesc()
+        d.src0, d.c0, d.cs0, d.h0, d.w0 = x_nhwc8.data_ptr(), self.cin, 8, H, W
+        d.batch, d.H, d.W, d.ksize, d.stride = B, H, W, 7, 2
+        d.wpacked, d.scale, d.shift = self.wpacked.data_ptr(), self.scale.data_ptr(), self.shift.data_ptr()
+        d.cout, d.relu = 64, 1
+        d.dst, d.dst_cs, d.out_mode = dst.data_ptr(), dst.shape[3], _lib.OUT_NHWC
+        d.src_fmt = d.dst_fmt = _lib.FMT_F32
+        ho, wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+        if tuple(dst.shape) != (B, ho, wo, 64) or tuple(x_nhwc8.shape) != (B, H, W, 8):
+            raise ValueError(f"stem: shapes {tuple(x_nhwc8.shape)} -> {tuple(dst.shape)} do not match {(B, ho, wo, 64)}")
+        tm = PackedConv.timer
+        if tm is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        _lib.check(lib.sfh_stem7x7_fwd(ctypes.byref(d), _stream()), "stem7x7_fwd")
+        if tm is not None:
+            e1.record()
+            tm.records.append((self.tag, 2.0 * B * ho * wo * 64 * 49 * self.cin, e0, e1))
+        return dst
+
+
 class ResNetEngine:
     """ResNetSTN forward (models/resnet.py:235-254) on the HIP kernels (BasicBlock and Bottleneck depths)."""
 
@@ -532,6 +574,9 @@ class ResNetEngine:
         # the stem stays on the fp32 kernel: the 16-tap split-bf16 instance spills registers and
         # measured 1.59 ms against 0.55 ms
         L["stem"] = PackedConv(rn.conv0.weight, None, rn.bn1, 4, 4 * self.cs_in, stem_cin=in_channels, tag="resnet")
+        # bf16x6 mode with <= 8 input channels (every resnet_input mode but img+mask+uv): the tap-packed stem kernel
+        self.stem7 = (StemConv(rn.conv0, rn.bn1, in_channels) if (s3 and self.cs_in == 8 and rn.conv0.out_channels == 64
+                                                                  and os.environ.get("SFH_STEM7", "1") != "0") else None)
         self.blocks = []
         for li in range(1, 5):
             for bi, blk in enumerate(getattr(rn, f"layer{li}")):
@@ -566,14 +611,17 @@ class ResNetEngine:
         if y_nhwc.shape[3] != self.cs_in:
             raise ValueError(f"STN input has {y_nhwc.shape[3]} stored channels, engine expects {self.cs_in}")
         H2, W2 = (H + 1) // 2, (W + 1) // 2
-        s2d = ws.get("s2d", (B, H2, W2, 4 * self.cs_in))
-        _lib.check(lib.sfh_space_to_depth2(_ptr(y_nhwc), _ptr(s2d), B, H, W, self.cs_in, st), "space_to_depth2")
         c1 = ws.get("stem", (B, H2, W2, 64))
-        if L["stem"].s3:
-            s2d3 = ws.get("s2d.s3", s3_shape(B, H2, W2, 4 * self.cs_in), torch.bfloat16)
-            _lib.check(lib.sfh_f32_to_s3(_ptr(s2d), _ptr(s2d3), B * H2, W2, 4 * self.cs_in, st), "f32_to_s3")
-            s2d = s2d3
-        L["stem"].run(s2d, B, H2, W2, c1)
+        if self.stem7 is not None:
+            self.stem7.run(y_nhwc, B, H, W, c1)
+        else:
+            s2d = ws.get("s2d", (B, H2, W2, 4 * self.cs_in))
+            _lib.check(lib.sfh_space_to_depth2(_ptr(y_nhwc), _ptr(s2d), B, H, W, self.cs_in, st), "space_to_depth2")
+            if L["stem"].s3:
+                s2d3 = ws.get("s2d.s3", s3_shape(B, H2, W2, 4 * self.cs_in), torch.bfloat16)
+                _lib.check(lib.sfh_f32_to_s3(_ptr(s2d), _ptr(s2d3), B * H2, W2, 4 * self.cs_in, st), "f32_to_s3")
+                s2d = s2d3
+            L["stem"].run(s2d, B, H2, W2, c1)
         h, w = (H2 - 1) // 2 + 1, (W2 - 1) // 2 + 1
         x = ws.get("pool", (B, h, w, 64))
         _lib.check(lib.sfh_maxpool3x3s2_fwd(_ptr(c1), _ptr(x), B, H2, W2, 64, st), "maxpool3x3s2")
