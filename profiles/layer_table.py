@@ -24,7 +24,7 @@ if any('S3Cfg<2,' in r['Kernel_Name'] for r in step):
                   ("u3.skip", gm(128, 128, 180, 320)), ("u3.fuse", gm(128, 128, 180, 320)), ("u3.3", gm(128, 128, 180, 320)),
                   ("u4.skip", gm(64, 64, 360, 640)), ("u4.fuse", gm(64, 64, 360, 640)), ("u4.3", gm(64, 64, 360, 640))]
 dur = lambda r: (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e6
-is_conv = lambda n: 'conv_mfma' in n or 'conv_s3' in n or 'conv3x3_c4' in n
+is_conv = lambda n: 'conv_mfma' in n or 'conv_s3' in n or 'conv3x3_c4' in n or 'stem7x7' in n
 convs = [r for r in step if is_conv(r['Kernel_Name'])]
 tot = 0
 for (nm, g), r in zip(L, convs[:len(L)]):

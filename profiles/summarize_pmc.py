@@ -29,7 +29,7 @@ def rows(kind):
     for r in rr:
         if "nchw_to_nhwc" in r["Kernel_Name"]:
             in_resnet = False
-        elif "space_to_depth" in r["Kernel_Name"]:
+        elif "space_to_depth" in r["Kernel_Name"] or "stem7x7" in r["Kernel_Name"]:
             in_resnet = True
         r["_resnet"] = in_resnet
     return rr
@@ -44,6 +44,8 @@ def group(name, resnet=False):
         if resnet:
             return "s3_resnet"
         return {"3": "s3_conv3x3", "2": "s3_up2x2"}.get(m.group(1), "s3_conv1x1")
+    if "stem7x7" in name:
+        return "s3_stem7x7"
     for k in ("warp_kernel", "outconv", "maxpool", "avgpool", "space_to_depth", "nchw_to_nhwc", "pack_weights", "fold_bn", "ce_"):
         if k in name:
             return k
