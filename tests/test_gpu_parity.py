@@ -505,6 +505,38 @@ def test_fused_up_block_vs_unfused_and_oracle(E, monkeypatch, size):
     assert _maxerr(outs["1"]["theta"].cpu(), outs["0"]["theta"].cpu()) < 1e-5
 
 
+@pytest.mark.parametrize("shape", [(3, 45, 83), (1, 16, 16), (2, 90, 112), (2, 23, 70)])
+@pytest.mark.parametrize("cin", [7, 5, 8])
+def test_stem_kernel_vs_torch(E, shape, cin):
+    """7x7 stride-2 pad-3 conv + BatchNorm(eval) + ReLU (models/resnet.py:172,241-243) on the tap-packed
+    split-bf16 kernel: odd sizes, partial tiles, fewer than 8 real channels."""
+    B, H, W = shape
+    g = torch.Generator().manual_seed(B * 1000 + H + cin)
+    conv = torch.nn.Conv2d(cin, 64, 7, stride=2, padding=3, bias=False)
+    bn = torch.nn.BatchNorm2d(64)
+    with torch.no_grad():
+        conv.weight.normal_(0, 0.1, generator=g)
+        bn.weight.uniform_(0.5, 1.5, generator=g); bn.bias.uniform_(-0.3, 0.3, generator=g)
+        bn.running_mean.uniform_(-0.2, 0.2, generator=g); bn.running_var.uniform_(0.5, 1.5, generator=g)
+    bn.eval()
+    x = torch.randn(B, cin, H, W, generator=g)
+    with torch.no_grad():
+        want = torch.relu(bn(conv(x.double().float()))).double()
+        ref64 = torch.relu(torch.nn.functional.batch_norm(
+            torch.nn.functional.conv2d(x.double(), conv.weight.double(), None, 2, 3), bn.running_mean.double(),
+            bn.running_var.double(), bn.weight.double(), bn.bias.double(), False, 0.0, bn.eps))
+    conv.cuda(); bn.cuda()
+    st = E.StemConv(conv, bn, cin)
+    xin = E.nchw_to_nhwc(x.cuda(), 8)
+    ho, wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    out = torch.empty((B, ho, wo, 64), device="cuda")
+    st.run(xin, B, H, W, out)
+    torch.cuda.synchronize()
+    got = out.permute(0, 3, 1, 2).cpu().double()
+    assert (got - ref64).abs().max().item() < 3e-5 * max(1.0, ref64.abs().max().item())
+    assert (got - ref64).abs().max().item() < 4 * (want - ref64).abs().max().item() + 1e-6   # fp32-grade accuracy
+
+
 def test_u8_frame_preprocessing_matches_dataset(E):
     fr = synth.synth_frames_u8(3, 45, 80, seed=7)
     want = torch.from_numpy((fr.transpose(0, 3, 1, 2) / 255)).type(torch.FloatTensor)   # utils/dataset.py:154-159
