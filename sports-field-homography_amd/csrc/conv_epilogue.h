@@ -90,7 +90,7 @@ __device__ __forceinline__ void sfh_conv_epilogue(const sfh_conv_desc& d, const 
   // the fp32 residual beside an S3 destination and the border-class shift table exist only for the
   // 2x2 up-scatter conv (fused Up block); every other instance compiles them out
   unsigned voff[MT], rvoff[UPF ? MT : 1], cls[UPF ? MT : 1];
-  const bool res_s3 = s3 && !(UPF && d.residual_f32);
+  const bool res_s3 = s3 && !d.residual_f32;
 #pragma unroll
   for (int mi = 0; mi < MT; ++mi) {
     const int s = msub0 + mi;
@@ -155,10 +155,19 @@ __device__ __forceinline__ void sfh_conv_epilogue(const sfh_conv_desc& d, const 
             v[3] += __builtin_bit_cast(float, w[1] & 0xFFFF0000u);
           }
         } else {
-          const bool rf = UPF && s3;   // fp32 residual addressed independently of the S3 destination
-          const f32x4 q = __builtin_bit_cast(
-              f32x4, __builtin_amdgcn_raw_buffer_load_b128(rr_, (int)(rf ? rvoff[UPF ? mi : 0] : voff[mi]),
-                                                           (int)(rf ? (unsigned)ni * 64u : nioff), 0));
+          // fp32 NHWC residual; beside an S3 destination (residual_f32) it is addressed on its own
+          // (same pixel, channel stride cs) - computed here so that no other launch pays for it
+          unsigned ro = voff[mi], rn = nioff;
+          if (s3) {
+            if constexpr (UPF) {
+              ro = rvoff[mi];
+            } else {
+              ro = voff[mi] == kSfhOOB ? kSfhOOB
+                                       : (((unsigned)(pb[mi] * g.Ho + py[mi]) * wdst + (unsigned)px[mi]) * cs + c_lane) * 4u;
+            }
+            rn = (unsigned)ni * 64u;
+          }
+          const f32x4 q = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rr_, (int)ro, (int)rn, 0));
 #pragma unroll
           for (int j = 0; j < 4; ++j) v[j] += q[j];
         }

@@ -608,6 +608,7 @@ extern "C" int sfh_conv_s3_fwd(const sfh_conv_desc* dp, void* stream_) {
                 "conv_s3_fwd: up-scatter needs ksize 1 or 2, stride=1, cout/4 multiple of 64, one source");
   SFH_REQUIRE(d.ksize != 2 || d.out_mode == SFH_OUT_UPSCATTER2, "conv_s3_fwd: ksize 2 exists only as the up-scatter conv");
   SFH_REQUIRE(!d.residual_f32 || (d.residual && d.dst_fmt == SFH_FMT_S3), "conv_s3_fwd: residual_f32 needs a residual and an S3 dst");
+  SFH_REQUIRE(!d.residual_f32 || d.ksize == 2 || d.out_mode == SFH_OUT_NHWC, "conv_s3_fwd: residual_f32 with a plain output only");
   // buffering policy: short K -> two single-buffered workgroups per CU; long K -> one
   // double-buffered workgroup.  SFH_DEBUG_S3_DB=0/1 forces one variant (experiments).
   const int nstages = (d.c0 + (d.src1 ? d.c1 : 0)) / 32;

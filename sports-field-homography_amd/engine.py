@@ -373,6 +373,10 @@ class UNetEngine:
         MFMAs per product with fp32 accumulation (fp32-equivalent accuracy); "fp32" - fp32
         activations and fp32 MFMA throughout."""
         self.bilinear = bool(net.unet_bilinear)
+        # fused Up levels where the composed 2x2 conv runs first (see run()): the two full-resolution-most
+        # levels, where that conv is memory-heavy (measured per level: none 629, {4} 634, {3,4} 638, all 635
+        # frames/s).  SFH_DEBUG_UP_SWAP="" / "4" / "1,2,3,4" overrides.
+        self.up_swap = {int(t) for t in os.environ.get("SFH_DEBUG_UP_SWAP", "3,4").split(",") if t}
         if precision not in ("bf16x6", "fp32"):
             raise ValueError(f"precision={precision!r}: expected 'bf16x6' or 'fp32'")
         self.device = device
@@ -468,10 +472,18 @@ class UNetEngine:
             ey, ex = hs - 2 * hy, ws_ - 2 * wy   # F.pad of Up: diff 1 pads one row / column AFTER the tensor
             if f"up{i}.fused" in L and ey in (0, 1) and ex in (0, 1):
                 part = ws.get(f"up{i}.part", (B, hs, ws_, L[f"up{i}.skip"].cout_real))     # fp32 partial
-                L[f"up{i}.skip"].run(skip, B, hs, ws_, part)
                 mid = act(f"up{i}.conv.mid", (B, hs, ws_), L[f"up{i}.fused"].cout_real)
-                L[f"up{i}.fused"].run(y, B, hy + ey, wy + ex, mid, residual=part,
-                                      up_dst=(hs, ws_) if (ey or ex) else None)
+                fu, sk = L[f"up{i}.fused"], L[f"up{i}.skip"]
+                if i in self.up_swap:
+                    # composed 2x2 conv first: it writes the 4 B fp32 partial instead of reading one and writing
+                    # 6 B of S3; the MFMA-bound skip-half 3x3 conv then absorbs the residual, the ReLU and the split
+                    fu.relu, sk.relu = False, True
+                    fu.run(y, B, hy + ey, wy + ex, part, up_dst=(hs, ws_) if (ey or ex) else None)
+                    sk.run(skip, B, hs, ws_, mid, residual=part)
+                else:
+                    fu.relu, sk.relu = True, False
+                    sk.run(skip, B, hs, ws_, part)
+                    fu.run(y, B, hy + ey, wy + ex, mid, residual=part, up_dst=(hs, ws_) if (ey or ex) else None)
                 y = act(f"up{i}.conv.out", (B, hs, ws_), cout, f32=(i == 4))
                 L[f"up{i}.conv.3"].run(mid, B, hs, ws_, y)
                 continue
