@@ -21,8 +21,9 @@ if any('S3Cfg<2,' in r['Kernel_Name'] for r in step):
     # low-resolution tensor, credited with the u-half of the reference's 3x3 conv; no ConvTranspose launch
     L = L[:10] + [("u1.skip", gm(512, 512, 45, 80)), ("u1.fuse", gm(512, 512, 45, 80)), ("u1.3", gm(512, 512, 45, 80)),
                   ("u2.skip", gm(256, 256, 90, 160)), ("u2.fuse", gm(256, 256, 90, 160)), ("u2.3", gm(256, 256, 90, 160)),
-                  ("u3.skip", gm(128, 128, 180, 320)), ("u3.fuse", gm(128, 128, 180, 320)), ("u3.3", gm(128, 128, 180, 320)),
-                  ("u4.skip", gm(64, 64, 360, 640)), ("u4.fuse", gm(64, 64, 360, 640)), ("u4.3", gm(64, 64, 360, 640))]
+                  # u3 / u4: the composed 2x2 conv runs first, the skip-half 3x3 conv finishes (engine.UNetEngine.up_swap)
+                  ("u3.fuse", gm(128, 128, 180, 320)), ("u3.skip", gm(128, 128, 180, 320)), ("u3.3", gm(128, 128, 180, 320)),
+                  ("u4.fuse", gm(64, 64, 360, 640)), ("u4.skip", gm(64, 64, 360, 640)), ("u4.3", gm(64, 64, 360, 640))]
 dur = lambda r: (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e6
 is_conv = lambda n: 'conv_mfma' in n or 'conv_s3' in n or 'conv3x3_c4' in n or 'stem7x7' in n
 convs = [r for r in step if is_conv(r['Kernel_Name'])]
