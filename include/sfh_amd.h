@@ -98,6 +98,17 @@ typedef struct sfh_conv_desc {
    * one layer to the next makes a layer start on the part of its input that the previous launch wrote
    * last, i.e. the part still resident in L2 / Infinity Cache. */
   int32_t reverse_tiles;
+  /* OutConv fused behind the last 3x3 conv (sfh_conv_s3_fwd, cout == 64, plain output): with head_w set the
+   * launch also computes logits = head_w (head_nc x 64) . y + head_b for its pixels and writes them NCHW to
+   * head_logits (B,head_nc,H,W) and, if head_stn is set, cat((logits, frame)) zero-padded to 8 channels to
+   * head_stn (B,H,W,8) (frame: head_frame, fp32 NHWC with 4 stored channels) - what sfh_outconv_fwd does in
+   * a second pass over y.  head_skip_dst != 0: y itself is not stored. */
+  const float* head_w;
+  const float* head_b;
+  int32_t head_nc, head_skip_dst;
+  float* head_logits;
+  float* head_stn;
+  const float* head_frame;
 } sfh_conv_desc;
 
 const char* sfh_last_error(void);

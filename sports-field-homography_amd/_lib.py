@@ -30,6 +30,8 @@ class ConvDesc(C.Structure):
         ("src_fmt", _i), ("dst_fmt", _i), ("dst_pool", _p), ("pool_cs", _i),
         ("residual_f32", _i), ("shift_border", _p), ("up_dst_h", _i), ("up_dst_w", _i),
         ("reverse_tiles", _i),
+        ("head_w", _p), ("head_b", _p), ("head_nc", _i), ("head_skip_dst", _i),
+        ("head_logits", _p), ("head_stn", _p), ("head_frame", _p),
     ]
 
 

@@ -119,7 +119,7 @@ __device__ __forceinline__ void sfh_conv_epilogue(const sfh_conv_desc& d, const 
       rowi = (unsigned)(b * g.Ho + y);
       xo = (unsigned)x;
     }
-    voff[mi] = ok ? rowi * rowb + xo * xb + lane_co : kSfhOOB;
+    voff[mi] = (ok && !d.head_skip_dst) ? rowi * rowb + xo * xb + lane_co : kSfhOOB;
     if constexpr (UPF) {
       // fp32 NHWC residual beside an S3 destination (same pixel, channel stride cs)
       rvoff[mi] = ok ? ((rowi * wdst + xo) * cs + c_lane) * 4u : kSfhOOB;

@@ -353,6 +353,58 @@ __global__ __launch_bounds__(256, 2) void conv_s3_kernel(const sfh_conv_desc d, 
     }
   }
   sfh_conv_epilogue<C, 2, C::MT_M>(d, g, acc, n0 + 32 * wn, wm * C::MT_M, r0, x0, lq, lg);
+
+  // ---- OutConv fused behind the last conv (unet/unet_parts.py:74-77): acc now holds the activated outputs
+  if constexpr (C::KS == 3 && C::STRIDE == 1) {
+    if (d.head_w) {
+      float* const hl = smem_f;  // [2 cout halves][NSUBT groups][16 pixels][8 classes]
+      const int nc = d.head_nc;
+      __syncthreads();           // every wave is past its last operand read: the stage buffer is free
+      for (int k = 0; k < nc; ++k) {
+        f32x4 wk[2];
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) wk[ni] = *reinterpret_cast<const f32x4*>(d.head_w + k * 64 + 32 * wn + ni * 16 + 4 * lg);
+#pragma unroll
+        for (int mi = 0; mi < C::MT_M; ++mi) {
+          float p = 0.f;
+#pragma unroll
+          for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) p += acc[ni][mi][j] * wk[ni][j];
+          p += __shfl_xor(p, 16);
+          p += __shfl_xor(p, 32);
+          if (lg == 0) hl[((wn * C::NSUBT + wm * C::MT_M + mi) * 16 + lq) * 8 + k] = p;
+        }
+      }
+      __syncthreads();
+      // one thread per pixel of the tile (NSUBT * 16 <= 256)
+      if (tid < C::NSUBT * 16) {
+        const int s = tid >> 4, q = tid & 15;
+        const int sy = s / C::SUBX, sx = s - sy * C::SUBX;
+        const int oy = sy * C::SH + q / C::SW, ox = sx * C::SW + q % C::SW;
+        const int x = x0 + ox, r = r0 + oy;
+        const int b = (int)__umulhi((unsigned)r, g.rows_magic);
+        const int y = r - b * g.rows_per_img;
+        if (x < g.Wo && r < g.rows_total && y < g.Ho) {
+          float lgt[8];
+#pragma unroll
+          for (int k = 0; k < 8; ++k)
+            lgt[k] = k < nc ? hl[(s * 16 + q) * 8 + k] + hl[((C::NSUBT + s) * 16 + q) * 8 + k] + d.head_b[k] : 0.f;
+          const long hw = (long)g.Ho * g.Wo, pix = (long)y * g.Wo + x;
+          for (int k = 0; k < nc; ++k) d.head_logits[((long)b * nc + k) * hw + pix] = lgt[k];
+          if (d.head_stn) {
+            const f32x4 fr = *reinterpret_cast<const f32x4*>(d.head_frame + ((long)b * hw + pix) * 4);
+            float v8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            for (int k = 0; k < nc; ++k) v8[k] = lgt[k];
+            for (int k = 0; k < 3 && nc + k < 8; ++k) v8[nc + k] = fr[k];
+            float* o = d.head_stn + ((long)b * hw + pix) * 8;
+            *reinterpret_cast<f32x4*>(o) = (f32x4){v8[0], v8[1], v8[2], v8[3]};
+            *reinterpret_cast<f32x4*>(o + 4) = (f32x4){v8[4], v8[5], v8[6], v8[7]};
+          }
+        }
+      }
+    }
+  }
 }
 
 // ------------------------------------------------------------------ weight packing (split)
@@ -609,6 +661,12 @@ extern "C" int sfh_conv_s3_fwd(const sfh_conv_desc* dp, void* stream_) {
   SFH_REQUIRE(d.ksize != 2 || d.out_mode == SFH_OUT_UPSCATTER2, "conv_s3_fwd: ksize 2 exists only as the up-scatter conv");
   SFH_REQUIRE(!d.residual_f32 || (d.residual && d.dst_fmt == SFH_FMT_S3), "conv_s3_fwd: residual_f32 needs a residual and an S3 dst");
   SFH_REQUIRE(!d.residual_f32 || d.ksize == 2 || d.out_mode == SFH_OUT_NHWC, "conv_s3_fwd: residual_f32 with a plain output only");
+  SFH_REQUIRE(!d.shift_border || d.ksize == 2, "conv_s3_fwd: shift_border exists only for the 2x2 up-scatter conv");
+  if (d.head_w)
+    SFH_REQUIRE(d.ksize == 3 && d.stride == 1 && d.cout == 64 && d.out_mode == SFH_OUT_NHWC && !d.dst_pool && d.head_b &&
+                    d.head_logits && d.head_nc >= 1 && d.head_nc <= 8 && (!d.head_stn || (d.head_frame && d.head_nc <= 5)),
+                "conv_s3_fwd: the fused OutConv head needs a 3x3 stride-1 conv with 64 output channels and a plain output");
+  SFH_REQUIRE(!d.head_skip_dst || d.head_w, "conv_s3_fwd: head_skip_dst without a head");
   // buffering policy: short K -> two single-buffered workgroups per CU; long K -> one
   // double-buffered workgroup.  SFH_DEBUG_S3_DB=0/1 forces one variant (experiments).
   const int nstages = (d.c0 + (d.src1 ? d.c1 : 0)) / 32;

@@ -267,7 +267,7 @@ class PackedConv:
         return self
 
     def run(self, src0, batch, H, W, dst, src1=None, pool0=False, pad1=(0, 0), residual=None, tile=None,
-            dst_pool=None, up_dst=None):
+            dst_pool=None, up_dst=None, head=None):
         """src0/src1: NHWC float32 tensors (or S3 tensors (B,H,W,3,C) bf16 when the layer is s3);
         dst/residual/dst_pool: float32 NHWC, or S3 when their dtype is bfloat16.  H, W: conv input frame."""
         lib = _lib.load()
@@ -307,6 +307,12 @@ class PackedConv:
             d.tile = choose_tile(batch, ho, wo, self.stride, zr)
         d.wpacked, d.scale, d.shift = self.wpacked.data_ptr(), self.scale.data_ptr(), self.shift.data_ptr()
         d.cout, d.relu = self.cout, 1 if self.relu else 0
+        if head is not None:   # OutConv fused behind this conv (sfh_conv_desc.head_*)
+            d.head_w, d.head_b, d.head_nc = head["w"].data_ptr(), head["b"].data_ptr(), head["nc"]
+            d.head_logits = head["logits"].data_ptr()
+            d.head_stn = head["stn"].data_ptr() if head.get("stn") is not None else None
+            d.head_frame = head["frame"].data_ptr() if head.get("frame") is not None else None
+            d.head_skip_dst = 1 if head.get("skip_dst") else 0
         d.reverse_tiles = 1 if (self.s3 and PackedConv.snake and PackedConv._flip) else 0
         PackedConv._flip = not PackedConv._flip
         d.residual = residual.data_ptr() if residual is not None else None
@@ -443,12 +449,12 @@ class UNetEngine:
                 return ws.get(name, s3_shape(*shape_bhw, c), torch.bfloat16)
             return ws.get(name, tuple(shape_bhw) + (c,))
 
-        def dconv(name, src0, h, w, cout, src1=None, pool0=False, pad1=(0, 0), want_pool=False, out_f32=False):
+        def dconv(name, src0, h, w, cout, src1=None, pool0=False, pad1=(0, 0), want_pool=False, out_f32=False, head=None):
             mid = act(name + ".mid", (B, h, w), L[name + ".0"].cout_real)
             out = act(name + ".out", (B, h, w), cout, f32=out_f32)
             pooled = act(name + ".pool", (B, h // 2, w // 2), cout) if (want_pool and s3) else None
             L[name + ".0"].run(src0, B, h, w, mid, src1=src1, pool0=pool0, pad1=pad1)
-            L[name + ".3"].run(mid, B, h, w, out, dst_pool=pooled)
+            L[name + ".3"].run(mid, B, h, w, out, dst_pool=pooled, head=head)
             return out, pooled
 
         # encoder: in bf16x6 mode every Down's MaxPool2d(2) is written by the producer's epilogue;
@@ -464,6 +470,16 @@ class UNetEngine:
             feats.append(f)
             pooled.append(p)
         y = feats[4]
+        # OutConv (+ the STN input) rides in the epilogue of the last 3x3 conv when nothing else needs y
+        logits = torch.empty((B, self.nc, H, W), dtype=torch.float32, device=x.device)
+        if want_stn_in and self.nc + 3 > 8:
+            raise NotImplementedError("mask_classes > 5 with resnet_input='img+mask' needs a wider STN input buffer")
+        stn_in = ws.get("stn_in", (B, H, W, 8), zero=True) if want_stn_in else None
+        head = None
+        if (s3 and not want_argmax and not (want_uv and self.outuv is not None)
+                and L["up4.conv.3"].cout_real == 64 and os.environ.get("SFH_FUSE_HEAD", "1") != "0"):
+            head = {"w": self.outc_w, "b": self.outc_b, "nc": self.nc, "logits": logits, "stn": stn_in,
+                    "frame": xin if want_stn_in else None, "skip_dst": True}
         for i in range(1, 5):
             skip = feats[4 - i]
             hs, ws_ = _hw(skip)
@@ -485,7 +501,7 @@ class UNetEngine:
                     sk.run(skip, B, hs, ws_, part)
                     fu.run(y, B, hy + ey, wy + ex, mid, residual=part, up_dst=(hs, ws_) if (ey or ex) else None)
                 y = act(f"up{i}.conv.out", (B, hs, ws_), cout, f32=(i == 4))
-                L[f"up{i}.conv.3"].run(mid, B, hs, ws_, y)
+                L[f"up{i}.conv.3"].run(mid, B, hs, ws_, y, head=head if i == 4 else None)
                 continue
             cup = _chan(y) if self.bilinear else L[f"up{i}.up"].cout_real
             upb = act(f"up{i}.up", (B, 2 * hy, 2 * wy), cup)
@@ -501,16 +517,16 @@ class UNetEngine:
             else:
                 L[f"up{i}.up"].run(y, B, hy, wy, upb)
             dy, dx = hs - 2 * hy, ws_ - 2 * wy
-            y, _ = dconv(f"up{i}.conv", skip, hs, ws_, cout, src1=upb, pad1=(dy // 2, dx // 2), out_f32=(i == 4))
+            y, _ = dconv(f"up{i}.conv", skip, hs, ws_, cout, src1=upb, pad1=(dy // 2, dx // 2), out_f32=(i == 4),
+                         head=head if i == 4 else None)
         out = {"x_top": feats[4], "y4": y}
-        logits = torch.empty((B, self.nc, H, W), dtype=torch.float32, device=x.device)
         amax = torch.empty((B, H, W), dtype=torch.uint8, device=x.device) if want_argmax else None
-        stn_in = ws.get("stn_in", (B, H, W, 8), zero=True) if want_stn_in else None
-        if want_stn_in and self.nc + 3 > 8:
-            raise NotImplementedError("mask_classes > 5 with resnet_input='img+mask' needs a wider STN input buffer")
-        _lib.check(lib.sfh_outconv_fwd(_ptr(y), 64, _ptr(self.outc_w), _ptr(self.outc_b), self.nc, B, H, W,
-                                       _ptr(logits), _ptr(amax), _ptr(stn_in), 8 if want_stn_in else 0,
-                                       _ptr(xin) if want_stn_in else None, 4, st), "outconv")
+        if head is None:
+            _lib.check(lib.sfh_outconv_fwd(_ptr(y), 64, _ptr(self.outc_w), _ptr(self.outc_b), self.nc, B, H, W,
+                                           _ptr(logits), _ptr(amax), _ptr(stn_in), 8 if want_stn_in else 0,
+                                           _ptr(xin) if want_stn_in else None, 4, st), "outconv")
+        else:
+            out.pop("y4")   # not materialised: the fused head consumed it in registers
         out["logits"] = logits
         if want_argmax:
             out["argmax"] = amax
