@@ -1038,6 +1038,7 @@ extern "C" int sfh_conv_wgrad(const float* dz, int dz_cs, int M, const float* x,
 #define SFH_WG(KS_, NS_)                                         \
   (t == 0 ? launch_wgrad<KS_, NS_, 2, 32>(a, st)                  \
           : (t == 1 ? launch_wgrad<KS_, NS_, 4, 16>(a, st) : launch_wgrad<KS_, NS_, 8, 8>(a, st)))
+  if (ksize == 3 && N <= 16) return SFH_WG(3, 1);  // the network's first layer (3 input channels stored as 4)
   if (ksize == 3) return SFH_WG(3, 4);
   if (ksize == 1) return SFH_WG(1, 4);
   return SFH_WG(4, 2);
