@@ -505,6 +505,35 @@ def test_fused_up_block_vs_unfused_and_oracle(E, monkeypatch, size):
     assert _maxerr(outs["1"]["theta"].cpu(), outs["0"]["theta"].cpu()) < 1e-5
 
 
+@pytest.mark.parametrize("size", [(90, 112), (48, 64)])
+def test_fused_outconv_head_vs_outconv_kernel(E, monkeypatch, size):
+    """OutConv + cat((logits, x)) in the epilogue of the last 3x3 conv against the separate OutConv kernel."""
+    from sfh_amd.reconstructor import Reconstructor
+    B, (H, W) = 2, size
+    court = synth.load_court_template("ncaa_nc4_640x360", 4, B)[:, :, :H, :W].contiguous()
+    poi = synth.load_court_poi("pitch", B)
+    x = synth.smooth_frames(B, H, W, seed=41)
+    res = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("SFH_FUSE_HEAD", flag)
+        net = Reconstructor(court.cuda(), poi.cuda(), target_size=(W, H), unet_size=(W, H), warp_size=(W, H))
+        sd = synth.synth_state_dict(net.state_dict(), 41)
+        net.load_state_dict(sd)
+        net.cuda().eval()
+        un, _ = net._get_engines()
+        with torch.no_grad():
+            r = un.run(x.cuda(), want_stn_in=True)
+            torch.cuda.synchronize()
+        assert ("y4" in r) == (flag == "0")          # the 64-channel tensor is not stored when the head is fused
+        res[flag] = (r["logits"].clone(), r["stn_in"].clone())
+    assert _maxerr(res["1"][0].cpu(), res["0"][0].cpu()) < 2e-5
+    assert _maxerr(res["1"][1].cpu(), res["0"][1].cpu()) < 2e-5
+    assert torch.equal(res["1"][1][..., 4:7], res["0"][1][..., 4:7]) and float(res["1"][1][..., 7].abs().max()) == 0.0
+    with torch.no_grad():
+        logits, _, _ = torch_ref.forward_unet(x, sd, (W, H), (W, H))
+    assert _maxerr(res["1"][0].cpu(), logits) < 3e-4
+
+
 @pytest.mark.parametrize("shape", [(3, 45, 83), (1, 16, 16), (2, 90, 112), (2, 23, 70)])
 @pytest.mark.parametrize("cin", [7, 5, 8])
 def test_stem_kernel_vs_torch(E, shape, cin):
