@@ -70,8 +70,17 @@ __global__ __launch_bounds__(256) void warp_kernel(const float* __restrict__ the
                                                    const float* __restrict__ tmpl, long tmpl_bstride,
                                                    int ht, int wt, int h, int w, float out_scale,
                                                    float* __restrict__ out_f, int32_t* __restrict__ out_i) {
+  // normalised x of the block's 256 columns: one IEEE division per thread instead of four (the four rows
+  // of the block share them); same arithmetic per column, so the result is unchanged
+  __shared__ float xn_s[256];
+  {
+    const int xc = blockIdx.x * 256 + threadIdx.x;
+    xn_s[threadIdx.x] = norm_axis(xc < w ? xc : w - 1, w);
+  }
+  __syncthreads();
   const int b = blockIdx.z;
-  const int xq = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4;  // first of 4 pixels
+  const int lx = (threadIdx.x & 63) * 4;
+  const int xq = blockIdx.x * 256 + lx;  // first of 4 pixels
   const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
   if (y >= h || xq >= w) return;
   Homog H;
@@ -83,7 +92,7 @@ __global__ __launch_bounds__(256) void warp_kernel(const float* __restrict__ the
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     float u, v;
-    apply_h(H, norm_axis(xq + j, w), yn, u, v);
+    apply_h(H, xn_s[lx + j], yn, u, v);
     val[j] = (xq + j < w) ? sample_one<MODE>(tm, u, v, wt, ht) : 0.f;
   }
   const long o = ((long)b * h + y) * w + xq;
