@@ -67,3 +67,16 @@ def test_model_refuses_cpu_execution():
     net = Reconstructor(synth.load_court_template(batch_size=1), synth.load_court_poi(batch_size=1)).eval()
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         net.predict(torch.zeros(1, 3, 360, 640))
+
+
+def test_missing_library_fails_loudly(tmp_path):
+    """No HIP extension -> an explicit error, never a silent CPU / PyTorch path."""
+    import subprocess
+    import sys
+    code = ("import os, sys; sys.path.insert(0, %r); os.environ['SFH_AMD_LIB'] = %r\n"
+            "from sfh_amd import _lib\n"
+            "try:\n    _lib.load()\nexcept _lib.SfhError as e:\n    print('SfhError:', e); sys.exit(7)\n"
+            "sys.exit(0)\n") % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), str(tmp_path / "nope.so"))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 7, r.stdout + r.stderr
+    assert "not found" in r.stdout and "no CPU/PyTorch fallback" in r.stdout
