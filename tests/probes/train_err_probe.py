@@ -1,4 +1,4 @@
-"""Gradient error of the HIP training path and of the fp32 CPU oracle, both against an fp64 oracle."""
+"""(test tooling: imports the CPU oracle) Gradient error of the HIP training path and of the fp32 CPU oracle, both against an fp64 oracle."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
