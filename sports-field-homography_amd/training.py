@@ -594,6 +594,9 @@ class _TrainForward(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, *douts):
+        if ctx.tape is None:
+            raise RuntimeError("the HIP training node was already backpropagated: its activations are released "
+                               "after the first backward (retain_graph is not supported)")
         net, tape, f = ctx.net, ctx.tape, ctx.f
         d = dict(zip(ctx.keys, douts))
         dth = theta_gradient(net, f, d.get("theta"), d.get("poi"), d.get("warp_mask")) if f["theta"] is not None else None
