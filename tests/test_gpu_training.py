@@ -600,3 +600,39 @@ def test_post_step_weights_vs_cpu_restatement(T):
         agree += ((d_ref - d_hip).abs() <= 0.05 * (10 * lr)).sum().item()
         total += v.numel()
     assert agree / total > 0.95, agree / total
+
+
+def test_loss_trajectory_vs_cpu_restatement(T):
+    """Three full iterations (train.py:155-237) on the HIP TrainStep and on the CPU restatement from the same
+    weights and batch: the loss terms stay together step after step (profiles/r01_train_loss_curve.txt holds
+    the 12-step version)."""
+    from sfh_amd.reconstructor import Reconstructor
+    B, H, W = 4, 96, 128
+    lam = (2.0, 2.0, 8.0, 1.0)
+    court = synth.load_court_template("ncaa_nc4_640x360", 4, B)[:, :, :H, :W].contiguous()
+    poi = synth.load_court_poi("pitch", B)
+    net = Reconstructor(court, poi, target_size=(W, H), unet_size=(W, H), warp_size=(W, H))
+    sd = synth.synth_state_dict(net.state_dict(), 61)
+    net.load_state_dict(sd)
+    x = synth.frames_to_float(synth.synth_frames_u8(B, H, W, seed=61))
+    batch = _batch(B, H, W, poi.shape[1], 62)
+    ref = train_ref.leaf_state(sd)
+    params = [v for v in ref.values() if v.requires_grad]
+    opt = torch.optim.RMSprop(params, lr=1e-4, weight_decay=1e-8, momentum=0.9)
+    cpu = []
+    for _ in range(3):
+        pr = train_ref.forward_train(x, ref, court, poi, warp_size=(W, H), unet_size=(W, H), target_size=(W, H))
+        l = train_ref.losses(pr, batch, lambdas=lam)
+        opt.zero_grad()
+        l["total"].backward()
+        torch.nn.utils.clip_grad_value_(params, 0.1)
+        opt.step()
+        cpu.append(sum(l[k].item() for k in ("seg", "rec", "consist", "reproj")))
+    net.court_img, net.court_poi = court.cuda(), poi.cuda()
+    net.cuda().train()
+    ts = T.TrainStep(net, lr=1e-4, weight_decay=1e-8)
+    xb, bb = x.cuda(), {k: v.cuda() for k, v in batch.items()}
+    hip = [ts.step(xb, bb).sum().item() for _ in range(3)]
+    assert cpu[2] < cpu[0] and hip[2] < hip[0]
+    for a, b in zip(hip, cpu):
+        assert abs(a - b) < 1e-2 * b, (hip, cpu)
