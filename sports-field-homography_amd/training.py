@@ -680,6 +680,23 @@ class TrainStep:
         self.chunks = torch.from_numpy(ch.view(np.uint8).reshape(-1).copy()).to(dev)
         self.nchunks = len(chunks)
 
+    def state_dict(self):
+        """Optimizer state for checkpoint / resume, keyed like ``net.state_dict()`` (train.py:321-322 saves
+        the model only; resuming RMSprop needs its running averages too)."""
+        names = [self.names(p) for p in self.params]
+        return {"global_step": self.global_step,
+                "square_avg": {n: t.detach().clone() for n, t in zip(names, self.sq)},
+                "momentum_buffer": {n: t.detach().clone() for n, t in zip(names, self.buf)}}
+
+    def load_state_dict(self, state):
+        names = [self.names(p) for p in self.params]
+        if set(state["square_avg"]) != set(names) or set(state["momentum_buffer"]) != set(names):
+            raise RuntimeError("TrainStep.load_state_dict: parameter names do not match this model")
+        for n, sq, buf in zip(names, self.sq, self.buf):   # in place: the device tables point at these tensors
+            sq.copy_(state["square_avg"][n])
+            buf.copy_(state["momentum_buffer"][n])
+        self.global_step = int(state["global_step"])
+
     def loss_and_grads(self, x, batch):
         """forward + losses + backward; fills self.grads, returns {'seg','rec','reproj','consist'} as a
         float64 device tensor of 4 values.  batch: mask (B,H,W) int64, weight (B), poi (B,N,2),

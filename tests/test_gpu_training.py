@@ -636,3 +636,39 @@ def test_loss_trajectory_vs_cpu_restatement(T):
     assert cpu[2] < cpu[0] and hip[2] < hip[0]
     for a, b in zip(hip, cpu):
         assert abs(a - b) < 1e-2 * b, (hip, cpu)
+
+
+def test_train_step_checkpoint_resume(T):
+    """model state_dict + TrainStep.state_dict() -> a fresh process-equivalent object continues bit-close to
+    the uninterrupted run (BatchNorm running stats, RMSprop averages and momentum all travel)."""
+    import copy
+    from sfh_amd.reconstructor import Reconstructor
+    B, H, W = 2, 64, 96
+    court = synth.load_court_template("ncaa_nc4_640x360", 4, B)[:, :, :H, :W].contiguous().cuda()
+    poi = synth.load_court_poi("pitch", B).cuda()
+
+    def make(sd):
+        net = Reconstructor(court, poi, target_size=(W, H), unet_size=(W, H), warp_size=(W, H))
+        net.load_state_dict(sd)
+        return net.cuda().train()
+
+    x = synth.frames_to_float(synth.synth_frames_u8(B, H, W, seed=71)).cuda()
+    batch = {k: v.cuda() for k, v in _batch(B, H, W, poi.shape[1], 72).items()}
+    sd0 = synth.synth_state_dict(Reconstructor(court, poi, target_size=(W, H), unet_size=(W, H), warp_size=(W, H)).state_dict(), 71)
+    a = make(sd0)
+    ta = T.TrainStep(a, lr=1e-4)
+    for _ in range(2):
+        ta.step(x, batch)
+    ck_model = copy.deepcopy({k: v.detach().clone() for k, v in a.state_dict().items()})
+    ck_opt = ta.state_dict()
+    la = [ta.step(x, batch).sum().item() for _ in range(2)]
+    b = make(ck_model)
+    tb = T.TrainStep(b, lr=1e-4)
+    tb.load_state_dict(ck_opt)
+    assert tb.global_step == 2
+    lb = [tb.step(x, batch).sum().item() for _ in range(2)]
+    for u, v in zip(la, lb):
+        assert abs(u - v) < 2e-3 * abs(u), (la, lb)
+    worst = max(((pa.detach() - pb.detach()).abs().max() / (pa.detach().abs().max() + 1e-12)).item()
+                for pa, pb in zip(a.parameters(), b.parameters()))
+    assert worst < 5e-3, worst
