@@ -221,6 +221,11 @@ int sfh_homography_warp_fwd(const float* theta, const float* tmpl, int64_t tmpl_
                             int ht, int wt, int batch, int h, int w, int mode,
                             float out_scale, float* out_f32, int32_t* out_i32, void* stream);
 
+/* Test hook (never on the product path): exhaustive GPU sweep of the two exact-division shortcuts of the
+ * warp kernel against the IEEE divisions they replace - 1/z for every float with 2^-64 <= |z| <= 2^64, and
+ * create_meshgrid's (i/(n-1) - 0.5)*2 for every 0 <= i < n <= 16385.  mismatches: DEVICE int64[2].        */
+int sfh_selftest_warp_arith(int64_t* mismatches, void* stream);
+
 /* transform_poi (models/reconstructor.py:120-130): inverse(theta) applied to the court
  * points, then p/2 + 0.5 if normalize.  theta (B,3,3), poi (B,N,2) -> out (B,N,2).        */
 int sfh_poi_project_fwd(const float* theta, const float* poi, int batch, int npts,

@@ -14,6 +14,7 @@ Two kinds of output:
    deterministic synthetic weights of ``sfh_amd.synth``.  These pin ``oracle/torch_ref.py``.
 
 Usage:  python oracle/make_fixtures.py [--full]     (--full adds the 640x360 end-to-end vector)
+        python oracle/make_fixtures.py --configs c2,c5,c3   (BASELINE configs at their stated sizes)
 """
 import argparse
 import importlib.util
@@ -33,6 +34,7 @@ DATA = os.path.join(ROOT, "sports-field-homography_amd", "data")
 
 from sfh_amd import synth  # noqa: E402
 from oracle import torch_ref  # noqa: E402
+from oracle.fixture_inputs import c3_batch, grad_sample_index  # noqa: E402
 
 
 def _load(name, rel):
@@ -234,17 +236,136 @@ def make_full_golden(up_mod, rn_mod):
     print("full golden: theta", theta.numpy().reshape(B, 9), "consist", ce.numpy())
 
 
+def _pack2(am):
+    """(B,H,W) uint8 class ids 0..3 -> (B, H*W/4) uint8, four ids per byte (MSB first)."""
+    B = am.shape[0]
+    return np.packbits(np.unpackbits(am[..., None], axis=-1)[..., 6:].reshape(B, -1), axis=-1)
+
+
+MARGIN_BINS = np.array([0, 1e-5, 2e-5, 5e-5, 1e-4, 2e-4, 5e-4, 1e-3, 2e-3, 5e-3, 1e-2, 1e-1, 1, 1e3], np.float64)
+LOW_MARGIN = 1e-2   # pixels whose top-2 logit margin is below this are listed individually
+
+
+def _predict_golden(up_mod, rn_mod, x, court, poi, wh, chunk):
+    """Reference classes for UNet / ResNetSTN (eval mode, frames are independent), oracle for the Kornia
+    leg: theta, consistency score, POI, arg-max mask, top-2 margins, sub-sampled logits."""
+    W, H = wh
+    B = x.shape[0]
+    net = _loaded(_RefNet(up_mod, rn_mod), 0)
+    logits = torch.empty((B, 4, H, W))
+    theta = torch.empty((B, 1, 3, 3))
+    for i in range(0, B, chunk):
+        lg, _, _ = net.unet(x[i:i + chunk])
+        logits[i:i + chunk] = lg
+        theta[i:i + chunk] = net.resnet_reg(torch.cat((lg, x[i:i + chunk]), 1))
+        print("  frames", i, "...", i + chunk, flush=True)
+    wm = torch_ref.warp(theta, court, (W, H), nearest=True) * 4
+    ce = torch.nn.functional.cross_entropy(logits, wm.long(), reduction="none").mean(dim=(1, 2))
+    p = torch_ref.transform_poi(theta, poi)
+    am = torch.argmax(logits, 1).to(torch.uint8).numpy()
+    top2 = torch.topk(logits, 2, dim=1).values
+    margin = (top2[:, 0] - top2[:, 1]).numpy().reshape(B, -1)
+    low = np.nonzero(margin < LOW_MARGIN)
+    return dict(theta=theta.numpy(), consist=ce.numpy(), poi=p.numpy(), argmax_2bit=_pack2(am),
+                low_margin_frame=low[0].astype(np.int16), low_margin_pixel=low[1].astype(np.int32),
+                low_margin_value=margin[low].astype(np.float32),
+                margin_hist=np.stack([np.histogram(margin[b], MARGIN_BINS)[0] for b in range(B)]).astype(np.int32),
+                margin_bins=MARGIN_BINS, logits_sub=logits[:, :, 4::16, 4::16].numpy().copy(),
+                warp_mask_2bit=_pack2(wm.numpy().astype(np.uint8)))
+
+
+def make_c2_golden(up_mod, rn_mod):
+    """BASELINE config 2 at its stated size: 16 frames of 640x360, NCAA template, seed-0 weights and frames
+    (= bench.py's model; the first two frames are those of full_640x360.npz)."""
+    torch.set_num_threads(os.cpu_count())
+    B = 16
+    with torch.no_grad():
+        x = synth.frames_to_float(synth.synth_frames_u8(B, 360, 640, seed=0))
+        court = synth.load_court_template("ncaa_nc4_640x360", 4, B)
+        poi = synth.load_court_poi("pitch", B)
+        out = _predict_golden(up_mod, rn_mod, x, court, poi, (640, 360), 4)
+    np.savez_compressed(os.path.join(GOLD, "c2_640x360_b16.npz"), **out)
+    print("c2 golden: consist", out["consist"], "margin hist", out["margin_hist"].sum(0))
+
+
+def make_c5_golden(up_mod, rn_mod):
+    """BASELINE config 5: 1280x720 frames, 4-class pitch template (pitch_mask_v3_nc4_hd), 33-point POI
+    (predict.py:151-155,186-192); first 2 frames of the batch of 16 the GPU test runs."""
+    torch.set_num_threads(os.cpu_count())
+    B = 2
+    with torch.no_grad():
+        x = synth.frames_to_float(synth.synth_frames_u8(B, 720, 1280, seed=0))
+        court = synth.load_court_template("pitch_v3_nc4_1280x720", 4, B)
+        poi = synth.load_court_poi("pitch", B)
+        out = _predict_golden(up_mod, rn_mod, x, court, poi, (1280, 720), 1)
+    np.savez_compressed(os.path.join(GOLD, "c5_1280x720_b2.npz"), **out)
+    print("c5 golden: theta", out["theta"].reshape(B, 9), "consist", out["consist"])
+
+
+def make_c3_golden(up_mod, rn_mod):
+    """BASELINE config 3 at 640x360 (B=2 of the 16): the reference's own classes under ``net.train()``
+    (batch-statistics BatchNorm) + autograd, losses of train.py:181-224 (oracle/train_ref.losses), once in
+    fp32 and once in fp64.  Stored: loss values, theta, and for every parameter a fixed sample of the fp64
+    gradient plus the fp32 run's relative error against it (the yardstick for the GPU's error)."""
+    from oracle import train_ref
+    torch.set_num_threads(os.cpu_count())
+    B, H, W = 2, 360, 640
+    x = synth.frames_to_float(synth.synth_frames_u8(B, H, W, seed=0))
+    court = synth.load_court_template("ncaa_nc4_640x360", 4, B)
+    poi = synth.load_court_poi("pitch", B)
+    batch = c3_batch(B, H, W, poi.shape[1])
+    res = {}
+    for tag, dt in (("f32", torch.float32), ("f64", torch.float64)):
+        net = _loaded(_RefNet(up_mod, rn_mod), 0).to(dt).train()
+        xx = x.to(dt)
+        logits, _, _ = net.unet(xx)
+        theta = net.resnet_reg(torch.cat((logits, xx), 1))
+        preds = {"logits": logits, "theta": theta,
+                 "poi": torch_ref.transform_poi(theta, poi.to(dt)),
+                 "warp_mask": torch_ref.warp(theta, court.to(dt), (W, H), nearest=False)}
+        bt = {k: (v.to(dt) if v.is_floating_point() else v) for k, v in batch.items()}
+        ls = train_ref.losses(preds, bt)
+        ls["total"].backward()
+        res[tag] = ({k: float(v.detach()) for k, v in ls.items()}, theta.detach().double().numpy(),
+                    {k: p.grad.detach().double().numpy().ravel() for k, p in net.named_parameters()},
+                    logits.detach()[:, :, 4::16, 4::16].double().numpy())
+        print(tag, res[tag][0], flush=True)
+    out = {"theta_f32": res["f32"][1], "theta_f64": res["f64"][1],
+           "logits_sub_f32": res["f32"][3].astype(np.float32), "logits_sub_f64": res["f64"][3]}
+    for k in res["f32"][0]:
+        out[f"loss_f32.{k}"] = np.float64(res["f32"][0][k])
+        out[f"loss_f64.{k}"] = np.float64(res["f64"][0][k])
+    names = list(res["f64"][2])
+    out["names"] = np.array(names)
+    for i, k in enumerate(names):
+        g64, g32 = res["f64"][2][k], res["f32"][2][k]
+        idx = grad_sample_index(g64.size)
+        n64 = np.linalg.norm(g64)
+        out[f"g64.{i}"] = g64[idx]
+        out[f"stat.{i}"] = np.array([n64, np.linalg.norm(g32 - g64) / max(n64, 1e-300),
+                                     np.linalg.norm(g32[idx] - g64[idx]) / max(np.linalg.norm(g64[idx]), 1e-300)])
+    np.savez_compressed(os.path.join(GOLD, "c3_train_640x360_b2.npz"), **out)
+    st = np.array([out[f"stat.{i}"] for i in range(len(names))])
+    print("c3 golden: fp32-vs-fp64 per-tensor relative error: median %.2e  p90 %.2e  max %.2e" %
+          (np.median(st[:, 1]), np.quantile(st[:, 1], 0.9), st[:, 1].max()))
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--full", action="store_true")
     ap.add_argument("--data-only", action="store_true")
     ap.add_argument("--train-only", action="store_true", help="only tests/golden/train_blocks.npz")
+    ap.add_argument("--configs", default="", help="comma list of c2,c5,c3: only the full-size BASELINE-config vectors")
     a = ap.parse_args()
     os.makedirs(GOLD, exist_ok=True)
     make_data()
     if not a.data_only:
         up_mod = _load("ref_unet_parts", "unet/unet_parts.py")
         rn_mod = _load("ref_resnet", "models/resnet.py")
+        if a.configs:
+            for c in a.configs.split(","):
+                {"c2": make_c2_golden, "c5": make_c5_golden, "c3": make_c3_golden}[c](up_mod, rn_mod)
+            raise SystemExit(0)
         if a.train_only:
             make_train_goldens(up_mod, rn_mod)
             raise SystemExit(0)

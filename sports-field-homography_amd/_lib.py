@@ -59,6 +59,7 @@ SIGNATURES = {
     "sfh_upsample2x_bilinear_nhwc": (C.c_int, [_p, _p, C.c_int, C.c_int, C.c_int, C.c_int, _p]),
     "sfh_outconv_fwd": (C.c_int, [_p, C.c_int, _p, _p, C.c_int, C.c_int, C.c_int, C.c_int, _p, _p,
                                   _p, C.c_int, _p, C.c_int, _p]),
+    "sfh_selftest_warp_arith": (C.c_int, [_p, _p]),
     "sfh_homography_warp_fwd": (C.c_int, [_p, _p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int,
                                           C.c_int, C.c_int, C.c_float, _p, _p, _p]),
     "sfh_poi_project_fwd": (C.c_int, [_p, _p, C.c_int, C.c_int, C.c_int, _p, _p]),

@@ -15,6 +15,9 @@ SOURCES = ["capi.hip", "conv_mfma.hip", "conv_s3.hip", "pointwise.hip", "warp.hi
 # sampling against oracle/warp_ref.py); the flag is harmless elsewhere.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-ffp-contract=off",
          "-Wall", "-Wno-unused-function"]
+# warp.hip is VALU-issue-bound and the SLP vectoriser packs its scalar fp32 arithmetic into v_pk_*_f32
+# instructions, which issue at half rate on gfx950 (measured: profiles/micro/warp_variants.hip)
+EXTRA_FLAGS = {"warp.hip": ["-fno-slp-vectorize"]}
 
 
 def _stale(target, deps):
@@ -35,7 +38,7 @@ def build(force=False, verbose=True):
         obj = os.path.join(CSRC, s.replace(".hip", ".o"))
         objs.append(obj)
         if force or _stale(obj, [src] + headers):
-            cmd = [hipcc] + FLAGS + ["-c", src, "-o", obj]
+            cmd = [hipcc] + FLAGS + EXTRA_FLAGS.get(s, []) + ["-c", src, "-o", obj]
             if verbose:
                 print(" ".join(cmd), flush=True)
             procs.append((s, subprocess.Popen(cmd)))

@@ -51,69 +51,259 @@ __device__ __forceinline__ float fetch(const float* __restrict__ tm, float fx, f
   return 0.f;
 }
 
-template <int MODE>
-__device__ __forceinline__ float sample_one(const float* __restrict__ tm, float u, float v, int wt, int ht) {
-  const float px = unnorm(u, wt), py = unnorm(v, ht);
-  if (MODE == 0) return fetch(tm, rintf(px), rintf(py), wt, ht);  // round-half-to-even
-  const float x0 = floorf(px), y0 = floorf(py);
-  const float wx1 = __fsub_rn(px, x0), wx0 = __fsub_rn(1.0f, wx1);
-  const float wy1 = __fsub_rn(py, y0), wy0 = __fsub_rn(1.0f, wy1);
-  float r = __fmul_rn(fetch(tm, x0, y0, wt, ht), __fmul_rn(wy0, wx0));
-  r = __fadd_rn(r, __fmul_rn(fetch(tm, x0 + 1.f, y0, wt, ht), __fmul_rn(wy0, wx1)));
-  r = __fadd_rn(r, __fmul_rn(fetch(tm, x0, y0 + 1.f, wt, ht), __fmul_rn(wy1, wx0)));
-  r = __fadd_rn(r, __fmul_rn(fetch(tm, x0 + 1.f, y0 + 1.f, wt, ht), __fmul_rn(wy1, wx1)));
-  return r;
+// ---------------------------------------------------------------------------------------------
+// Second-generation forward kernel: the same arithmetic bit for bit in about half the vector instructions.
+// The kernel is VALU-issue-bound (profiles/r02_warp_*.txt), so every choice below removes vector
+// instructions per pixel:
+//
+// * 1/(Z + 1e-8): hardware reciprocal (1 ulp) + two Newton steps in FMA arithmetic = the correctly
+//   rounded quotient for every |z| in [2^-64, 2^64] (exhaustive sweep on the GPU: sfh_selftest_warp_arith);
+//   i/(n-1) of create_meshgrid: q0 = i*r and one FMA residual step with the correctly rounded r = 1/(n-1)
+//   (exhaustive for every n <= 16384).  A wave-uniform test on theta selects this path; huge or non-finite
+//   matrices take the IEEE divisions.
+// * A wave covers 64*J consecutive pixels of RPT rows, lane -> pixel lane + 64*j: every store is one
+//   coalesced 256-byte wave instruction, the taps of one instruction fall into one or two cache lines,
+//   and t0*xn, t3*xn, t6*xn are row-invariant - a thread keeps them in registers over its rows, so a
+//   homogeneous coordinate costs two additions per pixel.  The row constants (t1*yn, t4*yn, t7*yn) are
+//   computed once by lane rr of the wave and broadcast through v_readlane (scalar operands afterwards).
+// * (NOLOAD is a measurement variant of profiles/micro/warp_variants.hip: taps are not fetched.)
+// * Taps go through a buffer descriptor on the template: an invalid tap gets an out-of-range offset and
+//   the hardware returns 0 (grid_sample's zeros padding) - no divergent branches, all taps of a row in
+//   flight together.
+// * When |t8| - |t6| - |t7| > 0 by a margin, |Z| > 1e-8 on the whole frame and the select between
+//   1/(Z + 1e-8) and 1 disappears (wave-uniform).
+// Packed fp32 instructions (v_pk_add/mul/fma_f32, two rows per instruction) were measured SLOWER
+// (4.31 vs 4.72 TB/s at 640x360 B=1024): they issue at half rate here.
+
+// LEVEL 0: IEEE divisions (any theta); 1: fast reciprocal; 2: fast reciprocal and |Z| > 1e-8 everywhere
+template <int LEVEL>
+__device__ __forceinline__ float recip_rn(float z) {
+  if (LEVEL == 0) return __fdiv_rn(1.0f, z);
+  // caller guarantees |z| <= 2^60 (a tiny or zero z gives a result the caller discards)
+  float r = __builtin_amdgcn_rcpf(z);
+  float e = __builtin_fmaf(-z, r, 1.0f);
+  r = __builtin_fmaf(e, r, r);
+  e = __builtin_fmaf(-z, r, 1.0f);
+  return __builtin_fmaf(e, r, r);
 }
 
-template <int MODE>
-__global__ __launch_bounds__(256) void warp_kernel(const float* __restrict__ theta,
-                                                   const float* __restrict__ tmpl, long tmpl_bstride,
-                                                   int ht, int wt, int h, int w, float out_scale,
-                                                   float* __restrict__ out_f, int32_t* __restrict__ out_i) {
-  // normalised x of the block's 256 columns: one IEEE division per thread instead of four (the four rows
-  // of the block share them); same arithmetic per column, so the result is unchanged
-  __shared__ float xn_s[256];
-  {
-    const int xc = blockIdx.x * 256 + threadIdx.x;
-    xn_s[threadIdx.x] = norm_axis(xc < w ? xc : w - 1, w);
+// i / d for integral 0 <= i <= d < 2^14, rd = __fdiv_rn(1, d)
+__device__ __forceinline__ float div_small(float i, float d, float rd) {
+  const float q0 = __fmul_rn(i, rd);
+  return __builtin_fmaf(__builtin_fmaf(-q0, d, i), rd, q0);
+}
+
+template <bool SMALL>
+__device__ __forceinline__ float norm_axis2(int i, int n, float rd) {
+  const float q = SMALL ? div_small((float)i, (float)(n - 1), rd) : __fdiv_rn((float)i, (float)(n - 1));
+  return __fmul_rn(__fsub_rn(q, 0.5f), 2.0f);
+}
+
+__device__ __forceinline__ float tap_ld(__amdgpu_buffer_rsrc_t rs, unsigned off) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)off, 0, 0));
+}
+
+constexpr unsigned kTapOOB = 0xFFFFFFFCu;   // beyond any descriptor's num_records: the load returns 0
+
+// rx, ry integral-valued floats -> byte offset of the tap or kTapOOB.  LEVEL 0 tolerates NaN / inf.
+template <int LEVEL>
+__device__ __forceinline__ unsigned tap_off(float rx, float ry, int wt, int ht) {
+  if (LEVEL == 0) {
+    const bool ok = (rx >= 0.f) & (rx <= (float)(wt - 1)) & (ry >= 0.f) & (ry <= (float)(ht - 1));
+    const float fi = __builtin_fmaf(ry, (float)wt, rx);             // exact: < 2^24 (checked by the launcher)
+    return ok ? ((unsigned)(int)fi << 2) : kTapOOB;
   }
-  __syncthreads();
+  // finite coordinates: v_cvt_i32_f32 saturates, one unsigned compare per axis
+  const int ix = (int)rx, iy = (int)ry;
+  const bool ok = ((unsigned)ix < (unsigned)wt) & ((unsigned)iy < (unsigned)ht);
+  return ok ? (__umul24((unsigned)iy, (unsigned)wt) + (unsigned)ix) << 2 : kTapOOB;   // valid => iy, wt < 2^24
+}
+
+// OUT: 0 = int32 mask only (predict), 1 = float only (forward / training), 2 = both
+template <int MODE, int J, int RPT, int OUT, int LEVEL, bool SMALL, bool NOLOAD = false>
+__device__ __forceinline__ void warp2_body(const float (&t)[9], int b, int lane, int c0, int r0,
+                                           const float* __restrict__ tmpl, long tmpl_bstride,
+                                           int ht, int wt, int h, int w, float rdw, float rdh, float out_scale,
+                                           float* __restrict__ out_f, int32_t* __restrict__ out_i) {
+  float a0[J], a3[J], a6[J];
+  unsigned coff[J];
+#pragma unroll
+  for (int j = 0; j < J; ++j) {
+    const int c = c0 + 64 * j;
+    const float xn = norm_axis2<SMALL>(c < w ? c : w - 1, w, rdw);
+    a0[j] = __fmul_rn(t[0], xn);
+    a3[j] = __fmul_rn(t[3], xn);
+    a6[j] = __fmul_rn(t[6], xn);
+    coff[j] = c < w ? (unsigned)c * 4u : kTapOOB;
+  }
+  // lane rr holds the row constants of row r0 + rr
+  const float ynl = norm_axis2<SMALL>(r0 + (lane & (RPT - 1)), h, rdh);
+  const float c1l = __fmul_rn(t[1], ynl), c4l = __fmul_rn(t[4], ynl), c7l = __fmul_rn(t[7], ynl);
+  const __amdgpu_buffer_rsrc_t rt = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(tmpl + (long)b * tmpl_bstride), 0, ht * wt * 4, 0x00020000);
+  const int nrows = (h - r0 < RPT) ? h - r0 : RPT;
+  const long rowbase = ((long)b * h + r0) * w;
+  // rows beyond the frame fall outside these descriptors: their stores are dropped
+  const __amdgpu_buffer_rsrc_t rof = __builtin_amdgcn_make_buffer_rsrc(
+      OUT != 0 ? out_f + rowbase : nullptr, 0, OUT != 0 ? nrows * w * 4 : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t roi = __builtin_amdgcn_make_buffer_rsrc(
+      OUT != 1 ? out_i + rowbase : nullptr, 0, OUT != 1 ? nrows * w * 4 : 0, 0x00020000);
+  const float sx = 0.5f * (float)wt, sy = 0.5f * (float)ht;
+  constexpr int NT = MODE == 0 ? 1 : 4;
+  unsigned off[J][NT];
+  float wgt[J][NT], tv[J][NT];
+
+  // tap offsets (and bilinear weights) of row r0 + rr
+  auto coords = [&](int rr) {
+    const float c1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, c1l), rr));
+    const float c4 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, c4l), rr));
+    const float c7 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, c7l), rr));
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+      const float X = __fadd_rn(__fadd_rn(a0[j], c1), t[2]);
+      const float Y = __fadd_rn(__fadd_rn(a3[j], c4), t[5]);
+      const float Z = __fadd_rn(__fadd_rn(a6[j], c7), t[8]);
+      const float r = recip_rn<LEVEL>(__fadd_rn(Z, 1e-8f));
+      const float s = (LEVEL == 2 || fabsf(Z) > 1e-8f) ? r : 1.0f;
+      // unnorm(): fma(fl(u + 1), size/2, -0.5)
+      const float px = __builtin_fmaf(__fadd_rn(__fmul_rn(s, X), 1.0f), sx, -0.5f);
+      const float py = __builtin_fmaf(__fadd_rn(__fmul_rn(s, Y), 1.0f), sy, -0.5f);
+      if (MODE == 0) {
+        off[j][0] = tap_off<LEVEL>(rintf(px), rintf(py), wt, ht);
+      } else {
+        const float x0 = floorf(px), y0 = floorf(py);
+        const float wx1 = __fsub_rn(px, x0), wx0 = __fsub_rn(1.0f, wx1);
+        const float wy1 = __fsub_rn(py, y0), wy0 = __fsub_rn(1.0f, wy1);
+        wgt[j][0] = __fmul_rn(wy0, wx0);
+        wgt[j][1] = __fmul_rn(wy0, wx1);
+        wgt[j][2] = __fmul_rn(wy1, wx0);
+        wgt[j][3] = __fmul_rn(wy1, wx1);
+        if (LEVEL == 0) {
+          off[j][0] = tap_off<0>(x0, y0, wt, ht);
+          off[j][1] = tap_off<0>(x0 + 1.f, y0, wt, ht);
+          off[j][2] = tap_off<0>(x0, y0 + 1.f, wt, ht);
+          off[j][3] = tap_off<0>(x0 + 1.f, y0 + 1.f, wt, ht);
+        } else {
+          // the four taps share one address computation; per-axis validity of x0, x0+1, y0, y0+1
+          const int ix = (int)x0, iy = (int)y0;   // saturating conversions of finite values
+          const unsigned ux = (unsigned)ix, uy = (unsigned)iy, uw = (unsigned)wt, uh = (unsigned)ht;
+          // ix, iy may be saturated: validity masks every use, the wrapped products are never used
+          const unsigned o00 = (unsigned)(__mul24(iy, wt) + ix) << 2;   // 24-bit multiply: exact whenever a tap is valid
+          off[j][0] = (ux < uw && uy < uh) ? o00 : kTapOOB;
+          off[j][1] = (ux + 1u < uw && uy < uh) ? o00 + 4u : kTapOOB;
+          off[j][2] = (ux < uw && uy + 1u < uh) ? o00 + uw * 4u : kTapOOB;
+          off[j][3] = (ux + 1u < uw && uy + 1u < uh) ? o00 + uw * 4u + 4u : kTapOOB;
+        }
+      }
+    }
+  };
+
+  // Software pipeline over the rows: the taps of row rr+1 are issued BEFORE the stores of row rr and are
+  // consumed one row of coordinate arithmetic later - the wait for them never covers a younger store
+  // (loads and stores share the in-order vmcnt counter) and their latency overlaps the thread's own work.
+  auto issue_taps = [&]() {
+#pragma unroll
+    for (int j = 0; j < J; ++j)
+#pragma unroll
+      for (int k = 0; k < NT; ++k) tv[j][k] = NOLOAD ? __builtin_bit_cast(float, off[j][k] & 0x3fffffffu) : tap_ld(rt, off[j][k]);
+  };
+  coords(0);
+  issue_taps();
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int rr = 0; rr < RPT; ++rr) {
+    // no early exit for rows beyond the frame (their stores fall outside the descriptors): a branch here
+    // lets the optimiser sink the prefetched taps back into the next row's block
+    float val[J];
+    float w0[J][NT];
+    if (MODE == 1) {
+#pragma unroll
+      for (int j = 0; j < J; ++j)
+#pragma unroll
+        for (int k = 0; k < NT; ++k) w0[j][k] = wgt[j][k];
+    }
+    if (rr + 1 < RPT) coords(rr + 1);     // a row beyond the frame: harmless, its taps are never stored
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+      val[j] = tv[j][0];
+      if (MODE == 1) {
+        val[j] = __fmul_rn(tv[j][0], w0[j][0]);
+        val[j] = __fadd_rn(val[j], __fmul_rn(tv[j][1], w0[j][1]));
+        val[j] = __fadd_rn(val[j], __fmul_rn(tv[j][2], w0[j][2]));
+        val[j] = __fadd_rn(val[j], __fmul_rn(tv[j][3], w0[j][3]));
+      }
+    }
+    if (rr + 1 < RPT) issue_taps();
+    __builtin_amdgcn_sched_barrier(0);    // the scheduler would sink these loads to their uses one row later
+    const int soff = rr * w * 4;
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+      if (OUT != 0) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val[j]), rof, (int)coff[j], soff, 0);
+      if (OUT != 1)
+        __builtin_amdgcn_raw_buffer_store_b32((unsigned)(int32_t)__fmul_rn(val[j], out_scale), roi, (int)coff[j], soff, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+template <int MODE, int J, int RPT, int OUT, bool NOLOAD = false>
+__global__ __launch_bounds__(256) void warp2_kernel(const float* __restrict__ theta,
+                                                    const float* __restrict__ tmpl, long tmpl_bstride,
+                                                    int ht, int wt, int h, int w, float rdw, float rdh, float out_scale,
+                                                    float* __restrict__ out_f, int32_t* __restrict__ out_i) {
+  // rdw = 1/(w-1), rdh = 1/(h-1) rounded to nearest (the launcher computes them: wave-uniform IEEE divisions
+  // would cost every thread two dozen instructions)
+  static_assert((RPT & (RPT - 1)) == 0 && RPT <= 64, "RPT: power of two");
+  const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int b = blockIdx.z;
-  const int lx = (threadIdx.x & 63) * 4;
-  const int xq = blockIdx.x * 256 + lx;  // first of 4 pixels
-  const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
-  if (y >= h || xq >= w) return;
-  Homog H;
+  const int c0 = blockIdx.x * (64 * J) + lane;
+  const int r0 = (blockIdx.y * 4 + wv) * RPT;
+  if (r0 >= h) return;
+  float t[9];
 #pragma unroll
-  for (int k = 0; k < 9; ++k) H.t[k] = theta[b * 9 + k];  // wave-uniform -> scalar loads
-  const float* tm = tmpl + (long)b * tmpl_bstride;
-  const float yn = norm_axis(y, h);
-  float val[4];
+  for (int k = 0; k < 9; ++k) t[k] = theta[b * 9 + k];
+  // wave-uniform classification of theta (|xn|, |yn| <= 1 on the whole frame)
+  bool fin = true;
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    float u, v;
-    apply_h(H, xn_s[lx + j], yn, u, v);
-    val[j] = (xq + j < w) ? sample_one<MODE>(tm, u, v, wt, ht) : 0.f;
+  for (int k = 0; k < 9; ++k) fin &= fabsf(t[k]) <= 0x1p59f;      // false for NaN
+  const float zs = fabsf(t[6]) + fabsf(t[7]) + fabsf(t[8]);
+  const bool live = (fabsf(t[8]) - fabsf(t[6]) - fabsf(t[7])) > 1e-6f * zs + 1e-7f;   // => |Z| > 1e-8 everywhere
+#define SFH_WARP2_GO(LEVEL, SMALL) \
+  warp2_body<MODE, J, RPT, OUT, LEVEL, SMALL, NOLOAD>(t, b, lane, c0, r0, tmpl, tmpl_bstride, ht, wt, h, w, rdw, rdh, out_scale, out_f, out_i)
+  if (fin && w <= 16384 && h <= 16384) {
+    if (live) SFH_WARP2_GO(2, true); else SFH_WARP2_GO(1, true);
+  } else {
+    SFH_WARP2_GO(0, false);
   }
-  const long o = ((long)b * h + y) * w + xq;
-  const bool vec = (xq + 3 < w) && ((w & 3) == 0);
-  if (out_f) {
-    if (vec) {
-      *reinterpret_cast<f32x4*>(out_f + o) = (f32x4){val[0], val[1], val[2], val[3]};
-    } else {
-      for (int j = 0; j < 4 && xq + j < w; ++j) out_f[o + j] = val[j];
-    }
+#undef SFH_WARP2_GO
+}
+
+// Exhaustive arithmetic self-tests (called by tests/, never by the product path): count the inputs on which
+// the fast forms above differ from the IEEE divisions they replace.
+__global__ void selftest_recip_kernel(unsigned lo, unsigned long long count, unsigned long long* bad) {
+  unsigned long long n = 0;
+  for (unsigned long long i = blockIdx.x * (unsigned long long)blockDim.x + threadIdx.x; i < count;
+       i += (unsigned long long)gridDim.x * blockDim.x) {
+    const float z = __builtin_bit_cast(float, (unsigned)(lo + i));
+    const float a = recip_rn<1>(z), c = __fdiv_rn(1.0f, z);
+    n += (__builtin_bit_cast(unsigned, a) != __builtin_bit_cast(unsigned, c)) && !(a != a && c != c);
+    const float a2 = recip_rn<1>(-z), c2 = __fdiv_rn(1.0f, -z);
+    n += (__builtin_bit_cast(unsigned, a2) != __builtin_bit_cast(unsigned, c2)) && !(a2 != a2 && c2 != c2);
   }
-  if (out_i) {
-    int32_t iv[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) iv[j] = (int32_t)__fmul_rn(val[j], out_scale);  // trunc, like .type(int32)
-    if (vec) {
-      *reinterpret_cast<int4*>(out_i + o) = make_int4(iv[0], iv[1], iv[2], iv[3]);
-    } else {
-      for (int j = 0; j < 4 && xq + j < w; ++j) out_i[o + j] = iv[j];
-    }
+  if (n) atomicAdd(bad, n);
+}
+
+__global__ void selftest_axis_kernel(int nmax, unsigned long long* bad) {
+  // every (i, n) with 2 <= n <= nmax, 0 <= i < n: blockIdx.x + 2 = n
+  const int n = blockIdx.x + 2;
+  if (n > nmax) return;
+  const float rd = __fdiv_rn(1.0f, (float)(n - 1));
+  unsigned long long c = 0;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    const float a = norm_axis2<true>(i, n, rd), r = norm_axis(i, n);   // product rule: SMALL only for n <= 16384
+    c += __builtin_bit_cast(unsigned, a) != __builtin_bit_cast(unsigned, r);
   }
+  if (c) atomicAdd(bad, c);
 }
 
 // inverse(theta) in fp64 (adjugate / determinant), rounded to fp32, then the same pinned
@@ -272,14 +462,57 @@ extern "C" int sfh_homography_warp_fwd(const float* theta, const float* tmpl, in
               "homography_warp: bad geometry b=%d h=%d w=%d ht=%d wt=%d", batch, h, w, ht, wt);
   SFH_REQUIRE(mode == 0 || mode == 1, "homography_warp: mode %d (0 nearest, 1 bilinear)", mode);
   SFH_REQUIRE(tmpl_bstride == 0 || tmpl_bstride >= (int64_t)ht * wt, "homography_warp: bad template stride");
-  const dim3 grid((unsigned)sfh_cdiv(w, 256), (unsigned)sfh_cdiv(h, 4), (unsigned)batch);
-  if (mode == 0)
-    hipLaunchKernelGGL(warp_kernel<0>, grid, dim3(256), 0, (hipStream_t)stream, theta, tmpl,
-                       (long)tmpl_bstride, ht, wt, h, w, out_scale, out_f32, out_i32);
-  else
-    hipLaunchKernelGGL(warp_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, theta, tmpl,
-                       (long)tmpl_bstride, ht, wt, h, w, out_scale, out_f32, out_i32);
+  SFH_REQUIRE((int64_t)ht * wt <= (1 << 22) && (int64_t)h * w * 4 * 64 < (1ll << 31),
+              "homography_warp: template %dx%d or frame %dx%d too large for 32-bit tap / row-block offsets", wt, ht, w, h);
+  const float rdw = 1.0f / (float)(w - 1), rdh = 1.0f / (float)(h - 1);   // IEEE single divisions
+  // Wave shape: 64*J consecutive pixels x RPT rows.  J = 5 when the row splits into 320-pixel segments
+  // (640, 1280, 1920 ...), else 4; bilinear (4 taps and 4 weights per pixel in flight): J = 2.
+  // RPT: the largest of 8 / 4 / 2 that still leaves about eight waves per SIMD on 256 CUs.
+  const int J = mode == 1 ? 2 : ((w % 320 == 0) ? 5 : 4);
+  const long segs = (long)sfh_cdiv(w, 64 * J) * batch;
+  int rpt = mode == 1 ? 4 : 8;
+  while (rpt > 2 && segs * sfh_cdiv(h, rpt) < 16384) rpt >>= 1;
+  const int out = (out_f32 && out_i32) ? 2 : (out_f32 ? 1 : 0);
+  const dim3 grid((unsigned)sfh_cdiv(w, 64 * J), (unsigned)sfh_cdiv(h, 4 * rpt), (unsigned)batch);
+#define SFH_WARP_LAUNCH(MODE, JJ, RR, OO)                                                                    \
+  hipLaunchKernelGGL((warp2_kernel<MODE, JJ, RR, OO>), grid, dim3(256), 0, (hipStream_t)stream, theta, tmpl, \
+                     (long)tmpl_bstride, ht, wt, h, w, rdw, rdh, out_scale, out_f32, out_i32)
+#define SFH_WARP_OUT(MODE, JJ, RR)                    \
+  do {                                                \
+    if (out == 0) SFH_WARP_LAUNCH(MODE, JJ, RR, 0);   \
+    else if (out == 1) SFH_WARP_LAUNCH(MODE, JJ, RR, 1); \
+    else SFH_WARP_LAUNCH(MODE, JJ, RR, 2);            \
+  } while (0)
+#define SFH_WARP_RPT(MODE, JJ)                \
+  do {                                        \
+    if (rpt == 8) SFH_WARP_OUT(MODE, JJ, 8);  \
+    else if (rpt == 4) SFH_WARP_OUT(MODE, JJ, 4); \
+    else SFH_WARP_OUT(MODE, JJ, 2);           \
+  } while (0)
+  if (mode == 1) {
+    if (rpt == 4) SFH_WARP_OUT(1, 2, 4); else SFH_WARP_OUT(1, 2, 2);
+  } else if (J == 5) {
+    SFH_WARP_RPT(0, 5);
+  } else {
+    SFH_WARP_RPT(0, 4);
+  }
+#undef SFH_WARP_RPT
+#undef SFH_WARP_OUT
+#undef SFH_WARP_LAUNCH
   return sfh_check_launch("warp_kernel");
+}
+
+extern "C" int sfh_selftest_warp_arith(int64_t* mismatches, void* stream) {
+  // exhaustive: every float z with 2^-64 <= |z| <= 2^64 for the reciprocal; every (i, n), n <= 16385 for the axis.
+  // mismatches: DEVICE pointer to two int64 counters (zeroed here).
+  SFH_REQUIRE(mismatches, "selftest_warp_arith: null pointer");
+  if (hipMemsetAsync(mismatches, 0, 16, (hipStream_t)stream) != hipSuccess) return sfh_check_launch("memset");
+  const unsigned lo = __builtin_bit_cast(unsigned, 0x1p-64f), hi = __builtin_bit_cast(unsigned, 0x1p64f);
+  hipLaunchKernelGGL(selftest_recip_kernel, dim3(4096), dim3(256), 0, (hipStream_t)stream, lo,
+                     (unsigned long long)(hi - lo) + 1, (unsigned long long*)mismatches);
+  hipLaunchKernelGGL(selftest_axis_kernel, dim3(16384), dim3(256), 0, (hipStream_t)stream, 16385,
+                     (unsigned long long*)mismatches + 1);
+  return sfh_check_launch("selftest_warp_arith");
 }
 
 extern "C" int sfh_poi_project_fwd(const float* theta, const float* poi, int batch, int npts,

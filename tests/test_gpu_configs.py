@@ -1,0 +1,256 @@
+"""BASELINE.json configs at their STATED sizes on the GPU, against vectors produced by the reference's own
+classes (oracle/make_fixtures.py --configs c2,c5,c3; the Kornia leg - warp / POI - is the pinned-order
+restatement oracle/warp_ref.py, see its header for the pin status):
+
+* C2: 640x360, batch 16, NCAA template: theta / poi / consistency / logits, arg-max mask with the number
+  of differing pixels and the margin they sit at, exact warp for the GPU's own theta, rounded POI pixels.
+* C5: 1280x720, batch 16 through the real sub-batch path, 4-class pitch template, 33-point POI.
+* C3: one training forward + backward at 640x360 (B=2 of the 16): losses and, for every parameter, the
+  gradient against an fp64 run of the reference classes - bounded by a multiple of the error the
+  reference's own fp32 run has against fp64.
+
+Measured figures are appended to gpurun_out/parity_r02.jsonl when that directory exists (they are quoted
+in DESIGN.md).
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import train_ref, warp_ref  # noqa: E402
+from sfh_amd import synth  # noqa: E402
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLD = os.path.join(HERE, "golden")
+torch.set_num_threads(max(1, min(16, os.cpu_count() or 1)))
+
+
+def _record(tag, **kw):
+    out = os.path.join(os.path.dirname(HERE), "gpurun_out")
+    print(tag, json.dumps({k: v for k, v in kw.items() if k != "table"}))
+    if os.path.isdir(out):
+        with open(os.path.join(out, "parity_r02.jsonl"), "a") as f:
+            f.write(json.dumps(dict(case=tag, **kw)) + "\n")
+
+
+def _unpack2(packed, shape):
+    b = np.unpackbits(packed, axis=-1).reshape(shape + (2,))
+    return (b[..., 0] * 2 + b[..., 1]).astype(np.uint8)
+
+
+def _net(template, wh, B, precision, seed=0, nearest=True):
+    from sfh_amd.reconstructor import Reconstructor
+    court = synth.load_court_template(template, 4, B)
+    poi = synth.load_court_poi("pitch", B)
+    net = Reconstructor(court.cuda(), poi.cuda(), target_size=wh, unet_size=wh, warp_size=wh,
+                        warp_with_nearest=nearest)
+    net.precision = precision
+    sd = synth.synth_state_dict(net.state_dict(), seed)
+    net.load_state_dict(sd)
+    return net.cuda().eval(), sd, court, poi
+
+
+def _check_predict(tag, out, g, court, wh, nframes_golden):
+    """Every output of predict() for the first `nframes_golden` frames against the golden vector, the exact
+    warp check for all frames."""
+    W, H = wh
+    n = nframes_golden
+    B = out["theta"].shape[0]
+    theta = out["theta"].cpu()
+    logits = out["logits"].cpu()
+    dtheta = float((theta[:n] - torch.from_numpy(g["theta"])).abs().max())
+    dlog = float((logits[:n, :, 4::16, 4::16] - torch.from_numpy(g["logits_sub"])).abs().max())
+    dcons = float((out["consist_score"].cpu()[:n] - torch.from_numpy(g["consist"])).abs().max())
+    dpoi = float((out["poi"].cpu()[:n] - torch.from_numpy(g["poi"])).abs().max())
+    assert dtheta < 1e-4, dtheta                  # north_star: homography within 1e-4 abs
+    assert dlog < 5e-4, dlog
+    assert dpoi < 1e-4, dpoi
+
+    # ---- arg-max mask: which pixels differ, and at what top-2 margin of the reference logits
+    am_ref = _unpack2(g["argmax_2bit"], (n, H, W))
+    am = logits[:n].argmax(1).numpy().astype(np.uint8)
+    diff = np.argwhere(am != am_ref)
+    margin = np.full((n, H * W), np.inf, np.float32)       # only margins below 1e-2 are stored
+    margin[g["low_margin_frame"], g["low_margin_pixel"]] = g["low_margin_value"]
+    margin = margin.reshape(n, H, W)
+    dmarg = margin[diff[:, 0], diff[:, 1], diff[:, 2]] if len(diff) else np.zeros(0, np.float32)
+    # a pixel may flip only if the top-2 logits are closer than the two logits can each have moved
+    safe = 4.0 * dlog
+    assert (dmarg < safe).all(), (len(diff), float(dmarg.max()), safe)
+    below = int((g["low_margin_value"] < safe).sum())
+
+    # ---- nearest warp: the oracle's warp of the GPU's OWN theta must equal the GPU mask on every pixel
+    wm = out["warp_mask"].cpu()
+    want = (warp_ref.homography_warp(theta, court[:B], H, W, "nearest") * 4).to(torch.int32)
+    nexact = int((wm != want).sum())
+    assert nexact == 0, nexact
+    wm_ref = _unpack2(g["warp_mask_2bit"], (n, H, W))
+    warp_vs_golden = float((wm[:n].numpy() != wm_ref).mean())    # moves only with the 1e-7-level theta difference
+    assert warp_vs_golden < 2e-3
+    assert dcons < 2e-3 + 20.0 * warp_vs_golden, (dcons, warp_vs_golden)
+
+    # ---- POI pixel coordinates int(round(p * W)) (predict.py:383): exact away from rounding ties
+    p_ref, p = g["poi"], out["poi"].cpu().numpy()[:n]
+    scale = np.array([W, H], np.float32)
+    pix_ref, pix = np.rint(p_ref * scale), np.rint(p * scale)
+    frac = np.abs((p_ref * scale) - np.floor(p_ref * scale) - 0.5)
+    tie_band = 4.0 * dpoi * max(W, H) + 1e-6
+    off_tie = frac > tie_band
+    assert np.array_equal(pix[off_tie], pix_ref[off_tie])
+    _record(tag, frames=B, frames_vs_golden=n, max_abs_dtheta=dtheta, max_abs_dlogits_sub=dlog,
+            max_abs_dconsist=dcons, max_abs_dpoi=dpoi, argmax_pixels=int(n * H * W), argmax_differ=int(len(diff)),
+            argmax_differ_max_margin=float(dmarg.max()) if len(diff) else 0.0, safe_margin=safe,
+            pixels_below_safe_margin=below, margin_hist=g["margin_hist"].sum(0).tolist(),
+            margin_bins=g["margin_bins"].tolist(), warp_mismatch_vs_oracle_of_gpu_theta=nexact,
+            warp_mismatch_frac_vs_golden_theta=warp_vs_golden, poi_points=int(off_tie.size),
+            poi_points_in_tie_band=int((~off_tie).sum()), poi_pixels_differ=int((pix != pix_ref).sum()))
+
+
+@pytest.mark.parametrize("precision", ["bf16x6", "fp32"])
+def test_c2_640x360_batch16_golden(precision):
+    g = np.load(os.path.join(GOLD, "c2_640x360_b16.npz"))
+    net, _, court, _ = _net("ncaa_nc4_640x360", (640, 360), 16, precision)
+    x = synth.frames_to_float(synth.synth_frames_u8(16, 360, 640, seed=0))
+    with torch.no_grad():
+        out = net.predict(x.cuda(), consistency=True, project_poi=True)
+    torch.cuda.synchronize()
+    assert out["warp_mask"].dtype == torch.int32 and tuple(out["warp_mask"].shape) == (16, 360, 640)
+    _check_predict(f"C2 640x360 B=16 {precision}", out, g, court, (640, 360), 16)
+
+
+def test_c5_1280x720_batch16_pitch_template_poi():
+    """predict.py's HD configuration (predict.py:151-155,186-192): 16 frames in one call - whatever sub-batching
+    the 32-bit tensor addressing needs happens inside predict()."""
+    g = np.load(os.path.join(GOLD, "c5_1280x720_b2.npz"))
+    net, _, court, _ = _net("pitch_v3_nc4_1280x720", (1280, 720), 16, "bf16x6")
+    x = synth.frames_to_float(synth.synth_frames_u8(16, 720, 1280, seed=0))
+    with torch.no_grad():
+        out = net.predict(x.cuda(), consistency=True, project_poi=True)
+    torch.cuda.synchronize()
+    assert tuple(out["logits"].shape) == (16, 4, 720, 1280) and tuple(out["poi"].shape) == (16, 33, 2)
+    _check_predict("C5 1280x720 B=16 bf16x6", out, g, court, (1280, 720), 2)
+    # frames are independent (eval-mode BatchNorm): a frame gives the same bits wherever it sits in the batch
+    with torch.no_grad():
+        solo = net.predict(x[:2].cuda(), consistency=True, project_poi=True)
+    assert torch.equal(solo["theta"], out["theta"][:2]) and torch.equal(solo["warp_mask"], out["warp_mask"][:2])
+    assert torch.equal(solo["logits"], out["logits"][:2])
+
+
+def test_warp_arithmetic_selftest():
+    """The warp kernel's reciprocal (hardware rcp + two FMA Newton steps) and meshgrid division (one FMA
+    residual step) give the IEEE quotients on EVERY input of their domain (exhaustive sweep on the GPU)."""
+    import ctypes
+    from sfh_amd import _lib
+    lib = _lib.load()
+    bad = torch.ones(2, dtype=torch.int64, device="cuda")
+    _lib.check(lib.sfh_selftest_warp_arith(ctypes.c_void_p(bad.data_ptr()),
+                                           ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "selftest")
+    torch.cuda.synchronize()
+    assert bad.tolist() == [0, 0], bad.tolist()
+
+
+def test_public_methods_direct():
+    """net.forward_unet(), net.warp(), net.transform_poi() called the way the reference's callers do
+    (models/reconstructor.py:109-158), not through predict()."""
+    from oracle import torch_ref
+    net, sd, court, poi = _net("ncaa_nc4_640x360", (640, 360), 2, "bf16x6", seed=19)
+    x = synth.smooth_frames(2, 360, 640, seed=5)
+    with torch.no_grad():
+        logits, x_top, uv = net.forward_unet(x.cuda())
+        want_l, want_top, _ = torch_ref.forward_unet(x, sd)
+    assert uv is None and tuple(x_top.shape) == (2, 1024, 22, 40)
+    assert float((logits.cpu() - want_l).abs().max()) < 5e-4
+    assert float((x_top.cpu() - want_top).abs().max()) < 5e-4 * max(1.0, float(want_top.abs().max()))
+    th = torch.tensor(synth.REALISTIC_THETAS).reshape(2, 1, 3, 3)
+    with torch.no_grad():
+        wm = net.warp(th.cuda(), net.court_img)           # nearest (warp_with_nearest=True), float output
+        pp = net.transform_poi(th.cuda(), net.court_poi)
+        pr = net.transform_poi(th.cuda(), net.court_poi, normalize=False)
+    assert wm.dtype == torch.float32 and tuple(wm.shape) == (2, 360, 640)
+    assert torch.equal(wm.cpu(), warp_ref.homography_warp(th, court, 360, 640, "nearest"))
+    assert float((pp.cpu() - torch_ref.transform_poi(th, poi)).abs().max()) < 1e-5
+    assert float((pr.cpu() - torch_ref.transform_poi(th, poi, normalize=False)).abs().max()) < 1e-5
+    net.warp_with_nearest = False
+    with torch.no_grad():
+        wb = net.warp(th.cuda(), net.court_img)
+    assert float((wb.cpu() - warp_ref.homography_warp(th, court, 360, 640, "bilinear")).abs().max()) < 1e-6
+
+
+@pytest.mark.parametrize("precision", ["bf16x6", "fp32"])
+def test_c3_training_step_640x360_vs_fp64_reference(precision, monkeypatch):
+    """BASELINE config 3 at 640x360 (2 of the 16 frames): the reference classes under train() + autograd
+    produced loss values and gradients in fp32 and in fp64 (oracle/make_fixtures.py:make_c3_golden).  The HIP
+    training path must reproduce the losses, and every parameter gradient must sit within 4x of the distance
+    the reference's own fp32 run keeps from the fp64 gradient (per tensor, or the upper quartile of its stage where
+    the tensor's own fp32 figure is smaller).  Both train precisions: the split-bf16 default and fp32 MFMA."""
+    from oracle.fixture_inputs import c3_batch, grad_sample_index
+    from sfh_amd.reconstructor import Reconstructor
+    monkeypatch.setenv("SFH_TRAIN_PRECISION", precision)
+    g = np.load(os.path.join(GOLD, "c3_train_640x360_b2.npz"))
+    B, H, W = 2, 360, 640
+    court = synth.load_court_template("ncaa_nc4_640x360", 4, B)
+    poi = synth.load_court_poi("pitch", B)
+    net = Reconstructor(court.cuda(), poi.cuda(), target_size=(W, H), unet_size=(W, H), warp_size=(W, H))
+    net.load_state_dict(synth.synth_state_dict(net.state_dict(), 0))
+    net.cuda().train()
+    x = synth.frames_to_float(synth.synth_frames_u8(B, H, W, seed=0))
+    batch = {k: v.cuda() for k, v in c3_batch(B, H, W, poi.shape[1]).items()}
+    preds = net(x.cuda())
+    loss = train_ref.losses(preds, batch)
+    loss["total"].backward()
+    torch.cuda.synchronize()
+    assert float((preds["theta"].detach().cpu().double() - torch.from_numpy(g["theta_f64"])).abs().max()) < 1e-4
+    dl = float((preds["logits"].detach().cpu()[:, :, 4::16, 4::16].double() - torch.from_numpy(g["logits_sub_f64"])).abs().max())
+    dl32 = float(np.abs(g["logits_sub_f32"].astype(np.float64) - g["logits_sub_f64"]).max())
+    assert dl < 3.0 * dl32 + 2e-5, (dl, dl32)
+    lrec = {}
+    for k in ("seg", "rec", "reproj", "consist", "total"):
+        got, w64, w32 = float(loss[k].detach()), float(g[f"loss_f64.{k}"]), float(g[f"loss_f32.{k}"])
+        lrec[k] = (got, w32, w64)
+        # trunc(warp * 4) targets of the consistency term flip with the last bit of the bilinear warp
+        tol = 3.0 * abs(w32 - w64) + (1e-3 if k in ("consist", "total") else 2e-5) * max(1.0, abs(w64))
+        assert abs(got - w64) < tol, (k, got, w32, w64)
+    names = [str(n) for n in g["names"]]
+    params = dict(net.named_parameters())
+
+    def stage(k):   # tensors of one stage see the same upstream gradient noise
+        p = k.split(".")
+        if p[0] != "resnet_reg":
+            return p[0]
+        return "resnet_reg." + (p[1] if p[1].startswith("layer") or p[1] == "reg" else "stem")
+
+    e32_stage = {}
+    for i, k in enumerate(names):
+        if g[f"stat.{i}"][0] >= 1e-9:
+            e32_stage.setdefault(stage(k), []).append(float(g[f"stat.{i}"][2]))
+    e32_stage = {k: float(np.quantile(v, 0.75)) for k, v in e32_stage.items()}
+    rows, worst = [], []
+    for i, k in enumerate(names):
+        g64 = g[f"g64.{i}"]
+        n64, e32_full, e32 = g[f"stat.{i}"]
+        grad = params[k].grad
+        assert grad is not None, k
+        got = grad.detach().reshape(-1)[torch.from_numpy(grad_sample_index(grad.numel())).cuda()].cpu().double().numpy()
+        ns = np.linalg.norm(g64)
+        if ns < 1e-12 * max(1.0, n64) or n64 < 1e-9:
+            # conv bias in front of BatchNorm: the exact gradient is zero
+            assert np.abs(got).max() < 1e-6, (k, np.abs(got).max())
+            continue
+        e = np.linalg.norm(got - g64) / ns
+        rows.append((k, e, e32))
+        # The error of either fp32-grade run against fp64 is made of discrete events (ReLU / max-pool decisions
+        # that flip with the forward rounding), so a single tensor's fp32 figure can be luckily small: the
+        # yardstick is the larger of the tensor's own fp32 error and the upper-quartile fp32 error of its stage.
+        if e > 4.0 * max(e32, e32_stage[stage(k)]) + 1e-5:
+            worst.append((k, e, e32))
+    ratios = np.array([e / max(e32, 1e-6) for _, e, e32 in rows])
+    errs = np.array([e for _, e, _ in rows])
+    _record(f"C3 train 640x360 B=2 {precision}", losses=lrec, tensors=len(rows), median_err=float(np.median(errs)),
+            max_err=float(errs.max()), median_ratio_to_fp32=float(np.median(ratios)), max_ratio_to_fp32=float(ratios.max()),
+            over_bound=[(k, float(e), float(e32)) for k, e, e32 in worst], max_abs_dlogits=dl, fp32_max_abs_dlogits=dl32,
+            table=[(k, float(e), float(e32)) for k, e, e32 in rows])
+    assert not worst, worst
