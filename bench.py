@@ -60,6 +60,22 @@ def pmc_traffic(tag):
         return None
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: start N ranks (one process per GPU) through
+    torch.distributed.run as a CHILD process and relay its output.  This process never touches the GPU
+    (no torch import, no HIP call), so nothing is re-executed under an initialised device."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
 def train_bench(args):
     """Config 3 (train.py:155-237): forward under net.train(), CE + SmoothL1 + RRMSE + consistency CE,
     backward, clip_grad_value_(0.1), RMSprop(momentum 0.9).  The model's forward/backward run on the HIP
@@ -118,15 +134,55 @@ def train_bench(args):
         loss = step()
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
-    print(json.dumps({
+    return ({
         "metric": "training steps: frames/sec at %dx%d batch=%d (forward + losses + backward + clip + RMSprop)" % (W, H, B),
         "value": round(B * args.steps / el, 2), "unit": "frames/s", "n_gpus": 1, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(el / args.steps * 1e3, 2), "higher_is_better": True,
         "dtype": "bf16x6->f32 convs (fp32 MFMA backward-filter)", "data": "synthetic", "final_loss": float(loss.detach()),
         "losses_and_optimizer": "torch ops (caller side)" if args.train_autograd else "HIP kernels (training.TrainStep)",
         "peak_mem_gib": round(torch.cuda.max_memory_allocated() / 2**30, 2),
-        "config": {"workload": "BASELINE config 3: Reconstructor training step, CE + SmoothL1 + RRMSE + consistency CE"}}),
-        flush=True)
+        "config": {"workload": "BASELINE config 3: Reconstructor training step, CE + SmoothL1 + RRMSE + consistency CE"}})
+
+
+def extra_configs(args):
+    """BASELINE configs 3 and 5 on this GPU, a few steps each (driver-observed numbers for every
+    single-GPU config in one default run): C5 = predict() with consistency + POI on 16 frames of
+    1280x720 against the 4-class pitch template; C3 = one training step per batch of 16 at 640x360."""
+    import copy
+    import torch
+    from sfh_amd import synth
+    from sfh_amd.reconstructor import Reconstructor
+    res = {}
+    dev = torch.device("cuda", 0)
+    B, W, H = 16, 1280, 720
+    court = synth.load_court_template("pitch_v3_nc4_1280x720", 4, B).to(dev)
+    poi = synth.load_court_poi("pitch", B).to(dev)
+    net = Reconstructor(court, poi, target_size=(W, H), unet_size=(W, H), warp_size=(W, H), warp_with_nearest=True)
+    net.load_state_dict(synth.synth_state_dict(net.state_dict(), 0))
+    net.to(dev).eval()
+    x = synth.frames_to_float(synth.synth_frames_u8(B, H, W, seed=0)).to(dev)
+    with torch.no_grad():
+        for _ in range(2):
+            net.predict(x, consistency=True, project_poi=True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        n = 4
+        for _ in range(n):
+            net.predict(x, consistency=True, project_poi=True)
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+    res["C5_1280x720_batch16_pitch_template_poi"] = {
+        "value": round(B * n / el, 2), "unit": "frames/s", "ms_per_step": round(el / n * 1e3, 2), "steps": n, "warmup": 2,
+        "workload": "predict(consistency=True, project_poi=True), 1280x720, batch 16, pitch_mask_v3_nc4_hd template, 33-point POI"}
+    del net, x, court, poi
+    torch.cuda.empty_cache()
+    a = copy.copy(args)
+    a.batch, a.width, a.height, a.steps, a.warmup, a.train_autograd = 16, 640, 360, 4, 2, False
+    t = train_bench(a)
+    res["C3_train_step_640x360_batch16"] = {k: t[k] for k in ("value", "unit", "ms_per_step", "steps", "warmup", "dtype",
+                                                              "losses_and_optimizer", "peak_mem_gib", "final_loss")}
+    res["C3_train_step_640x360_batch16"]["workload"] = t["config"]["workload"]
+    return res
 
 
 def main():
@@ -147,9 +203,14 @@ def main():
     ap.add_argument("--train-autograd", action="store_true",
                     help="with --train: losses, clip and RMSprop as the caller's torch ops around the model's "
                          "autograd node (the reference's train.py structure) instead of the all-HIP TrainStep")
+    ap.add_argument("--no-extra-configs", action="store_true",
+                    help="skip the short C3 (training step) and C5 (1280x720) measurements appended at N=1")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return self_launch(args.gpus)
     if args.train or args.train_autograd:
-        return train_bench(args)
+        print(json.dumps(train_bench(args)), flush=True)
+        return
 
     import torch
     import torch.distributed as dist
@@ -160,8 +221,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N>1 must be launched with torch.distributed.run (one process per GPU)")
+        raise SystemExit(f"--gpus {args.gpus} but the launcher started {world} rank(s)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
@@ -268,6 +328,15 @@ def main():
                                   f"torch {torch.__version__} CPU fp32, {ncpu} threads, {model}",
                         "max_abs_dtheta_gpu_vs_cpu": dth}
 
+    # the other single-GPU BASELINE configs, a few steps each, AFTER the headline region (N = 1 only): the
+    # headline fields above are not touched by them
+    other_configs = None
+    if rank == 0 and world == 1 and not args.no_extra_configs and (W, H, B) == (640, 360, 16):
+        del frames, out
+        net._engines = None
+        torch.cuda.empty_cache()
+        other_configs = extra_configs(args)
+
     if rank == 0:
         line = {
             "metric": "frames/sec at 640x360 batch=16 (1/2/4/8 GPU) + homography L1 vs ref",
@@ -285,6 +354,7 @@ def main():
             "roofline": roofline,
             "cpu_baseline": cpu_baseline,
             "kernel_groups": other,
+            "other_configs": other_configs,
         }
         print(json.dumps(line), flush=True)
     if world > 1:
