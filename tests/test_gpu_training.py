@@ -120,9 +120,21 @@ def _nchw(t):
 
 @pytest.mark.parametrize("stride,ks,res", [(1, 3, False), (1, 3, True), (2, 3, False), (2, 1, False), (1, 1, True)])
 @pytest.mark.parametrize("shape", [(2, 13, 18), (3, 8, 40)])
-def test_conv_bn_act_backward(T, stride, ks, res, shape):
-    """conv (+bias) -> BatchNorm(train) (+residual) -> ReLU: outputs, input and parameter gradients."""
+@pytest.mark.parametrize("seed", [20240917, 1063, 1092, 1094])
+def test_conv_bn_act_backward(T, stride, ks, res, shape, seed):
+    """conv (+bias) -> BatchNorm(train) (+residual) -> ReLU: outputs, input and parameter gradients.
+
+    The conv's default initialisation draws from torch's global generator.  Round 1 saw this test fail once and
+    closed it by seeding that generator; the cause (tests/probes/conv_bn_seed_probe.py, 100 seeds x 10 cases x 2
+    precisions): in 3 of 2000 runs ONE pre-activation sits within rounding distance of zero, so the ReLU decision
+    of the fp32-grade run and of the fp64 oracle differ for that element - the output moves by 1e-6, but that
+    element's whole gradient toggles and the max-norm error of dx / dW jumps to 4e-3..5e-2.  torch's own CPU fp32
+    autograd shows the same jump (seed 1092: 3e-1 on the residual gradient).  It is a property of ReLU, not of the
+    kernels: the test therefore sends no gradient into elements whose fp64 pre-activation is closer to zero than
+    1e-4, and the three seeds that hit such an element stay in the parametrisation.  Every other run of the sweep
+    was below 1.6e-6 against the 2e-5 bound."""
     B, H, W = shape
+    torch.manual_seed(seed)
     g = torch.Generator().manual_seed(11 + stride + ks)
     conv = torch.nn.Conv2d(64, 128, ks, stride=stride, padding=ks // 2, bias=(stride == 1))
     bn = torch.nn.BatchNorm2d(128)
@@ -141,8 +153,11 @@ def test_conv_bn_act_backward(T, stride, ks, res, shape):
     ref.train()
     xr = x.double().requires_grad_(True)
     rr = r.double().requires_grad_(True) if res else None
-    yr = ref.bn(ref.conv(xr))
-    yr = torch.relu(yr + rr if res else yr)
+    pre = ref.bn(ref.conv(xr))
+    pre = pre + rr if res else pre
+    near_zero = pre.detach().abs() < 1e-4
+    dy = dy * (~near_zero).float()          # no gradient into ReLU decisions that rounding can flip
+    yr = torch.relu(pre)
     yr.backward(dy.double())
 
     holder.cuda().train()
@@ -162,6 +177,8 @@ def test_conv_bn_act_backward(T, stride, ks, res, shape):
         else:
             assert _relerr(tape.param_grads[k], p.grad) < 2e-5, k
     assert _relerr(holder.bn.running_var, ref.bn.running_var) < 1e-6
+    if seed != 20240917:      # these seeds were picked because such an element exists in one of the cases
+        test_conv_bn_act_backward.near_zero = getattr(test_conv_bn_act_backward, "near_zero", 0) + int(near_zero.sum())
 
 
 def test_concat_pool_convT_backward(T):
