@@ -29,3 +29,23 @@ static inline int sfh_check_launch(const char* what) {
 }
 
 static inline int sfh_cdiv(int a, int b) { return (a + b - 1) / b; }
+
+// Kernels that use more than 64 KB of dynamic LDS need hipFuncAttributeMaxDynamicSharedMemorySize raised once
+// per (kernel instance, device).  The template parameter gives every call site its own flag word; bit d of it
+// records device d.  The only process-wide state of the library besides the last-error string: idempotent,
+// lock-free, and correct when several host threads or devices race (setting the attribute twice is harmless).
+#include <atomic>
+template <int = 0>
+static inline void sfh_allow_big_lds_impl(const void* fn, std::atomic<unsigned long long>& done) {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  const unsigned long long bit = 1ull << (dev & 63);
+  if (done.load(std::memory_order_acquire) & bit) return;
+  (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  done.fetch_or(bit, std::memory_order_release);
+}
+#define sfh_allow_big_lds(fn)                                  \
+  do {                                                         \
+    static std::atomic<unsigned long long> sfh_done_{0};       \
+    sfh_allow_big_lds_impl(fn, sfh_done_);                     \
+  } while (0)

@@ -376,163 +376,6 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const sfh_conv_desc d
 }
 
 // ------------------------------------------------------------------------------------------
-// v2: one workgroup (4 waves, one per SIMD) per CU, LDS double-buffered, staging by LDS-DMA.
-//
-// Measured on v1 (profiles/diag_stamps.py): with two waves per SIMD a wave cannot make progress
-// through its staging code while the co-resident wave streams fp32 MFMAs, so the two waves
-// effectively take turns and every non-MFMA instruction is matrix time lost.  v2 therefore keeps
-// ONE wave per SIMD and puts everything else into the gaps of its own MFMA stream:
-//   * stage s+1 goes global -> LDS by `buffer_load_dwordx4 ... lds` (no VGPRs, no ds_write, no
-//     address arithmetic: per-slot byte offsets are loop-invariant VGPRs, the channel advance is a
-//     scalar offset, out-of-frame slots carry an out-of-range offset and land as zeros);
-//   * those 15 DMA instructions and the 72 operand ds_read_b128 are interleaved one per MFMA;
-//   * one barrier per stage: [vmcnt(0); barrier] guarantees stage s+1 has landed for every wave
-//     and that every wave has finished reading the buffer the next DMA batch overwrites.
-template <class C>
-__global__ __launch_bounds__(256, 2) void conv_mfma_v2_kernel(const sfh_conv_desc d, const ConvGeom g) {
-  static_assert(C::TG == 1, "v2 handles single tap-group configurations");
-  extern __shared__ __attribute__((aligned(16))) float smem_f[];
-  // halo region padded to whole 256-slot DMA rounds so every wave-piece is in bounds (the
-  // padding slots carry the out-of-range offset, land as zeros and are never read)
-  constexpr int HPADSLOTS = C::NSL * 256;
-  constexpr int BUF = HPADSLOTS + C::TPS * 256;  // f32x4 per stage buffer
-  f32x4* const lds = reinterpret_cast<f32x4*>(smem_f);
-  typedef __attribute__((address_space(3))) void* lds_ptr_t;
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: LDS-DMA bases stay in SGPRs
-  const int lq = lane & 15, lg = lane >> 4;
-  const TileCoord tc = decode_block<C>(g);
-  if (!tc.live) return;
-  const int nb = tc.nb, r0 = tc.r0, x0 = tc.x0, n0 = nb * 64;
-
-  const int nst0 = (d.c0 + C::CKS - 1) / C::CKS;
-  const int nst1 = d.src1 ? (d.c1 + C::CKS - 1) / C::CKS : 0;
-  const int nst = nst0 + nst1;
-
-  const __amdgpu_buffer_rsrc_t rs0 =
-      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.src0), 0, (int)g.bytes0, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float*>(d.src1 ? d.src1 : d.src0), 0, (int)(d.src1 ? g.bytes1 : 0u), 0x00020000);
-  const unsigned wstage_bytes = C::TPS * 4096u;
-  const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float*>(d.wpacked) + (size_t)nb * nst * (C::TPS * 1024), 0, (int)(nst * wstage_bytes),
-      0x00020000);
-  const unsigned wvoff = tid * 16u;
-
-  unsigned hoff0[C::NSL], hoff1[C::NSL];
-#pragma unroll
-  for (int i = 0; i < C::NSL; ++i) {
-    hoff0[i] = halo_voffset<C>(d, g, 0, tid + 256 * i, r0, x0);
-    hoff1[i] = d.src1 ? halo_voffset<C>(d, g, 1, tid + 256 * i, r0, x0) : kOOB;
-  }
-
-  // issue the DMA batch of stage `st` into buffer `b` (wave-uniform LDS bases)
-  auto dma_stage = [&](int st, int b) {
-    f32x4* const hb = lds + b * BUF;
-    f32x4* const wb = hb + HPADSLOTS;
-    const bool first = st < nst0;
-    const unsigned cb = (unsigned)(first ? st : st - nst0) * (C::CKS * 4u);
-    const __amdgpu_buffer_rsrc_t rs = first ? rs0 : rs1;
-#pragma unroll
-    for (int i = 0; i < C::NSL; ++i)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(hb + wv * 64 + 256 * i), 16,
-                                               (int)(first ? hoff0[i] : hoff1[i]), (int)cb, 0, 0);
-    const unsigned wbyte = (unsigned)st * wstage_bytes;
-#pragma unroll
-    for (int t = 0; t < C::TPS; ++t)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_ptr_t)(wb + t * 256 + wv * 64), 16, (int)wvoff,
-                                               (int)(wbyte + t * 4096u), 0, 0);
-  };
-
-  int pixbase[C::MT_M];
-#pragma unroll
-  for (int mi = 0; mi < C::MT_M; ++mi) {
-    const int s = wv * C::MT_M + mi;
-    const int sy = s / C::SUBX, sx = s - sy * C::SUBX;
-    const int oy = sy * C::SH + lq / C::SW, ox = sx * C::SW + lq % C::SW;
-    pixbase[mi] = lg * C::HPIXP + oy * C::STRIDE * C::HW + ox * C::STRIDE;
-  }
-
-  f32x4 acc[4][C::MT_M];
-#pragma unroll
-  for (int ni = 0; ni < 4; ++ni)
-#pragma unroll
-    for (int mi = 0; mi < C::MT_M; ++mi) acc[ni][mi] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-  constexpr int NDMA = C::NSL + C::TPS;           // DMA instructions per stage (upper bound)
-  constexpr int NMF = 16 * C::MT_M, NRD = C::MT_M + 4;
-  static_assert(NRD + NDMA < NMF && C::TPS >= 2, "not enough MFMAs in a tap to carry the interleave");
-
-  auto stage = [&](int st, int cur) {
-    const f32x4* const halo = lds + cur * BUF;
-    const f32x4* const wlds = halo + HPADSLOTS;
-    f32x4 xv[2][C::MT_M], wv4[2][4];
-    auto ld_tap = [&](int tl, int buf) {
-      constexpr int KK = C::KS * C::KS;
-      const int sub = tl / KK, kk = tl % KK;
-      const int toff = sub * 4 * C::HPIXP + (kk / C::KS) * C::HW + (kk % C::KS);
-#pragma unroll
-      for (int mi = 0; mi < C::MT_M; ++mi) xv[buf][mi] = halo[pixbase[mi] + toff];
-#pragma unroll
-      for (int ni = 0; ni < 4; ++ni) wv4[buf][ni] = wlds[(tl * 4 + ni) * 64 + lane];
-    };
-    ld_tap(0, 0);
-    // unconditional (no branch inside the MFMA block): past the last stage the batch re-reads
-    // the final stage into the idle buffer
-    dma_stage(st + 1 < nst ? st + 1 : st, cur ^ 1);
-    __builtin_amdgcn_sched_group_barrier(0x100, NRD, 0);  // DS_READ: tap 0 operands
-#pragma unroll
-    for (int tl = 0; tl < C::TPS; ++tl) {
-      const int cb_ = tl & 1;
-      if (tl + 1 < C::TPS) ld_tap(tl + 1, cb_ ^ 1);
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int ni = 0; ni < 4; ++ni)
-#pragma unroll
-          for (int mi = 0; mi < C::MT_M; ++mi)
-            acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv4[cb_][ni][j], xv[cb_][mi][j],
-                                                               acc[ni][mi], 0, 0, 0);
-      if (tl + 1 < C::TPS) {
-#pragma unroll
-        for (int i = 0; i < NRD; ++i) {
-          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
-          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // DS_READ (next tap)
-        }
-      }
-      if (tl == 0) {  // the next stage's DMA batch rides behind the following MFMAs
-#pragma unroll
-        for (int i = 0; i < NDMA; ++i) {
-          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
-          __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // VMEM read (LDS-DMA)
-        }
-        __builtin_amdgcn_sched_group_barrier(0x008, NMF - NRD - NDMA, 0);
-      } else if (tl + 1 < C::TPS) {
-        __builtin_amdgcn_sched_group_barrier(0x008, NMF - NRD, 0);
-      } else {
-        __builtin_amdgcn_sched_group_barrier(0x008, NMF, 0);
-      }
-    }
-  };
-
-  dma_stage(0, 0);
-  for (int st = 0; st < nst; st += 2) {
-    // explicit drain: hipcc's own wait before the barrier does not always cover every LDS-DMA
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();  // stage st landed (vmcnt(0) + barrier); buffer 1 free for the next DMA batch
-    stage(st, 0);
-    if (st + 1 < nst) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-      stage(st + 1, 1);
-    }
-  }
-  sfh_conv_epilogue<C, 4, C::MT_M>(d, g, acc, n0, wv * C::MT_M, r0, x0, lq, lg);
-}
-
-// ------------------------------------------------------------------------------------------
 // First UNet layer (3 input channels stored as 4): tap-packed K.  The generic kernel spends a
 // 16-channel stage (4 MFMA k-steps) per tap on 3 real channels; here one MFMA k-step (k = 4) IS
 // one tap: k index = channel (r, g, b, 0), nine k-steps in total.  All weights of the 64 couts
@@ -706,33 +549,8 @@ int launch_conv(const sfh_conv_desc& d, hipStream_t stream) {
   g.nblk_n = d.cout / 64;
   const long nblocks = (long)sfh_cdiv(g.ntiles, 8) * 8 * g.nblk_n;
   SFH_REQUIRE(nblocks < (1L << 31), "conv grid too large");
-  // v2 (one workgroup per CU, LDS-DMA double buffering) is kept as an experiment: measured
-  // 115.8 TFLOP/s on the DoubleConv launches against 123.1 for v1 (two workgroups per CU,
-  // register-staged buffer loads), so v1 is the default.  SFH_DEBUG_CONV_V2=1 selects v2.
-  static const bool force_v1 = !(getenv("SFH_DEBUG_CONV_V2") && atoi(getenv("SFH_DEBUG_CONV_V2")));
-  if constexpr (C::TG == 1 && 2 * (C::NSL * 256 + C::TPS * 256) * 16 <= 160 * 1024) {
-    if (!d.pool0 && !force_v1) {
-      static bool attr2_set = false;
-      if (!attr2_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_v2_kernel<C>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr2_set = true;
-      }
-      hipLaunchKernelGGL(conv_mfma_v2_kernel<C>, dim3((unsigned)nblocks), dim3(256), 2 * (C::NSL * 256 + C::TPS * 256) * 16,
-                         stream, d, g);
-      return sfh_check_launch("conv_mfma_v2_kernel");
-    }
-  }
-  static bool attr_set = false;  // idempotent; benign if raced
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_kernel<C>),
-                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
-  }
-  // debug knob (experiments only): extra dynamic LDS per workgroup to lower residency
-  static const int extra_lds = getenv("SFH_DEBUG_CONV_EXTRA_LDS") ? atoi(getenv("SFH_DEBUG_CONV_EXTRA_LDS")) : 0;
-  hipLaunchKernelGGL(conv_mfma_kernel<C>, dim3((unsigned)nblocks), dim3(256), C::LDS_BYTES + extra_lds,
-                     stream, d, g);
+  sfh_allow_big_lds(reinterpret_cast<const void*>(&conv_mfma_kernel<C>));
+  hipLaunchKernelGGL(conv_mfma_kernel<C>, dim3((unsigned)nblocks), dim3(256), C::LDS_BYTES, stream, d, g);
   return sfh_check_launch("conv_mfma_kernel");
 }
 

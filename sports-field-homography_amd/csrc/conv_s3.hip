@@ -18,12 +18,14 @@
 //     contiguous runs (measured: pixel-strided 16-byte pieces cost 17 % of the MFMA rate, contiguous
 //     ones nothing); the producer's epilogue splits;
 //   * the input halo of a 32-channel stage goes global -> LDS by buffer_load ... lds (LDS-DMA,
-//     no VGPRs, out-of-frame slots read zeros through the descriptor's range check), double
-//     buffered: one barrier per stage, DMA of stage s+1 issued inside the MFMA stream of stage s;
+//     no VGPRs, out-of-frame slots read zeros through the descriptor's range check);
 //   * weights never touch LDS: the four waves of a workgroup form a 2(M) x 2(N) grid, each wave
 //     loads its own pre-packed, pre-split 1 KB fragments (16 couts x 32 k x bf16) straight from
 //     L2 into registers one tap ahead.
-// Workgroup tile: 256 pixels x 64 couts, one workgroup (4 waves, one per SIMD) per CU.
+// Workgroup tile: 256 pixels x 64 couts, 4 waves.  Default: ONE LDS buffer and TWO workgroups per CU, so
+// that staging / prologue / epilogue of one workgroup hide under the other's MFMAs; grids of at most 320
+// workgroups (one per CU at best) take the double-buffered variant (DB): two LDS buffers, one barrier per
+// stage, the DMA of stage s+1 issued inside the MFMA stream of stage s.
 #include <stdlib.h>
 
 #include <type_traits>
@@ -68,7 +70,6 @@ struct S3Geom {
   unsigned rows_magic;
   unsigned bytes0, bytes1;
   int nb_group;  // cout blocks of one pixel tile that run back to back on one XCD (1 .. nblk_n)
-  int xcd_interleave;
 };
 
 __device__ __forceinline__ bf16x8 as_bf(const u32x4& v) { return __builtin_bit_cast(bf16x8, v); }
@@ -149,10 +150,10 @@ __global__ __launch_bounds__(256, 2) void conv_s3_kernel(const sfh_conv_desc d, 
   const int gi = kk_ / per, rr = kk_ - gi * per;
   const int nb = gi * g.nb_group + rr % g.nb_group;
   // each XCD owns a contiguous range of pixel tiles (whole tile rows), so vertically adjacent tiles
-  // share their halo rows in that XCD's L2 (xcd_interleave: the old round-robin order, for A/B runs)
+  // share their halo rows in that XCD's L2 (the round-robin order tile = tl * 8 + xcd measured 1.4x the L2 fills)
   // reverse_tiles: every XCD walks its range backwards, i.e. starts on what it wrote last in the previous launch
   const int tl = d.reverse_tiles ? tpx - 1 - rr / g.nb_group : rr / g.nb_group;
-  const int tile = g.xcd_interleave ? tl * 8 + xcd : xcd * tpx + tl;
+  const int tile = xcd * tpx + tl;
   if (tile >= g.ntiles) return;
   const int ty = tile / g.tiles_x, tx = tile - ty * g.tiles_x;
   const int x0 = tx * C::TW;
@@ -551,38 +552,25 @@ int launch_s3(const sfh_conv_desc& d, hipStream_t stream) {
     // DoubleConv ms per batch vs budget for the group's weights): 0.5 MB 22.41, 2 MB 22.10, 16 MB 21.92,
     // 64 MB 21.61, unbounded 21.74 - re-reading the input tile once per cout block costs more than
     // streaming weights that no longer fit the 4 MB L2 (they hit the 256 MB Infinity Cache), so the budget
-    // is 64 MB: every layer of this model is fully grouped (SFH_DEBUG_S3_L2KB / _NBGROUP override).
+    // is 64 MB: every layer of this model is fully grouped.
     const long wblock = (long)((d.c0 + (d.src1 ? d.c1 : 0)) / 32) * C::NTAP * 12288;
-    static const char* l2kb = getenv("SFH_DEBUG_S3_L2KB");
-    const long budget = l2kb ? (long)atoi(l2kb) << 10 : (64L << 20);
+    const long budget = 64L << 20;
     int G = d.out_mode == SFH_OUT_UPSCATTER2 ? g.nblk_n : (int)(budget / (wblock > 0 ? wblock : 1));
-    static const char* ov = getenv("SFH_DEBUG_S3_NBGROUP");
-    if (ov) G = atoi(ov);
     if (G < 1) G = 1;
     if (G > g.nblk_n) G = g.nblk_n;
     while (g.nblk_n % G) --G;  // groups must tile the cout blocks
     g.nb_group = G;
-    static const char* il = getenv("SFH_DEBUG_S3_XCD_INTERLEAVE");
-    g.xcd_interleave = il ? atoi(il) : 0;
   }
   const long nblocks = (long)sfh_cdiv(g.ntiles, 8) * 8 * g.nblk_n;
   SFH_REQUIRE(nblocks < (1L << 31), "conv_s3: grid too large");
   // small grids (at most ~one workgroup per CU anyway, e.g. ResNet layer3/4): the double-buffered
-  // variant overlaps each stage's DMA latency with the previous stage's MFMAs (SFH_DEBUG_S3_DBLIM
-  // overrides the threshold, 0 = never)
+  // variant overlaps each stage's DMA latency with the previous stage's MFMAs
   if constexpr (!DB && C::LDS_BYTES <= 160 * 1024) {
-    static const char* force = getenv("SFH_DEBUG_S3_DB");
-    static const char* lim = getenv("SFH_DEBUG_S3_DBLIM");
-    if (!force && nblocks <= (lim ? atol(lim) : 320)) return launch_s3<C, true>(d, stream);
+    if (nblocks <= 320) return launch_s3<C, true>(d, stream);
   }
   // (an LDS-free variant for 1x1 / transposed convs that streams both operands straight into
   // registers was measured slower: 3.69 ms vs 2.96 ms per step for the four ConvTranspose launches)
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_s3_kernel<C, DB>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
-  }
+  sfh_allow_big_lds(reinterpret_cast<const void*>(&conv_s3_kernel<C, DB>));
   hipLaunchKernelGGL((conv_s3_kernel<C, DB>), dim3((unsigned)nblocks), dim3(256),
                      DB ? C::LDS_BYTES : C::LDS_BYTES / 2, stream, d, g);
   return sfh_check_launch("conv_s3_kernel");
@@ -667,15 +655,11 @@ extern "C" int sfh_conv_s3_fwd(const sfh_conv_desc* dp, void* stream_) {
                     d.head_logits && d.head_nc >= 1 && d.head_nc <= 8 && (!d.head_stn || (d.head_frame && d.head_nc <= 5)),
                 "conv_s3_fwd: the fused OutConv head needs a 3x3 stride-1 conv with 64 output channels and a plain output");
   SFH_REQUIRE(!d.head_skip_dst || d.head_w, "conv_s3_fwd: head_skip_dst without a head");
-  // buffering policy: short K -> two single-buffered workgroups per CU; long K -> one
-  // double-buffered workgroup.  SFH_DEBUG_S3_DB=0/1 forces one variant (experiments).
-  const int nstages = (d.c0 + (d.src1 ? d.c1 : 0)) / 32;
-  static const char* force = getenv("SFH_DEBUG_S3_DB");
-  const bool db = force ? atoi(force) != 0 : false;  // measured: two single-buffered workgroups per CU are never slower since the row-major S3 layout
+  // buffering policy (launch_s3): two single-buffered workgroups per CU, except grids of at most 320
+  // workgroups, which take the double-buffered variant
 #define SFH_S3CASE(KS, ST, TILE, SH, SW, TH, TW)                      \
   if (d.ksize == KS && d.stride == ST && d.tile == TILE) {             \
     using CFG = S3Cfg<KS, ST, SH, SW, TH, TW>;                         \
-    if (db) return launch_s3<CFG, true>(d, stream);                    \
     return launch_s3<CFG, false>(d, stream);                           \
   }
   SFH_S3CASE(3, 1, SFH_TILE_8x32, 1, 16, 8, 32)

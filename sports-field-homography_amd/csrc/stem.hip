@@ -172,12 +172,7 @@ extern "C" int sfh_stem7x7_fwd(const sfh_conv_desc* dp, void* stream) {
   g.tiles_y = sfh_cdiv(g.Ho, StemCfg::TH);
   g.ntiles = g.tiles_x * g.tiles_y * d.batch;
   SFH_REQUIRE((unsigned long long)d.batch * g.Ho * g.Wo * d.dst_cs * 4ULL < 0xFFFFFFF0ULL, "stem7x7_fwd: destination exceeds 4 GiB");
-  static bool attr = false;
-  if (!attr) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&stem7x7_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              StemCfg::LDS_BYTES);
-    attr = true;
-  }
+  sfh_allow_big_lds(reinterpret_cast<const void*>(&stem7x7_kernel));
   hipLaunchKernelGGL(stem7x7_kernel, dim3((unsigned)g.ntiles), dim3(256), StemCfg::LDS_BYTES, (hipStream_t)stream, d, g);
   return sfh_check_launch("stem7x7_kernel");
 }

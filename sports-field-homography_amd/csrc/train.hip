@@ -1091,12 +1091,7 @@ extern "C" int sfh_stem_bwd_data(const float* dz, const float* w, int cin, int c
     hipLaunchKernelGGL(stem_bwd_data_kernel<1>, grid, dim3(256), 49 * 64 * 4 * sizeof(float), (hipStream_t)stream, dz, w,
                        cin, c_off, nc, H, W, Ho, Wo, dlogits_nchw);
   } else {
-    static bool attr = false;
-    if (!attr) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&stem_bwd_data_kernel<2>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 49 * 64 * 8 * (int)sizeof(float));
-      attr = true;
-    }
+    sfh_allow_big_lds(reinterpret_cast<const void*>(&stem_bwd_data_kernel<2>));
     hipLaunchKernelGGL(stem_bwd_data_kernel<2>, grid, dim3(256), 49 * 64 * 8 * sizeof(float), (hipStream_t)stream, dz, w,
                        cin, c_off, nc, H, W, Ho, Wo, dlogits_nchw);
   }

@@ -116,13 +116,26 @@ class ConvTimer:
         return out
 
 
+class LaunchOrder:
+    """Direction in which consecutive conv launches of ONE engine (or one training tape) walk their pixel tiles:
+    alternating ("snake", sfh_conv_desc.reverse_tiles), so that a launch starts on what the same XCD wrote
+    last.  Per owner, not process-wide: the order a model sees does not depend on what else ran."""
+
+    def __init__(self, snake=None):
+        self.snake = (os.environ.get("SFH_SNAKE", "1") != "0") if snake is None else bool(snake)
+        self._flip = False
+
+    def next(self):
+        r = self.snake and self._flip
+        self._flip = not self._flip
+        return r
+
+
 class PackedConv:
     """One conv-shaped layer: fragment-ordered weights + folded per-channel epilogue."""
 
-    timer = None   # set to a ConvTimer to time every launch (class-wide)
-    # consecutive launches walk their pixel tiles in opposite directions (see sfh_conv_desc.reverse_tiles)
-    snake = os.environ.get("SFH_SNAKE", "1") != "0"
-    _flip = False
+    timer = None   # set to a ConvTimer to time every launch (bench.py / profiling only)
+    order = None   # LaunchOrder of the owning engine (set by the engine); None = always forward
 
     def __init__(self, weight, bias, bn, ksize, c0, c1=0, relu=True, transposed=False, stride=1,
                  stem_cin=0, tag="conv", s3=False):
@@ -313,8 +326,7 @@ class PackedConv:
             d.head_stn = head["stn"].data_ptr() if head.get("stn") is not None else None
             d.head_frame = head["frame"].data_ptr() if head.get("frame") is not None else None
             d.head_skip_dst = 1 if head.get("skip_dst") else 0
-        d.reverse_tiles = 1 if (self.s3 and PackedConv.snake and PackedConv._flip) else 0
-        PackedConv._flip = not PackedConv._flip
+        d.reverse_tiles = 1 if (self.s3 and self.order is not None and self.order.next()) else 0
         d.residual = residual.data_ptr() if residual is not None else None
         d.residual_f32 = 1 if (residual is not None and residual.dtype == torch.float32
                                and dst.dtype == torch.bfloat16) else 0
@@ -356,19 +368,22 @@ class PackedConv:
 
 
 class _Workspace:
-    """Named NHWC buffers cached per (batch, H, W)."""
+    """Named activation buffers, one per name: a call with another shape (a different batch size, the tail
+    chunk of a sub-batched call) replaces the buffer instead of keeping a second full activation set in HBM."""
 
     def __init__(self, device):
         self.device = device
         self.bufs = {}
 
     def get(self, name, shape, dtype=torch.float32, zero=False):
-        key = (name, tuple(shape), dtype)
-        t = self.bufs.get(key)
-        if t is None:
+        key = (tuple(shape), dtype)
+        cur = self.bufs.get(name)
+        if cur is None or cur[0] != key:
+            self.bufs.pop(name, None)      # release the old block to the allocator before asking for the new one
             t = (torch.zeros if zero else torch.empty)(shape, dtype=dtype, device=self.device)
-            self.bufs[key] = t
-        return t
+            self.bufs[name] = (key, t)
+            return t
+        return cur[1]
 
 
 class UNetEngine:
@@ -381,8 +396,8 @@ class UNetEngine:
         self.bilinear = bool(net.unet_bilinear)
         # fused Up levels where the composed 2x2 conv runs first (see run()): the two full-resolution-most
         # levels, where that conv is memory-heavy (measured per level: none 629, {4} 634, {3,4} 638, all 635
-        # frames/s).  SFH_DEBUG_UP_SWAP="" / "4" / "1,2,3,4" overrides.
-        self.up_swap = {int(t) for t in os.environ.get("SFH_DEBUG_UP_SWAP", "3,4").split(",") if t}
+        # frames/s)
+        self.up_swap = {3, 4}
         if precision not in ("bf16x6", "fp32"):
             raise ValueError(f"precision={precision!r}: expected 'bf16x6' or 'fp32'")
         self.device = device
@@ -419,6 +434,9 @@ class UNetEngine:
                                             tag="convT2x2", s3=s3)
             dc(f"up{i}.conv", up.conv, cin // 2, cin // 2)  # cat([skip, up]): cin/2 channels each in both variants
         self.L = L
+        self.order = LaunchOrder()
+        for layer in L.values():
+            layer.order = self.order
         self.outc_w = _f32c(net.outc.conv.weight.detach(), "outc.weight")
         self.outc_b = _f32c(net.outc.conv.bias.detach(), "outc.bias")
         self.outuv = None
@@ -629,6 +647,9 @@ class ResNetEngine:
                                                    tag="resnet", s3=s3)
                 self.blocks.append((name, width, cout, blk.stride, blk.downsample is not None, hasattr(blk, "conv3")))
         self.L = L
+        self.order = LaunchOrder()
+        for layer in L.values():
+            layer.order = self.order
         self.reg_w = _f32c(rn.reg.weight.detach(), "reg.weight")
         self.reg_b = _f32c(rn.reg.bias.detach(), "reg.bias")
 

@@ -253,11 +253,11 @@ class MaskReader:
 
 
 # ------------------------------------------------------------------------------ court json
-class NumpyEncoder(json.JSONEncoder):
-    def default(self, obj):
-        if isinstance(obj, np.ndarray):
-            return obj.tolist()
-        return json.JSONEncoder.default(self, obj)
+def _json_default(obj):
+    """arrays and numpy scalars -> plain lists / numbers (the court json holds theta and poi as nested lists)"""
+    if hasattr(obj, "tolist"):
+        return obj.tolist()
+    raise TypeError(f"{type(obj).__name__} is not JSON serialisable")
 
 
 def format_score(score):
@@ -285,7 +285,7 @@ class CourtJsonWriter:
             rec["theta"] = np.asarray(theta)  # (1,3,3)
         if poi is not None:
             rec["poi"] = np.asarray(poi)
-        json.dump({name: rec}, self._f, cls=NumpyEncoder)
+        json.dump({name: rec}, self._f, default=_json_default)
         self._f.write("\n")
 
     def add_batch(self, names, preds):
@@ -306,7 +306,7 @@ class CourtJsonWriter:
             output = {k: v for line in f for k, v in json.loads(line).items()}
         output["model"] = self.model_name
         with open(self.path, "w") as f:
-            json.dump(output, f, cls=NumpyEncoder, indent=2)
+            json.dump(output, f, default=_json_default, indent=2)
         os.remove(self.tmp_path)
         return self.path
 

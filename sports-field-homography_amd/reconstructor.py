@@ -115,6 +115,7 @@ class Reconstructor(nn.Module):
         self.precision = os.environ.get("SFH_PRECISION", "bf16x6")
         self._engines = None       # (UNetEngine | None, ResNetEngine | None)
         self._engine_stamp = None
+        self._weights_generation = 0
         self._tmpl_shared = None   # (data_ptr, shape) -> bool cache
 
     # ------------------------------------------------------------------ engine plumbing
@@ -124,7 +125,14 @@ class Reconstructor(nn.Module):
         for t in list(self.parameters()) + list(self.buffers()):
             ver += t._version
             dev = t.device
-        return (dev, ver, self.training, self.precision)
+        return (dev, ver, self.training, self.precision, self._weights_generation)
+
+    def invalidate_engines(self):
+        """Packed weights and folded BatchNorm constants are cached per engine and rebuilt when a parameter's
+        torch ``_version`` moves.  Kernels that write parameters or buffers through raw device pointers
+        (training.TrainStep.step, the train-mode BatchNorm statistics) do not move it: they call this."""
+        self._weights_generation += 1
+        self._engines = None
 
     def _get_engines(self):
         stamp = self._param_stamp()

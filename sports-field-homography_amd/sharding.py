@@ -93,6 +93,11 @@ def flat_views(shapes, device, dtype=torch.float32):
     return flat, views
 
 
+def world_size(group=None):
+    """ranks of the initialised process group, 1 without one"""
+    return dist.get_world_size(group) if dist.is_initialized() else 1
+
+
 def allreduce_gradients(flat, group=None):
     """Sum the flat gradient buffer over the ranks (RCCL all-reduce over xGMI on GPUs, gloo in the CPU
     tests); returns the factor 1/world that turns the sum into the data-parallel mean - the optimizer

@@ -50,6 +50,7 @@ class Tape:
         self.lib = _lib.load()
         self.use_s3 = _use_s3()
         self._s3 = {}
+        self.order = E.LaunchOrder()
 
     def s3(self, t):
         """split-bf16 copy of an NHWC activation (converted once, kept while the tape lives)"""
@@ -163,6 +164,7 @@ def conv_bn_act(tape, names, conv, bn, srcs, B, H, W, relu=True, residual=None, 
     t1, c1 = (srcs[1][0], srcs[1][1]) if len(srcs) > 1 else (None, 0)
     s3 = tape.use_s3 and c0 % 32 == 0 and c1 % 32 == 0 and c0 == t0.shape[3] and (t1 is None or c1 == t1.shape[3])
     pc = PackedConv(w, conv.bias, None, ks, c0, c1, relu=False, stride=stride, tag="train_fwd", s3=s3)
+    pc.order = tape.order
     ho, wo = (H - 1) // stride + 1, (W - 1) // stride + 1
     z = _empty((B, ho, wo, cout), t0)
     pc.run(tape.s3(t0) if s3 else t0, B, H, W, z, src1=(tape.s3(t1) if s3 else t1) if t1 is not None else None,
@@ -196,6 +198,7 @@ def conv_bn_act(tape, names, conv, bn, srcs, B, H, W, relu=True, residual=None, 
         if not need_dx:
             return
         bd = PackedConv.backward_data(w, ks, s3=s3)
+        bd.order = tape.order
         dx = _empty((B, H, W, bd.cout), dz)
         bd.run((dz_s3 if dz_s3 is not None else E.f32_to_s3(dz)) if s3 else dz, B, H, W, dx)
         if t1 is None:
@@ -582,7 +585,7 @@ class _TrainForward(torch.autograd.Function):
     gradients (returned in the order of net.parameters())."""
 
     @staticmethod
-    def forward(ctx, net, x, *params):
+    def forward(ctx, net, info, x, *params):
         tape = Tape()
         x = E._f32c(x.detach(), "input frames")
         f = run_forward(net, tape, x)
@@ -590,6 +593,8 @@ class _TrainForward(torch.autograd.Function):
         keys = [k for k in _OUT_KEYS if f[k] is not None]
         outs = [f[k].view(B, 1, 3, 3) if k == "theta" else f[k] for k in keys]
         ctx.tape, ctx.f, ctx.net, ctx.keys = tape, f, net, keys
+        info["keys"] = keys          # the caller labels the outputs with the node's own key list
+        net.invalidate_engines()     # BatchNorm running statistics were updated through raw device pointers
         return tuple(outs)
 
     @staticmethod
@@ -606,7 +611,7 @@ class _TrainForward(torch.autograd.Function):
         names = _Names(net)
         grads = tuple(g.get(names(p)) for p in net.parameters())
         ctx.tape = ctx.f = None
-        return (None, None) + grads
+        return (None, None, None) + grads
 
 
 def ctx_split(ops):
@@ -622,10 +627,9 @@ def train_forward(net, x):
     if not net.use_unet and net.resnet_input.name != "IMG":
         raise NotImplementedError  # like the reference: without the UNet only the frame can feed the STN
     params = tuple(net.parameters())
-    outs = _TrainForward.apply(net, x, *params)
-    keys = [k for k in _OUT_KEYS if (k in ("logits",) and net.use_unet) or (k == "uv" and net.use_unet and net.unet_uv)
-            or (k in ("theta", "poi") and net.use_resnet) or (k == "warp_mask" and net.use_resnet and net.warper)]
-    return dict(zip(keys, outs))
+    info = {}
+    outs = _TrainForward.apply(net, info, x, *params)
+    return dict(zip(info["keys"], outs))
 
 
 # ------------------------------------------------------------------- the whole step on HIP kernels
@@ -666,25 +670,49 @@ class TrainStep:
         self.sq = [torch.zeros_like(p) for p in self.params]
         self.buf = [torch.zeros_like(p) for p in self.params]
         CH = 65536
-        tab = np.zeros((len(self.params), 4), dtype=np.int64)
         chunks = []
-        for i, (p, g, s, b) in enumerate(zip(self.params, self.grads, self.sq, self.buf)):
-            tab[i] = (p.data_ptr(), g.data_ptr(), s.data_ptr(), b.data_ptr())
+        for i, p in enumerate(self.params):
             n = p.numel()
             for off in range(0, n, CH):
                 chunks.append((i, min(CH, n - off), off))
         ch = np.zeros(len(chunks), dtype=np.dtype([("t", "<i4"), ("c", "<i4"), ("o", "<i8")]))
         for j, (t, c, o) in enumerate(chunks):
             ch[j] = (t, c, o)
-        self.table = torch.from_numpy(tab.view(np.uint8).reshape(-1).copy()).to(dev)
         self.chunks = torch.from_numpy(ch.view(np.uint8).reshape(-1).copy()).to(dev)
         self.nchunks = len(chunks)
+        self._build_table()
+
+    def _build_table(self):
+        """device table (parameter, gradient, square_avg, momentum_buffer addresses) of the optimizer kernel"""
+        import numpy as np
+        tab = np.zeros((len(self.params), 4), dtype=np.int64)
+        for i, (p, g, s, b) in enumerate(zip(self.params, self.grads, self.sq, self.buf)):
+            tab[i] = (p.data_ptr(), g.data_ptr(), s.data_ptr(), b.data_ptr())
+        self._pptrs = [p.data_ptr() for p in self.params]
+        self.table = torch.from_numpy(tab.view(np.uint8).reshape(-1).copy()).to(self.gflat.device)
+
+    def _check_parameter_storage(self):
+        """The optimizer kernel writes the parameters through the addresses captured in the table: if the model's
+        storage was replaced since (net.to(), .float(), p.data = ...), rebuild the table - or refuse when the
+        parameters left this device or changed shape / dtype."""
+        cur = list(self.net.parameters())
+        if len(cur) != len(self.params) or any(a is not b for a, b in zip(cur, self.params)):
+            raise RuntimeError("TrainStep: the model's parameter objects changed since this TrainStep was built; "
+                               "create a new TrainStep (optimizer state can be carried over with state_dict())")
+        for p, g in zip(self.params, self.grads):
+            if p.device != g.device or p.dtype != torch.float32 or tuple(p.shape) != tuple(g.shape) or not p.is_contiguous():
+                raise RuntimeError(f"TrainStep: a parameter is now {p.dtype} {tuple(p.shape)} on {p.device}; expected "
+                                   f"contiguous float32 {tuple(g.shape)} on {g.device}")
+        if [p.data_ptr() for p in self.params] != self._pptrs:
+            self._build_table()
 
     def state_dict(self):
         """Optimizer state for checkpoint / resume, keyed like ``net.state_dict()`` (train.py:321-322 saves
         the model only; resuming RMSprop needs its running averages too)."""
         names = [self.names(p) for p in self.params]
         return {"global_step": self.global_step,
+                "hyper_parameters": dict(self.hp), "lambdas": dict(self.lam), "rec_mse": self.rec_mse,
+                "focal_flags": self.focal_flags, "consist_start_iter": self.consist_start_iter,
                 "square_avg": {n: t.detach().clone() for n, t in zip(names, self.sq)},
                 "momentum_buffer": {n: t.detach().clone() for n, t in zip(names, self.buf)}}
 
@@ -692,14 +720,26 @@ class TrainStep:
         names = [self.names(p) for p in self.params]
         if set(state["square_avg"]) != set(names) or set(state["momentum_buffer"]) != set(names):
             raise RuntimeError("TrainStep.load_state_dict: parameter names do not match this model")
+        for n, sq, buf in zip(names, self.sq, self.buf):
+            for what, src in (("square_avg", state["square_avg"][n]), ("momentum_buffer", state["momentum_buffer"][n])):
+                if tuple(src.shape) != tuple(sq.shape) or src.dtype != sq.dtype:
+                    raise RuntimeError(f"TrainStep.load_state_dict: {what}[{n}] is {src.dtype} {tuple(src.shape)}, "
+                                       f"expected {sq.dtype} {tuple(sq.shape)}")
         for n, sq, buf in zip(names, self.sq, self.buf):   # in place: the device tables point at these tensors
             sq.copy_(state["square_avg"][n])
             buf.copy_(state["momentum_buffer"][n])
         self.global_step = int(state["global_step"])
+        # hyper-parameters travel with the state (a learning rate lowered by ReduceLROnPlateau survives a resume)
+        if "hyper_parameters" in state:
+            self.hp.update(state["hyper_parameters"])
+            self.lam.update(state.get("lambdas", {}))
+            self.rec_mse = int(state.get("rec_mse", self.rec_mse))
+            self.focal_flags = int(state.get("focal_flags", self.focal_flags))
+            self.consist_start_iter = int(state.get("consist_start_iter", self.consist_start_iter))
 
     def loss_and_grads(self, x, batch):
-        """forward + losses + backward; fills self.grads, returns {'seg','rec','reproj','consist'} as a
-        float64 device tensor of 4 values.  batch: mask (B,H,W) int64, weight (B), poi (B,N,2),
+        """forward + losses + backward; fills self.grads, returns a float64 device tensor of 4 values in the
+        order [seg, rec, consist, reproj] (each already times its lambda).  batch: mask (B,H,W) int64, weight (B), poi (B,N,2),
         nonzeros (B,N), num_nonzero (B)."""
         net, lib = self.net, _lib.load()
         if not net.training:
@@ -722,7 +762,9 @@ class TrainStep:
             raise ValueError("batch['mask'] must be a contiguous int64 tensor (B,H,W)")
         dlogits = _empty(logits.shape, x)
         dwarp = _empty(warp.shape, x)
-        l_cons = self.lam["consist"] if self.global_step * B >= self.consist_start_iter else 0.0
+        # train.py:214 gates on global_step * batch_size with the GLOBAL batch
+        from . import sharding
+        l_cons = self.lam["consist"] if self.global_step * B * sharding.world_size() >= self.consist_start_iter else 0.0
         _lib.check(lib.sfh_train_losses(_ptr(logits), _ptr(mask), _ptr(E._f32c(batch["weight"], "weight")), _ptr(warp),
                                         net.mask_classes, B, H, W, self.lam["seg"], self.lam["rec"], self.rec_mse,
                                         l_cons, self.focal_flags, _ptr(dlogits), _ptr(dwarp), _ptr(losses), st), "train_losses")
@@ -739,6 +781,7 @@ class TrainStep:
 
     def step(self, x, batch):
         """-> float64 device tensor [seg, rec, consist, reproj] (each already times its lambda)."""
+        self._check_parameter_storage()
         losses = self.loss_and_grads(x, batch)
         lib, hp = _lib.load(), self.hp
         from . import sharding
@@ -748,6 +791,7 @@ class TrainStep:
         _lib.check(lib.sfh_rmsprop_step(_ptr(self.table), _ptr(self.chunks), self.nchunks, hp["lr"], hp["alpha"],
                                         hp["eps"], hp["wd"], hp["mu"], hp["clip"], gscale, _stream()), "rmsprop_step")
         self.global_step += 1
+        self.net.invalidate_engines()   # weights changed through raw device pointers: predict() must re-pack
         return losses
 
 

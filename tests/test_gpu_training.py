@@ -177,8 +177,7 @@ def test_conv_bn_act_backward(T, stride, ks, res, shape, seed):
         else:
             assert _relerr(tape.param_grads[k], p.grad) < 2e-5, k
     assert _relerr(holder.bn.running_var, ref.bn.running_var) < 1e-6
-    if seed != 20240917:      # these seeds were picked because such an element exists in one of the cases
-        test_conv_bn_act_backward.near_zero = getattr(test_conv_bn_act_backward, "near_zero", 0) + int(near_zero.sum())
+
 
 
 def test_concat_pool_convT_backward(T):
@@ -679,13 +678,78 @@ def test_train_step_checkpoint_resume(T):
     ck_model = copy.deepcopy({k: v.detach().clone() for k, v in a.state_dict().items()})
     ck_opt = ta.state_dict()
     la = [ta.step(x, batch).sum().item() for _ in range(2)]
-    b = make(ck_model)
-    tb = T.TrainStep(b, lr=1e-4)
-    tb.load_state_dict(ck_opt)
-    assert tb.global_step == 2
-    lb = [tb.step(x, batch).sum().item() for _ in range(2)]
-    for u, v in zip(la, lb):
-        assert abs(u - v) < 2e-3 * abs(u), (la, lb)
-    worst = max(((pa.detach() - pb.detach()).abs().max() / (pa.detach().abs().max() + 1e-12)).item()
-                for pa, pb in zip(a.parameters(), b.parameters()))
-    assert worst < 5e-3, worst
+
+    def resume(drop=None):
+        b = make(ck_model)
+        tb = T.TrainStep(b, lr=3e-5)              # another lr on purpose: the checkpoint's hyper-parameters win
+        st = {k: (dict(v) if isinstance(v, dict) else v) for k, v in ck_opt.items()}
+        if drop:
+            st[drop] = {n: torch.zeros_like(t) for n, t in st[drop].items()}
+        tb.load_state_dict(st)
+        assert tb.global_step == 2 and tb.hp["lr"] == 1e-4
+        lb = [tb.step(x, batch).sum().item() for _ in range(2)]
+        dl = max(abs(u - v) / abs(u) for u, v in zip(la, lb))
+        # distance between the two runs' UPDATES since the checkpoint, relative to the update itself
+        num = den = 0.0
+        for (k, pa), pb in zip(a.named_parameters(), b.parameters()):
+            ua, ub = pa.detach().double() - ck_model[k].double(), pb.detach().double() - ck_model[k].double()
+            num += float((ua - ub).pow(2).sum())
+            den += float(ua.pow(2).sum())
+        return dl, (num / den) ** 0.5
+
+    dl, dw = resume()
+    print("resume: loss deviation %.2e, update deviation %.2e" % (dl, dw))
+    # Same arithmetic up to the summation order of the split-K atomics in backward-filter.  RMSprop divides by
+    # sqrt(square_avg): elements whose gradient is rounding noise still move by about lr per step, in a direction
+    # that noise decides, so the two runs are close in the norm of the update, not element by element.
+    assert dl < 2e-4 and dw < 1e-2, (dl, dw)      # measured 6e-5 / 9e-4; without a state tensor 2e-2 / 0.7-0.9
+    # the check has teeth: a resume that loses either optimizer state tensor is far outside that bound
+    for drop in ("momentum_buffer", "square_avg"):
+        dl_bad, dw_bad = resume(drop)
+        print("resume without %s: loss deviation %.2e, update deviation %.2e" % (drop, dl_bad, dw_bad))
+        assert dw_bad > 0.3 and dw_bad > 6 * dw, (drop, dw_bad, dw)
+    bad = dict(ck_opt)
+    bad["square_avg"] = {n: t[..., :1] if t.dim() else t for n, t in ck_opt["square_avg"].items()}
+    with pytest.raises(RuntimeError):
+        T.TrainStep(make(ck_model)).load_state_dict(bad)      # wrong-shaped entry: no silent broadcast
+
+
+def test_predict_after_train_steps_uses_fresh_weights(T):
+    """TrainStep.step writes weights and BatchNorm statistics through raw device pointers (no torch version
+    bump): predict() afterwards must re-pack - equal to a fresh model loaded from the trained state_dict.
+    Also: replaced parameter storage (net.float() / p.data = ...) is picked up by the optimizer table."""
+    from sfh_amd.reconstructor import Reconstructor
+    B, H, W = 2, 64, 96
+    court = synth.load_court_template("ncaa_nc4_640x360", 4, B)[:, :, :H, :W].contiguous().cuda()
+    poi = synth.load_court_poi("pitch", B).cuda()
+    kw = dict(target_size=(W, H), unet_size=(W, H), warp_size=(W, H), warp_with_nearest=True)
+    net = Reconstructor(court, poi, **kw)
+    net.load_state_dict(synth.synth_state_dict(net.state_dict(), 81))
+    net.cuda()
+    x = synth.frames_to_float(synth.synth_frames_u8(B, H, W, seed=81)).cuda()
+    batch = {k: v.cuda() for k, v in _batch(B, H, W, poi.shape[1], 82).items()}
+    with torch.no_grad():
+        before = net.eval().predict(x, consistency=True)
+    ts = T.TrainStep(net.train(), lr=1e-3)
+    # freeze BatchNorm bookkeeping that WOULD bump a torch version, so only the raw-pointer writes remain
+    for _ in range(3):
+        ts.step(x, batch)
+    with torch.no_grad():
+        after = net.eval().predict(x, consistency=True)
+    fresh = Reconstructor(court, poi, **kw)
+    fresh.load_state_dict({k: v.detach().clone() for k, v in net.state_dict().items()})
+    with torch.no_grad():
+        want = fresh.cuda().eval().predict(x, consistency=True)
+    assert not torch.equal(before["theta"], after["theta"])
+    for k in ("theta", "logits", "warp_mask", "consist_score"):
+        assert torch.equal(after[k], want[k]), k
+    # parameter storage replaced behind the optimizer's back: the table follows
+    net.train()
+    p0 = next(net.parameters())
+    old_ptr = p0.data_ptr()
+    p0.data = p0.data.clone()
+    assert p0.data_ptr() != old_ptr
+    w_before = p0.detach().clone()
+    ts.step(x, batch)
+    torch.cuda.synchronize()
+    assert not torch.equal(p0.detach(), w_before)             # the NEW storage was updated
