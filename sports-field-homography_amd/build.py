@@ -10,7 +10,7 @@ import sys
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB = os.path.join(_HERE, "libsfh_amd.so")
-SOURCES = ["capi.hip", "conv_mfma.hip", "conv_s3.hip", "pointwise.hip", "warp.hip", "train.hip", "stem.hip"]
+SOURCES = ["capi.hip", "conv_mfma.hip", "conv_s3.hip", "pointwise.hip", "warp.hip", "train.hip", "stem.hip", "wgrad_s3.hip"]
 # warp.hip's coordinate arithmetic must not be contracted into FMAs (bit-exact nearest
 # sampling against oracle/warp_ref.py); the flag is harmless elsewhere.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-ffp-contract=off",

@@ -129,6 +129,23 @@ def _colsum(lib, t, C=None, cs=None):
     return acc.to(torch.float32)
 
 
+def wgrad_s3_ok(ksize, stride, M, srcs):
+    """the split-bf16 backward-filter kernel (csrc/wgrad_s3.hip) covers 3x3 stride-1 convs with cout % 64 == 0
+    whose sources are whole S3 tensors (every source's channel count a multiple of 32, all of them used)"""
+    return ksize == 3 and stride == 1 and M % 64 == 0 and all(n % 32 == 0 and n == t.shape[3] for (t, n, *_r) in srcs)
+
+
+def _wgrad_s3(lib, tape, dz_s3, M, srcs, B, H, W, cin_store):
+    """raw (M, 9, cin_store) on the bf16 matrix cores; srcs as in _wgrad (fp32 NHWC tensors whose S3 copies the
+    tape holds since the forward pass)."""
+    raw = torch.zeros((M, 9, cin_store), dtype=torch.float32, device=dz_s3.device)
+    for (t, n, n_off, pt, pl) in srcs:
+        xs = tape.s3(t)
+        _lib.check(lib.sfh_conv_wgrad_s3(_ptr(dz_s3), M, _ptr(xs), t.shape[3], t.shape[1], t.shape[2], n, pt, pl,
+                                         B, H, W, _ptr(raw), cin_store, n_off, _stream()), "conv_wgrad_s3")
+    return raw
+
+
 def _wgrad(lib, dz, srcs, B, H, W, ksize, cin_store):
     """raw (M, k*k, cin_store) = sum_p dz[p] (x) xin[p + tap]; srcs = [(tensor, channels, n_off, pad_top, pad_left)]."""
     M = dz.shape[3]
@@ -175,8 +192,12 @@ def conv_bn_act(tape, names, conv, bn, srcs, B, H, W, relu=True, residual=None, 
         dy = tape.pop_grad(y)
         if dy is None:
             raise RuntimeError("conv_bn_act: no gradient reached this layer")
+        wsrc = [(t0, min(c0 + 3 & ~3, t0.shape[3]), 0, 0, 0)]
+        if t1 is not None:
+            wsrc.append((t1, c1, c0, srcs[1][2], srcs[1][3]))
+        wg_s3 = s3 and wgrad_s3_ok(ks, stride, cout, wsrc)
         dz, dgamma, dbeta, dres, dz_s3 = _bn_backward(lib, dy, y, z, mi, bn, relu, residual is not None,
-                                                      want_s3=s3 and need_dx and stride == 1)
+                                                      want_s3=s3 and stride == 1 and (need_dx or wg_s3))
         g = tape.param_grads
         g[names(bn.weight)], g[names(bn.bias)] = dgamma, dbeta
         if conv.bias is not None:
@@ -190,10 +211,10 @@ def conv_bn_act(tape, names, conv, bn, srcs, B, H, W, relu=True, residual=None, 
             _lib.check(lib.sfh_zero_stuff2(_ptr(dz), _ptr(u), B, ho, wo, H, W, cout, _stream()), "zero_stuff2")
             dz = u
         cin_store = t0.shape[3] if t1 is None else c0 + c1
-        wsrc = [(t0, min(c0 + 3 & ~3, t0.shape[3]), 0, 0, 0)]
-        if t1 is not None:
-            wsrc.append((t1, c1, c0, srcs[1][2], srcs[1][3]))
-        raw = _wgrad(lib, dz, wsrc, B, H, W, ks, cin_store)
+        if wg_s3:
+            raw = _wgrad_s3(lib, tape, dz_s3, cout, wsrc, B, H, W, cin_store)
+        else:
+            raw = _wgrad(lib, dz, wsrc, B, H, W, ks, cin_store)
         g[names(conv.weight)] = raw.view(cout, ks, ks, cin_store)[..., :c0 + c1].permute(0, 3, 1, 2).contiguous()
         if not need_dx:
             return
