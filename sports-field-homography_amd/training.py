@@ -553,7 +553,8 @@ def run_forward(net, tape, x):
             ww, wh = net.warp_size
             f["warp_mask"], _ = E.homography_warp(theta4, net.court_img, wh, ww, net.warp_with_nearest,
                                                   shared_template=f["shared"])
-    tape._s3.clear()   # the split-bf16 copies only feed forward convolutions
+    # the split-bf16 copies of the conv inputs stay on the tape: backward-filter reads them again (1.5x the
+    # fp32 activations in HBM, released with the tape after the backward pass)
     return f
 
 
