@@ -11,7 +11,7 @@ OUT=$ROOTD/gpurun_out
 mkdir -p $OUT
 rm -rf $OUT/${TAG}_trace $OUT/${TAG}_fetch $OUT/${TAG}_write $OUT/${TAG}_mfma
 cd /tmp && export TMPDIR=/tmp
-ARGS="--steps 3 --warmup 1 --no-cpu-baseline"
+ARGS="--steps 3 --warmup 1 --no-cpu-baseline --no-extra-configs"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_trace -- python3 $ROOTD/bench.py $ARGS > $OUT/${TAG}_trace.log 2>&1
 echo "trace done"
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/${TAG}_fetch -- python3 $ROOTD/bench.py $ARGS > $OUT/${TAG}_fetch.log 2>&1

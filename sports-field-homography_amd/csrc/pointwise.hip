@@ -478,14 +478,28 @@ __global__ void maxpool3x3s2_kernel(const float* __restrict__ x, float* __restri
 // AdaptiveAvgPool2d(1) + Linear in two small launches: channel means with one thread per (frame, channel)
 // (coalesced over channels, 64 channels per block so that a 16-frame batch fills 128 CUs instead of 16),
 // then nout dot products per frame.
-__global__ __launch_bounds__(64) void avgpool_mean_kernel(const float* __restrict__ x, int HW, int C,
-                                                          float* __restrict__ mean) {
-  const int b = blockIdx.y, c = blockIdx.x * 64 + threadIdx.x;
-  if (c >= C) return;
-  const float* xb = x + (long)b * HW * C + c;
-  float s = 0.f;
-  for (int i = 0; i < HW; ++i) s += xb[(long)i * C];
-  mean[(long)b * C + c] = s / (float)HW;
+__global__ __launch_bounds__(256) void avgpool_mean_kernel(const float* __restrict__ x, int HW, int C,
+                                                           float* __restrict__ mean) {
+  // 64 channels x 4 pixel slices per block; four independent partial sums per thread keep loads in flight
+  // (one dependent chain over the 240 pixels of the last ResNet stage took 58 us)
+  __shared__ float part[4][64];
+  const int b = blockIdx.y, cl = threadIdx.x & 63, sl = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (c < C) {
+    const float* xb = x + (long)b * HW * C + c;
+    int i = sl;
+    for (; i + 12 < HW; i += 16) {
+      s0 += xb[(long)i * C];
+      s1 += xb[(long)(i + 4) * C];
+      s2 += xb[(long)(i + 8) * C];
+      s3 += xb[(long)(i + 12) * C];
+    }
+    for (; i < HW; i += 4) s0 += xb[(long)i * C];
+  }
+  part[sl][cl] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (sl == 0 && c < C) mean[(long)b * C + c] = ((part[0][cl] + part[1][cl]) + (part[2][cl] + part[3][cl])) / (float)HW;
 }
 
 __global__ __launch_bounds__(256) void avgpool_linear_kernel(
@@ -703,7 +717,7 @@ extern "C" int sfh_avgpool_linear_fwd(const float* x, const float* w, const floa
                                       int H, int W, int C, int nout, float* feat, float* out, void* stream) {
   SFH_REQUIRE(x && w && bias && feat && out && batch > 0 && batch <= 65535 && H > 0 && W > 0 && C > 0 && nout > 0,
               "avgpool_linear: bad argument");
-  hipLaunchKernelGGL(avgpool_mean_kernel, dim3((unsigned)sfh_cdiv(C, 64), (unsigned)batch), dim3(64), 0,
+  hipLaunchKernelGGL(avgpool_mean_kernel, dim3((unsigned)sfh_cdiv(C, 64), (unsigned)batch), dim3(256), 0,
                      (hipStream_t)stream, x, H * W, C, feat);
   int rc = sfh_check_launch("avgpool_mean_kernel");
   if (rc) return rc;

@@ -249,9 +249,12 @@ class Reconstructor(nn.Module):
 
     def _chunked(self, fn, x, *args):
         mf = self._max_frames(x)
-        if x.shape[0] <= mf:
+        B = x.shape[0]
+        if B <= mf:
             return fn(x, 0, *args)
-        outs = [fn(x[i:i + mf], i, *args) for i in range(0, x.shape[0], mf)]
+        n = -(-B // mf)                 # fewest sub-batches that fit the descriptor range ...
+        size = -(-B // n)               # ... of equal size (16 frames at 1280x720: 8 + 8, not 12 + 4)
+        outs = [fn(x[i:i + size], i, *args) for i in range(0, B, size)]
         return {k: torch.cat([o[k] for o in outs], 0) for k in outs[0]}
 
     def forward(self, x):

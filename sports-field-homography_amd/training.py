@@ -51,6 +51,24 @@ class Tape:
         self.use_s3 = _use_s3()
         self._s3 = {}
         self.order = E.LaunchOrder()
+        self._arena = {}      # dtype -> [zero-filled buffer, next free element]
+
+    # Zero-initialised accumulators (fp64 BatchNorm / reduction sums, fp32 split-K weight gradients): a training
+    # step needs ~240 of them; carving them out of two buffers zeroed by ONE fill each replaces that many
+    # fill launches.  Chunk sizes: 1 Mi doubles, 64 Mi floats (the weight gradients of the default model are
+    # 52 M floats); a request that does not fit opens another chunk.
+    _ARENA_CHUNK = {torch.float64: 1 << 20, torch.float32: 1 << 26}
+
+    def zeros(self, shape, like, dtype=torch.float32):
+        n = 1
+        for d in shape:
+            n *= int(d)
+        cur = self._arena.get(dtype)
+        if cur is None or cur[1] + n > cur[0].numel():
+            cur = self._arena[dtype] = [torch.zeros(max(n, self._ARENA_CHUNK[dtype]), dtype=dtype, device=like.device), 0]
+        out = cur[0][cur[1]:cur[1] + n].view(shape)
+        cur[1] += (n + 63) & ~63          # 256- / 512-byte aligned slices
+        return out
 
     def s3(self, t):
         """split-bf16 copy of an NHWC activation (converted once, kept while the tape lives)"""
@@ -84,19 +102,19 @@ class Tape:
 
 
 # --------------------------------------------------------------------------------------- layers
-def _bn_forward(lib, z, bn, relu, residual=None, tape=None):
-    """Batch-statistics BatchNorm (+residual) (+ReLU); updates the running stats in place.  With a tape in
-    split-bf16 mode the S3 copy the next convolution needs is written by the same kernel."""
+def _bn_forward(lib, z, bn, relu, residual, tape, want_s3=True):
+    """Batch-statistics BatchNorm (+residual) (+ReLU); updates the running stats in place.  In split-bf16 mode
+    (and want_s3) the S3 copy the next convolution needs is written by the same kernel."""
     B, H, W, C = z.shape
     npix = B * H * W
-    acc = _zeros((2 * C,), z, torch.float64)
+    acc = tape.zeros((2 * C,), z, torch.float64)
     _lib.check(lib.sfh_bn_stats(_ptr(z), npix, C, _ptr(acc), _stream()), "bn_stats")
     mi = _empty((2 * C,), z)
     _lib.check(lib.sfh_bn_finalize(_ptr(acc), npix, C, float(bn.eps), BN_MOMENTUM, _ptr(bn.running_mean),
                                    _ptr(bn.running_var), _ptr(mi), _stream()), "bn_finalize")
     bn.num_batches_tracked += 1
     y = _empty(z.shape, z)
-    y_s3 = E.s3_empty(B, H, W, C, z.device) if (tape is not None and tape.use_s3 and C % 32 == 0) else None
+    y_s3 = E.s3_empty(B, H, W, C, z.device) if (want_s3 and tape.use_s3 and C % 32 == 0) else None
     _lib.check(lib.sfh_bn_apply(_ptr(z), _ptr(mi), _ptr(bn.weight.detach()), _ptr(bn.bias.detach()),
                                 _ptr(residual), 1 if relu else 0, npix, C, _ptr(y), _ptr(y_s3), W, _stream()), "bn_apply")
     if y_s3 is not None:
@@ -104,10 +122,10 @@ def _bn_forward(lib, z, bn, relu, residual=None, tape=None):
     return y, mi
 
 
-def _bn_backward(lib, dy, y, z, mi, bn, relu, want_dres, want_s3=False):
+def _bn_backward(lib, tape, dy, y, z, mi, bn, relu, want_dres, want_s3=False):
     B, H, W, C = z.shape
     npix = B * H * W
-    acc = _zeros((2 * C,), z, torch.float64)
+    acc = tape.zeros((2 * C,), z, torch.float64)
     _lib.check(lib.sfh_bn_bwd_reduce(_ptr(dy), _ptr(y), _ptr(z), _ptr(mi), 1 if relu else 0, npix, C, _ptr(acc),
                                      _stream()), "bn_bwd_reduce")
     dz = _empty(z.shape, z)
@@ -138,7 +156,7 @@ def wgrad_s3_ok(ksize, stride, M, srcs):
 def _wgrad_s3(lib, tape, dz_s3, M, srcs, B, H, W, cin_store):
     """raw (M, 9, cin_store) on the bf16 matrix cores; srcs as in _wgrad (fp32 NHWC tensors whose S3 copies the
     tape holds since the forward pass)."""
-    raw = torch.zeros((M, 9, cin_store), dtype=torch.float32, device=dz_s3.device)
+    raw = tape.zeros((M, 9, cin_store), dz_s3)
     for (t, n, n_off, pt, pl) in srcs:
         xs = tape.s3(t)
         _lib.check(lib.sfh_conv_wgrad_s3(_ptr(dz_s3), M, _ptr(xs), t.shape[3], t.shape[1], t.shape[2], n, pt, pl,
@@ -146,10 +164,10 @@ def _wgrad_s3(lib, tape, dz_s3, M, srcs, B, H, W, cin_store):
     return raw
 
 
-def _wgrad(lib, dz, srcs, B, H, W, ksize, cin_store):
+def _wgrad(lib, dz, srcs, B, H, W, ksize, cin_store, tape=None):
     """raw (M, k*k, cin_store) = sum_p dz[p] (x) xin[p + tap]; srcs = [(tensor, channels, n_off, pad_top, pad_left)]."""
     M = dz.shape[3]
-    raw = _zeros((M, ksize * ksize, cin_store), dz)
+    raw = (tape.zeros if tape is not None else _zeros)((M, ksize * ksize, cin_store), dz)
     for (t, n, n_off, pt, pl) in srcs:
         # t may be a channel slice of an NHWC tensor: the pixel stride is stride(2), not shape[3]
         _lib.check(lib.sfh_conv_wgrad(_ptr(dz), dz.shape[3], M, _ptr(t), t.stride(2), t.shape[1], t.shape[2], n,
@@ -186,7 +204,7 @@ def conv_bn_act(tape, names, conv, bn, srcs, B, H, W, relu=True, residual=None, 
     z = _empty((B, ho, wo, cout), t0)
     pc.run(tape.s3(t0) if s3 else t0, B, H, W, z, src1=(tape.s3(t1) if s3 else t1) if t1 is not None else None,
            pad1=(srcs[1][2], srcs[1][3]) if t1 is not None else (0, 0))
-    y, mi = _bn_forward(lib, z, bn, relu, residual, tape if s3_out else None)   # s3_out: a conv consumes y
+    y, mi = _bn_forward(lib, z, bn, relu, residual, tape, want_s3=s3_out)   # s3_out: a conv consumes y
 
     def backward():
         dy = tape.pop_grad(y)
@@ -196,14 +214,14 @@ def conv_bn_act(tape, names, conv, bn, srcs, B, H, W, relu=True, residual=None, 
         if t1 is not None:
             wsrc.append((t1, c1, c0, srcs[1][2], srcs[1][3]))
         wg_s3 = s3 and wgrad_s3_ok(ks, stride, cout, wsrc)
-        dz, dgamma, dbeta, dres, dz_s3 = _bn_backward(lib, dy, y, z, mi, bn, relu, residual is not None,
+        dz, dgamma, dbeta, dres, dz_s3 = _bn_backward(lib, tape, dy, y, z, mi, bn, relu, residual is not None,
                                                       want_s3=s3 and stride == 1 and (need_dx or wg_s3))
         g = tape.param_grads
         g[names(bn.weight)], g[names(bn.bias)] = dgamma, dbeta
         if conv.bias is not None:
             # a bias in front of a batch-statistics BatchNorm has exactly zero gradient (the batch mean
             # absorbs it); autograd's value is rounding noise around 0
-            g[names(conv.bias)] = _zeros((cout,), dz)
+            g[names(conv.bias)] = tape.zeros((cout,), dz)
         if residual is not None:
             tape.add_grad(residual, dres)
         if stride == 2:  # zero-stuff dz to the input resolution: stride-1 backward from here on
@@ -214,7 +232,7 @@ def conv_bn_act(tape, names, conv, bn, srcs, B, H, W, relu=True, residual=None, 
         if wg_s3:
             raw = _wgrad_s3(lib, tape, dz_s3, cout, wsrc, B, H, W, cin_store)
         else:
-            raw = _wgrad(lib, dz, wsrc, B, H, W, ks, cin_store)
+            raw = _wgrad(lib, dz, wsrc, B, H, W, ks, cin_store, tape)
         g[names(conv.weight)] = raw.view(cout, ks, ks, cin_store)[..., :c0 + c1].permute(0, 3, 1, 2).contiguous()
         if not need_dx:
             return
@@ -277,7 +295,7 @@ def conv_transpose2x2(tape, names, up, x):
         g[names(up.bias)] = _colsum(lib, du)
         s = _empty((B, h, w, 4 * cout), x)  # s[(py*2+px)*cout + co] = du[2y+py][2x+px][co]
         _lib.check(lib.sfh_space_to_depth2(_ptr(du), _ptr(s), B, 2 * h, 2 * w, cout, _stream()), "space_to_depth2")
-        raw = _wgrad(lib, s, [(x, cin, 0, 0, 0)], B, h, w, 1, cin)      # (4*cout, 1, cin)
+        raw = _wgrad(lib, s, [(x, cin, 0, 0, 0)], B, h, w, 1, cin, tape)      # (4*cout, 1, cin)
         g[names(up.weight)] = raw.view(2, 2, cout, cin).permute(3, 2, 0, 1).contiguous()
         bd = PackedConv.backward_data(wt, 1, transposed=True, s3=s3)
         dx = _empty((B, h, w, bd.cout), x)
@@ -318,8 +336,8 @@ def out_conv(tape, names, oc, y, B, H, W, frame_nhwc=None, stn_cs=0):
 
     def backward(dlogits):
         """dlogits: (B,nc,H,W) contiguous - total gradient wrt the logits."""
-        acc_w = _zeros((nc * cin,), y, torch.float64)
-        acc_b = _zeros((nc,), y, torch.float64)
+        acc_w = tape.zeros((nc * cin,), y, torch.float64)
+        acc_b = tape.zeros((nc,), y, torch.float64)
         dy = _empty(y.shape, y)
         _lib.check(lib.sfh_outconv_bwd(_ptr(y), cin, _ptr(wt), _ptr(dlogits), nc, B, H, W, _ptr(dy), _ptr(acc_w),
                                        _ptr(acc_b), _stream()), "outconv_bwd")
@@ -400,7 +418,7 @@ class ResNetTrainer:
         pc = PackedConv(w0, None, None, 4, 4 * cs, relu=False, stem_cin=cin, tag="train_fwd")
         z0 = _empty((B, H2, W2, 64), stn_in)
         pc.run(s2d, B, H2, W2, z0)
-        c1, mi0 = _bn_forward(lib, z0, rn.bn1, True)
+        c1, mi0 = _bn_forward(lib, z0, rn.bn1, True, None, tape, want_s3=False)
         h, w = (H2 - 1) // 2 + 1, (W2 - 1) // 2 + 1
         x = _empty((B, h, w, 64), stn_in)
         _lib.check(lib.sfh_maxpool3x3s2_fwd(_ptr(c1), _ptr(x), B, H2, W2, 64, st()), "maxpool3x3s2")
@@ -410,7 +428,7 @@ class ResNetTrainer:
             dx = tape.pop_grad(x_pool)
             dc1 = _empty(c1.shape, c1)
             _lib.check(lib.sfh_maxpool3x3s2_bwd(_ptr(c1), _ptr(dx), _ptr(dc1), B, H2, W2, 64, st()), "maxpool3x3s2_bwd")
-            dz, dgamma, dbeta, _, _ = _bn_backward(lib, dc1, c1, z0, mi0, rn.bn1, True, False)
+            dz, dgamma, dbeta, _, _ = _bn_backward(lib, tape, dc1, c1, z0, mi0, rn.bn1, True, False)
             g = tape.param_grads
             g[names(rn.bn1.weight)], g[names(rn.bn1.bias)] = dgamma, dbeta
             # the 4x4 backward-filter instance holds 32 input channels: wider inputs go in slices
@@ -455,8 +473,8 @@ class ResNetTrainer:
 
         def head_backward():
             dth = tape.pop_grad(theta)
-            acc_w = _zeros((9 * C,), feat, torch.float64)
-            acc_b = _zeros((9,), feat, torch.float64)
+            acc_w = tape.zeros((9 * C,), feat, torch.float64)
+            acc_b = tape.zeros((9,), feat, torch.float64)
             dfeat = _empty(feat.shape, feat)
             _lib.check(lib.sfh_avgpool_linear_bwd(_ptr(feat), _ptr(wr), _ptr(dth), B, fh, fw, C, 9, _ptr(dfeat),
                                                   _ptr(acc_w), _ptr(acc_b), st()), "avgpool_linear_bwd")
