@@ -203,6 +203,11 @@ def main():
     ap.add_argument("--train-autograd", action="store_true",
                     help="with --train: losses, clip and RMSprop as the caller's torch ops around the model's "
                          "autograd node (the reference's train.py structure) instead of the all-HIP TrainStep")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="process-group backend (nccl = RCCL over xGMI; gloo only to rehearse the multi-rank path)")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="rehearsal on a one-GPU box: every rank uses cuda:0 (needs --dist-backend gloo; the value "
+                         "then measures nothing)")
     ap.add_argument("--no-extra-configs", action="store_true",
                     help="skip the short C3 (training step) and C5 (1280x720) measurements appended at N=1")
     args = ap.parse_args()
@@ -222,11 +227,18 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
         raise SystemExit(f"--gpus {args.gpus} but the launcher started {world} rank(s)")
+    if args.share_gpu:
+        if args.dist_backend != "gloo":
+            raise SystemExit("--share-gpu is a rehearsal mode and needs --dist-backend gloo (RCCL wants one GPU per rank)")
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)
+        if args.dist_backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend="gloo")
 
     B, W, H = args.batch, args.width, args.height
     tmpl_name = "ncaa_nc4_640x360" if (W, H) == (640, 360) else "pitch_v3_nc4_1280x720"
@@ -350,7 +362,9 @@ def main():
                                    f"batch {B}/GPU, req_outputs=theta,warp_mask"
                                    + (",consistency,poi" if args.consistency else ""),
                        "frames_per_gpu_per_step": B, "global_batch": B * world,
-                       "parallelism": f"frame-sharded x{world}, all_gather(theta) over RCCL" if world > 1 else "single GPU"},
+                       "parallelism": (f"frame-sharded x{world}, all_gather(theta) over "
+                                       + ("RCCL" if args.dist_backend == "nccl" else "gloo (REHEARSAL, ranks share a GPU)" if args.share_gpu else "gloo")
+                                       if world > 1 else "single GPU")},
             "roofline": roofline,
             "cpu_baseline": cpu_baseline,
             "kernel_groups": other,
