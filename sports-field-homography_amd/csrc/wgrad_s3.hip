@@ -192,11 +192,19 @@ int launch(WgS3Args a, hipStream_t stream) {
   a.nty = sfh_cdiv(a.H, TR);
   a.ntiles = a.ntx * a.nty * a.batch;
   const int mn = a.mblk * a.nblk;
-  int nsplit = 1536 / mn;                 // about three rounds of two workgroups per CU
-  if (nsplit < 1) nsplit = 1;
+  // about three rounds of two workgroups per CU - and a multiple of 8: split s runs on XCD s % 8, so that
+  // fewer than 8 (or 12: 8 + 4) splits leave XCDs idle (22x40 layers: 3 splits ran on 3 of the 8 XCDs, 103
+  // instead of 250 TFLOP/s-equivalent)
+  int nsplit = ((1536 / mn + 7) / 8) * 8;
+  if (nsplit < 8) nsplit = 8;
   if (nsplit > a.ntiles) nsplit = a.ntiles;
   a.tps = sfh_cdiv(a.ntiles, nsplit);
   a.nsplit = sfh_cdiv(a.ntiles, a.tps);
+  if (a.nsplit > 8 && a.nsplit % 8 != 0 && a.nsplit < 32) {   // e.g. 13 of 16: shave the tail to a multiple of 8
+    const int want = (a.nsplit / 8) * 8;
+    const int tps2 = sfh_cdiv(a.ntiles, want);
+    if (sfh_cdiv(a.ntiles, tps2) % 8 == 0) { a.tps = tps2; a.nsplit = sfh_cdiv(a.ntiles, tps2); }
+  }
   const long nblocks = (long)sfh_cdiv(a.nsplit, 8) * 8 * mn;
   SFH_REQUIRE(nblocks < (1L << 31), "conv_wgrad_s3: grid too large");
   sfh_allow_big_lds(reinterpret_cast<const void*>(&wgrad_s3_kernel<TR, TW>));
