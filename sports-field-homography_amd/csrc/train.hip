@@ -37,15 +37,32 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__
     const int lanes = 256 / cq;
     const int q = threadIdx.x % cq, pl = threadIdx.x / cq;
     double s0[4] = {0, 0, 0, 0}, s1[4] = {0, 0, 0, 0};
-    if (pl < lanes)
-      for (long p = (long)blockIdx.x * lanes + pl; p < npix; p += (long)gridDim.x * lanes) {
-        const f32x4 v = *reinterpret_cast<const f32x4*>(z + p * C + c0 + 4 * q);
+    if (pl < lanes) {
+      // four pixels per iteration: 64 B per thread in flight (one 16-byte load per thread kept the chip at 2 TB/s)
+      const long stride = (long)gridDim.x * lanes;
+      long p = (long)blockIdx.x * lanes + pl;
+      const float* zc = z + c0 + 4 * q;
+      for (; p + 3 * stride < npix; p += 4 * stride) {
+        f32x4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const f32x4*>(zc + (p + u * stride) * C);
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            s0[j] += (double)v[u][j];
+            s1[j] += (double)v[u][j] * (double)v[u][j];
+          }
+      }
+      for (; p < npix; p += stride) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(zc + p * C);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           s0[j] += (double)v[j];
           s1[j] += (double)v[j] * (double)v[j];
         }
       }
+    }
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       __syncthreads();
@@ -146,21 +163,44 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
     const int lanes = 256 / cq;
     const int q = threadIdx.x % cq, pl = threadIdx.x / cq;
     double s0[4] = {0, 0, 0, 0}, s1[4] = {0, 0, 0, 0};
-    if (pl < lanes)
-      for (long p = (long)blockIdx.x * lanes + pl; p < npix; p += (long)gridDim.x * lanes) {
-        const long o = p * C + c0 + 4 * q;
-        const f32x4 g = *reinterpret_cast<const f32x4*>(dy + o);
-        const f32x4 zz = *reinterpret_cast<const f32x4*>(z + o);
-        f32x4 yy = {1.f, 1.f, 1.f, 1.f};
-        if (relu) yy = *reinterpret_cast<const f32x4*>(y + o);
+    if (pl < lanes) {
+      const long stride = (long)gridDim.x * lanes;
+      long p = (long)blockIdx.x * lanes + pl;
+      float mean[4], invstd[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        mean[j] = mi[c0 + 4 * q + j];
+        invstd[j] = mi[C + c0 + 4 * q + j];
+      }
+      auto add = [&](const f32x4& g, const f32x4& zz, const f32x4& yy) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const float gj = yy[j] > 0.f ? g[j] : 0.f;
-          const float xh = (zz[j] - mi[c0 + 4 * q + j]) * mi[C + c0 + 4 * q + j];
+          const float xh = (zz[j] - mean[j]) * invstd[j];
           s0[j] += (double)gj;
           s1[j] += (double)gj * (double)xh;
         }
+      };
+      // two pixels per iteration: six 16-byte loads per thread in flight
+      for (; p + stride < npix; p += 2 * stride) {
+        const long o0 = p * C + c0 + 4 * q, o1 = (p + stride) * C + c0 + 4 * q;
+        const f32x4 g0 = *reinterpret_cast<const f32x4*>(dy + o0), g1 = *reinterpret_cast<const f32x4*>(dy + o1);
+        const f32x4 z0 = *reinterpret_cast<const f32x4*>(z + o0), z1 = *reinterpret_cast<const f32x4*>(z + o1);
+        f32x4 y0 = {1.f, 1.f, 1.f, 1.f}, y1 = {1.f, 1.f, 1.f, 1.f};
+        if (relu) {
+          y0 = *reinterpret_cast<const f32x4*>(y + o0);
+          y1 = *reinterpret_cast<const f32x4*>(y + o1);
+        }
+        add(g0, z0, y0);
+        add(g1, z1, y1);
       }
+      for (; p < npix; p += stride) {
+        const long o = p * C + c0 + 4 * q;
+        f32x4 yy = {1.f, 1.f, 1.f, 1.f};
+        if (relu) yy = *reinterpret_cast<const f32x4*>(y + o);
+        add(*reinterpret_cast<const f32x4*>(dy + o), *reinterpret_cast<const f32x4*>(z + o), yy);
+      }
+    }
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       __syncthreads();
