@@ -131,6 +131,18 @@ class LaunchOrder:
         return r
 
 
+_UNIT = {}
+
+
+def _unit_epilogue(n, dev):
+    """(ones, zeros) of n floats on dev, shared read-only by every backward-data conv (56 per training step)"""
+    key = (n, str(dev))
+    v = _UNIT.get(key)
+    if v is None:
+        v = _UNIT[key] = (torch.ones(n, dtype=torch.float32, device=dev), torch.zeros(n, dtype=torch.float32, device=dev))
+    return v
+
+
 class PackedConv:
     """One conv-shaped layer: fragment-ordered weights + folded per-channel epilogue."""
 
@@ -275,8 +287,7 @@ class PackedConv:
             self.wpacked = torch.empty(n, dtype=torch.float32, device=dev)
             _lib.check(lib.sfh_pack_conv_weights(_ptr(w), _ptr(self.wpacked), ksize, c0, 0, self.cout, mode, aux,
                                                  _stream()), "pack_conv_weights")
-        self.scale = torch.ones(self.cout, dtype=torch.float32, device=dev)
-        self.shift = torch.zeros(self.cout, dtype=torch.float32, device=dev)
+        self.scale, self.shift = _unit_epilogue(self.cout, dev)
         return self
 
     def run(self, src0, batch, H, W, dst, src1=None, pool0=False, pad1=(0, 0), residual=None, tile=None,

@@ -233,7 +233,8 @@ def conv_bn_act(tape, names, conv, bn, srcs, B, H, W, relu=True, residual=None, 
             raw = _wgrad_s3(lib, tape, dz_s3, cout, wsrc, B, H, W, cin_store)
         else:
             raw = _wgrad(lib, dz, wsrc, B, H, W, ks, cin_store, tape)
-        g[names(conv.weight)] = raw.view(cout, ks, ks, cin_store)[..., :c0 + c1].permute(0, 3, 1, 2).contiguous()
+        # a strided view: the copy into the gradient buffer (TrainStep) or autograd's accumulation does the permute
+        g[names(conv.weight)] = raw.view(cout, ks, ks, cin_store)[..., :c0 + c1].permute(0, 3, 1, 2)
         if not need_dx:
             return
         bd = PackedConv.backward_data(w, ks, s3=s3)
@@ -296,7 +297,7 @@ def conv_transpose2x2(tape, names, up, x):
         s = _empty((B, h, w, 4 * cout), x)  # s[(py*2+px)*cout + co] = du[2y+py][2x+px][co]
         _lib.check(lib.sfh_space_to_depth2(_ptr(du), _ptr(s), B, 2 * h, 2 * w, cout, _stream()), "space_to_depth2")
         raw = _wgrad(lib, s, [(x, cin, 0, 0, 0)], B, h, w, 1, cin, tape)      # (4*cout, 1, cin)
-        g[names(up.weight)] = raw.view(2, 2, cout, cin).permute(3, 2, 0, 1).contiguous()
+        g[names(up.weight)] = raw.view(2, 2, cout, cin).permute(3, 2, 0, 1)
         bd = PackedConv.backward_data(wt, 1, transposed=True, s3=s3)
         dx = _empty((B, h, w, bd.cout), x)
         bd.run(E.f32_to_s3(s) if s3 else s, B, h, w, dx)
@@ -816,7 +817,8 @@ class TrainStep:
                    "reproj_loss")
         g = run_backward(net, tape, f, [dlogits], theta_gradient(net, f, None, dpoi, dwarp))
         for p, dst in zip(self.params, self.grads):
-            dst.copy_(g[self.names(p)].reshape(dst.shape))
+            src = g[self.names(p)]
+            dst.copy_(src if tuple(src.shape) == tuple(dst.shape) else src.reshape(dst.shape))   # strided views copy in one pass
         return losses
 
     def step(self, x, batch):
