@@ -460,6 +460,66 @@ __global__ void pack_s3_weights_kernel(const float* __restrict__ w, unsigned sho
   }
 }
 
+// Same packing for the two layouts a training step re-packs after every optimizer update (mode 0: forward
+// OIHW, mode 3: backward-data = channels swapped + taps flipped), 3x3 and 1x1: one thread = (cout, 8 cins) for
+// ALL taps, so that it reads whole contiguous runs of the checkpoint tensor (72 floats in mode 0, nine floats
+// per cin in mode 3) instead of one float every 36 bytes (the per-tap kernel above moved 0.5 TB/s).
+template <int KS, int MODE>
+__global__ __launch_bounds__(256) void pack_s3_weights_alltaps_kernel(const float* __restrict__ w,
+                                                                      unsigned short* __restrict__ packed, int c0, int c1,
+                                                                      int coutv, int aux, long total) {
+  constexpr int NT = KS * KS;
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;  // (nb, st, ng, lane)
+  if (idx >= total) return;
+  const int nst0 = c0 / 32, nst = nst0 + c1 / 32;
+  long r = idx;
+  const int lane = r & 63; r >>= 6;
+  const int ng = r & 3; r >>= 2;
+  const int st = r % nst;
+  const int nb = r / nst;
+  const int cv = nb * 64 + ng * 16 + (lane & 15);
+  const int cin_total = c0 + c1;
+  const int cl = (st < nst0 ? st : st - nst0) * 32 + 8 * (lane >> 4);
+  const int cin0 = st < nst0 ? cl : c0 + cl;
+  float v[8][NT];
+  if (MODE == 0) {
+    const float* src = w + ((size_t)cv * cin_total + cin0) * NT;     // 8 * NT contiguous floats, 16-byte aligned
+#pragma unroll
+    for (int q = 0; q < 2 * NT; ++q) {
+      const f32x4 t = *reinterpret_cast<const f32x4*>(src + 4 * q);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[(4 * q + e) / NT][(4 * q + e) % NT] = t[e];
+    }
+  } else {  // backward-data: w[cin][cv][flipped tap], zero rows for cv >= aux (padded output channels)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float* src = w + ((size_t)(cin0 + j) * aux + cv) * NT;
+#pragma unroll
+      for (int t = 0; t < NT; ++t) v[j][t] = cv < aux ? src[NT - 1 - t] : 0.f;
+    }
+  }
+  typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    u16x8 p0, p1, p2;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float x = v[j][t];
+      const __bf16 v0 = (__bf16)x;
+      const float r1 = x - (float)v0;
+      const __bf16 v1 = (__bf16)r1;
+      const __bf16 v2 = (__bf16)(r1 - (float)v1);
+      p0[j] = __builtin_bit_cast(unsigned short, v0);
+      p1[j] = __builtin_bit_cast(unsigned short, v1);
+      p2[j] = __builtin_bit_cast(unsigned short, v2);
+    }
+    const long base = ((((long)nb * nst + st) * NT + t) * 3) * 4096 + (long)ng * 1024 + lane * 16;  // bytes
+    *reinterpret_cast<u16x8*>(packed + (base + 0 * 4096) / 2) = p0;
+    *reinterpret_cast<u16x8*>(packed + (base + 1 * 4096) / 2) = p1;
+    *reinterpret_cast<u16x8*>(packed + (base + 2 * 4096) / 2) = p2;
+  }
+}
+
 // fp32 NHWC (B,H,W,cs) -> S3 (B,H,W,3,cs) and back (tests, network input, debugging)
 // element (row, x, c, plane) of an S3 tensor (rows, cs/32, 3, 4, W, 8)
 __device__ __forceinline__ long s3_elem(long row, int x, int c, int plane, int W, int cs) {
@@ -595,6 +655,19 @@ extern "C" int sfh_pack_s3_weights(const float* w, void* packed, int ksize, int 
                   (mode == 3 && c1 == 0 && (ksize == 1 || ksize == 3) && aux > 0 && aux <= cout_virtual) ||
                   (mode == 4 && ksize == 1 && c1 == 0 && aux > 0 && c0 == 4 * aux),
               "pack_s3_weights: bad mode/geometry (mode %d, ksize %d)", mode, ksize);
+  if ((mode == 0 || mode == 3) && (ksize == 3 || ksize == 1)) {
+    const long tot = n / 48 / (ksize * ksize);   // one thread per (cout, 8 cins), all taps
+    const dim3 grid((unsigned)((tot + 255) / 256));
+#define SFH_PACK_AT(KS_, M_)                                                                                  \
+  hipLaunchKernelGGL((pack_s3_weights_alltaps_kernel<KS_, M_>), grid, dim3(256), 0, (hipStream_t)stream, w,   \
+                     (unsigned short*)packed, c0, c1, cout_virtual, aux, tot)
+    if (ksize == 3 && mode == 0) SFH_PACK_AT(3, 0);
+    else if (ksize == 3) SFH_PACK_AT(3, 3);
+    else if (mode == 0) SFH_PACK_AT(1, 0);
+    else SFH_PACK_AT(1, 3);
+#undef SFH_PACK_AT
+    return sfh_check_launch("pack_s3_weights_alltaps_kernel");
+  }
   const long total = n / 48;  // one thread per (lane, 8 channels) of all three planes
   hipLaunchKernelGGL(pack_s3_weights_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
                      (hipStream_t)stream, w, (unsigned short*)packed, ksize, c0, c1, cout_virtual, mode, aux, total);
