@@ -124,6 +124,129 @@ static void launch2(const float* th, const float* tm, int ht, int wt, int B, int
   else hipLaunchKernelGGL((warp2_kernel<MODE, J, RPT, 0>), grid, dim3(256), 0, 0, th, tm, 0L, ht, wt, h, w, 1.0f / (float)(w - 1), 1.0f / (float)(h - 1), sc, of, oi);
 }
 
+
+// ---- LDS-tiled variant ("LDS tile caching" of the template, as BASELINE.json's north_star names it): a block
+// of 64 columns x 32 rows stages the template window its pixels can touch - the bounding box of the four
+// mapped tile corners (a projective map with Z > 0 on the corners maps the tile into their convex hull),
+// +-2 pixels of margin, zero outside the template - in LDS; taps are then ds_reads without range checks.
+// Blocks whose window is too large, or whose Z is not safely positive, take the descriptor path.
+// Measurement variant only: same arithmetic as warp2_kernel (results compared bit for bit below).
+namespace {
+constexpr int kWinMax = 12288;   // floats of LDS per block (48 KB: three blocks per CU)
+
+template <int MODE, int OUT>
+__global__ __launch_bounds__(256) void warp3_kernel(const float* __restrict__ theta, const float* __restrict__ tmpl,
+                                                    long tmpl_bstride, int ht, int wt, int h, int w, float rdw, float rdh,
+                                                    float out_scale, float* __restrict__ out_f, int32_t* __restrict__ out_i) {
+  constexpr int RPT = 8;
+  __shared__ float win[kWinMax];
+  __shared__ int geo[4];
+  const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int b = blockIdx.z;
+  const int cb = blockIdx.x * 64, rb = blockIdx.y * 32;
+  float t[9];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) t[k] = theta[b * 9 + k];
+  const float sx = 0.5f * (float)wt, sy = 0.5f * (float)ht;
+  const float* tm = tmpl + (long)b * tmpl_bstride;
+  // ---- window of the tile: corners (cb, rb), (cb+63, rb), (cb, rb+31), (cb+63, rb+31) clipped to the frame
+  bool use_lds;
+  int wx0, wy0, ww, wh;
+  {
+    const int cx = min(cb + ((lane & 1) ? 63 : 0), w - 1), cy = min(rb + ((lane & 2) ? 31 : 0), h - 1);
+    const float xn = norm_axis2<true>(cx, w, rdw), yn = norm_axis2<true>(cy, h, rdh);
+    const float X = __fadd_rn(__fadd_rn(__fmul_rn(t[0], xn), __fmul_rn(t[1], yn)), t[2]);
+    const float Y = __fadd_rn(__fadd_rn(__fmul_rn(t[3], xn), __fmul_rn(t[4], yn)), t[5]);
+    const float Z = __fadd_rn(__fadd_rn(__fmul_rn(t[6], xn), __fmul_rn(t[7], yn)), t[8]);
+    const float r = 1.0f / (Z + 1e-8f);
+    float px = __builtin_fmaf(X * r + 1.0f, sx, -0.5f), py = __builtin_fmaf(Y * r + 1.0f, sy, -0.5f);
+    bool good = Z > 1e-3f && fabsf(px) < 1e6f && fabsf(py) < 1e6f;
+    float lox = px, hix = px, loy = py, hiy = py;
+#pragma unroll
+    for (int m = 1; m < 4; m <<= 1) {
+      lox = fminf(lox, __shfl_xor(lox, m)); hix = fmaxf(hix, __shfl_xor(hix, m));
+      loy = fminf(loy, __shfl_xor(loy, m)); hiy = fmaxf(hiy, __shfl_xor(hiy, m));
+      good = good && __shfl_xor((int)good, m);
+    }
+    // clip to the template plus the zero border a tap can reach: [-2, size + 1]
+    wx0 = (int)fmaxf(floorf(lox) - 2.f, -2.f); wy0 = (int)fmaxf(floorf(loy) - 2.f, -2.f);
+    const int wx1 = (int)fminf(floorf(hix) + 3.f, (float)(wt + 1)), wy1 = (int)fminf(floorf(hiy) + 3.f, (float)(ht + 1));
+    ww = wx1 - wx0 + 1; wh = wy1 - wy0 + 1;
+    use_lds = good && ww > 0 && wh > 0 && (long)ww * wh <= kWinMax;
+    if (threadIdx.x == 0) { geo[0] = use_lds; geo[1] = wx0; geo[2] = wy0; geo[3] = ww | (wh << 16); }
+  }
+  __syncthreads();
+  use_lds = geo[0] != 0; wx0 = geo[1]; wy0 = geo[2]; ww = geo[3] & 0xFFFF; wh = geo[3] >> 16;
+  if (use_lds) {
+    for (int i = threadIdx.x; i < ww * wh; i += 256) {
+      const int yy = i / ww, xx = i - yy * ww;
+      const int gx = wx0 + xx, gy = wy0 + yy;
+      win[i] = ((unsigned)gx < (unsigned)wt && (unsigned)gy < (unsigned)ht) ? tm[gy * wt + gx] : 0.f;
+    }
+  }
+  __syncthreads();
+  const int c = cb + lane;
+  const int r0 = rb + wv * RPT;
+  if (r0 >= h) return;
+  const float xn = norm_axis2<true>(c < w ? c : w - 1, w, rdw);
+  const float a0 = __fmul_rn(t[0], xn), a3 = __fmul_rn(t[3], xn), a6 = __fmul_rn(t[6], xn);
+  const __amdgpu_buffer_rsrc_t rt = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(tm), 0, ht * wt * 4, 0x00020000);
+  const float fx0 = (float)wx0, fy0 = (float)wy0, fxm = (float)(wx0 + ww - 2), fym = (float)(wy0 + wh - 2);
+#pragma unroll
+  for (int rr = 0; rr < RPT; ++rr) {
+    const int y = r0 + rr;
+    if (y >= h) break;
+    const float yn = norm_axis2<true>(y, h, rdh);
+    const float X = __fadd_rn(__fadd_rn(a0, __fmul_rn(t[1], yn)), t[2]);
+    const float Y = __fadd_rn(__fadd_rn(a3, __fmul_rn(t[4], yn)), t[5]);
+    const float Z = __fadd_rn(__fadd_rn(a6, __fmul_rn(t[7], yn)), t[8]);
+    const float r = recip_rn<1>(__fadd_rn(Z, 1e-8f));
+    const float s = fabsf(Z) > 1e-8f ? r : 1.0f;
+    const float px = __builtin_fmaf(__fadd_rn(__fmul_rn(s, X), 1.0f), sx, -0.5f);
+    const float py = __builtin_fmaf(__fadd_rn(__fmul_rn(s, Y), 1.0f), sy, -0.5f);
+    float val;
+    if (use_lds) {
+      if (MODE == 0) {
+        const float rx = fminf(fmaxf(rintf(px), fx0), fxm + 1.f), ry = fminf(fmaxf(rintf(py), fy0), fym + 1.f);
+        val = win[((int)ry - wy0) * ww + ((int)rx - wx0)];
+      } else {
+        const float x0 = floorf(px), y0 = floorf(py);
+        const float wx1 = __fsub_rn(px, x0), wx0f = __fsub_rn(1.0f, wx1), wy1 = __fsub_rn(py, y0), wy0f = __fsub_rn(1.0f, wy1);
+        const float cx = fminf(fmaxf(x0, fx0), fxm), cy = fminf(fmaxf(y0, fy0), fym);   // inside by construction; the clamp guards LDS
+        const int i00 = ((int)cy - wy0) * ww + ((int)cx - wx0);
+        val = __fmul_rn(win[i00], __fmul_rn(wy0f, wx0f));
+        val = __fadd_rn(val, __fmul_rn(win[i00 + 1], __fmul_rn(wy0f, wx1)));
+        val = __fadd_rn(val, __fmul_rn(win[i00 + ww], __fmul_rn(wy1, wx0f)));
+        val = __fadd_rn(val, __fmul_rn(win[i00 + ww + 1], __fmul_rn(wy1, wx1)));
+      }
+    } else {
+      if (MODE == 0) {
+        val = tap_ld(rt, tap_off<0>(rintf(px), rintf(py), wt, ht));
+      } else {
+        const float x0 = floorf(px), y0 = floorf(py);
+        const float wx1 = __fsub_rn(px, x0), wx0f = __fsub_rn(1.0f, wx1), wy1 = __fsub_rn(py, y0), wy0f = __fsub_rn(1.0f, wy1);
+        val = __fmul_rn(tap_ld(rt, tap_off<0>(x0, y0, wt, ht)), __fmul_rn(wy0f, wx0f));
+        val = __fadd_rn(val, __fmul_rn(tap_ld(rt, tap_off<0>(x0 + 1.f, y0, wt, ht)), __fmul_rn(wy0f, wx1)));
+        val = __fadd_rn(val, __fmul_rn(tap_ld(rt, tap_off<0>(x0, y0 + 1.f, wt, ht)), __fmul_rn(wy1, wx0f)));
+        val = __fadd_rn(val, __fmul_rn(tap_ld(rt, tap_off<0>(x0 + 1.f, y0 + 1.f, wt, ht)), __fmul_rn(wy1, wx1)));
+      }
+    }
+    if (c < w) {
+      const long o = ((long)b * h + y) * w + c;
+      if (OUT != 0) out_f[o] = val;
+      if (OUT != 1) out_i[o] = (int32_t)__fmul_rn(val, out_scale);
+    }
+  }
+}
+}  // namespace
+
+template <int MODE>
+static void launch3(const float* th, const float* tm, int ht, int wt, int B, int h, int w, float sc, float* of, int32_t* oi) {
+  dim3 grid((w + 63) / 64, (h + 31) / 32, B);
+  if (of) hipLaunchKernelGGL((warp3_kernel<MODE, 1>), grid, dim3(256), 0, 0, th, tm, 0L, ht, wt, h, w, 1.0f / (float)(w - 1), 1.0f / (float)(h - 1), sc, of, oi);
+  else hipLaunchKernelGGL((warp3_kernel<MODE, 0>), grid, dim3(256), 0, 0, th, tm, 0L, ht, wt, h, w, 1.0f / (float)(w - 1), 1.0f / (float)(h - 1), sc, of, oi);
+}
+
 template <int J, int RPT>
 static void launch_noload(const float* th, const float* tm, int ht, int wt, int B, int h, int w, float sc, int32_t* oi) {
   dim3 grid((w + 64 * J - 1) / (64 * J), (h + 4 * RPT - 1) / (4 * RPT), B);
@@ -182,6 +305,7 @@ int main(int argc, char** argv) {
 #define RUN2(J, R) { auto f = [&]() { launch2<0, J, R>(dth, dtm, ht, wt, B, h, w, 4.0f, nullptr, o2); }; float us = timeit(f, iters); report("v2 nearest J" #J " RPT" #R, us, check ? cmp_i() : -1); }
         RUN2(5, 2) RUN2(5, 4) RUN2(5, 8) RUN2(4, 4) RUN2(2, 8) RUN2(10, 4)
         { auto f = [&]() { launch_noload<5, 4>(dth, dtm, ht, wt, B, h, w, 4.0f, o2); }; report("v2 nearest J5 RPT4 NOLOAD", timeit(f, iters), -1); }
+        { CK(hipMemset(o2, 0xff, npx * 4)); auto f = [&]() { launch3<0>(dth, dtm, ht, wt, B, h, w, 4.0f, nullptr, o2); }; float us = timeit(f, iters); report("v3 nearest LDS window", us, check ? cmp_i() : -1); }
 #undef RUN2
         auto so = [&]() { hipLaunchKernelGGL(store_only, dim3((unsigned)((npx + 2047) / 2048)), dim3(256), 0, 0, o2, (long)npx); };
         report("store-only", timeit(so, iters), -1);
@@ -194,6 +318,7 @@ int main(int argc, char** argv) {
 #define RUN2(J, R) { auto f = [&]() { launch2<1, J, R>(dth, dtm, ht, wt, B, h, w, 1.0f, f2, nullptr); }; float us = timeit(f, iters); report("v2 bilinear J" #J " RPT" #R, us, check ? cmp_f() : -1); }
         RUN2(5, 2) RUN2(5, 4) RUN2(2, 4) RUN2(2, 8)
 #undef RUN2
+        { CK(hipMemset(f2, 0xff, npx * 4)); auto f = [&]() { launch3<1>(dth, dtm, ht, wt, B, h, w, 1.0f, f2, nullptr); }; float us = timeit(f, iters); report("v3 bilinear LDS window", us, check ? cmp_f() : -1); }
       }
       CK(hipFree(dth)); CK(hipFree(o1)); CK(hipFree(o2)); CK(hipFree(f1)); CK(hipFree(f2));
     }
