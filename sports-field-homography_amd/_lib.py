@@ -123,6 +123,10 @@ def load():
             "`python -c 'import __graft_entry__ as g; g.build()'` (needs hipcc). "
             "There is no CPU/PyTorch fallback for this path."
         )
+    # PyTorch first: it ships its own HIP runtime (torch/lib/libamdhip64.so) and owns device memory and streams.
+    # Loading libsfh_amd.so before torch would bring /opt/rocm's copy of the runtime into the process as well,
+    # and the second copy then sees no device ("no ROCm-capable device is detected" at the first launch).
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
