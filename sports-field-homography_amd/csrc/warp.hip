@@ -5,15 +5,12 @@
 // F.grid_sample(padding 'zeros', align_corners=False), fused with predict()'s
 // `* mask_classes` and `.type(torch.int32)` (models/reconstructor.py:223,240).
 //
-// HBM-bound: per batch the compulsory traffic is B*h*w*4 B of output + one template image
-// (the template is one image replicated over the batch: utils/dataset.py:59) + 36 B of
-// theta per frame.  The coordinate arithmetic uses individually rounded fp32 operations
-// (__fmul_rn/__fadd_rn/__fdiv_rn: no FMA contraction) in exactly the order of
-// oracle/warp_ref.py, so nearest-mode results are integer-identical to the oracle.
-//
-// Work decomposition: one thread = 4 consecutive output pixels of one row (one 16-byte
-// store per output tensor); a 256-thread block covers a 4-row x 256-col strip, so all taps
-// of a block fall into a few template rows (L1/L2-resident; the template is <= 3.7 MB).
+// Compulsory traffic per batch: B*h*w*4 B of output + one template image (the template is one image
+// replicated over the batch: utils/dataset.py:59) + 36 B of theta per frame.  The coordinate arithmetic
+// uses individually rounded fp32 operations (__fmul_rn/__fadd_rn, no FMA contraction except where the
+// reference's own kernel fuses) in exactly the order of oracle/warp_ref.py, so nearest-mode results are
+// integer-identical to the oracle.  Work decomposition and the instruction-count choices: see the comment
+// in front of warp2_body.
 #include <hip/amd_detail/amd_hip_unsafe_atomics.h>
 
 #include "common.h"
@@ -143,7 +140,6 @@ __device__ __forceinline__ void warp2_body(const float (&t)[9], int b, int lane,
       const_cast<float*>(tmpl + (long)b * tmpl_bstride), 0, ht * wt * 4, 0x00020000);
   const int nrows = (h - r0 < RPT) ? h - r0 : RPT;
   const long rowbase = ((long)b * h + r0) * w;
-  // rows beyond the frame fall outside these descriptors: their stores are dropped
   const __amdgpu_buffer_rsrc_t rof = __builtin_amdgcn_make_buffer_rsrc(
       OUT != 0 ? out_f + rowbase : nullptr, 0, OUT != 0 ? nrows * w * 4 : 0, 0x00020000);
   const __amdgpu_buffer_rsrc_t roi = __builtin_amdgcn_make_buffer_rsrc(
@@ -212,7 +208,7 @@ __device__ __forceinline__ void warp2_body(const float (&t)[9], int b, int lane,
   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
   for (int rr = 0; rr < RPT; ++rr) {
-    // no early exit for rows beyond the frame (their stores fall outside the descriptors): a branch here
+    // no early exit for rows beyond the frame (their coordinates are computed and discarded): a `break` here
     // lets the optimiser sink the prefetched taps back into the next row's block
     float val[J];
     float w0[J][NT];
@@ -235,12 +231,17 @@ __device__ __forceinline__ void warp2_body(const float (&t)[9], int b, int lane,
     }
     if (rr + 1 < RPT) issue_taps();
     __builtin_amdgcn_sched_barrier(0);    // the scheduler would sink these loads to their uses one row later
-    const int soff = rr * w * 4;
+    // The row offset travels in the SCALAR offset, which the buffer range check does not see (it checks the
+    // vector offset only): a row beyond the frame must be skipped explicitly.  Wave-uniform branch around the
+    // stores only, so the prefetched taps above stay where they are.
+    if (rr < nrows) {
+      const int soff = rr * w * 4;
 #pragma unroll
-    for (int j = 0; j < J; ++j) {
-      if (OUT != 0) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val[j]), rof, (int)coff[j], soff, 0);
-      if (OUT != 1)
-        __builtin_amdgcn_raw_buffer_store_b32((unsigned)(int32_t)__fmul_rn(val[j], out_scale), roi, (int)coff[j], soff, 0);
+      for (int j = 0; j < J; ++j) {
+        if (OUT != 0) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val[j]), rof, (int)coff[j], soff, 0);
+        if (OUT != 1)
+          __builtin_amdgcn_raw_buffer_store_b32((unsigned)(int32_t)__fmul_rn(val[j], out_scale), roi, (int)coff[j], soff, 0);
+      }
     }
     __builtin_amdgcn_sched_barrier(0);
   }
@@ -462,8 +463,8 @@ extern "C" int sfh_homography_warp_fwd(const float* theta, const float* tmpl, in
               "homography_warp: bad geometry b=%d h=%d w=%d ht=%d wt=%d", batch, h, w, ht, wt);
   SFH_REQUIRE(mode == 0 || mode == 1, "homography_warp: mode %d (0 nearest, 1 bilinear)", mode);
   SFH_REQUIRE(tmpl_bstride == 0 || tmpl_bstride >= (int64_t)ht * wt, "homography_warp: bad template stride");
-  SFH_REQUIRE((int64_t)ht * wt <= (1 << 22) && (int64_t)h * w * 4 * 64 < (1ll << 31),
-              "homography_warp: template %dx%d or frame %dx%d too large for 32-bit tap / row-block offsets", wt, ht, w, h);
+  SFH_REQUIRE((int64_t)ht * wt <= (1 << 22) && w <= (1 << 20) && h <= (1 << 20),
+              "homography_warp: template %dx%d (at most 4 Mi pixels: exact fp32 tap index) or frame %dx%d too large", wt, ht, w, h);
   const float rdw = 1.0f / (float)(w - 1), rdh = 1.0f / (float)(h - 1);   // IEEE single divisions
   // Wave shape: 64*J consecutive pixels x RPT rows.  J = 5 when the row splits into 320-pixel segments
   // (640, 1280, 1920 ...), else 4; bilinear (4 taps and 4 weights per pixel in flight): J = 2.

@@ -153,6 +153,39 @@ def test_warp_arithmetic_selftest():
     assert bad.tolist() == [0, 0], bad.tolist()
 
 
+@pytest.mark.parametrize("hw", [(61, 97), (45, 640), (7, 130), (360, 640)])
+@pytest.mark.parametrize("nearest", [True, False])
+def test_warp_writes_nothing_outside_its_output(hw, nearest):
+    """Frame heights that are not a multiple of the rows a wave handles, widths that are not a multiple of 64:
+    the bytes behind the last frame (and between nothing else) must stay untouched, and every frame must equal
+    the oracle - a row of the last partial tile must not spill into the next frame or past the tensor."""
+    import ctypes
+    from sfh_amd import _lib
+    lib = _lib.load()
+    h, w = hw
+    B = 3
+    th = torch.tensor(synth.REALISTIC_THETAS)[[0, 1, 0]].reshape(B, 3, 3).contiguous()
+    th[2] = torch.eye(3) + 0.03 * torch.randn(3, 3, generator=torch.Generator().manual_seed(h))
+    tmpl = synth.load_court_template("ncaa_nc4_640x360", 4, 1)
+    guard = 4096
+    of = torch.full((B * h * w + guard,), -7.0, device="cuda")
+    oi = torch.full((B * h * w + guard,), -7, dtype=torch.int32, device="cuda")
+    p = lambda t: ctypes.c_void_p(t.data_ptr())
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    thc, tc = th.cuda(), tmpl.cuda()
+    _lib.check(lib.sfh_homography_warp_fwd(p(thc), p(tc), 0, 360, 640, B, h, w, 0 if nearest else 1, 4.0, p(of), p(oi), st), "warp")
+    torch.cuda.synchronize()
+    assert float(of[B * h * w:].min()) == -7.0 and float(of[B * h * w:].max()) == -7.0
+    assert int(oi[B * h * w:].min()) == -7 and int(oi[B * h * w:].max()) == -7
+    want = warp_ref.homography_warp(th.reshape(B, 1, 3, 3), tmpl.expand(B, -1, -1, -1), h, w, "nearest" if nearest else "bilinear")
+    got = of[:B * h * w].reshape(B, h, w).cpu()
+    if nearest:
+        assert torch.equal(got, want)
+        assert torch.equal(oi[:B * h * w].reshape(B, h, w).cpu(), (want * 4).to(torch.int32))
+    else:
+        assert float((got - want).abs().max()) < 1e-6
+
+
 def test_public_methods_direct():
     """net.forward_unet(), net.warp(), net.transform_poi() called the way the reference's callers do
     (models/reconstructor.py:109-158), not through predict()."""
