@@ -231,9 +231,9 @@ __device__ __forceinline__ void warp2_body(const float (&t)[9], int b, int lane,
     }
     if (rr + 1 < RPT) issue_taps();
     __builtin_amdgcn_sched_barrier(0);    // the scheduler would sink these loads to their uses one row later
-    // The row offset travels in the SCALAR offset, which the buffer range check does not see (it checks the
-    // vector offset only): a row beyond the frame must be skipped explicitly.  Wave-uniform branch around the
-    // stores only, so the prefetched taps above stay where they are.
+    // A row beyond the frame is skipped explicitly (its offset rides in the scalar operand; on gfx950 the
+    // descriptor's range check was observed to cover vector + scalar offset, but nothing here depends on it).
+    // Wave-uniform branch around the stores only, so the prefetched taps above stay where they are.
     if (rr < nrows) {
       const int soff = rr * w * 4;
 #pragma unroll
