@@ -232,6 +232,8 @@ extern "C" int sfh_conv_wgrad_s3(const void* dz_s3, int M, const void* x_s3, int
   a.mblk = M / 64; a.nblk = N / 32;
   a.bytes_dz = (unsigned)bdz; a.bytes_x = (unsigned)bx;
   a.ntx = a.nty = a.ntiles = a.nsplit = a.tps = 0;
+  // 96-pixel tiles (3x32 / 6x16 / 12x8: three k-steps per LDS fill, so that the MFMAs of one workgroup outlast
+  // the DMA wait of its co-resident partner) were measured no faster: 25.7 vs 24.0 ms per step for all launches.
   // tile shape with the least padded area (ties: the widest).  Weighting the area by the rate each shape
   // reaches on full tiles (2x32 250, 4x16 190, 8x8 103 TFLOP/s-equivalent) and so moving the 45x80 and 22x40
   // layers to 2x32 tiles was measured slower overall (31.0 vs 27.8 ms per step for all launches).
