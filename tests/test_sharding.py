@@ -104,3 +104,32 @@ def test_allreduce_without_process_group_is_identity():
     flat, views = sharding.flat_views([(2, 2), (3,)], "cpu")
     views[0].fill_(2.0)
     assert sharding.allreduce_gradients(flat) == 1.0 and float(flat.sum()) == 8.0
+
+
+def test_bench_self_launch_builds_one_child_per_gpu(monkeypatch):
+    """`python bench.py --gpus N` without a launcher starts torch.distributed.run as a CHILD (this process never
+    touches the GPU) on 127.0.0.1 with N ranks and hands its own arguments through."""
+    import importlib.util
+    import subprocess
+    spec = importlib.util.spec_from_file_location(
+        "bench_under_test", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    seen = {}
+
+    def fake_call(cmd, env=None):
+        seen["cmd"], seen["env"] = cmd, env
+        return 7
+
+    monkeypatch.setattr(subprocess, "call", fake_call)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "3", "--warmup", "1"])
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 7                                  # the child's exit code is this process's
+    cmd = seen["cmd"]
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node=4" in cmd and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and int(cmd[cmd.index("--master-port") + 1]) > 0
+    assert cmd[-6:] == ["--gpus", "4", "--steps", "3", "--warmup", "1"] and cmd[-7].endswith("bench.py")
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    assert "torch.cuda" not in "".join(m for m in sys.modules if m.startswith("bench_under_test"))
