@@ -186,6 +186,25 @@ def test_warp_writes_nothing_outside_its_output(hw, nearest):
         assert float((got - want).abs().max()) < 1e-6
 
 
+def test_warp_huge_and_non_finite_theta_take_the_ieee_path():
+    """A wave-uniform test on theta routes |t| > 2^59, inf and NaN to the IEEE-division / NaN-tolerant path of the
+    warp kernel (LEVEL 0): exact against the oracle in nearest mode (non-finite coordinates sample 0)."""
+    from sfh_amd import engine as E
+    base = torch.tensor(synth.REALISTIC_THETAS)
+    th = torch.stack([base[0] * 1e25, base[1] * -3e30, base[0].clone(), base[1].clone(), torch.eye(3)])
+    th[2, 0, 1] = float("inf")
+    th[3, 2, 2] = float("nan")
+    th[4, 0, 0] = 2.0 ** 60          # finite, but beyond the range the fast reciprocal was verified on
+    tmpl = synth.load_court_template("ncaa_nc4_640x360", 4, th.shape[0])
+    want = warp_ref.homography_warp(th.reshape(-1, 1, 3, 3), tmpl, 61, 97, "nearest")
+    of, oi = E.homography_warp(th.reshape(-1, 1, 3, 3).cuda(), tmpl.cuda(), 61, 97, True, scale=4.0, want_f32=True,
+                               want_i32=True, shared_template=True)
+    torch.cuda.synchronize()
+    assert torch.equal(of.cpu(), want)
+    assert torch.equal(oi.cpu(), (want * 4).to(torch.int32))
+    assert float(want[:2].abs().sum()) > 0       # the scaled matrices still hit the template
+
+
 def test_public_methods_direct():
     """net.forward_unet(), net.warp(), net.transform_poi() called the way the reference's callers do
     (models/reconstructor.py:109-158), not through predict()."""
