@@ -58,7 +58,8 @@ def build_diag(verbose=True):
     by the product path."""
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     out = os.path.join(_HERE, "libsfh_amd_diag.so")
-    cmd = [hipcc] + FLAGS + ["-DSFH_DIAG_STAMPS", "-shared", "-o", out] + [os.path.join(CSRC, s) for s in SOURCES]
+    # -fgpu-rdc: the stamp accumulator (conv_mfma.hip) is referenced from other translation units
+    cmd = [hipcc] + FLAGS + ["-DSFH_DIAG_STAMPS", "-fgpu-rdc", "-shared", "-o", out] + [os.path.join(CSRC, s) for s in SOURCES]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)

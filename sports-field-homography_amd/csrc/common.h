@@ -49,3 +49,33 @@ static inline void sfh_allow_big_lds_impl(const void* fn, std::atomic<unsigned l
     static std::atomic<unsigned long long> sfh_done_{0};       \
     sfh_allow_big_lds_impl(fn, sfh_done_);                     \
   } while (0)
+
+// Diagnostic build only (-DSFH_DIAG_STAMPS -fgpu-rdc, libsfh_amd_diag.so; profiles/diag_stamps.py): per-segment
+// s_memtime sums of a kernel's phases, accumulated per wave and added to g_stamps (conv_mfma.hip) by lane 0.
+// SFH_STAMP(i) closes segment i; BASE offsets a kernel's segments inside the 16 counters.
+#ifdef SFH_DIAG_STAMPS
+extern __device__ unsigned long long g_stamps[16];
+#define SFH_STAMP(i)                                                                         \
+  do {                                                                                       \
+    unsigned long long t_;                                                                   \
+    __builtin_amdgcn_sched_barrier(0);                                                       \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");               \
+    __builtin_amdgcn_sched_barrier(0);                                                       \
+    seg_[i] += t_ - tprev_;                                                                  \
+    tprev_ = t_;                                                                             \
+  } while (0)
+#define SFH_STAMP_INIT()                                                                     \
+  unsigned long long seg_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev_;                             \
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tprev_)::"memory")
+#define SFH_STAMP_FLUSH_AT(BASE)                                                             \
+  do {                                                                                       \
+    if ((threadIdx.x & 63) == 0)                                                             \
+      for (int i_ = 0; i_ < 8; ++i_) atomicAdd(&g_stamps[(BASE) + i_], seg_[i_]);            \
+  } while (0)
+#define SFH_STAMP_FLUSH() SFH_STAMP_FLUSH_AT(0)
+#else
+#define SFH_STAMP(i) do {} while (0)
+#define SFH_STAMP_INIT() do {} while (0)
+#define SFH_STAMP_FLUSH() do {} while (0)
+#define SFH_STAMP_FLUSH_AT(BASE) do {} while (0)
+#endif

@@ -38,28 +38,10 @@
 #include "common.h"
 #include "conv_epilogue.h"
 
-// Diagnostic build only (-DSFH_DIAG_STAMPS, libsfh_amd_diag.so): per-segment s_memtime sums of
-// the stage loop, accumulated per wave and added to g_stamps by lane 0.  Never compiled into
-// the shipped library.
+// Diagnostic build only (-DSFH_DIAG_STAMPS, libsfh_amd_diag.so): the stamp macros live in common.h; this
+// translation unit owns the accumulator and its reader.  Never compiled into the shipped library.
 #ifdef SFH_DIAG_STAMPS
 __device__ unsigned long long g_stamps[16];
-#define SFH_STAMP(i)                                                                         \
-  do {                                                                                       \
-    unsigned long long t_;                                                                   \
-    __builtin_amdgcn_sched_barrier(0);                                                       \
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");               \
-    __builtin_amdgcn_sched_barrier(0);                                                       \
-    seg_[i] += t_ - tprev_;                                                                  \
-    tprev_ = t_;                                                                             \
-  } while (0)
-#define SFH_STAMP_INIT()                                                                     \
-  unsigned long long seg_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev_;                             \
-  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tprev_)::"memory")
-#define SFH_STAMP_FLUSH()                                                                    \
-  do {                                                                                       \
-    if ((threadIdx.x & 63) == 0)                                                             \
-      for (int i_ = 0; i_ < 8; ++i_) atomicAdd(&g_stamps[i_], seg_[i_]);                     \
-  } while (0)
 extern "C" int sfh_debug_read_stamps(unsigned long long* host_out, int reset) {
   if (hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 16) != hipSuccess) return -2;
   if (reset) {
@@ -68,10 +50,6 @@ extern "C" int sfh_debug_read_stamps(unsigned long long* host_out, int reset) {
   }
   return 0;
 }
-#else
-#define SFH_STAMP(i) do {} while (0)
-#define SFH_STAMP_INIT() do {} while (0)
-#define SFH_STAMP_FLUSH() do {} while (0)
 #endif
 
 namespace {

@@ -129,6 +129,7 @@ __global__ __launch_bounds__(256, 2) void conv_s3_kernel(const sfh_conv_desc d, 
   extern __shared__ __attribute__((aligned(16))) float smem_f[];
   u32x4* const lds = reinterpret_cast<u32x4*>(smem_f);
   typedef __attribute__((address_space(3))) void* lds_ptr_t;
+  SFH_STAMP_INIT();
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -330,9 +331,13 @@ __global__ __launch_bounds__(256, 2) void conv_s3_kernel(const sfh_conv_desc d, 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   } else {
     // single buffer: [DMA stage st] [drain + barrier] [compute] [barrier: buffer free again]
+    // (diag build: segments 8 prologue, 9 DMA wait + barrier, 10 MFMA stage, 11 buffer-free barrier + DMA issue, 12 epilogue)
+    SFH_STAMP(0);
     for (int st = 0; st < nst; st += 2) {
       stage_barrier();
+      SFH_STAMP(1);
       stage(st, 0, std::false_type{});
+      SFH_STAMP(2);
       if (st + 1 < nst) {
         if (d.src1 && st + 1 == nst0) {
 #pragma unroll
@@ -340,8 +345,11 @@ __global__ __launch_bounds__(256, 2) void conv_s3_kernel(const sfh_conv_desc d, 
         }
         __syncthreads();
         dma_stage(st + 1, 0);
+        SFH_STAMP(3);
         stage_barrier();
+        SFH_STAMP(1);
         stage(st + 1, 0, std::integral_constant<bool, SWAPS>{});
+        SFH_STAMP(2);
       }
       if (st + 2 < nst) {
         if (d.src1 && st + 2 == nst0) {
@@ -350,10 +358,15 @@ __global__ __launch_bounds__(256, 2) void conv_s3_kernel(const sfh_conv_desc d, 
         }
         __syncthreads();
         dma_stage(st + 2, 0);
+        SFH_STAMP(3);
       }
     }
   }
   sfh_conv_epilogue<C, 2, C::MT_M>(d, g, acc, n0 + 32 * wn, wm * C::MT_M, r0, x0, lq, lg);
+  if (!DB) {
+    SFH_STAMP(4);
+    SFH_STAMP_FLUSH_AT(8);
+  }
 
   // ---- OutConv fused behind the last conv (unet/unet_parts.py:74-77): acc now holds the activated outputs
   if constexpr (C::KS == 3 && C::STRIDE == 1) {
