@@ -29,6 +29,9 @@ BF16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA peak
 # bf16x6 mode: one fp32-accurate product = 6 bf16 MFMA products, so the MFMA roofline of the
 # ALGORITHMIC (fp32-equivalent) work is the bf16 peak / 6
 BF16X6_PEAK_TFLOPS = BF16_MFMA_PEAK_TFLOPS / 6.0
+# f16x3 mode (default): two fp16 planes per operand, 3 fp16 MFMA products per product (fp16 and bf16 MFMA have the
+# same dense peak)
+F16X3_PEAK_TFLOPS = BF16_MFMA_PEAK_TFLOPS / 3.0
 
 
 def usable_cores():
@@ -291,16 +294,21 @@ def main():
     summ = timer.summary()
     n, fl, ms = summ.get("doubleconv3x3", (0, 0.0, 1.0))
     achieved = fl / (ms * 1e-3) / 1e12 if n else 0.0
-    x6 = net.precision == "bf16x6"
-    peak = BF16X6_PEAK_TFLOPS if x6 else FP32_MFMA_PEAK_TFLOPS
+    prec = net.precision
+    nprod = {"bf16x6": 6, "f16x3": 3}.get(prec)
+    peak = {"bf16x6": BF16X6_PEAK_TFLOPS, "f16x3": F16X3_PEAK_TFLOPS}.get(prec, FP32_MFMA_PEAK_TFLOPS)
+    x6 = nprod is not None
+    half = "fp16" if prec == "f16x3" else "bf16"
     roofline = {"bound": "mfma", "achieved": round(achieved, 2), "peak": round(peak, 1),
                 "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
                 "traffic": pmc_traffic("doubleconv3x3") if (W, H, B) == (640, 360, 16) else None,
-                "peak_basis": ("2500 TFLOP/s dense bf16 MFMA / 6 bf16 products per fp32-accurate product; the "
-                               "launches execute 6x the algorithmic FLOPs on the bf16 matrix cores "
-                               f"(= {achieved * 6:.0f} TFLOP/s of bf16 MFMA work, {achieved * 6 / BF16_MFMA_PEAK_TFLOPS:.1%} of 2.5 PFLOP/s)"
+                "peak_basis": (f"2500 TFLOP/s dense {half} MFMA / {nprod} {half} products per fp32-grade product; the "
+                               f"launches execute {nprod}x the algorithmic FLOPs on the {half} matrix cores "
+                               f"(= {achieved * (nprod or 1):.0f} TFLOP/s of {half} MFMA work, "
+                               f"{achieved * (nprod or 1) / BF16_MFMA_PEAK_TFLOPS:.1%} of 2.5 PFLOP/s)"
                                if x6 else "157.3 TFLOP/s dense fp32 MFMA (v_mfma_f32_16x16x4_f32)"),
-                "kernel": ("conv_s3_kernel<3x3> (DoubleConv, split-bf16)" if x6 else "conv_mfma_kernel<3x3,s1> (DoubleConv)"),
+                "kernel": ((f"conv_s3_kernel<3x3, {'2 fp16' if prec == 'f16x3' else '3 bf16'} planes> (DoubleConv, split operands)")
+                           if x6 else "conv_mfma_kernel<3x3,s1> (DoubleConv)"),
                 "launches": n,
                 "avg_launch_ms": round(ms / max(n, 1), 4),
                 "algorithmic_gflop_per_launch": round(fl / max(n, 1) / 1e9, 2),
@@ -345,7 +353,7 @@ def main():
     other_configs = None
     if rank == 0 and world == 1 and not args.no_extra_configs and (W, H, B) == (640, 360, 16):
         del frames, out
-        net._engines = None
+        net.invalidate_engines()
         torch.cuda.empty_cache()
         other_configs = extra_configs(args)
 
@@ -355,13 +363,15 @@ def main():
             "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16x6->f32 (3-way bf16 split operands, 6 bf16 MFMA products, fp32 accumulate; fp32-equivalent)"
-                     if x6 else "f32",
+            "dtype": {"bf16x6": "bf16x6->f32 (3-way bf16 split operands, 6 bf16 MFMA products, fp32 accumulate; fp32-equivalent)",
+                      "f16x3": "f16x3->f32 (2-way fp16 split operands = 22 significand bits, 3 fp16 MFMA products, fp32 "
+                               "accumulate; end-to-end error at the level of an fp32 run, see DESIGN.md section 2)"}.get(prec, "f32"),
             "data": "synthetic",
             "config": {"workload": f"predict(): UNet seg + ResNet34-STN + nearest warp, {W}x{H}, "
                                    f"batch {B}/GPU, req_outputs=theta,warp_mask"
                                    + (",consistency,poi" if args.consistency else ""),
                        "frames_per_gpu_per_step": B, "global_batch": B * world,
+                       "precision": prec, "range_fallbacks": int(getattr(net, "range_fallbacks", 0)),
                        "parallelism": (f"frame-sharded x{world}, all_gather(theta) over "
                                        + ("RCCL" if args.dist_backend == "nccl" else "gloo (REHEARSAL, ranks share a GPU)" if args.share_gpu else "gloo")
                                        if world > 1 else "single GPU")},

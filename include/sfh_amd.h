@@ -43,9 +43,19 @@ extern "C" {
  * S3 : "split-3" bf16 (B, H, cs/32, 3 planes, 4 groups, W, 8): v = plane0 + plane1 + plane2 exactly,
  *      plane0 = bf16(v), plane1 = bf16(v - plane0), plane2 = bf16(v - plane0 - plane1); channel c of
  *      pixel (y, x) lives in block c/32, group (c%32)/8, lane c%8 - each (block, plane, group) of an
- *      image row is W x 16 contiguous bytes. */
+ *      image row is W x 16 contiguous bytes.
+ * H2 : "split-2" fp16 (B, H, cs/32, 2 planes, 4 groups, W, 8), the same layout with two planes:
+ *      u = v * 2^SFH_H2_ACT_EXP saturated to +-65504, plane0 = f16(u), plane1 = f16(u - plane0) (both RNE):
+ *      22 significand bits of v while plane1 is a normal fp16 number (|v| >= 2^-5), an absolute error
+ *      <= 2^-27 below that (fp16 subnormals are honoured by the conversions and by the MFMA).  |v| must stay
+ *      below 16376: the producing kernel saturates and raises sfh_conv_desc.h2_overflow.  The exponent trades
+ *      range against the absolute error floor; end to end the result does not depend on it between 0 and 6
+ *      (tests/probes/f16x3_error_probe.py), 2 leaves 4x the range of the largest activation the synthetic
+ *      ResNet-STN checkpoints of the tests produce. */
 #define SFH_FMT_F32 0
 #define SFH_FMT_S3 1
+#define SFH_FMT_H2 2
+#define SFH_H2_ACT_EXP 2
 
 /* Output modes of sfh_conv_fwd. */
 #define SFH_OUT_NHWC 0        /* dst[b][y][x][co]                                        */
@@ -109,6 +119,9 @@ typedef struct sfh_conv_desc {
   float* head_logits;
   float* head_stn;
   const float* head_frame;
+  /* H2 destinations: device word that is OR-ed with 1 when a value had to be saturated to the fp16 range
+   * (optional).  The caller zeroes it and reads it back after the last launch of a forward pass. */
+  uint32_t* h2_overflow;
 } sfh_conv_desc;
 
 const char* sfh_last_error(void);
@@ -135,6 +148,21 @@ int sfh_pack_s3_weights(const float* w, void* packed, int ksize, int c0, int c1,
 /* fp32 NHWC (rows = B*H, W, cs) <-> S3 (rows, cs/32, 3, 4, W, 8) conversion */
 int sfh_f32_to_s3(const float* src, void* dst, int64_t rows, int W, int cs, void* stream);
 int sfh_s3_to_f32(const void* src, float* dst, int64_t rows, int W, int cs, void* stream);
+
+/* The same convolution with TWO fp16 planes per operand ("f16x3": sources in H2 format, src_fmt = SFH_FMT_H2 in
+ * the descriptor of sfh_conv_s3_fwd): three fp16 MFMAs per 32 k (w0x1 + w1x0 + w0x0, fp32 accumulation) instead
+ * of six bf16 ones.  Operands carry 22 significand bits; the dropped product is <= 2^-22 of the full one.  Measured
+ * end to end (tests/probes/f16x3_error_probe.py) the representation error is below half of what the fp32
+ * accumulation order already costs.  Weights are packed as planes of w * 2^wexp (wexp chosen by the caller so
+ * that max |w| * 2^wexp lies in [2^13, 2^14)): the caller multiplies the layer's `scale` by 2^-(wexp +
+ * SFH_H2_ACT_EXP).  Modes and geometry as sfh_pack_s3_weights; packed size = 2/3 of the S3 size. */
+int64_t sfh_packed_h2_weight_bytes(int ksize, int c0, int c1, int cout_virtual);
+int sfh_pack_h2_weights(const float* w, void* packed, int ksize, int c0, int c1, int cout_virtual,
+                        int mode, int aux, int wexp, void* stream);
+/* fp32 NHWC (rows = B*H, W, cs) <-> H2 (rows, cs/32, 2, 4, W, 8); overflow: optional device word, OR-ed with 1
+ * when a value was saturated. */
+int sfh_f32_to_h2(const float* src, void* dst, int64_t rows, int W, int cs, uint32_t* overflow, void* stream);
+int sfh_h2_to_f32(const void* src, float* dst, int64_t rows, int W, int cs, void* stream);
 
 /* First UNet layer (inc.double_conv.0, unet/unet_parts.py:15; 3 input channels stored as 4):
  * tap-packed fp32 MFMA kernel, k = channel, one MFMA k-step per tap.  Same descriptor/epilogue as

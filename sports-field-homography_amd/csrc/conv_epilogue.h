@@ -35,16 +35,52 @@ __device__ __forceinline__ void sfh_split4(const f32x4& v, sfh_u32x2 (&out)[3]) 
   }
 }
 
+// two-plane fp16 split ("H2", include/sfh_amd.h) of 4 fp32 values: u = clamp(v * 2^SFH_H2_ACT_EXP) so that the
+// low plane of ordinary activations stays a NORMAL fp16 number (22 significand bits kept), plane0 = f16(u),
+// plane1 = f16(u - plane0), both round-to-nearest-even (v_cvt_pk_f16_f32).  Values beyond the fp16 range
+// saturate; `over` collects max |u| so that the caller can report it.
+typedef _Float16 sfh_f16x2 __attribute__((ext_vector_type(2)));
+constexpr float kSfhH2Scale = (float)(1 << SFH_H2_ACT_EXP), kSfhH2InvScale = 1.f / (float)(1 << SFH_H2_ACT_EXP);
+constexpr float kSfhH2Max = 65504.f;
+
+__device__ __forceinline__ unsigned sfh_cvt_pk_h(float a, float b) {  // v_cvt_pk_f16_f32 (RNE)
+  return __builtin_bit_cast(unsigned, __builtin_convertvector((sfh_f32x2){a, b}, sfh_f16x2));
+}
+__device__ __forceinline__ sfh_f32x2 sfh_unpack_h(unsigned w) {
+  return __builtin_convertvector(__builtin_bit_cast(sfh_f16x2, w), sfh_f32x2);
+}
+
+__device__ __forceinline__ void sfh_split4_h2(const f32x4& v, sfh_u32x2 (&out)[2], float& over) {
+  f32x4 u;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float t = v[j] * kSfhH2Scale;
+    over = fmaxf(over, fabsf(t));
+    u[j] = fminf(fmaxf(t, -kSfhH2Max), kSfhH2Max);
+  }
+  const unsigned w0 = sfh_cvt_pk_h(u[0], u[1]), w1 = sfh_cvt_pk_h(u[2], u[3]);
+  const sfh_f32x2 b0 = sfh_unpack_h(w0), b1 = sfh_unpack_h(w1);
+  out[0][0] = w0;
+  out[0][1] = w1;
+  out[1][0] = sfh_cvt_pk_h(u[0] - b0[0], u[1] - b0[1]);
+  out[1][1] = sfh_cvt_pk_h(u[2] - b1[0], u[3] - b1[1]);
+}
+
 constexpr unsigned kSfhOOB = 0xFFFFFFF0u;  // byte offset that the buffer range check rejects
 
 // CFG supplies SUBX, SH, SW, FLATROWS; G supplies Ho, Wo, rows_total, rows_per_img, rows_magic.
 // All global accesses are buffer loads/stores with 32-bit byte offsets: a pixel outside the frame
 // carries kSfhOOB and its stores are dropped by the descriptor's range check (no branches, no
 // 64-bit address arithmetic); the plane / cout-group advance rides in the scalar offset.
-template <class CFG, int NI, int MT, class G>
+// FMTS: bit 0 - the kernel may be asked for an S3 destination, bit 1 - for an H2 destination (the other
+// format's code is compiled out).
+template <class CFG, int NI, int MT, int FMTS = 1, class G>
 __device__ __forceinline__ void sfh_conv_epilogue(const sfh_conv_desc& d, const G& g, f32x4 (&acc)[NI][MT],
                                                   int n0, int msub0, int r0, int x0, int lq, int lg) {
-  const bool s3 = d.dst_fmt == SFH_FMT_S3;
+  const bool h2 = (FMTS & 2) && d.dst_fmt == SFH_FMT_H2;
+  const bool s3 = h2 || ((FMTS & 1) && d.dst_fmt == SFH_FMT_S3);  // a split (plane) format
+  const unsigned np4 = h2 ? 8u : 12u;                              // (plane, group) runs per 32-channel block
+  float over = 0.f;
   // S3 layout (B, H, cs/32, 3 planes, 4 groups of 8 ch, W, 8) bf16: for one image row every
   // (channel block, plane, group) is a contiguous run of W x 16 bytes, so that 16 consecutive pixels
   // of a lane group are 256 contiguous bytes (lane groups lg and lg^1 hold the two 8-byte halves of
@@ -58,7 +94,7 @@ __device__ __forceinline__ void sfh_conv_epilogue(const sfh_conv_desc& d, const 
     if (d.up_dst_h) hdst = (unsigned)d.up_dst_h;
   }
   const unsigned run = wdst * 16u;                            // bytes of one (block, plane, group) run
-  const unsigned rowb = s3 ? (cs >> 5) * 12u * run : wdst * cs * 4u;  // bytes per image row
+  const unsigned rowb = s3 ? (cs >> 5) * np4 * run : wdst * cs * 4u;  // bytes per image row
   const unsigned planeb = 4u * run;                           // S3: next plane
   const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(d.dst, 0, (int)kSfhOOB, 0x00020000);
   const __amdgpu_buffer_rsrc_t rr_ = __builtin_amdgcn_make_buffer_rsrc(
@@ -80,10 +116,10 @@ __device__ __forceinline__ void sfh_conv_epilogue(const sfh_conv_desc& d, const 
   // byte offset of channel (corel + 4*lg) relative to the pixel's row/x position; cout group ni
   // adds ni_off(ni) (+16 channels = +2 groups; corel is a multiple of 32)
   const unsigned c_lane = (unsigned)(corel + 4 * lg);
-  const unsigned lane_co = s3 ? ((c_lane >> 5) * 12u + ((c_lane & 31u) >> 3)) * run + ((c_lane >> 2) & 1u) * 8u
+  const unsigned lane_co = s3 ? ((c_lane >> 5) * np4 + ((c_lane & 31u) >> 3)) * run + ((c_lane >> 2) & 1u) * 8u
                               : c_lane * 4u;
   auto ni_off = [&](int ni) -> unsigned {
-    return s3 ? ((unsigned)(ni >> 1) * 12u + (unsigned)(ni & 1) * 2u) * run : (unsigned)ni * 64u;
+    return s3 ? ((unsigned)(ni >> 1) * np4 + (unsigned)(ni & 1) * 2u) * run : (unsigned)ni * 64u;
   };
   const unsigned xb = s3 ? 16u : cs * 4u;  // bytes per pixel step along x
   int pb[MT], py[MT], px[MT];
@@ -144,7 +180,20 @@ __device__ __forceinline__ void sfh_conv_epilogue(const sfh_conv_desc& d, const 
 #pragma unroll
       for (int j = 0; j < 4; ++j) v[j] = v[j] * sc[ni][j] + shv[j];
       if (d.residual) {
-        if (res_s3) {
+        if (res_s3 && h2) {
+          if constexpr ((FMTS & 2) != 0) {
+            f32x4 q = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int p = 1; p >= 0; --p) {
+              const sfh_u32x2 w = __builtin_bit_cast(
+                  sfh_u32x2, __builtin_amdgcn_raw_buffer_load_b64(rr_, (int)voff[mi], (int)(nioff + p * planeb), 0));
+              const sfh_f32x2 a = sfh_unpack_h(w[0]), b = sfh_unpack_h(w[1]);
+              q[0] += a[0]; q[1] += a[1]; q[2] += b[0]; q[3] += b[1];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] += q[j] * kSfhH2InvScale;
+          }
+        } else if (res_s3) {
 #pragma unroll
           for (int p = 2; p >= 0; --p) {
             const sfh_u32x2 w = __builtin_bit_cast(
@@ -177,7 +226,15 @@ __device__ __forceinline__ void sfh_conv_epilogue(const sfh_conv_desc& d, const 
         for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
       }
       acc[ni][mi] = v;
-      if (s3) {
+      if (h2) {
+        if constexpr ((FMTS & 2) != 0) {
+          sfh_u32x2 pl[2];
+          sfh_split4_h2(v, pl, over);
+#pragma unroll
+          for (int p = 0; p < 2; ++p)
+            __builtin_amdgcn_raw_buffer_store_b64(pl[p], rd, (int)voff[mi], (int)(nioff + p * planeb), 0);
+        }
+      } else if (s3) {
         sfh_u32x2 pl[3];
         sfh_split4(v, pl);
 #pragma unroll
@@ -193,11 +250,11 @@ __device__ __forceinline__ void sfh_conv_epilogue(const sfh_conv_desc& d, const 
     const int Hp = g.Ho >> 1, Wp = g.Wo >> 1;
     const unsigned pcs = (unsigned)d.pool_cs;
     const unsigned prun = (unsigned)Wp * 16u;
-    const unsigned prowb = s3 ? (pcs >> 5) * 12u * prun : (unsigned)Wp * pcs * 4u;
+    const unsigned prowb = s3 ? (pcs >> 5) * np4 * prun : (unsigned)Wp * pcs * 4u;
     const unsigned pplaneb = 4u * prun;
     const unsigned pxb = s3 ? 16u : pcs * 4u;
     auto pni_off = [&](int ni) -> unsigned {
-      return s3 ? ((unsigned)(ni >> 1) * 12u + (unsigned)(ni & 1) * 2u) * prun : (unsigned)ni * 64u;
+      return s3 ? ((unsigned)(ni >> 1) * np4 + (unsigned)(ni & 1) * 2u) * prun : (unsigned)ni * 64u;
     };
     const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc(d.dst_pool, 0, (int)kSfhOOB, 0x00020000);
 #pragma unroll
@@ -213,7 +270,7 @@ __device__ __forceinline__ void sfh_conv_epilogue(const sfh_conv_desc& d, const 
                           (CFG::SH == 2 ? (lq < 8) : true);
       const unsigned pc = (unsigned)(n0 + 4 * lg);
       const unsigned pv = writer ? (unsigned)(pb[mi] * Hp + (y >> 1)) * prowb + (unsigned)(x >> 1) * pxb +
-                                       (s3 ? ((pc >> 5) * 12u + ((pc & 31u) >> 3)) * prun + ((pc >> 2) & 1u) * 8u
+                                       (s3 ? ((pc >> 5) * np4 + ((pc & 31u) >> 3)) * prun + ((pc >> 2) & 1u) * 8u
                                            : pc * 4u)
                                  : kSfhOOB;
 #pragma unroll
@@ -230,7 +287,16 @@ __device__ __forceinline__ void sfh_conv_epilogue(const sfh_conv_desc& d, const 
 #pragma unroll
         for (int j = 0; j < 4; ++j) m[j] = fmaxf(m[j], __shfl_xor(m[j], 1));
         const unsigned nioff = pni_off(ni);
-        if (s3) {
+        if (h2) {
+          if constexpr ((FMTS & 2) != 0) {
+            sfh_u32x2 pl[2];
+            float dummy = 0.f;   // the pooled values are a subset of the values checked above
+            sfh_split4_h2(m, pl, dummy);
+#pragma unroll
+            for (int p = 0; p < 2; ++p)
+              __builtin_amdgcn_raw_buffer_store_b64(pl[p], rp, (int)pv, (int)(nioff + p * pplaneb), 0);
+          }
+        } else if (s3) {
           sfh_u32x2 pl[3];
           sfh_split4(m, pl);
 #pragma unroll
@@ -241,5 +307,10 @@ __device__ __forceinline__ void sfh_conv_epilogue(const sfh_conv_desc& d, const 
         }
       }
     }
+  }
+  // H2 destination: a value beyond the fp16 range was saturated - leave a mark for the host (the engine
+  // re-runs such a batch with the three-plane bf16 format, which has fp32's exponent range)
+  if constexpr ((FMTS & 2) != 0) {
+    if (h2 && d.h2_overflow && over > kSfhH2Max) atomicOr(d.h2_overflow, 1u);
   }
 }

@@ -427,7 +427,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c4_kernel(const sfh_conv_desc 
       for (int mi = 0; mi < 4; ++mi)
         acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[t][ni], xv[mi], acc[ni][mi], 0, 0, 0);
   }
-  sfh_conv_epilogue<C4Cfg, 4, 4>(d, g, acc, n0, wv * 4, r0, x0, lq, lg);
+  sfh_conv_epilogue<C4Cfg, 4, 4, 3>(d, g, acc, n0, wv * 4, r0, x0, lq, lg);  // S3 or H2 destination
 }
 
 __global__ void pack_c4_weights_kernel(const float* __restrict__ w, float* __restrict__ packed, int cin,
@@ -629,6 +629,7 @@ extern "C" int sfh_conv_fwd(const sfh_conv_desc* dp, void* stream_) {
     SFH_REQUIRE(d.h0 == d.H && d.w0 == d.W, "conv_fwd: source 0 is %dx%d, frame is %dx%d", d.h0, d.w0, d.H, d.W);
   SFH_REQUIRE(d.src_fmt == SFH_FMT_F32, "conv_fwd: the fp32 kernel reads fp32 NHWC sources (src_fmt=%d)", d.src_fmt);
   SFH_REQUIRE(!d.dst_pool, "conv_fwd: fused pool output is provided by sfh_conv_s3_fwd only");
+  SFH_REQUIRE(d.dst_fmt == SFH_FMT_F32 || d.dst_fmt == SFH_FMT_S3, "conv_fwd: the fp32 kernel writes fp32 or S3 (dst_fmt=%d)", d.dst_fmt);
   if (d.out_mode == SFH_OUT_UPSCATTER2)
     SFH_REQUIRE(d.ksize == 1 && d.stride == 1 && (d.cout / 4) % 64 == 0 && !d.residual,
                 "conv_fwd: up-scatter needs ksize=1, stride=1, cout/4 multiple of 64");

@@ -36,14 +36,17 @@
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 namespace {
 
 constexpr unsigned kOOB = 0xFFFFFFF0u;
 
-template <int KS_, int STRIDE_, int SH_, int SW_, int TH_, int TW_>
+// NP_ = planes per operand: 3 = S3 tensors, bf16, six products per fp32 product ("bf16x6");
+//                           2 = H2 tensors, fp16, three products ("f16x3", include/sfh_amd.h)
+template <int KS_, int STRIDE_, int SH_, int SW_, int TH_, int TW_, int NP_ = 3>
 struct S3Cfg {
-  static constexpr int KS = KS_, STRIDE = STRIDE_;
+  static constexpr int KS = KS_, STRIDE = STRIDE_, NP = NP_;
   static constexpr int SH = SH_, SW = SW_, TH = TH_, TW = TW_;
   static constexpr int PAD = KS / 2;          // padding before (3x3: 1, 1x1: 0, 4x4 stem: 2)
   static constexpr int PADA = (KS - 1) / 2;   // padding after  (3x3: 1, 1x1: 0, 4x4 stem: 1)
@@ -53,7 +56,7 @@ struct S3Cfg {
   static constexpr int HW = (TW - 1) * STRIDE + KS;
   static constexpr int HPIX = HH * HW;
   static constexpr int HPIXP = (HPIX + 15) / 16 * 16;
-  static constexpr int HSLOTS = 12 * HPIXP;  // [3 planes][4 channel groups of 8][pixels] x 16 B
+  static constexpr int HSLOTS = 4 * NP * HPIXP;  // [NP planes][4 channel groups of 8][pixels] x 16 B
   static constexpr int NSL = (HSLOTS + 255) / 256;
   static constexpr int BUF = NSL * 256;      // slots per LDS buffer (DMA rounds are whole)
   static constexpr int LDS_BYTES = 2 * BUF * 16;
@@ -73,6 +76,7 @@ struct S3Geom {
 };
 
 __device__ __forceinline__ bf16x8 as_bf(const u32x4& v) { return __builtin_bit_cast(bf16x8, v); }
+__device__ __forceinline__ f16x8 as_hf(const u32x4& v) { return __builtin_bit_cast(f16x8, v); }
 
 // pad_y / pad_x: rows / columns before the output pixel covered by the window (C::PAD except for the
 // 2x2 up-scatter conv, whose window position depends on the output quadrant)
@@ -97,7 +101,7 @@ __device__ __forceinline__ unsigned s3_halo_voffset(const sfh_conv_desc& d, cons
   }
   const int x = x0 * C::STRIDE - pad_x + hx;
   if (x < 0 || x >= d.W) return kOOB;
-  // S3 layout (B, H, cs/32, 3, 4, W, 8) bf16: byte offset of (row, channel block 0, plane/group pl, x)
+  // S3 / H2 layout (B, H, cs/32, NP, 4, W, 8): byte offset of (row, channel block 0, plane/group pl, x)
   unsigned rowi, xs_, ws_, nblk;
   if (which == 0) {
     if (C::KS == 2 && (y >= d.h0 || x >= d.w0)) return kOOB;  // fused Up with F.pad: the extra row / column reads 0
@@ -113,7 +117,7 @@ __device__ __forceinline__ unsigned s3_halo_voffset(const sfh_conv_desc& d, cons
     ws_ = (unsigned)d.w1;
     nblk = (unsigned)d.cs1 >> 5;
   }
-  return ((rowi * nblk * 12u + (unsigned)pl) * ws_ + xs_) * 16u;
+  return ((rowi * nblk * (4u * C::NP) + (unsigned)pl) * ws_ + xs_) * 16u;
 }
 
 }  // namespace
@@ -124,8 +128,15 @@ namespace {
 //             stream, one barrier per stage - best for long K (>= 4 stages).
 // DB = false: one LDS buffer, two workgroups per CU: stage DMA / prologue / epilogue of one
 //             workgroup hide under the other's MFMAs - best for short K (64..128 channels, 1x1).
+// Two-plane (H2) instances need 158 registers and 45 KB of LDS per workgroup, so three workgroups per CU would fit;
+// measured (B=16, 640x360, two alternating runs on one device): 10.02-10.07 ms per batch for the DoubleConv
+// launches with three, 9.96 ms with two - the register cap of 168 costs more than the third workgroup hides.
+#ifndef SFH_H2_WAVES_PER_SIMD
+#define SFH_H2_WAVES_PER_SIMD 2
+#endif
 template <class C, bool DB>
-__global__ __launch_bounds__(256, 2) void conv_s3_kernel(const sfh_conv_desc d, const S3Geom g) {
+__global__ __launch_bounds__(256, (C::NP == 2 && !DB) ? SFH_H2_WAVES_PER_SIMD : 2) void conv_s3_kernel(const sfh_conv_desc d,
+                                                                                                   const S3Geom g) {
   extern __shared__ __attribute__((aligned(16))) float smem_f[];
   u32x4* const lds = reinterpret_cast<u32x4*>(smem_f);
   typedef __attribute__((address_space(3))) void* lds_ptr_t;
@@ -175,8 +186,9 @@ __global__ __launch_bounds__(256, 2) void conv_s3_kernel(const sfh_conv_desc d, 
       __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.src0), 0, (int)g.bytes0, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float*>(d.src1 ? d.src1 : d.src0), 0, (int)(d.src1 ? g.bytes1 : 0u), 0x00020000);
-  // packed weights of this cout block: [stage][tap][plane 3][cout group 4][lane 64][8 bf16]
-  constexpr unsigned WTAP = 3u * 4u * 1024u;  // bytes per (stage, tap)
+  // packed weights of this cout block: [stage][tap][plane NP][cout group 4][lane 64][8 x 16 bit]
+  constexpr int NP = C::NP;
+  constexpr unsigned WTAP = (unsigned)NP * 4u * 1024u;  // bytes per (stage, tap)
   const unsigned wtotal = (unsigned)nst * C::NTAP * WTAP;
   const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<char*>(reinterpret_cast<const char*>(d.wpacked)) + (size_t)nb * wtotal, 0, (int)wtotal,
@@ -200,8 +212,9 @@ __global__ __launch_bounds__(256, 2) void conv_s3_kernel(const sfh_conv_desc d, 
   auto dma_piece = [&](int st, int b, int i) {
     u32x4* const hb = lds + b * C::BUF;
     const bool first = st < nst0;
-    // stage = one 32-channel block = 12 (plane, group) runs of W x 16 bytes of the row
-    const unsigned cb = first ? (unsigned)st * (192u * (unsigned)d.w0) : (unsigned)(st - nst0) * (192u * (unsigned)d.w1);
+    // stage = one 32-channel block = 4 * NP (plane, group) runs of W x 16 bytes of the row
+    constexpr unsigned SB = 64u * (unsigned)NP;
+    const unsigned cb = first ? (unsigned)st * (SB * (unsigned)d.w0) : (unsigned)(st - nst0) * (SB * (unsigned)d.w1);
     __builtin_amdgcn_raw_ptr_buffer_load_lds(first ? rs0 : rs1, (lds_ptr_t)(hb + wv * 64 + 256 * i), 16,
                                              (int)hoff[i], (int)cb, 0, 0);
   };
@@ -211,9 +224,9 @@ __global__ __launch_bounds__(256, 2) void conv_s3_kernel(const sfh_conv_desc d, 
   };
 
   // weight fragments of one tap for this wave: [plane][cout group of the wave]
-  auto load_w = [&](u32x4 (&w)[3][2], unsigned soff) {
+  auto load_w = [&](u32x4 (&w)[NP][2], unsigned soff) {
 #pragma unroll
-    for (int p = 0; p < 3; ++p)
+    for (int p = 0; p < NP; ++p)
 #pragma unroll
       for (int ni = 0; ni < 2; ++ni)
         w[p][ni] = __builtin_amdgcn_raw_buffer_load_b128(rsw, (int)(wvoff + ni * 1024u), (int)(soff + p * 4096u), 0);
@@ -233,7 +246,7 @@ __global__ __launch_bounds__(256, 2) void conv_s3_kernel(const sfh_conv_desc d, 
 #pragma unroll
     for (int mi = 0; mi < C::MT_M; ++mi) acc[ni][mi] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  u32x4 wa[3][2], wb[3][2];  // weight fragments: current tap / next tap
+  u32x4 wa[NP][2], wb[NP][2];  // weight fragments: current tap / next tap
   unsigned wsoff = 0;         // byte offset of the NEXT (stage, tap) fragment set
   const unsigned wlast = wtotal - WTAP;
   load_w(wa, 0);
@@ -251,13 +264,13 @@ __global__ __launch_bounds__(256, 2) void conv_s3_kernel(const sfh_conv_desc d, 
     // operand ring of three register sets: the reads of step s+2 are issued in step s, i.e. two
     // steps (~380 cycles of MFMA) ahead of their use - one step is not enough to cover the LDS
     // latency with four waves reading (measured: 358 cycles per 192-cycle step before)
-    u32x4 xq[3][3];
+    u32x4 xq[3][NP];
     auto ld_x = [&](int s, int buf) {
       const int t = s / C::MT_M, mi = s % C::MT_M;
       const int toff = (t / C::KS) * C::HW + (t % C::KS);
       const int moff = (mi / C::SUBX) * C::SH * C::STRIDE * C::HW + (mi % C::SUBX) * C::SW * C::STRIDE;
 #pragma unroll
-      for (int p = 0; p < 3; ++p) xq[buf][p] = halo[pixbase0 + (p * 4 * C::HPIXP + moff + toff)];
+      for (int p = 0; p < NP; ++p) xq[buf][p] = halo[pixbase0 + (p * 4 * C::HPIXP + moff + toff)];
     };
     ld_x(0, 0);
     if (NSTEP > 1) ld_x(1, 1);
@@ -266,8 +279,8 @@ __global__ __launch_bounds__(256, 2) void conv_s3_kernel(const sfh_conv_desc d, 
     for (int s = 0; s < NSTEP; ++s) {
       const int t = s / C::MT_M, mi = s % C::MT_M;
       const int xb = s % 3;
-      u32x4 (&wc)[3][2] = ((t & 1) != (SW ? 1 : 0)) ? wb : wa;
-      u32x4 (&wnx)[3][2] = ((t & 1) != (SW ? 1 : 0)) ? wa : wb;
+      u32x4 (&wc)[NP][2] = ((t & 1) != (SW ? 1 : 0)) ? wb : wa;
+      u32x4 (&wnx)[NP][2] = ((t & 1) != (SW ? 1 : 0)) ? wa : wb;
       if (s + 2 < NSTEP) ld_x(s + 2, (s + 2) % 3);
       if (mi == 0) {
         load_w(wnx, wsoff);  // next tap (or tap 0 of the next stage): one tap of MFMAs ahead
@@ -280,20 +293,26 @@ __global__ __launch_bounds__(256, 2) void conv_s3_kernel(const sfh_conv_desc d, 
         for (int q = 0; q < PPS; ++q)
           if (s * PPS + q < C::NSL) dma_piece(stn, cur ^ 1, s * PPS + q);
       }
-      // six partial products, smallest first; the two cout groups are interleaved so that
-      // consecutive MFMAs never depend on each other
-      constexpr int PW[6] = {0, 1, 2, 0, 1, 0}, PX[6] = {2, 1, 0, 1, 0, 0};
+      // the kept partial products (six of 3 x 3 bf16 planes, three of 2 x 2 fp16 planes), smallest first; the
+      // two cout groups are interleaved so that consecutive MFMAs never depend on each other
+      constexpr int NPROD = NP == 3 ? 6 : 3;
+      constexpr int PW[6] = {0, 1, NP == 3 ? 2 : 0, 0, 1, 0}, PX[6] = {NP == 3 ? 2 : 1, NP == 3 ? 1 : 0, 0, 1, 0, 0};
 #pragma unroll
-      for (int k6 = 0; k6 < 6; ++k6)
+      for (int k6 = 0; k6 < NPROD; ++k6)
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
-          acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf(wc[PW[k6]][ni]), as_bf(xq[xb][PX[k6]]),
-                                                               acc[ni][mi], 0, 0, 0);
+        for (int ni = 0; ni < 2; ++ni) {
+          if constexpr (NP == 3)
+            acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf(wc[PW[k6]][ni]), as_bf(xq[xb][PX[k6]]),
+                                                                 acc[ni][mi], 0, 0, 0);
+          else
+            acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(as_hf(wc[PW[k6]][ni]), as_hf(xq[xb][PX[k6]]),
+                                                                acc[ni][mi], 0, 0, 0);
+        }
       // keep each step's memory instructions inside the step, operand reads of the next step
-      // right behind the first MFMA so that ~11 MFMAs (176 cycles) cover their LDS latency
+      // right behind the first MFMA so that the step's other MFMAs cover their LDS latency
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-      __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
-      __builtin_amdgcn_sched_group_barrier(0x008, 11, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, NP, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 2 * NPROD - 1, 0);
       __builtin_amdgcn_sched_barrier(0);
     }
   };
@@ -362,7 +381,7 @@ __global__ __launch_bounds__(256, 2) void conv_s3_kernel(const sfh_conv_desc d, 
       }
     }
   }
-  sfh_conv_epilogue<C, 2, C::MT_M>(d, g, acc, n0 + 32 * wn, wm * C::MT_M, r0, x0, lq, lg);
+  sfh_conv_epilogue<C, 2, C::MT_M, (NP == 3 ? 1 : 2)>(d, g, acc, n0 + 32 * wn, wm * C::MT_M, r0, x0, lq, lg);
   if (!DB) {
     SFH_STAMP(4);
     SFH_STAMP_FLUSH_AT(8);
@@ -422,10 +441,12 @@ __global__ __launch_bounds__(256, 2) void conv_s3_kernel(const sfh_conv_desc d, 
 }
 
 // ------------------------------------------------------------------ weight packing (split)
-// packed[nb][stage][tap][plane 3][cout group 4][lane 64][j 8] bf16
+// packed[nb][stage][tap][plane NP][cout group 4][lane 64][j 8] bf16 (NP = 3) or fp16 planes of w * wscale (NP = 2)
 //   cout = nb*64 + ng*16 + (lane&15);  channel-in-source = stage_local*32 + 8*(lane>>4) + j
+template <int NP>
 __global__ void pack_s3_weights_kernel(const float* __restrict__ w, unsigned short* __restrict__ packed,
-                                       int ks, int c0, int c1, int coutv, int transposed, int aux, long total) {
+                                       int ks, int c0, int c1, int coutv, int transposed, int aux, long total,
+                                       float wscale) {
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;  // one (lane, j-octet, all planes)
   if (idx >= total) return;
   const int ntap = ks * ks;
@@ -439,7 +460,7 @@ __global__ void pack_s3_weights_kernel(const float* __restrict__ w, unsigned sho
   const int ky = tap / ks, kx = tap % ks;
   const int cv = nb * 64 + ng * 16 + (lane & 15);
   const int cin_total = c0 + c1;
-  const long base = ((((long)nb * nst + st) * ntap + tap) * 3) * 4096 + (long)ng * 1024 + lane * 16;  // bytes / 1
+  const long base = ((((long)nb * nst + st) * ntap + tap) * NP) * 4096 + (long)ng * 1024 + lane * 16;  // bytes / 1
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     const int cl = (st < nst0 ? st : st - nst0) * 32 + 8 * (lane >> 4) + j;
@@ -463,13 +484,21 @@ __global__ void pack_s3_weights_kernel(const float* __restrict__ w, unsigned sho
     } else {
       v = w[(((size_t)cv * cin_total + cin) * ks + ky) * ks + kx];
     }
-    const __bf16 v0 = (__bf16)v;
-    const float r1 = v - (float)v0;
-    const __bf16 v1 = (__bf16)r1;
-    const __bf16 v2 = (__bf16)(r1 - (float)v1);
-    packed[(base + 0 * 4096) / 2 + j] = __builtin_bit_cast(unsigned short, v0);
-    packed[(base + 1 * 4096) / 2 + j] = __builtin_bit_cast(unsigned short, v1);
-    packed[(base + 2 * 4096) / 2 + j] = __builtin_bit_cast(unsigned short, v2);
+    if constexpr (NP == 3) {
+      const __bf16 v0 = (__bf16)v;
+      const float r1 = v - (float)v0;
+      const __bf16 v1 = (__bf16)r1;
+      const __bf16 v2 = (__bf16)(r1 - (float)v1);
+      packed[(base + 0 * 4096) / 2 + j] = __builtin_bit_cast(unsigned short, v0);
+      packed[(base + 1 * 4096) / 2 + j] = __builtin_bit_cast(unsigned short, v1);
+      packed[(base + 2 * 4096) / 2 + j] = __builtin_bit_cast(unsigned short, v2);
+    } else {
+      const float u = fminf(fmaxf(v * wscale, -65504.f), 65504.f);
+      const _Float16 h0 = (_Float16)u;
+      const _Float16 h1 = (_Float16)(u - (float)h0);
+      packed[(base + 0 * 4096) / 2 + j] = __builtin_bit_cast(unsigned short, h0);
+      packed[(base + 1 * 4096) / 2 + j] = __builtin_bit_cast(unsigned short, h1);
+    }
   }
 }
 
@@ -588,6 +617,45 @@ __global__ void s3_to_f32_kernel(const unsigned short* __restrict__ src, float* 
   dst[i] = v;
 }
 
+// fp32 NHWC <-> H2 (rows, cs/32, 2, 4, W, 8) fp16 (format: include/sfh_amd.h); thread mapping as f32_to_s3_kernel
+__global__ __launch_bounds__(256) void f32_to_h2_kernel(const float* __restrict__ src, unsigned short* __restrict__ dst,
+                                                        int W, int cs, int xchunks, long total, unsigned* overflow) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int g = (int)(i & 3), px = (int)((i >> 2) & 15);
+  long r = i >> 6;
+  const int xc = (int)(r % xchunks); r /= xchunks;
+  const int cb = (int)(r % (cs >> 5));
+  const long row = r / (cs >> 5);
+  const int x = xc * 16 + px;
+  if (x >= W) return;
+  const float* sp = src + (row * W + x) * cs + cb * 32 + g * 8;
+  const f32x4 a = *reinterpret_cast<const f32x4*>(sp), b = *reinterpret_cast<const f32x4*>(sp + 4);
+  sfh_u32x2 pa[2], pb[2];
+  float over = 0.f;
+  sfh_split4_h2(a, pa, over);
+  sfh_split4_h2(b, pb, over);
+  const long e = ((((row * (cs >> 5) + cb) * 2) * 4 + g) * W + x) * 8;
+  const long ps = 4L * W * 8;  // plane stride in elements
+  *reinterpret_cast<u32x4*>(dst + e) = (u32x4){pa[0][0], pa[0][1], pb[0][0], pb[0][1]};
+  *reinterpret_cast<u32x4*>(dst + e + ps) = (u32x4){pa[1][0], pa[1][1], pb[1][0], pb[1][1]};
+  if (overflow && over > kSfhH2Max) atomicOr(overflow, 1u);
+}
+
+__global__ void h2_to_f32_kernel(const unsigned short* __restrict__ src, float* __restrict__ dst, int W, int cs,
+                                 long total) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const long pix = i / cs;
+  const int c = i - pix * cs;
+  const long row = pix / W;
+  const int x = pix - row * W;
+  const long e = ((((row * (cs >> 5) + (c >> 5)) * 2) * 4 + ((c & 31) >> 3)) * W + x) * 8 + (c & 7);
+  const float lo = (float)__builtin_bit_cast(_Float16, src[e + 4L * W * 8]);
+  const float hi = (float)__builtin_bit_cast(_Float16, src[e]);
+  dst[i] = (lo + hi) * kSfhH2InvScale;
+}
+
 template <class C, bool DB>
 int launch_s3(const sfh_conv_desc& d, hipStream_t stream) {
   S3Geom g;
@@ -613,8 +681,8 @@ int launch_s3(const sfh_conv_desc& d, hipStream_t stream) {
     g.ntiles = g.tiles_x * g.tiles_y * d.batch;
     SFH_REQUIRE(g.Ho < 65536 && d.batch < 32768, "conv_s3: geometry too large");
   }
-  const unsigned long long b0 = 6ULL * d.batch * d.h0 * d.w0 * d.cs0;
-  const unsigned long long b1 = d.src1 ? 6ULL * d.batch * d.h1 * d.w1 * d.cs1 : 0ULL;
+  const unsigned long long b0 = 2ULL * C::NP * d.batch * d.h0 * d.w0 * d.cs0;
+  const unsigned long long b1 = d.src1 ? 2ULL * C::NP * d.batch * d.h1 * d.w1 * d.cs1 : 0ULL;
   SFH_REQUIRE(b0 < kOOB && b1 < kOOB, "conv_s3: a source tensor of %llu bytes exceeds the 4 GiB descriptor range; split the batch",
               b0 > b1 ? b0 : b1);
   g.bytes0 = (unsigned)b0;
@@ -626,7 +694,7 @@ int launch_s3(const sfh_conv_desc& d, hipStream_t stream) {
     // 64 MB 21.61, unbounded 21.74 - re-reading the input tile once per cout block costs more than
     // streaming weights that no longer fit the 4 MB L2 (they hit the 256 MB Infinity Cache), so the budget
     // is 64 MB: every layer of this model is fully grouped.
-    const long wblock = (long)((d.c0 + (d.src1 ? d.c1 : 0)) / 32) * C::NTAP * 12288;
+    const long wblock = (long)((d.c0 + (d.src1 ? d.c1 : 0)) / 32) * C::NTAP * (C::NP * 4096);
     const long budget = 64L << 20;
     int G = d.out_mode == SFH_OUT_UPSCATTER2 ? g.nblk_n : (int)(budget / (wblock > 0 ? wblock : 1));
     if (G < 1) G = 1;
@@ -682,9 +750,32 @@ extern "C" int sfh_pack_s3_weights(const float* w, void* packed, int ksize, int 
     return sfh_check_launch("pack_s3_weights_alltaps_kernel");
   }
   const long total = n / 48;  // one thread per (lane, 8 channels) of all three planes
-  hipLaunchKernelGGL(pack_s3_weights_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
-                     (hipStream_t)stream, w, (unsigned short*)packed, ksize, c0, c1, cout_virtual, mode, aux, total);
+  hipLaunchKernelGGL(pack_s3_weights_kernel<3>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                     (hipStream_t)stream, w, (unsigned short*)packed, ksize, c0, c1, cout_virtual, mode, aux, total, 1.f);
   return sfh_check_launch("pack_s3_weights_kernel");
+}
+
+extern "C" int64_t sfh_packed_h2_weight_bytes(int ksize, int c0, int c1, int cout_virtual) {
+  const int64_t n = sfh_packed_s3_weight_bytes(ksize, c0, c1, cout_virtual);
+  return n < 0 ? n : n / 3 * 2;
+}
+
+extern "C" int sfh_pack_h2_weights(const float* w, void* packed, int ksize, int c0, int c1, int cout_virtual,
+                                   int mode, int aux, int wexp, void* stream) {
+  const int64_t n = sfh_packed_h2_weight_bytes(ksize, c0, c1, cout_virtual);
+  SFH_REQUIRE(n > 0, "pack_h2_weights: bad geometry ks=%d c0=%d c1=%d cout=%d", ksize, c0, c1, cout_virtual);
+  SFH_REQUIRE(w && packed, "pack_h2_weights: null pointer");
+  SFH_REQUIRE(wexp >= -100 && wexp <= 100, "pack_h2_weights: wexp=%d out of range", wexp);
+  SFH_REQUIRE((mode == 0 && ksize != 4) || (mode == 1 && ksize == 1 && c1 == 0 && cout_virtual % 256 == 0) ||
+                  (mode == 2 && ksize == 4 && c1 == 0 && aux > 0 && aux <= c0 / 4) ||
+                  (mode == 3 && c1 == 0 && (ksize == 1 || ksize == 3) && aux > 0 && aux <= cout_virtual) ||
+                  (mode == 4 && ksize == 1 && c1 == 0 && aux > 0 && c0 == 4 * aux),
+              "pack_h2_weights: bad mode/geometry (mode %d, ksize %d)", mode, ksize);
+  const long total = n / 32;  // one thread per (lane, 8 channels) of both planes
+  hipLaunchKernelGGL(pack_s3_weights_kernel<2>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                     (hipStream_t)stream, w, (unsigned short*)packed, ksize, c0, c1, cout_virtual, mode, aux, total,
+                     ldexpf(1.f, wexp));
+  return sfh_check_launch("pack_h2_weights_kernel");
 }
 
 extern "C" int sfh_f32_to_s3(const float* src, void* dst, int64_t rows, int W, int cs, void* stream) {
@@ -704,11 +795,31 @@ extern "C" int sfh_s3_to_f32(const void* src, float* dst, int64_t rows, int W, i
   return sfh_check_launch("s3_to_f32_kernel");
 }
 
+extern "C" int sfh_f32_to_h2(const float* src, void* dst, int64_t rows, int W, int cs, uint32_t* overflow, void* stream) {
+  SFH_REQUIRE(src && dst && rows > 0 && W > 0 && cs > 0 && cs % 32 == 0, "f32_to_h2: cs must be a multiple of 32");
+  const int xchunks = (W + 15) / 16;
+  const long total = rows * (cs / 32) * xchunks * 64;
+  hipLaunchKernelGGL(f32_to_h2_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     src, (unsigned short*)dst, W, cs, xchunks, total, overflow);
+  return sfh_check_launch("f32_to_h2_kernel");
+}
+
+extern "C" int sfh_h2_to_f32(const void* src, float* dst, int64_t rows, int W, int cs, void* stream) {
+  SFH_REQUIRE(src && dst && rows > 0 && W > 0 && cs > 0 && cs % 32 == 0, "h2_to_f32: cs must be a multiple of 32");
+  const long total = rows * W * cs;
+  hipLaunchKernelGGL(h2_to_f32_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const unsigned short*)src, dst, W, cs, total);
+  return sfh_check_launch("h2_to_f32_kernel");
+}
+
 extern "C" int sfh_conv_s3_fwd(const sfh_conv_desc* dp, void* stream_) {
   SFH_REQUIRE(dp, "conv_s3_fwd: null descriptor");
   const sfh_conv_desc& d = *dp;
   hipStream_t stream = (hipStream_t)stream_;
   SFH_REQUIRE(d.src0 && d.wpacked && d.scale && d.shift && d.dst, "conv_s3_fwd: null pointer");
+  SFH_REQUIRE(d.src_fmt == SFH_FMT_S3 || d.src_fmt == SFH_FMT_H2, "conv_s3_fwd: sources must be S3 or H2 tensors (src_fmt=%d)", d.src_fmt);
+  SFH_REQUIRE(d.dst_fmt == SFH_FMT_F32 || d.dst_fmt == d.src_fmt,
+              "conv_s3_fwd: the destination is fp32 or the sources' own split format (src_fmt=%d, dst_fmt=%d)", d.src_fmt, d.dst_fmt);
   SFH_REQUIRE(d.batch > 0 && d.H > 0 && d.W > 0, "conv_s3_fwd: empty geometry");
   SFH_REQUIRE(d.cout > 0 && d.cout % 64 == 0, "conv_s3_fwd: cout=%d must be a multiple of 64", d.cout);
   SFH_REQUIRE(d.c0 > 0 && d.c0 % 32 == 0 && d.cs0 >= d.c0, "conv_s3_fwd: c0=%d must be a multiple of 32 (cs0=%d)", d.c0, d.cs0);
@@ -733,7 +844,7 @@ extern "C" int sfh_conv_s3_fwd(const sfh_conv_desc* dp, void* stream_) {
                     (d.ksize == 2 || !d.residual) && !d.src1,
                 "conv_s3_fwd: up-scatter needs ksize 1 or 2, stride=1, cout/4 multiple of 64, one source");
   SFH_REQUIRE(d.ksize != 2 || d.out_mode == SFH_OUT_UPSCATTER2, "conv_s3_fwd: ksize 2 exists only as the up-scatter conv");
-  SFH_REQUIRE(!d.residual_f32 || (d.residual && d.dst_fmt == SFH_FMT_S3), "conv_s3_fwd: residual_f32 needs a residual and an S3 dst");
+  SFH_REQUIRE(!d.residual_f32 || (d.residual && d.dst_fmt != SFH_FMT_F32), "conv_s3_fwd: residual_f32 needs a residual and a split-format dst");
   SFH_REQUIRE(!d.residual_f32 || d.ksize == 2 || d.out_mode == SFH_OUT_NHWC, "conv_s3_fwd: residual_f32 with a plain output only");
   SFH_REQUIRE(!d.shift_border || d.ksize == 2, "conv_s3_fwd: shift_border exists only for the 2x2 up-scatter conv");
   if (d.head_w)
@@ -745,7 +856,11 @@ extern "C" int sfh_conv_s3_fwd(const sfh_conv_desc* dp, void* stream_) {
   // workgroups, which take the double-buffered variant
 #define SFH_S3CASE(KS, ST, TILE, SH, SW, TH, TW)                      \
   if (d.ksize == KS && d.stride == ST && d.tile == TILE) {             \
-    using CFG = S3Cfg<KS, ST, SH, SW, TH, TW>;                         \
+    if (d.src_fmt == SFH_FMT_H2) {                                     \
+      using CFG = S3Cfg<KS, ST, SH, SW, TH, TW, 2>;                    \
+      return launch_s3<CFG, false>(d, stream);                         \
+    }                                                                  \
+    using CFG = S3Cfg<KS, ST, SH, SW, TH, TW, 3>;                      \
     return launch_s3<CFG, false>(d, stream);                           \
   }
   SFH_S3CASE(3, 1, SFH_TILE_8x32, 1, 16, 8, 32)

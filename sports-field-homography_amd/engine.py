@@ -36,20 +36,42 @@ def _f32c(t, what):
     return t
 
 
+# Split ("plane") activation formats of include/sfh_amd.h, identified by the tensor dtype:
+#   "s3": (B,H,C/32,3,4,W,8) bfloat16 - three bf16 planes, exact fp32 value            (precision "bf16x6")
+#   "h2": (B,H,C/32,2,4,W,8) float16  - two fp16 planes of v * 2^2, 22 significand bits (precision "f16x3")
+_SPLIT = {"s3": (torch.bfloat16, 3, _lib.FMT_S3), "h2": (torch.float16, 2, _lib.FMT_H2)}
+_SPLIT_DTYPES = {torch.bfloat16: "s3", torch.float16: "h2"}
+PRECISIONS = {"bf16x6": "s3", "f16x3": "h2", "fp32": None}
+
+
+def _fmt_of(t):
+    """"s3" / "h2" for a split tensor, None for fp32 NHWC"""
+    return _SPLIT_DTYPES.get(t.dtype)
+
+
+def _fmt_code(t):
+    f = _fmt_of(t)
+    return _SPLIT[f][2] if f else _lib.FMT_F32
+
+
 def _chan(t):
-    """channels per pixel of an activation tensor: fp32 NHWC (B,H,W,C) or S3 (B,H,C/32,3,4,W,8) bf16"""
-    return t.shape[2] * 32 if t.dtype == torch.bfloat16 else t.shape[3]
+    """channels per pixel of an activation tensor: fp32 NHWC (B,H,W,C) or split (B,H,C/32,planes,4,W,8)"""
+    return t.shape[2] * 32 if t.dtype in _SPLIT_DTYPES else t.shape[3]
 
 
 def _hw(t):
     """(H, W) of an activation tensor in either format"""
-    return (t.shape[1], t.shape[5]) if t.dtype == torch.bfloat16 else (t.shape[1], t.shape[2])
+    return (t.shape[1], t.shape[5]) if t.dtype in _SPLIT_DTYPES else (t.shape[1], t.shape[2])
+
+
+def split_shape(fmt, b, h, w, c):
+    if c % 32:
+        raise ValueError(f"split-format tensors need a multiple of 32 channels, got {c}")
+    return (b, h, c // 32, _SPLIT[fmt][1], 4, w, 8)
 
 
 def s3_shape(b, h, w, c):
-    if c % 32:
-        raise ValueError(f"S3 tensors need a multiple of 32 channels, got {c}")
-    return (b, h, c // 32, 3, 4, w, 8)
+    return split_shape("s3", b, h, w, c)
 
 
 def s3_empty(b, h, w, c, device):
@@ -77,7 +99,7 @@ def choose_tile(batch, ho, wo, stride, zrows=1):
     return best[1]
 
 
-def choose_tile_s3(batch, ho, wo, stride, zrows, nblk, ksize=3):
+def choose_tile_s3(batch, ho, wo, stride, zrows, nblk, ksize=3, wg_slots=_WG_SLOTS):
     """split-bf16 kernel: estimated time = rounds of resident workgroups x pixels per tile; the
     half-size tiles win when the full-size grid would leave most of the chip idle (ResNet layer3/4)
     and are the only ones whose stride-2 halo fits LDS."""
@@ -92,7 +114,7 @@ def choose_tile_s3(batch, ho, wo, stride, zrows, nblk, ksize=3):
         else:
             ty = -(-(batch * (ho + zrows)) // th)
         ntiles = ty * (-(-wo // tw))
-        rounds = -(-(ntiles * nblk) // _WG_SLOTS)
+        rounds = -(-(ntiles * nblk) // wg_slots)
         # equal estimates: prefer the larger tile (less per-workgroup overhead, more operand reuse)
         cost = (rounds * th * tw, ntiles * th * tw, -th * tw)
         if best is None or cost < best[0]:
@@ -150,12 +172,17 @@ class PackedConv:
     order = None   # LaunchOrder of the owning engine (set by the engine); None = always forward
 
     def __init__(self, weight, bias, bn, ksize, c0, c1=0, relu=True, transposed=False, stride=1,
-                 stem_cin=0, tag="conv", s3=False):
-        """s3=True: sources are split-bf16 (S3) tensors and the contraction runs as six bf16 MFMAs
-        per product (sfh_conv_s3_fwd); otherwise fp32 sources and fp32 MFMA (sfh_conv_fwd)."""
+                 stem_cin=0, tag="conv", s3=False, fmt=None):
+        """fmt="s3" (or s3=True): sources are split-bf16 (S3) tensors and the contraction runs as six bf16 MFMAs
+        per product; fmt="h2": two-plane fp16 (H2) sources, three fp16 MFMAs per product (both sfh_conv_s3_fwd);
+        otherwise fp32 sources and fp32 MFMA (sfh_conv_fwd)."""
         lib = _lib.load()
         self.tag = tag
-        self.s3 = bool(s3)
+        self.fmt = fmt if fmt is not None else ("s3" if s3 else None)
+        if self.fmt not in (None, "s3", "h2"):
+            raise ValueError(f"fmt={fmt!r}: expected None, 's3' or 'h2'")
+        self.s3 = self.fmt is not None     # "runs on the split-operand kernel"
+        self.escale = 1.0
         dev = weight.device
         w = _f32c(weight.detach(), "conv weight")
         self.ksize, self.c0, self.c1, self.relu, self.stride = ksize, c0, c1, relu, stride
@@ -188,12 +215,7 @@ class PackedConv:
         elif self.s3:
             if stem_cin:
                 mode, aux = 2, stem_cin
-            n = lib.sfh_packed_s3_weight_bytes(ksize, c0, c1, self.cout)
-            if n <= 0:
-                raise ValueError(f"unsupported S3 conv geometry ksize={ksize} c0={c0} c1={c1} cout={self.cout}")
-            self.wpacked = torch.empty(n, dtype=torch.uint8, device=dev)
-            _lib.check(lib.sfh_pack_s3_weights(_ptr(w), _ptr(self.wpacked), ksize, c0, c1, self.cout, mode, aux,
-                                               _stream()), "pack_s3_weights")
+            self._pack_split(w, ksize, c0, c1, mode, aux)
         else:
             n = lib.sfh_packed_weight_floats(ksize, c0, c1, self.cout)
             if n <= 0:
@@ -211,9 +233,37 @@ class PackedConv:
             args, eps = [None] * 4, 0.0
         _lib.check(lib.sfh_fold_bn(_ptr(b), *[_ptr(a) for a in args], eps, self.cout_real, rep,
                                    _ptr(self.scale), _ptr(self.shift), _stream()), "fold_bn")
+        if self.escale != 1.0:
+            self.scale.mul_(self.escale)     # a power of two: exact
+
+    def _pack_split(self, w, ksize, c0, c1, mode, aux):
+        """Pack w for the split-operand kernel in this layer's format.  H2: planes of w * 2^wexp with
+        max |w| * 2^wexp in [2^13, 2^14); self.escale = 2^-(wexp + H2_ACT_EXP) is what the accumulator has to be
+        multiplied with (the caller folds it into `scale`)."""
+        lib = _lib.load()
+        if self.fmt == "h2":
+            n = lib.sfh_packed_h2_weight_bytes(ksize, c0, c1, self.cout)
+        else:
+            n = lib.sfh_packed_s3_weight_bytes(ksize, c0, c1, self.cout)
+        if n <= 0:
+            raise ValueError(f"unsupported split-kernel conv geometry ksize={ksize} c0={c0} c1={c1} cout={self.cout}")
+        self.wpacked = torch.empty(n, dtype=torch.uint8, device=w.device)
+        if self.fmt == "h2":
+            import math
+            wmax = float(w.abs().max())
+            if not math.isfinite(wmax):
+                raise ValueError("conv weight holds non-finite values")
+            wexp = 13 - math.frexp(wmax)[1] + 1 if wmax > 0 else 0    # frexp: wmax = m * 2^e, 0.5 <= m < 1
+            wexp = max(-100, min(100, wexp))
+            self.escale = 2.0 ** -(wexp + _lib.H2_ACT_EXP)
+            _lib.check(lib.sfh_pack_h2_weights(_ptr(w), _ptr(self.wpacked), ksize, c0, c1, self.cout, mode, aux, wexp,
+                                               _stream()), "pack_h2_weights")
+        else:
+            _lib.check(lib.sfh_pack_s3_weights(_ptr(w), _ptr(self.wpacked), ksize, c0, c1, self.cout, mode, aux,
+                                               _stream()), "pack_s3_weights")
 
     @classmethod
-    def fused_up(cls, conv, bn, up, c0, tag="fusedup2x2"):
+    def fused_up(cls, conv, bn, up, c0, tag="fusedup2x2", fmt="s3"):
         """The u-half of conv3x3(cat([skip, ConvTranspose2d(x)])) (+bias, BN, ReLU) as ONE 2x2 conv over the
         low-resolution x with quadrant scatter (sfh_compose_up_weights): takes x (S3), adds the fp32
         partial of the skip-half conv as residual and writes the activated S3 output.  Split-bf16 kernel only."""
@@ -229,6 +279,7 @@ class PackedConv:
         if cout % 64 or cx % 32:
             raise ValueError("fused Up conv needs cout % 64 == 0 and a multiple of 32 low-resolution channels")
         self.tag, self.s3, self.c4, self.stem_cin = tag, True, False, 0
+        self.fmt, self.escale = fmt, 1.0
         self.ksize, self.c0, self.c1, self.relu, self.stride, self.transposed = 2, cx, 0, True, 1, True
         self.cout, self.cout_real = 4 * cout, cout
         self.flops_per_out_pixel = 2.0 * cout * 9 * c1   # the part of the reference conv this launch stands for
@@ -243,12 +294,11 @@ class PackedConv:
         _lib.check(lib.sfh_compose_up_weights(_ptr(wc), cout, c0, c1, _ptr(wt), cx, _ptr(bt), _ptr(self.scale),
                                               _ptr(self.shift), _ptr(w2), _ptr(self.shift_border), _stream()),
                    "compose_up_weights")
-        n = lib.sfh_packed_s3_weight_bytes(2, cx, 0, self.cout)
-        if n <= 0:
-            raise ValueError(f"unsupported fused Up geometry cx={cx} cout={cout}")
-        self.wpacked = torch.empty(n, dtype=torch.uint8, device=dev)
-        _lib.check(lib.sfh_pack_s3_weights(_ptr(w2), _ptr(self.wpacked), 2, cx, 0, self.cout, 0, 0, _stream()),
-                   "pack_s3_weights")
+        self._pack_split(w2, 2, cx, 0, 0, 0)
+        # the skip-half conv of the block applies the same BatchNorm scale to ITS accumulator (UNetEngine)
+        self.scale_bn = self.scale.clone()
+        if self.escale != 1.0:
+            self.scale.mul_(self.escale)
         return self
 
     @classmethod
@@ -269,6 +319,7 @@ class PackedConv:
             assert tuple(w.shape[2:]) == (ksize, ksize) and ksize in (1, 3)
             c0, mode, aux = cout, 3, cin
         self.tag, self.s3, self.c4, self.stem_cin = tag, bool(s3), False, 0
+        self.fmt, self.escale = ("s3" if s3 else None), 1.0
         self.ksize, self.c0, self.c1, self.relu, self.stride, self.transposed = ksize, c0, 0, False, 1, False
         if cin % 64:
             raise ValueError(f"backward-data conv needs a multiple of 64 input channels, got {cin}")
@@ -292,17 +343,24 @@ class PackedConv:
 
     def run(self, src0, batch, H, W, dst, src1=None, pool0=False, pad1=(0, 0), residual=None, tile=None,
             dst_pool=None, up_dst=None, head=None):
-        """src0/src1: NHWC float32 tensors (or S3 tensors (B,H,W,3,C) bf16 when the layer is s3);
-        dst/residual/dst_pool: float32 NHWC, or S3 when their dtype is bfloat16.  H, W: conv input frame."""
+        """src0/src1: NHWC float32 tensors, or split tensors of the layer's format (S3 bfloat16 / H2 float16);
+        dst/residual/dst_pool: float32 NHWC or the same split format (by dtype).  H, W: conv input frame."""
         lib = _lib.load()
         d = ConvDesc()
         d.src0 = src0.data_ptr()
         d.c0, d.cs0 = self.c0, _chan(src0)
         d.h0, d.w0 = _hw(src0)
-        if (src0.dtype == torch.bfloat16) != self.s3:
-            raise ValueError(f"layer s3={self.s3} got a source of dtype {src0.dtype}")
-        d.src_fmt = _lib.FMT_S3 if self.s3 else _lib.FMT_F32
-        d.dst_fmt = _lib.FMT_S3 if dst.dtype == torch.bfloat16 else _lib.FMT_F32
+        if _fmt_of(src0) != self.fmt or (src1 is not None and _fmt_of(src1) != self.fmt):
+            raise ValueError(f"layer of format {self.fmt} got a source of dtype {src0.dtype}")
+        d.src_fmt = _fmt_code(src0)
+        d.dst_fmt = _fmt_code(dst)
+        if self.fmt is not None and _fmt_of(dst) not in (None, self.fmt):
+            raise ValueError(f"layer of format {self.fmt} cannot write a {dst.dtype} destination")
+        for t in (dst_pool, residual):
+            if t is not None and _fmt_of(t) not in (None, _fmt_of(dst)):
+                raise ValueError(f"dst_pool / residual of dtype {t.dtype} beside a {dst.dtype} destination")
+        ovf = getattr(self, "overflow", None)
+        d.h2_overflow = ovf.data_ptr() if (ovf is not None and _fmt_of(dst) == "h2") else None
         if dst_pool is not None:
             d.dst_pool, d.pool_cs = dst_pool.data_ptr(), _chan(dst_pool)
         d.pool0 = 1 if pool0 else 0
@@ -340,7 +398,7 @@ class PackedConv:
         d.reverse_tiles = 1 if (self.s3 and self.order is not None and self.order.next()) else 0
         d.residual = residual.data_ptr() if residual is not None else None
         d.residual_f32 = 1 if (residual is not None and residual.dtype == torch.float32
-                               and dst.dtype == torch.bfloat16) else 0
+                               and dst.dtype in _SPLIT_DTYPES) else 0
         sb = getattr(self, "shift_border", None)
         d.shift_border = sb.data_ptr() if sb is not None else None
         d.dst, d.dst_cs = dst.data_ptr(), _chan(dst)
@@ -400,30 +458,33 @@ class _Workspace:
 class UNetEngine:
     """forward_unet (models/reconstructor.py:132-158) on the HIP kernels."""
 
-    def __init__(self, net, device, precision="bf16x6"):
+    def __init__(self, net, device, precision="bf16x6", overflow=None):
         """precision: "bf16x6" - activations in split-bf16 (S3) format, contractions as six bf16
-        MFMAs per product with fp32 accumulation (fp32-equivalent accuracy); "fp32" - fp32
-        activations and fp32 MFMA throughout."""
+        MFMAs per product with fp32 accumulation (fp32-equivalent accuracy); "f16x3" - two-plane fp16 (H2)
+        activations, three fp16 MFMAs per product (22-bit operands; `overflow`: int32 device word that the kernels
+        raise when an activation leaves the fp16 range); "fp32" - fp32 activations and fp32 MFMA throughout."""
         self.bilinear = bool(net.unet_bilinear)
         # fused Up levels where the composed 2x2 conv runs first (see run()): the two full-resolution-most
         # levels, where that conv is memory-heavy (measured per level: none 629, {4} 634, {3,4} 638, all 635
         # frames/s)
         self.up_swap = {3, 4}
-        if precision not in ("bf16x6", "fp32"):
-            raise ValueError(f"precision={precision!r}: expected 'bf16x6' or 'fp32'")
+        if precision not in PRECISIONS:
+            raise ValueError(f"precision={precision!r}: expected one of {sorted(PRECISIONS)}")
         self.device = device
         self.ws = _Workspace(device)
         self.nc = net.mask_classes
-        self.s3 = precision == "bf16x6"
+        self.fmt = fmt = PRECISIONS[precision]
+        self.s3 = fmt is not None          # split-format activations
         s3 = self.s3
+        self.overflow = overflow if fmt == "h2" else None
         L = {}
 
-        def dc(name, block, c0, c1=0, first_s3=s3):
+        def dc(name, block, c0, c1=0, first_fmt=fmt):
             (cv1, bn1), (cv2, bn2) = block.convs()
-            L[name + ".0"] = PackedConv(cv1.weight, cv1.bias, bn1, 3, c0, c1, tag="doubleconv3x3", s3=first_s3)
-            L[name + ".3"] = PackedConv(cv2.weight, cv2.bias, bn2, 3, cv1.out_channels, tag="doubleconv3x3", s3=s3)
+            L[name + ".0"] = PackedConv(cv1.weight, cv1.bias, bn1, 3, c0, c1, tag="doubleconv3x3", fmt=first_fmt)
+            L[name + ".3"] = PackedConv(cv2.weight, cv2.bias, bn2, 3, cv1.out_channels, tag="doubleconv3x3", fmt=fmt)
 
-        dc("inc", net.inc, 3, first_s3=False)  # 3-channel input: fp32 kernel (writes S3 when s3)
+        dc("inc", net.inc, 3, first_fmt=None)  # 3-channel input: fp32 kernel (writes the split format itself)
         for i, cin in enumerate((64, 128, 256, 512), start=1):
             dc(f"down{i}", getattr(net, f"down{i}").block, cin)
         for i, cin in enumerate((1024, 512, 256, 128), start=1):
@@ -435,19 +496,20 @@ class UNetEngine:
                 (cv1, bn1), _ = up.conv.convs()
                 c0s = cin // 2
                 L[f"up{i}.skip"] = PackedConv(cv1.weight.detach()[:, :c0s].contiguous(), None, None, 3, c0s, relu=False,
-                                              tag="doubleconv3x3", s3=True)
-                L[f"up{i}.fused"] = PackedConv.fused_up(cv1, bn1, up.up, c0s)
+                                              tag="doubleconv3x3", fmt=fmt)
+                L[f"up{i}.fused"] = PackedConv.fused_up(cv1, bn1, up.up, c0s, fmt=fmt)
                 # the partial enters the fused conv's epilogue as a residual, i.e. after the BatchNorm scale:
-                # the skip-half carries that scale itself (shift stays 0)
-                L[f"up{i}.skip"].scale.copy_(L[f"up{i}.fused"].scale[:cv1.out_channels])
+                # the skip-half carries that scale itself (shift stays 0), times its own operand scaling
+                L[f"up{i}.skip"].scale.copy_(L[f"up{i}.fused"].scale_bn[:cv1.out_channels] * L[f"up{i}.skip"].escale)
             if not self.bilinear:  # bilinear variant (A3b): parameter-free 2x upsampling kernel instead
                 L[f"up{i}.up"] = PackedConv(up.up.weight, up.up.bias, None, 1, cin, relu=False, transposed=True,
-                                            tag="convT2x2", s3=s3)
+                                            tag="convT2x2", fmt=fmt)
             dc(f"up{i}.conv", up.conv, cin // 2, cin // 2)  # cat([skip, up]): cin/2 channels each in both variants
         self.L = L
         self.order = LaunchOrder()
         for layer in L.values():
             layer.order = self.order
+            layer.overflow = self.overflow
         self.outc_w = _f32c(net.outc.conv.weight.detach(), "outc.weight")
         self.outc_b = _f32c(net.outc.conv.bias.detach(), "outc.bias")
         self.outuv = None
@@ -470,12 +532,12 @@ class UNetEngine:
         xin = ws.get("xin", (B, H, W, 4))
         _lib.check(lib.sfh_nchw_to_nhwc(_ptr(x), _ptr(xin), B, 3, H, W, 4, st), "nchw_to_nhwc")
 
-        s3 = self.s3
+        s3, fmt = self.s3, self.fmt
 
         def act(name, shape_bhw, c, f32=False):
-            """activation workspace: S3 (B,H,W,3,C) bf16 in bf16x6 mode, else fp32 NHWC"""
+            """activation workspace: the engine's split format (S3 bf16 / H2 fp16), else fp32 NHWC"""
             if s3 and not f32:
-                return ws.get(name, s3_shape(*shape_bhw, c), torch.bfloat16)
+                return ws.get(name, split_shape(fmt, *shape_bhw, c), _SPLIT[fmt][0])
             return ws.get(name, tuple(shape_bhw) + (c,))
 
         def dconv(name, src0, h, w, cout, src1=None, pool0=False, pad1=(0, 0), want_pool=False, out_f32=False, head=None):
@@ -538,11 +600,11 @@ class UNetEngine:
                 yf = y
                 if s3:
                     yf = ws.get(f"up{i}.yf", (B, hy, wy, cup))
-                    _lib.check(lib.sfh_s3_to_f32(_ptr(y), _ptr(yf), B * hy, wy, cup, st), "s3_to_f32")
+                    _split_to_f32_into(y, yf)
                 uf = ws.get(f"up{i}.uf", (B, 2 * hy, 2 * wy, cup)) if s3 else upb
                 _lib.check(lib.sfh_upsample2x_bilinear_nhwc(_ptr(yf), _ptr(uf), B, hy, wy, cup, st), "upsample2x")
                 if s3:
-                    _lib.check(lib.sfh_f32_to_s3(_ptr(uf), _ptr(upb), B * 2 * hy, 2 * wy, cup, st), "f32_to_s3")
+                    _f32_to_split_into(uf, upb, self.overflow)
             else:
                 L[f"up{i}.up"].run(y, B, hy, wy, upb)
             dy, dx = hs - 2 * hy, ws_ - 2 * wy
@@ -614,13 +676,16 @@ class StemConv:
 class ResNetEngine:
     """ResNetSTN forward (models/resnet.py:235-254) on the HIP kernels (BasicBlock and Bottleneck depths)."""
 
-    def __init__(self, rn, in_channels, device, precision="bf16x6"):
-        """precision "bf16x6": the 3x3 convs (stride 1 and 2) and the 1x1 stride-2 downsample convs run
-        on the split-bf16 kernel with S3 activations; the stem stays on the fp32 kernel."""
-        if precision not in ("bf16x6", "fp32"):
-            raise ValueError(f"precision={precision!r}: expected 'bf16x6' or 'fp32'")
-        self.s3 = precision == "bf16x6"
+    def __init__(self, rn, in_channels, device, precision="bf16x6", overflow=None):
+        """precision "bf16x6" / "f16x3": the 3x3 convs (stride 1 and 2) and the 1x1 stride-2 downsample convs run
+        on the split-operand kernel with S3 / H2 activations; the stem stays on the fp32 kernel (or, with at most
+        8 input channels, on the tap-packed split-bf16 stem kernel)."""
+        if precision not in PRECISIONS:
+            raise ValueError(f"precision={precision!r}: expected one of {sorted(PRECISIONS)}")
+        self.fmt = fmt = PRECISIONS[precision]
+        self.s3 = fmt is not None
         s3 = self.s3
+        self.overflow = overflow if fmt == "h2" else None
         self.device = device
         self.ws = _Workspace(device)
         self.cin = in_channels
@@ -641,26 +706,27 @@ class ResNetEngine:
                 cin = blk.conv1.in_channels
                 if hasattr(blk, "conv3"):  # Bottleneck (models/resnet.py:120-140): 1x1, 3x3 (stride), 1x1
                     width, cout = blk.conv1.out_channels, blk.conv3.out_channels
-                    L[name + ".conv1"] = PackedConv(blk.conv1.weight, None, blk.bn1, 1, cin, tag="resnet", s3=s3)
+                    L[name + ".conv1"] = PackedConv(blk.conv1.weight, None, blk.bn1, 1, cin, tag="resnet", fmt=fmt)
                     L[name + ".conv2"] = PackedConv(blk.conv2.weight, None, blk.bn2, 3, width, stride=blk.stride,
-                                                    tag="resnet", s3=s3)
+                                                    tag="resnet", fmt=fmt)
                     L[name + ".conv3"] = PackedConv(blk.conv3.weight, None, blk.bn3, 1, width, tag="resnet",
-                                                    s3=s3)  # ReLU after the residual add
+                                                    fmt=fmt)  # ReLU after the residual add
                 else:  # BasicBlock (models/resnet.py:64-82)
                     width = cout = blk.conv1.out_channels
                     L[name + ".conv1"] = PackedConv(blk.conv1.weight, None, blk.bn1, 3, cin, stride=blk.stride,
-                                                    tag="resnet", s3=s3)
+                                                    tag="resnet", fmt=fmt)
                     L[name + ".conv2"] = PackedConv(blk.conv2.weight, None, blk.bn2, 3, width, tag="resnet",
-                                                    s3=s3)  # ReLU after the residual add
+                                                    fmt=fmt)  # ReLU after the residual add
                 if blk.downsample is not None:
                     ds = blk.downsample
                     L[name + ".down"] = PackedConv(ds[0].weight, None, ds[1], 1, cin, relu=False, stride=blk.stride,
-                                                   tag="resnet", s3=s3)
+                                                   tag="resnet", fmt=fmt)
                 self.blocks.append((name, width, cout, blk.stride, blk.downsample is not None, hasattr(blk, "conv3")))
         self.L = L
         self.order = LaunchOrder()
         for layer in L.values():
             layer.order = self.order
+            layer.overflow = self.overflow
         self.reg_w = _f32c(rn.reg.weight.detach(), "reg.weight")
         self.reg_b = _f32c(rn.reg.bias.detach(), "reg.bias")
 
@@ -685,16 +751,16 @@ class ResNetEngine:
         h, w = (H2 - 1) // 2 + 1, (W2 - 1) // 2 + 1
         x = ws.get("pool", (B, h, w, 64))
         _lib.check(lib.sfh_maxpool3x3s2_fwd(_ptr(c1), _ptr(x), B, H2, W2, 64, st), "maxpool3x3s2")
-        s3 = self.s3
+        s3, fmt = self.s3, self.fmt
 
         def act(name, hh, ww, c):
             if s3:
-                return ws.get(name, s3_shape(B, hh, ww, c), torch.bfloat16)
+                return ws.get(name, split_shape(fmt, B, hh, ww, c), _SPLIT[fmt][0])
             return ws.get(name, (B, hh, ww, c))
 
-        if s3:  # the pooled stem output enters the S3 domain (small tensor: 1/16 of the frame area)
+        if s3:  # the pooled stem output enters the split domain (small tensor: 1/16 of the frame area)
             xs = act("pool.s3", h, w, 64)
-            _lib.check(lib.sfh_f32_to_s3(_ptr(x), _ptr(xs), B * h, w, 64, st), "f32_to_s3")
+            _f32_to_split_into(x, xs, self.overflow)
             x = xs
         for name, width, cout, stride, has_down, bottleneck in self.blocks:
             ho, wo = (h - 1) // stride + 1, (w - 1) // stride + 1
@@ -717,7 +783,7 @@ class ResNetEngine:
             x, h, w = out, ho, wo
         if s3:
             xf = ws.get("final.f32", (B, h, w, _chan(x)))
-            _lib.check(lib.sfh_s3_to_f32(_ptr(x), _ptr(xf), B * h, w, _chan(x), st), "s3_to_f32")
+            _split_to_f32_into(x, xf)
             x = xf
         theta = torch.empty((B, 9), dtype=torch.float32, device=x.device)
         pooled = ws.get("pooled", (B, x.shape[3]))
@@ -726,15 +792,56 @@ class ResNetEngine:
         return theta.view(B, 1, 3, 3)
 
 
-def s3_to_f32(t):
-    """(B,H,C/32,3,4,W,8) bf16 split tensor -> (B,H,W,C) float32 (exact sum of the planes)."""
+def _split_to_f32_into(t, out):
     lib = _lib.load()
     B = t.shape[0]
     H, W = _hw(t)
     C = _chan(t)
-    out = torch.empty((B, H, W, C), dtype=torch.float32, device=t.device)
-    _lib.check(lib.sfh_s3_to_f32(_ptr(t), _ptr(out), B * H, W, C, _stream()), "s3_to_f32")
+    if tuple(out.shape) != (B, H, W, C) or out.dtype != torch.float32:
+        raise ValueError(f"split_to_f32: destination {tuple(out.shape)} does not match {(B, H, W, C)}")
+    if _fmt_of(t) == "h2":
+        _lib.check(lib.sfh_h2_to_f32(_ptr(t), _ptr(out), B * H, W, C, _stream()), "h2_to_f32")
+    else:
+        _lib.check(lib.sfh_s3_to_f32(_ptr(t), _ptr(out), B * H, W, C, _stream()), "s3_to_f32")
     return out
+
+
+def _f32_to_split_into(t, out, overflow=None):
+    lib = _lib.load()
+    B, H, W, C = t.shape
+    if (out.shape[0],) + _hw(out) + (_chan(out),) != (B, H, W, C):
+        raise ValueError(f"f32_to_split: destination {tuple(out.shape)} does not match {(B, H, W, C)}")
+    if _fmt_of(out) == "h2":
+        _lib.check(lib.sfh_f32_to_h2(_ptr(t), _ptr(out), B * H, W, C, _ptr(overflow), _stream()), "f32_to_h2")
+    else:
+        _lib.check(lib.sfh_f32_to_s3(_ptr(t), _ptr(out), B * H, W, C, _stream()), "f32_to_s3")
+    return out
+
+
+def s3_to_f32(t):
+    """split tensor (S3: (B,H,C/32,3,4,W,8) bf16, exact sum of the planes; H2: (B,H,C/32,2,4,W,8) fp16) ->
+    (B,H,W,C) float32."""
+    out = torch.empty((t.shape[0],) + _hw(t) + (_chan(t),), dtype=torch.float32, device=t.device)
+    return _split_to_f32_into(t, out)
+
+
+def split_empty(fmt, b, h, w, c, device):
+    """uninitialised split-format activation tensor ("s3" or "h2") for c channels (c multiple of 32)"""
+    return torch.empty(split_shape(fmt, b, h, w, c), dtype=_SPLIT[fmt][0], device=device)
+
+
+def f32_to_split(t, fmt, overflow=None):
+    """(B,H,W,C) float32 -> split tensor of format "s3" or "h2" """
+    t = _f32c(t, "nhwc tensor")
+    return _f32_to_split_into(t, split_empty(fmt, *t.shape, t.device), overflow)
+
+
+def f32_to_h2(t, overflow=None):
+    """(B,H,W,C) float32 -> (B,H,C/32,2,4,W,8) fp16 two-plane tensor (include/sfh_amd.h, SFH_FMT_H2)."""
+    t = _f32c(t, "nhwc tensor")
+    B, H, W, C = t.shape
+    out = torch.empty(split_shape("h2", B, H, W, C), dtype=torch.float16, device=t.device)
+    return _f32_to_split_into(t, out, overflow)
 
 
 def f32_to_s3(t):
@@ -783,7 +890,7 @@ def resize_nchw(t, size_hw, mode, align_corners=False):
 
 
 def nhwc_to_nchw(t, channels=None):
-    if t.dtype == torch.bfloat16:
+    if t.dtype in _SPLIT_DTYPES:
         t = s3_to_f32(t)
     lib = _lib.load()
     B, H, W, cs = t.shape

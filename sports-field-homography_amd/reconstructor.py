@@ -108,12 +108,19 @@ class Reconstructor(nn.Module):
         self.warper = True if use_warper else None
         self._warp_hw = (warp_size[1], warp_size[0])
 
-        # Arithmetic of the conv stack: "bf16x6" (default) = split-bf16 activations, six bf16 MFMAs
-        # per product, fp32 accumulation (fp32-equivalent accuracy, see csrc/conv_s3.hip);
-        # "fp32" = fp32 MFMA throughout.  Plain attribute (or env SFH_PRECISION) so the constructor
-        # signature stays the reference's.
-        self.precision = os.environ.get("SFH_PRECISION", "bf16x6")
+        # Arithmetic of the conv stack (fp32 accumulation in all modes, see csrc/conv_s3.hip):
+        #   "f16x3" (default) = two-plane fp16 activations / weights (22 significand bits), three fp16 MFMAs per
+        #                       product; activations must stay below 16376 in magnitude - a batch that leaves that
+        #                       range is detected on the device and re-run in "bf16x6" (see _range_guarded);
+        #   "bf16x6"          = three-plane bf16 operands (the exact fp32 value), six bf16 MFMAs per product;
+        #   "fp32"            = fp32 MFMA throughout.
+        # Plain attribute (or env SFH_PRECISION) so the constructor signature stays the reference's.
+        self.precision = os.environ.get("SFH_PRECISION", "f16x3")
         self._engines = None       # (UNetEngine | None, ResNetEngine | None)
+        self._engines_by_precision = {}
+        self._h2_overflow = None   # int32 device word raised by the kernels of the "f16x3" mode
+        self._forced_precision = None
+        self.range_fallbacks = 0   # batches re-run in "bf16x6" because an activation left the fp16 range
         self._engine_stamp = None
         self._weights_generation = 0
         self._tmpl_shared = None   # (data_ptr, shape) -> bool cache
@@ -133,27 +140,59 @@ class Reconstructor(nn.Module):
         (training.TrainStep.step, the train-mode BatchNorm statistics) do not move it: they call this."""
         self._weights_generation += 1
         self._engines = None
+        self._engines_by_precision = {}
 
     def _get_engines(self):
         stamp = self._param_stamp()
-        if self._engines is None or stamp != self._engine_stamp:
+        if self._engine_stamp != stamp:
+            self._engines_by_precision = {}
+            self._engine_stamp = stamp
+        precision = self._forced_precision or self.precision
+        eng = self._engines_by_precision.get(precision)
+        if eng is None:
             dev = stamp[0]
             if dev is None or dev.type != "cuda":
                 raise RuntimeError(
                     f"Reconstructor parameters are on {dev}: move the model to the GPU with .to('cuda'); "
                     "the HIP path has no CPU fallback")
             with torch.cuda.device(dev):
-                un = E.UNetEngine(self, dev, self.precision) if self.use_unet else None
-                rn = E.ResNetEngine(self.resnet_reg, self._stn_in_channels, dev, self.precision) if self.use_resnet else None
-            self._engines = (un, rn)
-            self._engine_stamp = stamp
-        return self._engines
+                if precision == "f16x3" and (self._h2_overflow is None or self._h2_overflow.device != dev):
+                    self._h2_overflow = torch.zeros(1, dtype=torch.int32, device=dev)
+                ovf = self._h2_overflow if precision == "f16x3" else None
+                un = E.UNetEngine(self, dev, precision, overflow=ovf) if self.use_unet else None
+                rn = (E.ResNetEngine(self.resnet_reg, self._stn_in_channels, dev, precision, overflow=ovf)
+                      if self.use_resnet else None)
+            eng = self._engines_by_precision[precision] = (un, rn)
+        self._engines = eng
+        return eng
+
+    def _range_guarded(self, fn, *args):
+        """Run fn; in "f16x3" mode read back the device word the kernels raise when an activation had to be
+        saturated to the fp16 range (|v| >= 16376) and, if it is set, run fn again with the three-plane bf16
+        operands, which have fp32's exponent range.  Still the HIP path - there is no CPU fallback."""
+        ret = fn(*args)
+        if (self._forced_precision or self.precision) != "f16x3" or self._h2_overflow is None:
+            return ret
+        if int(self._h2_overflow.item()) == 0:     # one 4-byte read-back per call
+            return ret
+        self._h2_overflow.zero_()
+        self.range_fallbacks += 1
+        if self.range_fallbacks == 1:
+            import warnings
+            warnings.warn("sfh_amd: an activation left the fp16 range of the 'f16x3' mode; the batch was re-run "
+                          "with precision 'bf16x6' (set net.precision = 'bf16x6' to avoid the double work)")
+        self._forced_precision = "bf16x6"
+        try:
+            return fn(*args)
+        finally:
+            self._forced_precision = None
 
     def __getstate__(self):
         """The model is pickled into spawned worker processes (predict.py:130,252): ship parameters and
         configuration only - packed weights and workspaces are rebuilt in the worker on first use."""
         st = self.__dict__.copy()
-        st["_engines"] = st["_engine_stamp"] = st["_tmpl_shared"] = None
+        st["_engines"] = st["_engine_stamp"] = st["_tmpl_shared"] = st["_h2_overflow"] = None
+        st["_engines_by_precision"] = {}
         return st
 
     def _require_eval(self, what):
@@ -217,9 +256,11 @@ class Reconstructor(nn.Module):
     def forward_unet(self, x):
         """Reference: models/reconstructor.py:132-158.  Returns (logits, x_top, uv) in NCHW."""
         self._require_eval("forward_unet")
-        r = self._run_unet(x, want_uv=self.unet_uv)
-        x_top = E.nhwc_to_nchw(r["x_top"])
-        return r["logits"], x_top, r.get("uv")
+
+        def run(x):
+            r = self._run_unet(x, want_uv=self.unet_uv)
+            return r["logits"], E.nhwc_to_nchw(r["x_top"]), r.get("uv")
+        return self._range_guarded(run, x)
 
     def _stn(self, x, r):
         """theta = resnet_reg(cat(...)) for the configured input mode (reference: :174-185)."""
@@ -244,7 +285,7 @@ class Reconstructor(nn.Module):
     # (< 4 GiB).  Larger batches (e.g. 16 frames at 1280x720: the 64-channel full-resolution tensor
     # is 5.7 GB in S3 format) are processed in sub-batches and concatenated.
     def _max_frames(self, x):
-        per_frame = x.shape[2] * x.shape[3] * 64 * (6 if self.precision == "bf16x6" else 4)
+        per_frame = x.shape[2] * x.shape[3] * 64 * (4 if self.precision == "fp32" else 6)   # 6: S3, also the fallback of f16x3
         return max(1, 0xFFFFFFF0 // per_frame - 0)
 
     def _chunked(self, fn, x, *args):
@@ -267,6 +308,9 @@ class Reconstructor(nn.Module):
         return self._chunked(self._forward_one, x)
 
     def _forward_one(self, x, off):
+        return self._range_guarded(self._forward_one_unguarded, x, off)
+
+    def _forward_one_unguarded(self, x, off):
         ret = {}
         r = None
         if self.use_unet:
@@ -288,6 +332,9 @@ class Reconstructor(nn.Module):
         return self._chunked(self._predict_one, x, consistency, project_poi)
 
     def _predict_one(self, x, off, consistency, project_poi):
+        return self._range_guarded(self._predict_one_unguarded, x, off, consistency, project_poi)
+
+    def _predict_one_unguarded(self, x, off, consistency, project_poi):
         ret = {}
         r = None
         if self.use_unet:

@@ -38,7 +38,7 @@ def test_conv_desc_layout_matches_header():
     fields = []
     for decl in body.split(";"):
         decl = decl.strip()
-        m = re.match(r"(const float\*|float\*|int32_t)\s+(.*)", decl)
+        m = re.match(r"(const float\*|float\*|uint32_t\*|int32_t)\s+(.*)", decl)
         if m:
             fields += [f.strip() for f in m.group(2).split(",")]
     assert fields == [f[0] for f in _lib.ConvDesc._fields_]
@@ -51,6 +51,10 @@ def test_argument_validation_without_gpu():
     assert lib.sfh_packed_weight_floats(3, 64, 64, 128) == 2 * 8 * 9 * 1024
     assert lib.sfh_packed_weight_floats(5, 64, 0, 64) == -1       # unsupported kernel size
     assert lib.sfh_packed_weight_floats(3, 64, 0, 48) == -1       # cout not a multiple of 64
+    # split-operand formats: 3 bf16 planes (S3) / 2 fp16 planes (H2) of [cout/64][cin/32][tap][plane][4 KB]
+    assert lib.sfh_packed_s3_weight_bytes(3, 64, 0, 64) == 2 * 9 * 3 * 4096
+    assert lib.sfh_packed_h2_weight_bytes(3, 64, 0, 64) == 2 * 9 * 2 * 4096
+    assert lib.sfh_packed_h2_weight_bytes(3, 48, 0, 64) == -1     # cin not a multiple of 32
     d = _lib.ConvDesc()
     rc = lib.sfh_conv_fwd(ctypes.byref(d), None)                  # all-null descriptor
     assert rc == -1 and b"null" in lib.sfh_last_error()

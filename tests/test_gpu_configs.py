@@ -110,7 +110,7 @@ def _check_predict(tag, out, g, court, wh, nframes_golden):
             poi_points_in_tie_band=int((~off_tie).sum()), poi_pixels_differ=int((pix != pix_ref).sum()))
 
 
-@pytest.mark.parametrize("precision", ["bf16x6", "fp32"])
+@pytest.mark.parametrize("precision", ["f16x3", "bf16x6", "fp32"])
 def test_c2_640x360_batch16_golden(precision):
     g = np.load(os.path.join(GOLD, "c2_640x360_b16.npz"))
     net, _, court, _ = _net("ncaa_nc4_640x360", (640, 360), 16, precision)
@@ -122,17 +122,19 @@ def test_c2_640x360_batch16_golden(precision):
     _check_predict(f"C2 640x360 B=16 {precision}", out, g, court, (640, 360), 16)
 
 
-def test_c5_1280x720_batch16_pitch_template_poi():
+@pytest.mark.parametrize("precision", ["f16x3", "bf16x6"])
+def test_c5_1280x720_batch16_pitch_template_poi(precision):
     """predict.py's HD configuration (predict.py:151-155,186-192): 16 frames in one call - whatever sub-batching
     the 32-bit tensor addressing needs happens inside predict()."""
     g = np.load(os.path.join(GOLD, "c5_1280x720_b2.npz"))
-    net, _, court, _ = _net("pitch_v3_nc4_1280x720", (1280, 720), 16, "bf16x6")
+    net, _, court, _ = _net("pitch_v3_nc4_1280x720", (1280, 720), 16, precision)
     x = synth.frames_to_float(synth.synth_frames_u8(16, 720, 1280, seed=0))
     with torch.no_grad():
         out = net.predict(x.cuda(), consistency=True, project_poi=True)
     torch.cuda.synchronize()
     assert tuple(out["logits"].shape) == (16, 4, 720, 1280) and tuple(out["poi"].shape) == (16, 33, 2)
-    _check_predict("C5 1280x720 B=16 bf16x6", out, g, court, (1280, 720), 2)
+    _check_predict(f"C5 1280x720 B=16 {precision}", out, g, court, (1280, 720), 2)
+    assert net.range_fallbacks == 0
     # frames are independent (eval-mode BatchNorm): a frame gives the same bits wherever it sits in the batch
     with torch.no_grad():
         solo = net.predict(x[:2].cuda(), consistency=True, project_poi=True)
@@ -232,7 +234,7 @@ def test_public_methods_direct():
     assert float((wb.cpu() - warp_ref.homography_warp(th, court, 360, 640, "bilinear")).abs().max()) < 1e-6
 
 
-@pytest.mark.parametrize("precision", ["bf16x6", "fp32"])
+@pytest.mark.parametrize("precision", ["bf16x6", "fp32"])  # training precisions
 def test_c3_training_step_640x360_vs_fp64_reference(precision, monkeypatch):
     """BASELINE config 3 at 640x360 (2 of the 16 frames): the reference classes under train() + autograd
     produced loss values and gradients in fp32 and in fp64 (oracle/make_fixtures.py:make_c3_golden).  The HIP
