@@ -1,4 +1,5 @@
-"""Where does a split-bf16 conv workgroup (conv_s3_kernel, single-buffer variant) spend its wave time?
+"""Where does a split-operand conv workgroup (conv_s3_kernel, single-buffer variant) spend its wave time?
+Format from argv[1]: s3 (three bf16 planes, default) or h2 (two fp16 planes).
 Runs single layers through the DIAGNOSTIC build (in-kernel s_memtime stamps, `python -m sfh_amd.build --diag`):
     SFH_AMD_LIB=sports-field-homography_amd/libsfh_amd_diag.so python profiles/diag_stamps_s3.py
 Shares of wave time per phase are meaningful, not run times (the stamps fence the schedule)."""
@@ -15,6 +16,7 @@ from sfh_amd import _lib, engine as E  # noqa: E402
 lib = _lib.load()
 rd = lib.sfh_debug_read_stamps
 rd.argtypes = [ctypes.POINTER(ctypes.c_ulonglong), ctypes.c_int]
+FMT = sys.argv[1] if len(sys.argv) > 1 else "s3"
 SEG = ["prologue", "dma wait+barrier", "mfma stage", "free barrier+dma issue", "epilogue"]
 
 
@@ -22,10 +24,10 @@ def run(name, cin, cout, h, w, B=16, pool=False, residual=False, reps=3):
     torch.manual_seed(0)
     wt = torch.randn(cout, cin, 3, 3, device="cuda") * 0.05
     bn = torch.nn.BatchNorm2d(cout).cuda().eval()
-    pc = E.PackedConv(wt, torch.zeros(cout, device="cuda"), bn, 3, cin, s3=True)
-    x = E.f32_to_s3(torch.randn(B, h, w, cin, device="cuda"))
-    y = E.s3_empty(B, h, w, cout, "cuda")
-    yp = E.s3_empty(B, h // 2, w // 2, cout, "cuda") if pool else None
+    pc = E.PackedConv(wt, torch.zeros(cout, device="cuda"), bn, 3, cin, fmt=FMT)
+    x = E.f32_to_split(torch.randn(B, h, w, cin, device="cuda"), FMT)
+    y = E.split_empty(FMT, B, h, w, cout, "cuda")
+    yp = E.split_empty(FMT, B, h // 2, w // 2, cout, "cuda") if pool else None
     res = torch.randn(B, h, w, cout, device="cuda") if residual else None
     pc.run(x, B, h, w, y, dst_pool=yp, residual=res)
     torch.cuda.synchronize()

@@ -131,6 +131,12 @@ namespace {
 // Two-plane (H2) instances need 158 registers and 45 KB of LDS per workgroup, so three workgroups per CU would fit;
 // measured (B=16, 640x360, two alternating runs on one device): 10.02-10.07 ms per batch for the DoubleConv
 // launches with three, 9.96 ms with two - the register cap of 168 costs more than the third workgroup hides.
+#ifndef SFH_H2_WD
+#define SFH_H2_WD 2
+#endif
+#ifndef SFH_H2_XD
+#define SFH_H2_XD 2
+#endif
 #ifndef SFH_H2_WAVES_PER_SIMD
 #define SFH_H2_WAVES_PER_SIMD 2
 #endif
@@ -246,25 +252,35 @@ __global__ __launch_bounds__(256, (C::NP == 2 && !DB) ? SFH_H2_WAVES_PER_SIMD : 
 #pragma unroll
     for (int mi = 0; mi < C::MT_M; ++mi) acc[ni][mi] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  u32x4 wa[NP][2], wb[NP][2];  // weight fragments: current tap / next tap
+  // weight fragments: a ring of WD register sets, tap t of a stage lives in set (R0 + t) % WD and the set that
+  // tap t - 1 leaves is refilled with tap t + WD - 1.  Two sets (one tap ahead) are the default for both formats.
+  // Measured for the two-plane format, whose taps are half as long (B=16, 640x360, DoubleConv launches, two
+  // alternating runs on one device): WD 2 / XD 2 10.03-10.15 ms, WD 3 / XD 2 10.64-10.66, WD 3 / XD 3 10.58,
+  // WD 2 / XD 3 10.01-10.07: neither the weight stream from L2 nor the operand reads are what the MFMAs wait for.
+  constexpr int WD = (NP == 2 && C::NTAP % 3 == 0) ? SFH_H2_WD : 2;
+  constexpr int XD = NP == 2 ? SFH_H2_XD : 2;   // operand reads are issued XD steps ahead of their use
+  u32x4 wr[WD][NP][2];
   unsigned wsoff = 0;         // byte offset of the NEXT (stage, tap) fragment set
   const unsigned wlast = wtotal - WTAP;
-  load_w(wa, 0);
-  wsoff = WTAP <= wlast ? WTAP : wlast;
+#pragma unroll
+  for (int i = 0; i < WD - 1; ++i) {
+    load_w(wr[i], wsoff);
+    wsoff = (wsoff + WTAP <= wlast) ? wsoff + WTAP : wlast;
+  }
 
   // One stage = NTAP taps x MT_M pixel groups; per (tap, group): 3 operand reads + 12 MFMAs.
   // The reads of step s+1 are issued behind the first MFMAs of step s (two register sets,
   // static indices), the next tap's weight fragments one tap ahead, the next stage's DMA batch
   // behind the first steps of the stage.  SW selects which weight register set holds tap 0
   // (NTAP is odd, so the sets swap roles every stage).
-  auto stage = [&](int st, int cur, auto sw_tag) {
-    constexpr bool SW = decltype(sw_tag)::value;
+  auto stage = [&](int st, int cur, auto r0_tag) {
+    constexpr int R0 = decltype(r0_tag)::value;   // ring position of tap 0 in this stage
     constexpr int NSTEP = C::NTAP * C::MT_M;
     const u32x4* const halo = lds + cur * C::BUF;
     // operand ring of three register sets: the reads of step s+2 are issued in step s, i.e. two
     // steps (~380 cycles of MFMA) ahead of their use - one step is not enough to cover the LDS
     // latency with four waves reading (measured: 358 cycles per 192-cycle step before)
-    u32x4 xq[3][NP];
+    u32x4 xq[XD + 1][NP];
     auto ld_x = [&](int s, int buf) {
       const int t = s / C::MT_M, mi = s % C::MT_M;
       const int toff = (t / C::KS) * C::HW + (t % C::KS);
@@ -272,16 +288,17 @@ __global__ __launch_bounds__(256, (C::NP == 2 && !DB) ? SFH_H2_WAVES_PER_SIMD : 
 #pragma unroll
       for (int p = 0; p < NP; ++p) xq[buf][p] = halo[pixbase0 + (p * 4 * C::HPIXP + moff + toff)];
     };
-    ld_x(0, 0);
-    if (NSTEP > 1) ld_x(1, 1);
+#pragma unroll
+    for (int i = 0; i < XD; ++i)
+      if (i < NSTEP) ld_x(i, i);
     const int stn = st + 1 < nst ? st + 1 : st;  // unconditional DMA: no branch in the MFMA block
 #pragma unroll
     for (int s = 0; s < NSTEP; ++s) {
       const int t = s / C::MT_M, mi = s % C::MT_M;
-      const int xb = s % 3;
-      u32x4 (&wc)[NP][2] = ((t & 1) != (SW ? 1 : 0)) ? wb : wa;
-      u32x4 (&wnx)[NP][2] = ((t & 1) != (SW ? 1 : 0)) ? wa : wb;
-      if (s + 2 < NSTEP) ld_x(s + 2, (s + 2) % 3);
+      const int xb = s % (XD + 1);
+      u32x4 (&wc)[NP][2] = wr[(R0 + t) % WD];
+      u32x4 (&wnx)[NP][2] = wr[(R0 + t + WD - 1) % WD];
+      if (s + XD < NSTEP) ld_x(s + XD, (s + XD) % (XD + 1));
       if (mi == 0) {
         load_w(wnx, wsoff);  // next tap (or tap 0 of the next stage): one tap of MFMAs ahead
         wsoff = (wsoff + WTAP <= wlast) ? wsoff + WTAP : wlast;
@@ -317,7 +334,8 @@ __global__ __launch_bounds__(256, (C::NP == 2 && !DB) ? SFH_H2_WAVES_PER_SIMD : 
     }
   };
   // odd tap counts (1, 9) swap the roles of the two weight register sets every stage, even ones (16) do not
-  constexpr bool SWAPS = (C::NTAP % 2) == 1;
+  constexpr int SWAPS = C::NTAP % WD;   // ring position of tap 0 in odd stages (2 * NTAP = 0 mod WD)
+  static_assert((2 * C::NTAP) % WD == 0, "the stage loop is unrolled by two");
 
   dma_stage(0, 0);
   auto maybe_switch = [&](int st) {  // the DMA issued during stage st targets stage st+1
@@ -337,11 +355,11 @@ __global__ __launch_bounds__(256, (C::NP == 2 && !DB) ? SFH_H2_WAVES_PER_SIMD : 
     for (int st = 0; st < nst; st += 2) {
       maybe_switch(st);
       stage_barrier();  // stage st landed for every wave; the other buffer is free
-      stage(st, 0, std::false_type{});
+      stage(st, 0, std::integral_constant<int, 0>{});
       if (st + 1 < nst) {
         maybe_switch(st + 1);
         stage_barrier();
-        stage(st + 1, 1, std::integral_constant<bool, SWAPS>{});
+        stage(st + 1, 1, std::integral_constant<int, SWAPS>{});
       }
     }
     // the last stage re-issues its own DMA into the other buffer (branch-free MFMA block): it must
@@ -355,7 +373,7 @@ __global__ __launch_bounds__(256, (C::NP == 2 && !DB) ? SFH_H2_WAVES_PER_SIMD : 
     for (int st = 0; st < nst; st += 2) {
       stage_barrier();
       SFH_STAMP(1);
-      stage(st, 0, std::false_type{});
+      stage(st, 0, std::integral_constant<int, 0>{});
       SFH_STAMP(2);
       if (st + 1 < nst) {
         if (d.src1 && st + 1 == nst0) {
@@ -367,7 +385,7 @@ __global__ __launch_bounds__(256, (C::NP == 2 && !DB) ? SFH_H2_WAVES_PER_SIMD : 
         SFH_STAMP(3);
         stage_barrier();
         SFH_STAMP(1);
-        stage(st + 1, 0, std::integral_constant<bool, SWAPS>{});
+        stage(st + 1, 0, std::integral_constant<int, SWAPS>{});
         SFH_STAMP(2);
       }
       if (st + 2 < nst) {

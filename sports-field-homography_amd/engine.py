@@ -18,8 +18,24 @@ BN_EPS = 1e-5
 _TILES = ((_lib.TILE_8x32, 8, 32), (_lib.TILE_16x16, 16, 16), (_lib.TILE_32x8, 32, 8))
 
 
+_STREAM_CACHE = []   # [c_void_p] while an engine's run() is on the stack (torch.cuda.current_stream() costs ~9 us)
+
+
 def _stream():
+    if _STREAM_CACHE:
+        return _STREAM_CACHE[-1]
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class _stream_scope:
+    """Resolve the current HIP stream once for all launches of one engine run."""
+
+    def __enter__(self):
+        _STREAM_CACHE.append(ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+
+    def __exit__(self, *exc):
+        _STREAM_CACHE.pop()
+        return False
 
 
 def _ptr(t):
@@ -521,6 +537,10 @@ class UNetEngine:
         """x: (B,3,H,W) float32 NCHW on the GPU.  Returns dict with logits (NCHW, fresh),
         and optionally stn_in (NHWC8 workspace), argmax (B,H,W uint8), uv, plus the NHWC
         workspace tensors x_top / y4 for callers that need them."""
+        with _stream_scope():
+            return self._run(x, want_stn_in, want_argmax, want_uv)
+
+    def _run(self, x, want_stn_in, want_argmax, want_uv):
         lib = _lib.load()
         x = _f32c(x, "input frames")
         B, C, H, W = x.shape
@@ -732,6 +752,10 @@ class ResNetEngine:
 
     def run(self, y_nhwc, B, H, W):
         """y_nhwc: (B,H,W,cs_in) float32 with channels >= cin zero.  Returns theta (B,1,3,3)."""
+        with _stream_scope():
+            return self._run(y_nhwc, B, H, W)
+
+    def _run(self, y_nhwc, B, H, W):
         lib = _lib.load()
         ws, L, st = self.ws, self.L, _stream()
         if y_nhwc.shape[3] != self.cs_in:

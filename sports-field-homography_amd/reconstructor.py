@@ -121,18 +121,38 @@ class Reconstructor(nn.Module):
         self._h2_overflow = None   # int32 device word raised by the kernels of the "f16x3" mode
         self._forced_precision = None
         self.range_fallbacks = 0   # batches re-run in "bf16x6" because an activation left the fp16 range
+        # False: predict() / forward() skip the 4-byte read-back (a device synchronisation) after every call; a
+        # caller that pipelines several batches then asks range_overflowed() itself once it has synchronised
+        self.range_guard = True
         self._engine_stamp = None
         self._weights_generation = 0
         self._tmpl_shared = None   # (data_ptr, shape) -> bool cache
 
     # ------------------------------------------------------------------ engine plumbing
     def _param_stamp(self):
+        # walking the module tree costs ~1 ms per call (354 tensors behind ~200 modules), more than enqueueing the
+        # whole UNet: the tensor list is collected once.  load_state_dict(), .to() and optimizers change these
+        # tensors in place (their torch _version moves); code that REPLACES a Parameter object calls
+        # invalidate_engines().
+        lst = self.__dict__.get("_stamp_tensors")
+        if lst is None:
+            lst = self.__dict__["_stamp_tensors"] = list(self.parameters()) + list(self.buffers())
         dev = None
         ver = 0
-        for t in list(self.parameters()) + list(self.buffers()):
+        for t in lst:
             ver += t._version
-            dev = t.device
+        if lst:
+            dev = lst[-1].device
         return (dev, ver, self.training, self.precision, self._weights_generation)
+
+    def _apply(self, fn, *args, **kwargs):
+        # .to() / .cuda() / .float(): buffers are REPLACED by nn.Module._apply - drop the cached tensor list
+        self.__dict__.pop("_stamp_tensors", None)
+        return super()._apply(fn, *args, **kwargs)
+
+    def load_state_dict(self, *args, **kwargs):
+        self.__dict__.pop("_stamp_tensors", None)      # assign=True replaces the tensors
+        return super().load_state_dict(*args, **kwargs)
 
     def invalidate_engines(self):
         """Packed weights and folded BatchNorm constants are cached per engine and rebuilt when a parameter's
@@ -141,6 +161,7 @@ class Reconstructor(nn.Module):
         self._weights_generation += 1
         self._engines = None
         self._engines_by_precision = {}
+        self.__dict__.pop("_stamp_tensors", None)
 
     def _get_engines(self):
         stamp = self._param_stamp()
@@ -171,7 +192,7 @@ class Reconstructor(nn.Module):
         saturated to the fp16 range (|v| >= 16376) and, if it is set, run fn again with the three-plane bf16
         operands, which have fp32's exponent range.  Still the HIP path - there is no CPU fallback."""
         ret = fn(*args)
-        if (self._forced_precision or self.precision) != "f16x3" or self._h2_overflow is None:
+        if (self._forced_precision or self.precision) != "f16x3" or self._h2_overflow is None or not self.range_guard:
             return ret
         if int(self._h2_overflow.item()) == 0:     # one 4-byte read-back per call
             return ret
@@ -187,11 +208,21 @@ class Reconstructor(nn.Module):
         finally:
             self._forced_precision = None
 
+    def range_overflowed(self, reset=True):
+        """True if a kernel of the "f16x3" mode saturated an activation since the last reset (synchronises)."""
+        if self._h2_overflow is None:
+            return False
+        hit = bool(int(self._h2_overflow.item()))
+        if hit and reset:
+            self._h2_overflow.zero_()
+        return hit
+
     def __getstate__(self):
         """The model is pickled into spawned worker processes (predict.py:130,252): ship parameters and
         configuration only - packed weights and workspaces are rebuilt in the worker on first use."""
         st = self.__dict__.copy()
         st["_engines"] = st["_engine_stamp"] = st["_tmpl_shared"] = st["_h2_overflow"] = None
+        st.pop("_stamp_tensors", None)
         st["_engines_by_precision"] = {}
         return st
 
