@@ -4,14 +4,15 @@
 Workload (BASELINE.json configs[1]): ``Reconstructor.predict(x, consistency=False,
 project_poi=False)`` = UNet segmentation + ResNet34-STN + nearest homography warp of the
 court template, on synthetic uint8-derived frames already resident in HBM.  Arithmetic: the
-default "bf16x6" mode (fp32-equivalent split-bf16 contraction, see csrc/conv_s3.hip) or fp32 MFMA
-throughout with SFH_PRECISION=fp32.
+default "f16x3" mode (two fp16 planes per operand, three fp16 MFMAs per product, fp32 accumulation; see
+csrc/conv_s3.hip and DESIGN.md section 2), "bf16x6" (three bf16 planes, six MFMAs) with SFH_PRECISION=bf16x6, or
+fp32 MFMA throughout with SFH_PRECISION=fp32.
 One "step" = one batch of 16 frames per GPU.  With N > 1 (launched by torch.distributed.run,
 one process per GPU) every rank processes its own 16 frames (weak scaling) and the 3x3
 thetas are all-gathered over RCCL each step.
 
 Prints ONE JSON line (rank 0) with the contract fields plus
-  roofline     - live HIP-event timing of the DoubleConv 3x3 MFMA launches vs fp32 matrix peak
+  roofline     - live HIP-event timing of the DoubleConv 3x3 MFMA launches vs the matrix peak of the mode
   cpu_baseline - the CPU oracle (oracle/torch_ref.predict) timed on this box's host cores
                  (rank 0, N == 1 only; reported baseline, not the target).
 """
