@@ -122,6 +122,11 @@ typedef struct sfh_conv_desc {
   /* H2 destinations: device word that is OR-ed with 1 when a value had to be saturated to the fp16 range
    * (optional).  The caller zeroes it and reads it back after the last launch of a forward pass. */
   uint32_t* h2_overflow;
+  /* sfh_conv_s3_fwd, H2 sources: couts per workgroup. 0 = chosen by the launcher, 64 = the 4-wave workgroup
+   * (256 pixels x 64 couts, two per CU), 128 = the 8-wave workgroup (256 pixels x 128 couts, one per CU, two LDS
+   * buffers; needs stride 1, ksize 3 or 2, cout % 128 == 0 - per quadrant for the up-scatter conv -, at least 128
+   * input channels, no fused head). */
+  int32_t wg_couts;
 } sfh_conv_desc;
 
 const char* sfh_last_error(void);

@@ -33,7 +33,7 @@ class ConvDesc(C.Structure):
         ("reverse_tiles", _i),
         ("head_w", _p), ("head_b", _p), ("head_nc", _i), ("head_skip_dst", _i),
         ("head_logits", _p), ("head_stn", _p), ("head_frame", _p),
-        ("h2_overflow", _p),
+        ("h2_overflow", _p), ("wg_couts", _i),
     ]
 
 

@@ -44,9 +44,16 @@ constexpr unsigned kOOB = 0xFFFFFFF0u;
 
 // NP_ = planes per operand: 3 = S3 tensors, bf16, six products per fp32 product ("bf16x6");
 //                           2 = H2 tensors, fp16, three products ("f16x3", include/sfh_amd.h)
-template <int KS_, int STRIDE_, int SH_, int SW_, int TH_, int TW_, int NP_ = 3>
+// NWN_ = waves along the cout axis: 2 = the 4-wave workgroup (256 pixels x 64 couts), 4 = the 8-wave workgroup
+//        (256 pixels x 128 couts: the same halo feeds twice the MFMAs; one workgroup per CU, double-buffered)
+// NWM_ = waves along the pixel axis: 2 = each wave owns half of the tile's pixel groups; 1 = every wave covers all 256
+//        pixels for its own 32 couts (with NWN_ = 4: 4 waves, 256 pixels x 128 couts - no two waves of a workgroup
+//        request the same weight fragments, and the halo feeds twice the MFMAs)
+template <int KS_, int STRIDE_, int SH_, int SW_, int TH_, int TW_, int NP_ = 3, int NWN_ = 2, int NWM_ = 2>
 struct S3Cfg {
-  static constexpr int KS = KS_, STRIDE = STRIDE_, NP = NP_;
+  static constexpr int KS = KS_, STRIDE = STRIDE_, NP = NP_, NWN = NWN_, NWM = NWM_;
+  static constexpr int NT = 64 * NWM * NWN;   // threads
+  static constexpr int NCO = 32 * NWN;        // couts per workgroup
   static constexpr int SH = SH_, SW = SW_, TH = TH_, TW = TW_;
   static constexpr int PAD = KS / 2;          // padding before (3x3: 1, 1x1: 0, 4x4 stem: 2)
   static constexpr int PADA = (KS - 1) / 2;   // padding after  (3x3: 1, 1x1: 0, 4x4 stem: 1)
@@ -57,12 +64,12 @@ struct S3Cfg {
   static constexpr int HPIX = HH * HW;
   static constexpr int HPIXP = (HPIX + 15) / 16 * 16;
   static constexpr int HSLOTS = 4 * NP * HPIXP;  // [NP planes][4 channel groups of 8][pixels] x 16 B
-  static constexpr int NSL = (HSLOTS + 255) / 256;
-  static constexpr int BUF = NSL * 256;      // slots per LDS buffer (DMA rounds are whole)
+  static constexpr int NSL = (HSLOTS + NT - 1) / NT;
+  static constexpr int BUF = NSL * NT;       // slots per LDS buffer (DMA rounds are whole)
   static constexpr int LDS_BYTES = 2 * BUF * 16;
   static constexpr int SUBX = TW / SW;
   static constexpr int NSUBT = (TH / SH) * SUBX;
-  static constexpr int MT_M = NSUBT / 2;     // pixel groups per wave (2 x 2 wave grid)
+  static constexpr int MT_M = NSUBT / NWM;   // pixel groups per wave
   static constexpr bool FLATROWS = (STRIDE == 1);
   static_assert(SH * SW == 16 && (NSUBT == 16 || NSUBT == 8), "tile = 8 or 16 pixel groups of 16");
 };
@@ -137,12 +144,18 @@ namespace {
 #ifndef SFH_H2_XD
 #define SFH_H2_XD 2
 #endif
+#ifndef SFH_W128_NWM
+#define SFH_W128_NWM 1
+#endif
+#ifndef SFH_W8_MIN_BLOCKS
+#define SFH_W8_MIN_BLOCKS 384
+#endif
 #ifndef SFH_H2_WAVES_PER_SIMD
 #define SFH_H2_WAVES_PER_SIMD 2
 #endif
 template <class C, bool DB>
-__global__ __launch_bounds__(256, (C::NP == 2 && !DB) ? SFH_H2_WAVES_PER_SIMD : 2) void conv_s3_kernel(const sfh_conv_desc d,
-                                                                                                   const S3Geom g) {
+__global__ __launch_bounds__(C::NT, (C::NP == 2 && !DB) ? SFH_H2_WAVES_PER_SIMD : 2) void conv_s3_kernel(const sfh_conv_desc d,
+                                                                                                     const S3Geom g) {
   extern __shared__ __attribute__((aligned(16))) float smem_f[];
   u32x4* const lds = reinterpret_cast<u32x4*>(smem_f);
   typedef __attribute__((address_space(3))) void* lds_ptr_t;
@@ -151,7 +164,7 @@ __global__ __launch_bounds__(256, (C::NP == 2 && !DB) ? SFH_H2_WAVES_PER_SIMD : 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wv >> 1, wn = wv & 1;
+  const int wm = wv / C::NWN, wn = wv % C::NWN;
   const int lq = lane & 15, lg = lane >> 4;
 
   const int bid = blockIdx.x;
@@ -182,7 +195,7 @@ __global__ __launch_bounds__(256, (C::NP == 2 && !DB) ? SFH_H2_WAVES_PER_SIMD : 
     const int img = ty / g.tiles_y;
     r0 = (img << 16) | ((ty - img * g.tiles_y) * C::TH);
   }
-  const int n0 = nb * 64;
+  const int n0 = nb * C::NCO;
 
   const int nst0 = d.c0 / C::CKS;
   const int nst1 = d.src1 ? d.c1 / C::CKS : 0;
@@ -197,9 +210,9 @@ __global__ __launch_bounds__(256, (C::NP == 2 && !DB) ? SFH_H2_WAVES_PER_SIMD : 
   constexpr unsigned WTAP = (unsigned)NP * 4u * 1024u;  // bytes per (stage, tap)
   const unsigned wtotal = (unsigned)nst * C::NTAP * WTAP;
   const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<char*>(reinterpret_cast<const char*>(d.wpacked)) + (size_t)nb * wtotal, 0, (int)wtotal,
-      0x00020000);
-  const unsigned wvoff = lane * 16u + (unsigned)(2 * wn) * 1024u;
+      const_cast<char*>(reinterpret_cast<const char*>(d.wpacked)) + (size_t)(nb * (C::NWN / 2) + (wn >> 1)) * wtotal, 0,
+      (int)wtotal, 0x00020000);   // weights are packed per 64 couts: waves (wn >> 1) share a block
+  const unsigned wvoff = lane * 16u + (unsigned)(2 * (wn & 1)) * 1024u;
 
   // byte offsets of this thread's halo slots in the CURRENT source (recomputed once when the
   // stage loop crosses from source 0 to source 1)
@@ -212,7 +225,7 @@ __global__ __launch_bounds__(256, (C::NP == 2 && !DB) ? SFH_H2_WAVES_PER_SIMD : 
   }
   unsigned hoff[C::NSL];
 #pragma unroll
-  for (int i = 0; i < C::NSL; ++i) hoff[i] = s3_halo_voffset<C>(d, g, 0, tid + 256 * i, r0, x0, pad_y, pad_x);
+  for (int i = 0; i < C::NSL; ++i) hoff[i] = s3_halo_voffset<C>(d, g, 0, tid + C::NT * i, r0, x0, pad_y, pad_x);
 
   // LDS-DMA piece i (64 slots of this wave) of stage st into buffer b
   auto dma_piece = [&](int st, int b, int i) {
@@ -221,7 +234,7 @@ __global__ __launch_bounds__(256, (C::NP == 2 && !DB) ? SFH_H2_WAVES_PER_SIMD : 
     // stage = one 32-channel block = 4 * NP (plane, group) runs of W x 16 bytes of the row
     constexpr unsigned SB = 64u * (unsigned)NP;
     const unsigned cb = first ? (unsigned)st * (SB * (unsigned)d.w0) : (unsigned)(st - nst0) * (SB * (unsigned)d.w1);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(first ? rs0 : rs1, (lds_ptr_t)(hb + wv * 64 + 256 * i), 16,
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(first ? rs0 : rs1, (lds_ptr_t)(hb + wv * 64 + C::NT * i), 16,
                                              (int)hoff[i], (int)cb, 0, 0);
   };
   auto dma_stage = [&](int st, int b) {
@@ -304,7 +317,9 @@ __global__ __launch_bounds__(256, (C::NP == 2 && !DB) ? SFH_H2_WAVES_PER_SIMD : 
         wsoff = (wsoff + WTAP <= wlast) ? wsoff + WTAP : wlast;
       }
       // the next stage's LDS-DMA pieces, spread over the first steps
-      constexpr int PPS = (C::NSL + NSTEP - 1) / NSTEP;
+      // (8-wave workgroup: all of them in step 0, right BEHIND the weight request of that step - vector loads
+      //  return in order, so a weight fragment requested behind a DMA piece waits for that piece)
+      constexpr int PPS = C::NT == 512 ? C::NSL : (C::NSL + NSTEP - 1) / NSTEP;
       if (DB) {
 #pragma unroll
         for (int q = 0; q < PPS; ++q)
@@ -341,7 +356,7 @@ __global__ __launch_bounds__(256, (C::NP == 2 && !DB) ? SFH_H2_WAVES_PER_SIMD : 
   auto maybe_switch = [&](int st) {  // the DMA issued during stage st targets stage st+1
     if (d.src1 && st + 1 == nst0) {
 #pragma unroll
-      for (int i = 0; i < C::NSL; ++i) hoff[i] = s3_halo_voffset<C>(d, g, 1, tid + 256 * i, r0, x0, pad_y, pad_x);
+      for (int i = 0; i < C::NSL; ++i) hoff[i] = s3_halo_voffset<C>(d, g, 1, tid + C::NT * i, r0, x0, pad_y, pad_x);
     }
   };
   // hipcc's own wait before the barrier covers only part of the outstanding LDS-DMA (observed:
@@ -378,7 +393,7 @@ __global__ __launch_bounds__(256, (C::NP == 2 && !DB) ? SFH_H2_WAVES_PER_SIMD : 
       if (st + 1 < nst) {
         if (d.src1 && st + 1 == nst0) {
 #pragma unroll
-          for (int i = 0; i < C::NSL; ++i) hoff[i] = s3_halo_voffset<C>(d, g, 1, tid + 256 * i, r0, x0, pad_y, pad_x);
+          for (int i = 0; i < C::NSL; ++i) hoff[i] = s3_halo_voffset<C>(d, g, 1, tid + C::NT * i, r0, x0, pad_y, pad_x);
         }
         __syncthreads();
         dma_stage(st + 1, 0);
@@ -391,7 +406,7 @@ __global__ __launch_bounds__(256, (C::NP == 2 && !DB) ? SFH_H2_WAVES_PER_SIMD : 
       if (st + 2 < nst) {
         if (d.src1 && st + 2 == nst0) {
 #pragma unroll
-          for (int i = 0; i < C::NSL; ++i) hoff[i] = s3_halo_voffset<C>(d, g, 1, tid + 256 * i, r0, x0, pad_y, pad_x);
+          for (int i = 0; i < C::NSL; ++i) hoff[i] = s3_halo_voffset<C>(d, g, 1, tid + C::NT * i, r0, x0, pad_y, pad_x);
         }
         __syncthreads();
         dma_stage(st + 2, 0);
@@ -406,7 +421,7 @@ __global__ __launch_bounds__(256, (C::NP == 2 && !DB) ? SFH_H2_WAVES_PER_SIMD : 
   }
 
   // ---- OutConv fused behind the last conv (unet/unet_parts.py:74-77): acc now holds the activated outputs
-  if constexpr (C::KS == 3 && C::STRIDE == 1) {
+  if constexpr (C::KS == 3 && C::STRIDE == 1 && C::NWN == 2) {
     if (d.head_w) {
       float* const hl = smem_f;  // [2 cout halves][NSUBT groups][16 pixels][8 classes]
       const int nc = d.head_nc;
@@ -705,7 +720,7 @@ int launch_s3(const sfh_conv_desc& d, hipStream_t stream) {
               b0 > b1 ? b0 : b1);
   g.bytes0 = (unsigned)b0;
   g.bytes1 = (unsigned)b1;
-  g.nblk_n = d.cout / 64;
+  g.nblk_n = d.cout / C::NCO;
   {
     // weights of one cout block: (cin/32) stages x taps x 12 KB.  Measured on the UNet (B=16, 640x360,
     // DoubleConv ms per batch vs budget for the group's weights): 0.5 MB 22.41, 2 MB 22.10, 16 MB 21.92,
@@ -730,7 +745,7 @@ int launch_s3(const sfh_conv_desc& d, hipStream_t stream) {
   // (an LDS-free variant for 1x1 / transposed convs that streams both operands straight into
   // registers was measured slower: 3.69 ms vs 2.96 ms per step for the four ConvTranspose launches)
   sfh_allow_big_lds(reinterpret_cast<const void*>(&conv_s3_kernel<C, DB>));
-  hipLaunchKernelGGL((conv_s3_kernel<C, DB>), dim3((unsigned)nblocks), dim3(256),
+  hipLaunchKernelGGL((conv_s3_kernel<C, DB>), dim3((unsigned)nblocks), dim3(C::NT),
                      DB ? C::LDS_BYTES : C::LDS_BYTES / 2, stream, d, g);
   return sfh_check_launch("conv_s3_kernel");
 }
@@ -872,6 +887,33 @@ extern "C" int sfh_conv_s3_fwd(const sfh_conv_desc* dp, void* stream_) {
   SFH_REQUIRE(!d.head_skip_dst || d.head_w, "conv_s3_fwd: head_skip_dst without a head");
   // buffering policy (launch_s3): two single-buffered workgroups per CU, except grids of at most 320
   // workgroups, which take the double-buffered variant
+  // 8-wave workgroups (256 pixels x 128 couts, one per CU, two LDS buffers): long K, at least 128 couts (a 2x2
+  // up-scatter workgroup must stay inside one quadrant), grids of at least SFH_W8_MIN_BLOCKS such workgroups
+  const int nst_all = (d.c0 + (d.src1 ? d.c1 : 0)) / 32;
+  const bool w8_ok = d.stride == 1 && (d.ksize == 3 || d.ksize == 2) && d.cout % 128 == 0 && !d.head_w && nst_all >= 4 &&
+                     (d.ksize != 2 || (d.cout / 4) % 128 == 0) && d.src_fmt == SFH_FMT_H2;
+  SFH_REQUIRE(d.wg_couts == 0 || d.wg_couts == 64 || (d.wg_couts == 128 && w8_ok),
+              "conv_s3_fwd: wg_couts=%d is not available for this launch (see sfh_conv_desc.wg_couts)", d.wg_couts);
+#define SFH_S3CASE_W8(KS, ST, TILE, SH, SW, TH, TW)                                                          \
+  if (w8_ok && d.ksize == KS && d.stride == ST && d.tile == TILE) {                                           \
+    using CFG = S3Cfg<KS, ST, SH, SW, TH, TW, 2, 4, SFH_W128_NWM>;                                            \
+    const int Ho_ = d.H, Wo_ = d.W;                                                                           \
+    int zr_ = CFG::PAD;                                                                                       \
+    if ((Ho_ + zr_) & 1) ++zr_;                                                                               \
+    if (zr_ == 0) zr_ = (Ho_ & 1) ? 1 : 0;                                                                    \
+    const long tiles_ = (long)sfh_cdiv(Wo_, TW) * sfh_cdiv(d.batch * (Ho_ + zr_), TH);                        \
+    if (d.wg_couts == 128 || (d.wg_couts == 0 && tiles_ * (d.cout / 128) >= SFH_W8_MIN_BLOCKS))              \
+      return launch_s3<CFG, (SFH_W128_NWM == 2)>(d, stream);                                                  \
+  }
+  SFH_S3CASE_W8(3, 1, SFH_TILE_8x32, 1, 16, 8, 32)
+  SFH_S3CASE_W8(3, 1, SFH_TILE_16x16, 1, 16, 16, 16)
+  SFH_S3CASE_W8(3, 1, SFH_TILE_32x8, 2, 8, 32, 8)
+  SFH_S3CASE_W8(2, 1, SFH_TILE_8x32, 1, 16, 8, 32)
+  SFH_S3CASE_W8(2, 1, SFH_TILE_16x16, 1, 16, 16, 16)
+  if (SFH_W128_NWM == 2) {  // (the 4-wave 128-cout instance of this shape spills registers)
+    SFH_S3CASE_W8(2, 1, SFH_TILE_32x8, 2, 8, 32, 8)
+  }
+#undef SFH_S3CASE_W8
 #define SFH_S3CASE(KS, ST, TILE, SH, SW, TH, TW)                      \
   if (d.ksize == KS && d.stride == ST && d.tile == TILE) {             \
     if (d.src_fmt == SFH_FMT_H2) {                                     \

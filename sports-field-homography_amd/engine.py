@@ -358,7 +358,7 @@ class PackedConv:
         return self
 
     def run(self, src0, batch, H, W, dst, src1=None, pool0=False, pad1=(0, 0), residual=None, tile=None,
-            dst_pool=None, up_dst=None, head=None):
+            dst_pool=None, up_dst=None, head=None, wg_couts=0):
         """src0/src1: NHWC float32 tensors, or split tensors of the layer's format (S3 bfloat16 / H2 float16);
         dst/residual/dst_pool: float32 NHWC or the same split format (by dtype).  H, W: conv input frame."""
         lib = _lib.load()
@@ -412,6 +412,7 @@ class PackedConv:
             d.head_frame = head["frame"].data_ptr() if head.get("frame") is not None else None
             d.head_skip_dst = 1 if head.get("skip_dst") else 0
         d.reverse_tiles = 1 if (self.s3 and self.order is not None and self.order.next()) else 0
+        d.wg_couts = wg_couts   # 0: the launcher decides (sfh_conv_desc.wg_couts)
         d.residual = residual.data_ptr() if residual is not None else None
         d.residual_f32 = 1 if (residual is not None and residual.dtype == torch.float32
                                and dst.dtype in _SPLIT_DTYPES) else 0

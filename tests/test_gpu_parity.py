@@ -122,6 +122,57 @@ def test_s3_split_is_exact(E):
     assert torch.equal(rec, x)
 
 
+@pytest.mark.parametrize("tile", [0, 1, 2])
+@pytest.mark.parametrize("hw", [(17, 23), (45, 80), (22, 40)])
+def test_conv_h2_eight_wave_workgroup_matches_four_wave(E, tile, hw):
+    """The 8-wave workgroup (256 pixels x 128 couts, double-buffered; sfh_conv_desc.wg_couts = 128) against the
+    4-wave one on the same operands: same products, same accumulation order per output => identical bits; and
+    against an fp64 conv.  3x3 with pool output, residual, two sources with a pad offset; long K."""
+    H, W = hw
+    g = synth._rng(5, f"w8{H}x{W}")
+    B, c0, c1, cout = 2, 128, 64, 256
+    x0 = torch.from_numpy(g.normal(0, 1, (B, H, W, c0)).astype(np.float32)).cuda()
+    x1 = torch.from_numpy(g.normal(0, 1, (B, H - 1, W - 1, c1)).astype(np.float32)).cuda()
+    w = torch.from_numpy((g.normal(0, 1, (cout, c0 + c1, 3, 3)) * 0.03).astype(np.float32)).cuda()
+    b = torch.from_numpy(g.normal(0, 0.1, (cout,)).astype(np.float32)).cuda()
+    res = torch.from_numpy(g.normal(0, 1, (B, H, W, cout)).astype(np.float32)).cuda()
+    pc = E.PackedConv(w, b, None, 3, c0, c1, fmt="h2")
+    xs0, xs1 = E.f32_to_split(x0, "h2"), E.f32_to_split(x1, "h2")
+    outs = {}
+    for wg in (64, 128):
+        y = E.split_empty("h2", B, H, W, cout, "cuda")
+        yp = E.split_empty("h2", B, H // 2, W // 2, cout, "cuda")
+        pc.run(xs0, B, H, W, y, src1=xs1, pad1=(1, 0), dst_pool=yp, residual=E.f32_to_split(res, "h2"), tile=tile, wg_couts=wg)
+        torch.cuda.synchronize()
+        outs[wg] = (E.s3_to_f32(y), E.s3_to_f32(yp))
+    assert torch.equal(outs[64][0], outs[128][0]) and torch.equal(outs[64][1], outs[128][1])
+    xin = torch.zeros(B, c0 + c1, H, W, dtype=torch.float64)
+    xin[:, :c0] = x0.cpu().double().permute(0, 3, 1, 2)
+    xin[:, c0:, 1:, :W - 1] = x1.cpu().double().permute(0, 3, 1, 2)
+    want = torch.nn.functional.conv2d(xin, w.cpu().double(), b.cpu().double(), padding=1)
+    # the residual went through the H2 format (22 bits) before it was added
+    want = torch.relu(want + E.s3_to_f32(E.f32_to_split(res, "h2")).cpu().double().permute(0, 3, 1, 2))
+    assert _maxerr(_nchw(outs[128][0]).double(), want) < 3e-5
+    # fp32 destination, no residual, single source (the partial of a fused Up block)
+    pc2 = E.PackedConv(w[:, :c0].contiguous(), None, None, 3, c0, relu=False, fmt="h2")
+    f = {}
+    for wg in (64, 128):
+        yf = torch.empty((B, H, W, cout), device="cuda")
+        pc2.run(xs0, B, H, W, yf, tile=tile, wg_couts=wg)
+        torch.cuda.synchronize()
+        f[wg] = yf
+    assert torch.equal(f[64], f[128])
+
+
+def test_conv_h2_wg_couts_argument_is_checked(E):
+    w = torch.zeros(64, 128, 3, 3, device="cuda")
+    pc = E.PackedConv(w, None, None, 3, 128, fmt="h2")
+    x = E.split_empty("h2", 1, 16, 16, 128, "cuda")
+    y = E.split_empty("h2", 1, 16, 16, 64, "cuda")
+    with pytest.raises(ValueError, match="wg_couts"):
+        pc.run(x, 1, 16, 16, y, wg_couts=128)      # 64 couts: no 128-cout workgroup
+
+
 def test_h2_split_format(E):
     """H2 (two fp16 planes of v * 2^2): 22 significand bits over the whole normal range, absolute error <= 2^-27
     below it, saturation + the overflow word beyond +-16376; the layout is the S3 layout with two planes."""
