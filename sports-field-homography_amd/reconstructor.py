@@ -187,11 +187,12 @@ class Reconstructor(nn.Module):
         self._engines = eng
         return eng
 
-    def _range_guarded(self, fn, *args):
-        """Run fn; in "f16x3" mode read back the device word the kernels raise when an activation had to be
-        saturated to the fp16 range (|v| >= 16376) and, if it is set, run fn again with the three-plane bf16
-        operands, which have fp32's exponent range.  Still the HIP path - there is no CPU fallback."""
-        ret = fn(*args)
+    def _range_guarded(self, fn, x, off, *args):
+        """Run fn(x, off, *args); in "f16x3" mode read back the device word the kernels raise when an activation had
+        to be saturated to the fp16 range (|v| >= 16376) and, if it is set, run fn again with the three-plane bf16
+        operands, which have fp32's exponent range (in as many sub-batches as their 6 bytes per element need).
+        Still the HIP path - there is no CPU fallback."""
+        ret = fn(x, off, *args)
         if (self._forced_precision or self.precision) != "f16x3" or self._h2_overflow is None or not self.range_guard:
             return ret
         if int(self._h2_overflow.item()) == 0:     # one 4-byte read-back per call
@@ -204,7 +205,7 @@ class Reconstructor(nn.Module):
                           "with precision 'bf16x6' (set net.precision = 'bf16x6' to avoid the double work)")
         self._forced_precision = "bf16x6"
         try:
-            return fn(*args)
+            return self._chunked(fn, x, *args, base=off)
         finally:
             self._forced_precision = None
 
@@ -288,10 +289,14 @@ class Reconstructor(nn.Module):
         """Reference: models/reconstructor.py:132-158.  Returns (logits, x_top, uv) in NCHW."""
         self._require_eval("forward_unet")
 
-        def run(x):
+        def run(x, off):
             r = self._run_unet(x, want_uv=self.unet_uv)
-            return r["logits"], E.nhwc_to_nchw(r["x_top"]), r.get("uv")
-        return self._range_guarded(run, x)
+            o = {"logits": r["logits"], "x_top": E.nhwc_to_nchw(r["x_top"])}
+            if r.get("uv") is not None:
+                o["uv"] = r["uv"]
+            return o
+        o = self._chunked(lambda xi, off: self._range_guarded(run, xi, off), x)
+        return o["logits"], o["x_top"], o.get("uv")
 
     def _stn(self, x, r):
         """theta = resnet_reg(cat(...)) for the configured input mode (reference: :174-185)."""
@@ -312,21 +317,23 @@ class Reconstructor(nn.Module):
         with torch.cuda.device(x.device):
             return rn.run(y, B, H, W)
 
-    # The conv kernels address every activation tensor through 32-bit buffer descriptors
-    # (< 4 GiB).  Larger batches (e.g. 16 frames at 1280x720: the 64-channel full-resolution tensor
-    # is 5.7 GB in S3 format) are processed in sub-batches and concatenated.
+    # The conv kernels address every activation tensor through 32-bit buffer descriptors (< 4 GiB).  Larger batches
+    # are processed in equal sub-batches and concatenated: the 64-channel full-resolution tensor of 16 frames at
+    # 1280x720 is 3.8 GB with 4 bytes per element (f16x3, fp32: one launch) and 5.7 GB in the three-plane bf16 format
+    # (8 + 8 frames).
     def _max_frames(self, x):
-        per_frame = x.shape[2] * x.shape[3] * 64 * (4 if self.precision == "fp32" else 6)   # 6: S3, also the fallback of f16x3
-        return max(1, 0xFFFFFFF0 // per_frame - 0)
+        prec = self._forced_precision or self.precision
+        per_frame = x.shape[2] * x.shape[3] * 64 * (6 if prec == "bf16x6" else 4)
+        return max(1, 0xFFFFFFF0 // per_frame)
 
-    def _chunked(self, fn, x, *args):
+    def _chunked(self, fn, x, *args, base=0):
         mf = self._max_frames(x)
         B = x.shape[0]
         if B <= mf:
-            return fn(x, 0, *args)
+            return fn(x, base, *args)
         n = -(-B // mf)                 # fewest sub-batches that fit the descriptor range ...
-        size = -(-B // n)               # ... of equal size (16 frames at 1280x720: 8 + 8, not 12 + 4)
-        outs = [fn(x[i:i + size], i, *args) for i in range(0, B, size)]
+        size = -(-B // n)               # ... of equal size (8 + 8, not 12 + 4)
+        outs = [fn(x[i:i + size], base + i, *args) for i in range(0, B, size)]
         return {k: torch.cat([o[k] for o in outs], 0) for k in outs[0]}
 
     def forward(self, x):
