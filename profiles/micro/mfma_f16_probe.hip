@@ -100,6 +100,26 @@ int main() {
   hipEvent_t e0, e1;
   hipEventCreate(&e0);
   hipEventCreate(&e1);
+  // occupancy: how much of the matrix pipe does ONE wave per SIMD fill in this step shape (2 reads + 6 MFMAs)?
+  {
+    for (int i = 0; i < 256; ++i) { unsigned r = (unsigned)rand(); hs[i] = (0x3800u | (r & 0x3FF)) | ((0x3800u | ((r >> 10) & 0x3FF)) << 16); }
+    hipMemcpy(seed, hs, 1024, hipMemcpyHostToDevice);
+    for (int wg = 1; wg <= 3; ++wg) {
+      const int iters = 2000, grid = 256 * wg;   // one round: wg workgroups of 4 waves per CU
+      float best = 1e9f;
+      for (int rep = 0; rep < 4; ++rep) {
+        hipEventRecord(e0);
+        hipLaunchKernelGGL((rate<1, 2>), dim3(grid), dim3(256), wg == 3 ? 50000 : 65536, 0, out, iters, seed);
+        hipEventRecord(e1);
+        hipEventSynchronize(e1);
+        float ms;
+        hipEventElapsedTime(&ms, e0, e1);
+        if (rep && ms < best) best = ms;
+      }
+      const double fl = (double)grid * 4 * iters * 72 * 3 * 2 * 2.0 * 16 * 16 * 32;
+      printf("f16 x3, %d workgroup(s) per CU (%d wave(s) per SIMD): %.3f ms  %.1f TFLOP/s of MFMA work\n", wg, wg, best, fl / best * 1e-9);
+    }
+  }
   for (int dat = 0; dat < 2; ++dat) {
     for (int i = 0; i < 256; ++i) {
       // two 16-bit values per word: dat 0 = small-exponent random mantissas, dat 1 = zeros
