@@ -38,10 +38,14 @@ __device__ __forceinline__ void sfh_split4(const f32x4& v, sfh_u32x2 (&out)[3]) 
 // two-plane fp16 split ("H2", include/sfh_amd.h) of 4 fp32 values: u = clamp(v * 2^SFH_H2_ACT_EXP) so that the
 // low plane of ordinary activations stays a NORMAL fp16 number (22 significand bits kept), plane0 = f16(u),
 // plane1 = f16(u - plane0), both round-to-nearest-even (v_cvt_pk_f16_f32).  Values beyond the fp16 range
-// saturate; `over` collects max |u| so that the caller can report it.
+// saturate (a NaN becomes -65504); `over` collects max |u| - or a NaN - so that the caller can report it with
+// sfh_h2_out_of_range(over): the host then repeats the work in a format with fp32's range, where NaN / Inf propagate.
 typedef _Float16 sfh_f16x2 __attribute__((ext_vector_type(2)));
 constexpr float kSfhH2Scale = (float)(1 << SFH_H2_ACT_EXP), kSfhH2InvScale = 1.f / (float)(1 << SFH_H2_ACT_EXP);
 constexpr float kSfhH2Max = 65504.f;
+// `over` is the running UNSIGNED-INTEGER maximum of the bit patterns of |u|: ordered like the floats, with Inf and every
+// NaN above all finite values, so a NaN sticks (fmaxf would drop it)
+__device__ __forceinline__ bool sfh_h2_out_of_range(unsigned over) { return over > 0x477FE000u; }   // bits of 65504.f
 
 __device__ __forceinline__ unsigned sfh_cvt_pk_h(float a, float b) {  // v_cvt_pk_f16_f32 (RNE)
   return __builtin_bit_cast(unsigned, __builtin_convertvector((sfh_f32x2){a, b}, sfh_f16x2));
@@ -50,12 +54,13 @@ __device__ __forceinline__ sfh_f32x2 sfh_unpack_h(unsigned w) {
   return __builtin_convertvector(__builtin_bit_cast(sfh_f16x2, w), sfh_f32x2);
 }
 
-__device__ __forceinline__ void sfh_split4_h2(const f32x4& v, sfh_u32x2 (&out)[2], float& over) {
+__device__ __forceinline__ void sfh_split4_h2(const f32x4& v, sfh_u32x2 (&out)[2], unsigned& over) {
   f32x4 u;
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const float t = v[j] * kSfhH2Scale;
-    over = fmaxf(over, fabsf(t));
+    const unsigned ab = __builtin_bit_cast(unsigned, t) & 0x7FFFFFFFu;
+    over = ab > over ? ab : over;
     u[j] = fminf(fmaxf(t, -kSfhH2Max), kSfhH2Max);
   }
   const unsigned w0 = sfh_cvt_pk_h(u[0], u[1]), w1 = sfh_cvt_pk_h(u[2], u[3]);
@@ -80,7 +85,7 @@ __device__ __forceinline__ void sfh_conv_epilogue(const sfh_conv_desc& d, const 
   const bool h2 = (FMTS & 2) && d.dst_fmt == SFH_FMT_H2;
   const bool s3 = h2 || ((FMTS & 1) && d.dst_fmt == SFH_FMT_S3);  // a split (plane) format
   const unsigned np4 = h2 ? 8u : 12u;                              // (plane, group) runs per 32-channel block
-  float over = 0.f;
+  unsigned over = 0u;
   // S3 layout (B, H, cs/32, 3 planes, 4 groups of 8 ch, W, 8) bf16: for one image row every
   // (channel block, plane, group) is a contiguous run of W x 16 bytes, so that 16 consecutive pixels
   // of a lane group are 256 contiguous bytes (lane groups lg and lg^1 hold the two 8-byte halves of
@@ -290,7 +295,7 @@ __device__ __forceinline__ void sfh_conv_epilogue(const sfh_conv_desc& d, const 
         if (h2) {
           if constexpr ((FMTS & 2) != 0) {
             sfh_u32x2 pl[2];
-            float dummy = 0.f;   // the pooled values are a subset of the values checked above
+            unsigned dummy = 0u;   // the pooled values are a subset of the values checked above
             sfh_split4_h2(m, pl, dummy);
 #pragma unroll
             for (int p = 0; p < 2; ++p)
@@ -311,6 +316,6 @@ __device__ __forceinline__ void sfh_conv_epilogue(const sfh_conv_desc& d, const 
   // H2 destination: a value beyond the fp16 range was saturated - leave a mark for the host (the engine
   // re-runs such a batch with the three-plane bf16 format, which has fp32's exponent range)
   if constexpr ((FMTS & 2) != 0) {
-    if (h2 && d.h2_overflow && over > kSfhH2Max) atomicOr(d.h2_overflow, 1u);
+    if (h2 && d.h2_overflow && sfh_h2_out_of_range(over)) atomicOr(d.h2_overflow, 1u);
   }
 }

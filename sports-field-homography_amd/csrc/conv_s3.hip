@@ -665,14 +665,14 @@ __global__ __launch_bounds__(256) void f32_to_h2_kernel(const float* __restrict_
   const float* sp = src + (row * W + x) * cs + cb * 32 + g * 8;
   const f32x4 a = *reinterpret_cast<const f32x4*>(sp), b = *reinterpret_cast<const f32x4*>(sp + 4);
   sfh_u32x2 pa[2], pb[2];
-  float over = 0.f;
+  unsigned over = 0u;
   sfh_split4_h2(a, pa, over);
   sfh_split4_h2(b, pb, over);
   const long e = ((((row * (cs >> 5) + cb) * 2) * 4 + g) * W + x) * 8;
   const long ps = 4L * W * 8;  // plane stride in elements
   *reinterpret_cast<u32x4*>(dst + e) = (u32x4){pa[0][0], pa[0][1], pb[0][0], pb[0][1]};
   *reinterpret_cast<u32x4*>(dst + e + ps) = (u32x4){pa[1][0], pa[1][1], pb[1][0], pb[1][1]};
-  if (overflow && over > kSfhH2Max) atomicOr(overflow, 1u);
+  if (overflow && sfh_h2_out_of_range(over)) atomicOr(overflow, 1u);
 }
 
 __global__ void h2_to_f32_kernel(const unsigned short* __restrict__ src, float* __restrict__ dst, int W, int cs,

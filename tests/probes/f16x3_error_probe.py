@@ -85,9 +85,9 @@ def conv_transpose2d(x, w, b=None, **kw):
     return _emul(_real_convT, x, w, b, kw)
 
 
-def main():
+def run(W, H, modes, verbose=True):
+    """-> {mode: (max |dlogits|, mean |dlogits|, max |dtheta|, argmax flips)} against the fp64 run"""
     global MODE
-    W, H = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (320, 180)
     B = 1
     torch.manual_seed(0)
     from sfh_amd.reconstructor import Reconstructor
@@ -100,13 +100,14 @@ def main():
     F.conv_transpose2d = conv_transpose2d
     res = {}
     try:
-        for m in os.environ.get("MODES", "fp64,fp32,bf16x6,f16x3,f16x3u").split(","):
+        for m in ["fp64"] + [m for m in modes if m != "fp64"]:
             MODE = m
             with torch.no_grad():
                 out = torch_ref.predict(x, sd, court, poi, warp_size=(W, H), unet_size=(W, H), target_size=(W, H),
                                         project_poi=True)
             res[m] = {k: out[k].double() for k in ("logits", "theta")}
-            print(m, "done", flush=True)
+            if verbose:
+                print(m, "done", flush=True)
     finally:
         F.conv2d = _real_conv2d
         F.conv_transpose2d = _real_convT
@@ -114,13 +115,19 @@ def main():
     lg = ref["logits"]
     top2 = lg.topk(2, dim=1).values
     margin = (top2[:, 0] - top2[:, 1])
-    print(f"size {W}x{H}, B={B}; errors against the fp64 run")
+    out = {}
+    if verbose:
+        print(f"size {W}x{H}, B={B}; errors against the fp64 run")
     for m in [k for k in res if k != "fp64"]:
         dl = (res[m]["logits"] - lg).abs()
         dt = (res[m]["theta"] - ref["theta"]).abs().max().item()
         flips = (res[m]["logits"].argmax(1) != lg.argmax(1)).sum().item()
-        print(f"  {m:8s} logits max {dl.max().item():.3e} mean {dl.mean().item():.3e}  theta max {dt:.3e}  argmax flips {flips} of {margin.numel()}")
+        out[m] = (dl.max().item(), dl.mean().item(), dt, flips)
+        if verbose:
+            print(f"  {m:8s} logits max {dl.max().item():.3e} mean {dl.mean().item():.3e}  theta max {dt:.3e}  argmax flips {flips} of {margin.numel()}")
+    return out
 
 
 if __name__ == "__main__":
-    main()
+    W_, H_ = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (320, 180)
+    run(W_, H_, os.environ.get("MODES", "fp64,fp32,bf16x6,f16x3,f16x3u").split(","))

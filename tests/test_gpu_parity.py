@@ -200,6 +200,14 @@ def test_h2_split_format(E):
     sb = E.f32_to_h2(big, ovf)
     assert int(ovf.item()) == 1
     assert abs(E.s3_to_f32(sb)[0, 0, 0, 0].item() - 65504.0 / 4) < 1e-3
+    # NaN / Inf cannot be carried by the format: they raise the same word (the caller repeats the work in a format
+    # with fp32's range), they are not silently clamped
+    for bad in (float("nan"), float("inf"), -float("inf")):
+        ovf.zero_()
+        big = x.clone()
+        big[1, 2, 3, 4] = bad
+        E.f32_to_h2(big, ovf)
+        assert int(ovf.item()) == 1, bad
 
 
 def test_down_pool_on_load_golden(E, golden_blocks):
