@@ -69,7 +69,9 @@ extern __device__ unsigned long long g_stamps[16];
   asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tprev_)::"memory")
 #define SFH_STAMP_FLUSH_AT(BASE)                                                             \
   do {                                                                                       \
-    if ((threadIdx.x & 63) == 0)                                                             \
+    /* one workgroup in 32 reports: 8 same-address atomics per wave of EVERY workgroup serialise and */ \
+    /* dominated the run time of short kernels (14,480 workgroups: 5.6 ms instead of 0.76 ms)        */ \
+    if ((threadIdx.x & 63) == 0 && (blockIdx.x & 31) == 0)                                   \
       for (int i_ = 0; i_ < 8; ++i_) atomicAdd(&g_stamps[(BASE) + i_], seg_[i_]);            \
   } while (0)
 #define SFH_STAMP_FLUSH() SFH_STAMP_FLUSH_AT(0)
