@@ -15,9 +15,12 @@ SOURCES = ["capi.hip", "conv_mfma.hip", "conv_s3.hip", "pointwise.hip", "warp.hi
 # sampling against oracle/warp_ref.py); the flag is harmless elsewhere.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-ffp-contract=off",
          "-Wall", "-Wno-unused-function"]
-# warp.hip is VALU-issue-bound and the SLP vectoriser packs its scalar fp32 arithmetic into v_pk_*_f32
-# instructions, which issue at half rate on gfx950 (measured: profiles/micro/warp_variants.hip)
-EXTRA_FLAGS = {"warp.hip": ["-fno-slp-vectorize"]}
+# The SLP vectoriser packs scalar fp32 arithmetic into v_pk_*_f32 instructions, which issue at half rate on gfx950:
+# warp.hip is VALU-issue-bound (measured: profiles/micro/warp_variants.hip), and the conv epilogues (scale, shift,
+# ReLU, plane split) run beside the co-resident workgroup's MFMAs, which already take half of the SIMD's issue slots
+# (conv_s3.hip with / without the flag: 9.84-9.92 / 9.47-9.61 ms per batch for the DoubleConv launches).
+_NO_SLP = ["-fno-slp-vectorize"]
+EXTRA_FLAGS = {"warp.hip": _NO_SLP, "conv_s3.hip": _NO_SLP, "conv_mfma.hip": _NO_SLP, "stem.hip": _NO_SLP}
 
 
 def _stale(target, deps):
@@ -59,7 +62,7 @@ def build_diag(verbose=True):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     out = os.path.join(_HERE, "libsfh_amd_diag.so")
     # -fgpu-rdc: the stamp accumulator (conv_mfma.hip) is referenced from other translation units
-    cmd = [hipcc] + FLAGS + ["-DSFH_DIAG_STAMPS", "-fgpu-rdc", "-shared", "-o", out] + [os.path.join(CSRC, s) for s in SOURCES]
+    cmd = [hipcc] + FLAGS + _NO_SLP + ["-DSFH_DIAG_STAMPS", "-fgpu-rdc", "-shared", "-o", out] + [os.path.join(CSRC, s) for s in SOURCES]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
