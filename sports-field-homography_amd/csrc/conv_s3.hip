@@ -1,31 +1,35 @@
-// conv_s3.hip - fp32-accurate convolution on the bf16 matrix cores ("split-3", S3).
+// conv_s3.hip - fp32-grade convolution on the 16-bit matrix cores with split operands.
 //
-// Every fp32 value v is stored as three bf16 planes v = v0 + v1 + v2 (v0 = bf16(v),
-// v1 = bf16(v - v0), v2 = bf16(v - v0 - v1): exact, 3 x 8 significand bits).  A product of two
-// such numbers is accumulated from the six partial products whose weight is >= 2^-16 of the
-// full product,
-//        w*x  ~=  w0x2 + w1x1 + w2x0 + w0x1 + w1x0 + w0x0            (dropped terms <= 2^-24),
-// each an exact bf16 x bf16 product accumulated in fp32 by v_mfma_f32_16x16x32_bf16.  The result
-// has the accuracy of an fp32 fmaf chain (oracle study in DESIGN.md: mean |err| 4.7e-7 vs 5.3e-7
-// for the fp32 MFMA chain at K = 4608) at 6 bf16 MFMAs per 32 k instead of 8 fp32 MFMAs of twice
-// the cycles: the ceiling is 2.5 PFLOP/s / 6 = 417 TFLOP/s of fp32-equivalent work, 2.65x the
-// fp32 matrix peak.
+// Two operand formats, one kernel source (S3Cfg::NP = planes per operand):
+//   * H2 ("f16x3", the default of the engines): every value is two fp16 planes of u = v * 2^e,
+//     p0 = f16(u), p1 = f16(u - p0) - 22 significand bits; e = 2 for activations, per layer for weights
+//     (max |w| 2^e in [2^13, 2^14), folded into the epilogue scale).  A product is accumulated from
+//            w*x  ~=  w0x1 + w1x0 + w0x0                                  (dropped term <= 2^-22)
+//     by v_mfma_f32_16x16x32_f16 in fp32: 3 MFMAs per 32 k, ceiling 2.5 PFLOP/s / 3 = 833 TFLOP/s of fp32-grade
+//     work.  The operand representation perturbs a whole forward pass less than the accumulation order of an
+//     fp32 run does (tests/test_oracle.py::test_f16x3_operand_representation_...); values beyond fp16's range
+//     raise sfh_conv_desc.h2_overflow and the host repeats the batch in the other format.
+//   * S3 ("bf16x6"): three bf16 planes v = v0 + v1 + v2 (v0 = bf16(v), v1 = bf16(v - v0), v2 = bf16(v - v0 - v1):
+//     exact, 3 x 8 significand bits, fp32's exponent range), six partial products
+//            w*x  ~=  w0x2 + w1x1 + w2x0 + w0x1 + w1x0 + w0x0            (dropped terms <= 2^-24)
+//     by v_mfma_f32_16x16x32_bf16: ceiling 2.5 PFLOP/s / 6 = 417 TFLOP/s, 2.65x the fp32 matrix peak.
 //
-// Data movement is designed around 6 bytes per element:
-//   * activations live in HBM as S3 tensors (B, H, C/32, 3 planes, 4 groups of 8 ch, W, 8) bf16:
+// Data movement (2 * NP bytes per element):
+//   * activations live in HBM as (B, H, C/32, NP planes, 4 groups of 8 ch, W, 8) 16-bit tensors:
 //     every (plane, group) of an image row is a contiguous run along x, so an LDS-DMA piece (64
 //     consecutive halo pixels of one plane/group) and a lane group's epilogue stores are long
 //     contiguous runs (measured: pixel-strided 16-byte pieces cost 17 % of the MFMA rate, contiguous
 //     ones nothing); the producer's epilogue splits;
 //   * the input halo of a 32-channel stage goes global -> LDS by buffer_load ... lds (LDS-DMA,
 //     no VGPRs, out-of-frame slots read zeros through the descriptor's range check);
-//   * weights never touch LDS: the four waves of a workgroup form a 2(M) x 2(N) grid, each wave
-//     loads its own pre-packed, pre-split 1 KB fragments (16 couts x 32 k x bf16) straight from
-//     L2 into registers one tap ahead.
-// Workgroup tile: 256 pixels x 64 couts, 4 waves.  Default: ONE LDS buffer and TWO workgroups per CU, so
-// that staging / prologue / epilogue of one workgroup hide under the other's MFMAs; grids of at most 320
-// workgroups (one per CU at best) take the double-buffered variant (DB): two LDS buffers, one barrier per
-// stage, the DMA of stage s+1 issued inside the MFMA stream of stage s.
+//   * weights never touch LDS: each wave loads its own pre-packed, pre-split 1 KB fragments
+//     (16 couts x 32 k x 16 bit) straight from L2 into registers one tap ahead.
+// Workgroup shapes (S3Cfg::NWM x NWN waves): 2 x 2 = 256 pixels x 64 couts (default); 1 x 4 = 256 pixels x 128
+// couts, every wave covering all pixels for its own 32 couts (H2, long K, >= 128 couts: no two waves request the
+// same weights and one halo feeds twice the MFMAs).  ONE LDS buffer and TWO workgroups per CU, so that staging /
+// prologue / epilogue of one workgroup run beside the other's MFMAs; grids of at most 320 workgroups (one per CU
+// at best) take the double-buffered variant (DB): two LDS buffers, one barrier per stage, the DMA of stage s+1
+// issued inside the MFMA stream of stage s.
 #include <stdlib.h>
 
 #include <type_traits>
