@@ -142,7 +142,12 @@ def train_bench(args):
         "metric": "training steps: frames/sec at %dx%d batch=%d (forward + losses + backward + clip + RMSprop)" % (W, H, B),
         "value": round(B * args.steps / el, 2), "unit": "frames/s", "n_gpus": 1, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(el / args.steps * 1e3, 2), "higher_is_better": True,
-        "dtype": "bf16x6->f32 convs, forward, backward-data and 3x3 backward-filter on the bf16 matrix cores (fp32-equivalent)", "data": "synthetic", "final_loss": float(loss.detach()),
+        "dtype": {"f16x3": "f16x3->f32 convs: forward, backward-data and 3x3 backward-filter on the fp16 matrix cores (two-plane "
+                           "fp16 operands, three products, fp32 accumulation; gradients carried at a power-of-two scale)",
+                  "bf16x6": "bf16x6->f32 convs, forward, backward-data and 3x3 backward-filter on the bf16 matrix cores (fp32-equivalent)",
+                  "fp32": "f32 (fp32 MFMA)"}[os.environ.get("SFH_TRAIN_PRECISION", "f16x3")],
+        "range_fallbacks": int(getattr(ts, "range_fallbacks", 0)) if ts is not None else None,
+        "data": "synthetic", "final_loss": float(loss.detach()),
         "losses_and_optimizer": "torch ops (caller side)" if args.train_autograd else "HIP kernels (training.TrainStep)",
         "peak_mem_gib": round(torch.cuda.max_memory_allocated() / 2**30, 2),
         "config": {"workload": "BASELINE config 3: Reconstructor training step, CE + SmoothL1 + RRMSE + consistency CE"}})

@@ -301,10 +301,11 @@ int sfh_bn_stats(const float* z, int64_t npix, int C, double* acc, void* stream)
 int sfh_bn_finalize(const double* acc, int64_t npix, int C, float eps, float momentum, float* running_mean,
                     float* running_var, float* mean_invstd, void* stream);
 /* y = [relu]((z - mean) * invstd * gamma + beta [+ residual]); y_s3 (optional, C % 32 == 0, W = row
- * length of the (rows, W, C) tensor): the same values again in the S3 layout for the next convolution. */
+ * length of the (rows, W, C) tensor): the same values again in the split layout split_fmt (SFH_FMT_S3 or
+ * SFH_FMT_H2; H2: `overflow` as in sfh_f32_to_h2) for the next convolution. */
 int sfh_bn_apply(const float* z, const float* mean_invstd, const float* gamma, const float* beta,
                  const float* residual, int relu, int64_t npix, int C, float* y, void* y_s3, int W,
-                 void* stream);
+                 int split_fmt, uint32_t* overflow, void* stream);
 /* backward of bn_apply: with g = dy * (y > 0) (or dy when relu == 0), acc[0][c] += sum g,
  * acc[1][c] += sum g * xhat  (= dbeta, dgamma);  then
  * dz = gamma * invstd * (g - acc[0]/N - xhat * acc[1]/N), and dres = g (gradient of the residual
@@ -313,7 +314,8 @@ int sfh_bn_bwd_reduce(const float* dy, const float* y, const float* z, const flo
                       int64_t npix, int C, double* acc, void* stream);
 int sfh_bn_bwd_apply(const float* dy, const float* y, const float* z, const float* mean_invstd,
                      const float* gamma, const double* acc, int relu, int64_t npix, int C, float* dz,
-                     float* dres, void* dz_s3, int W, void* stream);   /* dz_s3: optional S3 copy of dz */
+                     float* dres, void* dz_s3, int W, int split_fmt, uint32_t* overflow,
+                     void* stream);   /* dz_s3: optional split copy of dz (split_fmt, overflow: as sfh_bn_apply) */
 /* acc[c] += sum_p x[p][c] over a channel slice of a (npix, cs) tensor: conv / transposed-conv bias
  * gradients.                                                                                       */
 int sfh_colsum(const float* x, int64_t npix, int C, int cs, double* acc, void* stream);
@@ -346,7 +348,8 @@ int sfh_conv_wgrad(const float* dz, int dz_cs, int M, const float* x, int x_cs, 
  * first N channels (multiple of 32) are used.  raw (M, 9, raw_n) fp32, caller-zeroed, atomics.          */
 int sfh_conv_wgrad_s3(const void* dz_s3, int M, const void* x_s3, int x_channels, int xh, int xw, int N,
                       int pad_top, int pad_left, int batch, int H, int W, float* raw, int raw_n, int n_off,
-                      void* stream);
+                      int fmt, void* stream);   /* fmt: SFH_FMT_S3, or SFH_FMT_H2 (both tensors two-plane fp16, three
+                                                   fp16 MFMA products per product) */
 
 /* Backward of OutConv (unet/unet_parts.py:74-77): dlogits NCHW (B,nc,H,W), x NHWC (B,H,W,cin);
  * dx NHWC (optional), acc_w (nc*cin doubles) += dW, acc_b (nc doubles) += db (caller-zeroed).        */

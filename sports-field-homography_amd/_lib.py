@@ -76,9 +76,10 @@ SIGNATURES = {
                                       C.c_int, _p, _p, _p]),
     "sfh_bn_stats": (C.c_int, [_p, C.c_int64, C.c_int, _p, _p]),
     "sfh_bn_finalize": (C.c_int, [_p, C.c_int64, C.c_int, C.c_float, C.c_float, _p, _p, _p, _p]),
-    "sfh_bn_apply": (C.c_int, [_p, _p, _p, _p, _p, C.c_int, C.c_int64, C.c_int, _p, _p, C.c_int, _p]),
+    "sfh_bn_apply": (C.c_int, [_p, _p, _p, _p, _p, C.c_int, C.c_int64, C.c_int, _p, _p, C.c_int, C.c_int, _p, _p]),
     "sfh_bn_bwd_reduce": (C.c_int, [_p, _p, _p, _p, C.c_int, C.c_int64, C.c_int, _p, _p]),
-    "sfh_bn_bwd_apply": (C.c_int, [_p, _p, _p, _p, _p, _p, C.c_int, C.c_int64, C.c_int, _p, _p, _p, C.c_int, _p]),
+    "sfh_bn_bwd_apply": (C.c_int, [_p, _p, _p, _p, _p, _p, C.c_int, C.c_int64, C.c_int, _p, _p, _p, C.c_int, C.c_int, _p,
+                                   _p]),
     "sfh_colsum": (C.c_int, [_p, C.c_int64, C.c_int, C.c_int, _p, _p]),
     "sfh_maxpool2_fwd": (C.c_int, [_p, _p, C.c_int, C.c_int, C.c_int, C.c_int, _p]),
     "sfh_maxpool2_bwd": (C.c_int, [_p, _p, _p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _p]),
@@ -88,7 +89,7 @@ SIGNATURES = {
     "sfh_conv_wgrad": (C.c_int, [_p, C.c_int, C.c_int, _p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                  C.c_int, C.c_int, C.c_int, C.c_int, _p, C.c_int, C.c_int, _p]),
     "sfh_conv_wgrad_s3": (C.c_int, [_p, C.c_int, _p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
-                                    C.c_int, C.c_int, _p, C.c_int, C.c_int, _p]),
+                                    C.c_int, C.c_int, _p, C.c_int, C.c_int, C.c_int, _p]),
     "sfh_outconv_bwd": (C.c_int, [_p, C.c_int, _p, _p, C.c_int, C.c_int, C.c_int, C.c_int, _p, _p, _p, _p]),
     "sfh_maxpool3x3s2_bwd": (C.c_int, [_p, _p, _p, C.c_int, C.c_int, C.c_int, C.c_int, _p]),
     "sfh_avgpool_linear_bwd": (C.c_int, [_p, _p, _p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _p, _p, _p, _p]),

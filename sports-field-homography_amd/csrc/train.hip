@@ -12,6 +12,7 @@
 #include <hip/amd_detail/amd_hip_unsafe_atomics.h>
 
 #include "common.h"
+#include "conv_epilogue.h"   // sfh_split4_h2: the two-plane fp16 split of the H2 format
 
 namespace {
 
@@ -283,15 +284,27 @@ __device__ __forceinline__ bool tr_s3_thread(long i, int W, int C, int xchunks, 
   return x < W;
 }
 
-__device__ __forceinline__ long tr_s3_elem(long row, int x, int c, int W, int C) {
-  return ((((row * (C >> 5) + (c >> 5)) * 3) * 4 + ((c & 31) >> 3)) * W + x) * 8;
+__device__ __forceinline__ long tr_s3_elem(long row, int x, int c, int W, int C, int np = 3) {
+  return ((((row * (C >> 5) + (c >> 5)) * np) * 4 + ((c & 31) >> 3)) * W + x) * 8;
 }
 
+// the same 8 values as two fp16 planes (H2 format, include/sfh_amd.h); `over`: see sfh_split4_h2
+__device__ __forceinline__ void tr_split8_h2(const float (&v)[8], unsigned short* __restrict__ dst, long e, long ps,
+                                             unsigned& over) {
+  sfh_u32x2 pa[2], pb[2];
+  sfh_split4_h2((f32x4){v[0], v[1], v[2], v[3]}, pa, over);
+  sfh_split4_h2((f32x4){v[4], v[5], v[6], v[7]}, pb, over);
+  typedef unsigned int tr_u32x4 __attribute__((ext_vector_type(4)));
+  *reinterpret_cast<tr_u32x4*>(dst + e) = (tr_u32x4){pa[0][0], pa[0][1], pb[0][0], pb[0][1]};
+  *reinterpret_cast<tr_u32x4*>(dst + e + ps) = (tr_u32x4){pa[1][0], pa[1][1], pb[1][0], pb[1][1]};
+}
+
+template <int NP>   // planes of the split copy: 3 = S3 (bf16), 2 = H2 (fp16)
 __global__ __launch_bounds__(256) void bn_apply_s3_kernel(const float* __restrict__ z, const float* __restrict__ mi,
                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
                                                           const float* __restrict__ residual, int relu, int W, int C,
                                                           int xchunks, long total, float* __restrict__ y,
-                                                          unsigned short* __restrict__ y_s3) {
+                                                          unsigned short* __restrict__ y_s3, unsigned* __restrict__ overflow) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   if (i >= total) return;
   long row; int x, c0;
@@ -318,15 +331,22 @@ __global__ __launch_bounds__(256) void bn_apply_s3_kernel(const float* __restric
   }
   *reinterpret_cast<f32x4*>(y + o) = (f32x4){v[0], v[1], v[2], v[3]};
   *reinterpret_cast<f32x4*>(y + o + 4) = (f32x4){v[4], v[5], v[6], v[7]};
-  tr_split8(v, y_s3, tr_s3_elem(row, x, c0, W, C), 4L * W * 8);
+  if constexpr (NP == 3) {
+    tr_split8(v, y_s3, tr_s3_elem(row, x, c0, W, C), 4L * W * 8);
+  } else {
+    unsigned over = 0u;
+    tr_split8_h2(v, y_s3, tr_s3_elem(row, x, c0, W, C, 2), 4L * W * 8, over);
+    if (overflow && sfh_h2_out_of_range(over)) atomicOr(overflow, 1u);
+  }
 }
 
+template <int NP>
 __global__ __launch_bounds__(256) void bn_bwd_apply_s3_kernel(const float* __restrict__ dy, const float* __restrict__ y,
                                                               const float* __restrict__ z, const float* __restrict__ mi,
                                                               const float* __restrict__ gamma, const double* __restrict__ acc,
                                                               int relu, long npix, int W, int C, int xchunks, long total,
                                                               float* __restrict__ dz, float* __restrict__ dres,
-                                                              unsigned short* __restrict__ dz_s3) {
+                                                              unsigned short* __restrict__ dz_s3, unsigned* __restrict__ overflow) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   if (i >= total) return;
   long row; int x, c0;
@@ -357,7 +377,13 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_s3_kernel(const float* __res
     *reinterpret_cast<f32x4*>(dres + o) = (f32x4){gg[0], gg[1], gg[2], gg[3]};
     *reinterpret_cast<f32x4*>(dres + o + 4) = (f32x4){gg[4], gg[5], gg[6], gg[7]};
   }
-  tr_split8(v, dz_s3, tr_s3_elem(row, x, c0, W, C), 4L * W * 8);
+  if constexpr (NP == 3) {
+    tr_split8(v, dz_s3, tr_s3_elem(row, x, c0, W, C), 4L * W * 8);
+  } else {
+    unsigned over = 0u;
+    tr_split8_h2(v, dz_s3, tr_s3_elem(row, x, c0, W, C, 2), 4L * W * 8, over);
+    if (overflow && sfh_h2_out_of_range(over)) atomicOr(overflow, 1u);
+  }
 }
 
 // ------------------------------------------------------------------ max-pool 2x2 (floor)
@@ -966,14 +992,20 @@ extern "C" int sfh_bn_finalize(const double* acc, int64_t npix, int C, float eps
 
 extern "C" int sfh_bn_apply(const float* z, const float* mean_invstd, const float* gamma, const float* beta,
                             const float* residual, int relu, int64_t npix, int C, float* y, void* y_s3, int W,
-                            void* stream) {
+                            int split_fmt, uint32_t* overflow, void* stream) {
   SFH_REQUIRE(z && mean_invstd && gamma && beta && y && npix > 0 && C > 0 && C % 4 == 0, "bn_apply: bad argument");
   if (y_s3) {
-    SFH_REQUIRE(C % 32 == 0 && W > 0 && npix % W == 0, "bn_apply: the S3 copy needs C %% 32 == 0 and npix = rows * W");
+    SFH_REQUIRE(C % 32 == 0 && W > 0 && npix % W == 0, "bn_apply: the split copy needs C %% 32 == 0 and npix = rows * W");
+    SFH_REQUIRE(split_fmt == SFH_FMT_S3 || split_fmt == SFH_FMT_H2, "bn_apply: split_fmt=%d (S3 or H2)", split_fmt);
     const int xchunks = (W + 15) / 16;
     const long total = (npix / W) * (C / 32) * xchunks * 64;
-    hipLaunchKernelGGL(bn_apply_s3_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, z,
-                       mean_invstd, gamma, beta, residual, relu, W, C, xchunks, total, y, (unsigned short*)y_s3);
+    const dim3 grid((unsigned)((total + 255) / 256));
+    if (split_fmt == SFH_FMT_H2)
+      hipLaunchKernelGGL(bn_apply_s3_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, z, mean_invstd, gamma, beta,
+                         residual, relu, W, C, xchunks, total, y, (unsigned short*)y_s3, overflow);
+    else
+      hipLaunchKernelGGL(bn_apply_s3_kernel<3>, grid, dim3(256), 0, (hipStream_t)stream, z, mean_invstd, gamma, beta,
+                         residual, relu, W, C, xchunks, total, y, (unsigned short*)y_s3, overflow);
     return sfh_check_launch("bn_apply_s3_kernel");
   }
   const long total4 = (long)npix * C / 4;
@@ -994,16 +1026,21 @@ extern "C" int sfh_bn_bwd_reduce(const float* dy, const float* y, const float* z
 
 extern "C" int sfh_bn_bwd_apply(const float* dy, const float* y, const float* z, const float* mean_invstd,
                                 const float* gamma, const double* acc, int relu, int64_t npix, int C, float* dz,
-                                float* dres, void* dz_s3, int W, void* stream) {
+                                float* dres, void* dz_s3, int W, int split_fmt, uint32_t* overflow, void* stream) {
   SFH_REQUIRE(dy && z && mean_invstd && gamma && acc && dz && (y || !relu) && npix > 0 && C > 0 && C % 4 == 0,
               "bn_bwd_apply: bad argument");
   if (dz_s3) {
-    SFH_REQUIRE(C % 32 == 0 && W > 0 && npix % W == 0, "bn_bwd_apply: the S3 copy needs C %% 32 == 0 and npix = rows * W");
+    SFH_REQUIRE(C % 32 == 0 && W > 0 && npix % W == 0, "bn_bwd_apply: the split copy needs C %% 32 == 0 and npix = rows * W");
+    SFH_REQUIRE(split_fmt == SFH_FMT_S3 || split_fmt == SFH_FMT_H2, "bn_bwd_apply: split_fmt=%d (S3 or H2)", split_fmt);
     const int xchunks = (W + 15) / 16;
     const long total = (npix / W) * (C / 32) * xchunks * 64;
-    hipLaunchKernelGGL(bn_bwd_apply_s3_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                       dy, y, z, mean_invstd, gamma, acc, relu, (long)npix, W, C, xchunks, total, dz, dres,
-                       (unsigned short*)dz_s3);
+    const dim3 grid((unsigned)((total + 255) / 256));
+    if (split_fmt == SFH_FMT_H2)
+      hipLaunchKernelGGL(bn_bwd_apply_s3_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, dy, y, z, mean_invstd, gamma,
+                         acc, relu, (long)npix, W, C, xchunks, total, dz, dres, (unsigned short*)dz_s3, overflow);
+    else
+      hipLaunchKernelGGL(bn_bwd_apply_s3_kernel<3>, grid, dim3(256), 0, (hipStream_t)stream, dy, y, z, mean_invstd, gamma,
+                         acc, relu, (long)npix, W, C, xchunks, total, dz, dres, (unsigned short*)dz_s3, overflow);
     return sfh_check_launch("bn_bwd_apply_s3_kernel");
   }
   const long total4 = (long)npix * C / 4;

@@ -29,6 +29,7 @@ namespace {
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
 
@@ -50,13 +51,16 @@ __device__ __forceinline__ bf16x8 frag(s16x4 lo, s16x4 hi) {
   return __builtin_bit_cast(bf16x8, v);
 }
 
-template <int TR, int TW>
+// NP = planes per operand: 3 = S3 tensors (bf16, six products), 2 = H2 tensors (fp16 planes of v * 2^SFH_H2_ACT_EXP,
+// three products; the accumulators are multiplied by 2^-(2 * SFH_H2_ACT_EXP) before they are added to raw)
+template <int TR, int TW, int NP>
 __global__ __launch_bounds__(256, 2) void wgrad_s3_kernel(const WgS3Args a) {
   static_assert(TR * TW == 64 && (TW == 8 || TW == 16 || TW == 32), "64-pixel tiles, two 32-pixel k-steps");
+  constexpr int R4 = 4 * NP;                                         // (plane, group) runs per 32-channel block
   constexpr int HWD = TW + 2, HR = TR + 2, HP = HR * HWD;           // input halo of a tile
   constexpr int PX = ((HP - 4 + 15) / 16) * 16 + 4;                 // chunks per (plane, group) of the halo image
   constexpr int PD = 68;                                            // ... of the dz image (64 pixels)
-  constexpr int XCH = 12 * PX;
+  constexpr int XCH = R4 * PX;
   constexpr int NXI = (HP + 63) / 64;                               // DMA instructions per (plane, group) of the halo
   constexpr int RS = 32 / TW;                                       // tile rows per k-step
   extern __shared__ __attribute__((aligned(16))) u32x4 lds[];       // [halo image 12 * PX][dz image 24 * PD] chunks
@@ -111,13 +115,13 @@ __global__ __launch_bounds__(256, 2) void wgrad_s3_kernel(const WgS3Args a) {
         const int r = hp / HWD, c = hp - r * HWD;
         const int yy = y0 - 1 + r - a.pad_top, xx = x0 - 1 + c - a.pad_left;
         const bool ok = (unsigned)yy < (unsigned)a.xh && (unsigned)xx < (unsigned)a.xw;
-        voff[i] = ok ? (unsigned)((yy * CBX * 12 * a.xw + xx) * 16) : kOOB;
+        voff[i] = ok ? (unsigned)((yy * CBX * R4 * a.xw + xx) * 16) : kOOB;
         act[i] = hp < HP;
       }
-      const unsigned xsb = (unsigned)((b * a.xh * CBX + nb32) * 12) * (unsigned)a.xw * 16u;
+      const unsigned xsb = (unsigned)((b * a.xh * CBX + nb32) * R4) * (unsigned)a.xw * 16u;
 #pragma unroll
-      for (int j = 0; j < 3; ++j) {
-        const int pg = wv * 3 + j;                       // plane * 4 + group
+      for (int j = 0; j < NP; ++j) {
+        const int pg = wv * NP + j;                      // plane * 4 + group
         const unsigned soff = xsb + (unsigned)pg * (unsigned)a.xw * 16u;
 #pragma unroll
         for (int i = 0; i < NXI; ++i) {
@@ -127,13 +131,13 @@ __global__ __launch_bounds__(256, 2) void wgrad_s3_kernel(const WgS3Args a) {
       }
       const int py = lane / TW, px = lane - py * TW;
       const int y = y0 + py, x = x0 + px;
-      const unsigned dvoff = (y < a.H && x < a.W) ? (unsigned)((y * MB * 12 * a.W + x) * 16) : kOOB;
-      const unsigned dsb = (unsigned)((b * a.H * MB + mb64 * 2) * 12) * (unsigned)a.W * 16u;
+      const unsigned dvoff = (y < a.H && x < a.W) ? (unsigned)((y * MB * R4 * a.W + x) * 16) : kOOB;
+      const unsigned dsb = (unsigned)((b * a.H * MB + mb64 * 2) * R4) * (unsigned)a.W * 16u;
 #pragma unroll
-      for (int j = 0; j < 6; ++j) {
-        const int pg8 = wv * 6 + j;                      // plane * 8 + group of the 64 couts
+      for (int j = 0; j < 2 * NP; ++j) {
+        const int pg8 = wv * (2 * NP) + j;               // plane * 8 + group of the 64 couts
         const int p = pg8 >> 3, g8 = pg8 & 7;
-        const unsigned soff = dsb + (unsigned)(((g8 >> 2) * 12 + p * 4 + (g8 & 3))) * (unsigned)a.W * 16u;
+        const unsigned soff = dsb + (unsigned)(((g8 >> 2) * R4 + p * 4 + (g8 & 3))) * (unsigned)a.W * 16u;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rdz, (lds_ptr_t)(lds + XCH + pg8 * PD), 16, (int)dvoff, (int)soff, 0, 0);
       }
     }
@@ -142,30 +146,36 @@ __global__ __launch_bounds__(256, 2) void wgrad_s3_kernel(const WgS3Args a) {
     // ---- two k-steps of 32 pixels
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
-      bf16x8 af[2][3];
+      bf16x8 af[2][NP];
 #pragma unroll
       for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
-        for (int p = 0; p < 3; ++p) {
+        for (int p = 0; p < NP; ++p) {
           const unsigned ad = dzb + (unsigned)(((p * 8 + 2 * mb) * PD + 32 * s) * 16);
           af[mb][p] = frag(tr(ad), tr(ad + 64));
         }
 #pragma unroll
       for (int t9 = 0; t9 < 9; ++t9) {
         const int ky = t9 / 3, kx = t9 % 3;
-        bf16x8 bfr[3];
+        bf16x8 bfr[NP];
 #pragma unroll
-        for (int p = 0; p < 3; ++p) {
+        for (int p = 0; p < NP; ++p) {
           const unsigned ad = xb + (unsigned)(((p * 4) * PX + (s * RS + ky) * HWD + kx) * 16);
           bfr[p] = frag(tr(ad), tr(ad + 64));
         }
-        // six partial products, smallest first (as in the forward kernel)
-        constexpr int PA[6] = {0, 1, 2, 0, 1, 0}, PB[6] = {2, 1, 0, 1, 0, 0};
+        // the kept partial products, smallest first (as in the forward kernel)
+        constexpr int NPROD = NP == 3 ? 6 : 3;
+        constexpr int PA[6] = {0, 1, NP == 3 ? 2 : 0, 0, 1, 0}, PB[6] = {NP == 3 ? 2 : 1, NP == 3 ? 1 : 0, 0, 1, 0, 0};
 #pragma unroll
-        for (int k6 = 0; k6 < 6; ++k6)
+        for (int k6 = 0; k6 < NPROD; ++k6)
 #pragma unroll
-          for (int mb = 0; mb < 2; ++mb)
-            acc[mb][t9] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mb][PA[k6]], bfr[PB[k6]], acc[mb][t9], 0, 0, 0);
+          for (int mb = 0; mb < 2; ++mb) {
+            if constexpr (NP == 3)
+              acc[mb][t9] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mb][PA[k6]], bfr[PB[k6]], acc[mb][t9], 0, 0, 0);
+            else
+              acc[mb][t9] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, af[mb][PA[k6]]),
+                                                                  __builtin_bit_cast(f16x8, bfr[PB[k6]]), acc[mb][t9], 0, 0, 0);
+          }
       }
     }
     __syncthreads();   // every wave is done with the buffer before the next tile's DMA lands in it
@@ -180,14 +190,15 @@ __global__ __launch_bounds__(256, 2) void wgrad_s3_kernel(const WgS3Args a) {
     for (int t9 = 0; t9 < 9; ++t9)
 #pragma unroll
       for (int r = 0; r < 4; ++r)
-        unsafeAtomicAdd(a.raw + ((long)(m0 + 16 * mb + r) * 9 + t9) * a.raw_n + n, acc[mb][t9][r]);
+        unsafeAtomicAdd(a.raw + ((long)(m0 + 16 * mb + r) * 9 + t9) * a.raw_n + n,
+                        NP == 2 ? acc[mb][t9][r] * (1.f / (float)(1 << (2 * SFH_H2_ACT_EXP))) : acc[mb][t9][r]);
 }
 
-template <int TR, int TW>
+template <int TR, int TW, int NP>
 int launch(WgS3Args a, hipStream_t stream) {
   constexpr int HP = (TR + 2) * (TW + 2);
   constexpr int PX = ((HP - 4 + 15) / 16) * 16 + 4;
-  constexpr int LDS_BYTES = (12 * PX + 24 * 68) * 16;
+  constexpr int LDS_BYTES = (4 * NP * PX + 8 * NP * 68) * 16;
   a.ntx = sfh_cdiv(a.W, TW);
   a.nty = sfh_cdiv(a.H, TR);
   a.ntiles = a.ntx * a.nty * a.batch;
@@ -207,8 +218,8 @@ int launch(WgS3Args a, hipStream_t stream) {
   }
   const long nblocks = (long)sfh_cdiv(a.nsplit, 8) * 8 * mn;
   SFH_REQUIRE(nblocks < (1L << 31), "conv_wgrad_s3: grid too large");
-  sfh_allow_big_lds(reinterpret_cast<const void*>(&wgrad_s3_kernel<TR, TW>));
-  hipLaunchKernelGGL((wgrad_s3_kernel<TR, TW>), dim3((unsigned)nblocks), dim3(256), LDS_BYTES, stream, a);
+  sfh_allow_big_lds(reinterpret_cast<const void*>(&wgrad_s3_kernel<TR, TW, NP>));
+  hipLaunchKernelGGL((wgrad_s3_kernel<TR, TW, NP>), dim3((unsigned)nblocks), dim3(256), LDS_BYTES, stream, a);
   return sfh_check_launch("wgrad_s3_kernel");
 }
 
@@ -216,14 +227,16 @@ int launch(WgS3Args a, hipStream_t stream) {
 
 extern "C" int sfh_conv_wgrad_s3(const void* dz_s3, int M, const void* x_s3, int x_channels, int xh, int xw, int N,
                                  int pad_top, int pad_left, int batch, int H, int W, float* raw, int raw_n, int n_off,
-                                 void* stream) {
+                                 int fmt, void* stream) {
+  SFH_REQUIRE(fmt == SFH_FMT_S3 || fmt == SFH_FMT_H2, "conv_wgrad_s3: fmt=%d (S3 or H2)", fmt);
+  const unsigned long long bpe = fmt == SFH_FMT_H2 ? 4ULL : 6ULL;
   SFH_REQUIRE(dz_s3 && x_s3 && raw, "conv_wgrad_s3: null pointer");
   SFH_REQUIRE(batch > 0 && H > 0 && W > 0 && xh > 0 && xw > 0, "conv_wgrad_s3: bad geometry");
   SFH_REQUIRE(M > 0 && M % 64 == 0, "conv_wgrad_s3: M=%d must be a multiple of 64", M);
   SFH_REQUIRE(N > 0 && N % 32 == 0 && x_channels % 32 == 0 && x_channels >= N, "conv_wgrad_s3: N=%d of %d channels", N, x_channels);
   SFH_REQUIRE(n_off >= 0 && n_off + N <= raw_n, "conv_wgrad_s3: n_off=%d N=%d raw_n=%d", n_off, N, raw_n);
   SFH_REQUIRE(pad_top >= 0 && pad_left >= 0 && pad_top + xh <= H && pad_left + xw <= W, "conv_wgrad_s3: source does not fit the frame");
-  const unsigned long long bdz = 6ULL * batch * H * W * M, bx = 6ULL * batch * xh * xw * x_channels;
+  const unsigned long long bdz = bpe * batch * H * W * M, bx = bpe * batch * xh * xw * x_channels;
   SFH_REQUIRE(bdz < kOOB && bx < kOOB, "conv_wgrad_s3: a tensor of %llu bytes exceeds the 4 GiB descriptor range", bdz > bx ? bdz : bx);
   WgS3Args a;
   a.dz = dz_s3; a.M = M; a.x = x_s3; a.xc = x_channels; a.xh = xh; a.xw = xw; a.N = N;
@@ -240,7 +253,12 @@ extern "C" int sfh_conv_wgrad_s3(const void* dz_s3, int M, const void* x_s3, int
   const long c0 = (long)sfh_cdiv(H, 2) * sfh_cdiv(W, 32), c1 = (long)sfh_cdiv(H, 4) * sfh_cdiv(W, 16),
              c2 = (long)sfh_cdiv(H, 8) * sfh_cdiv(W, 8);
   hipStream_t st = (hipStream_t)stream;
-  if (c0 <= c1 && c0 <= c2) return launch<2, 32>(a, st);
-  if (c1 <= c2) return launch<4, 16>(a, st);
-  return launch<8, 8>(a, st);
+  if (fmt == SFH_FMT_H2) {
+    if (c0 <= c1 && c0 <= c2) return launch<2, 32, 2>(a, st);
+    if (c1 <= c2) return launch<4, 16, 2>(a, st);
+    return launch<8, 8, 2>(a, st);
+  }
+  if (c0 <= c1 && c0 <= c2) return launch<2, 32, 3>(a, st);
+  if (c1 <= c2) return launch<4, 16, 3>(a, st);
+  return launch<8, 8, 3>(a, st);
 }

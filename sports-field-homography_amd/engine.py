@@ -172,12 +172,14 @@ class LaunchOrder:
 _UNIT = {}
 
 
-def _unit_epilogue(n, dev):
-    """(ones, zeros) of n floats on dev, shared read-only by every backward-data conv (56 per training step)"""
-    key = (n, str(dev))
+def _unit_epilogue(n, dev, scale=1.0):
+    """(scale * ones, zeros) of n floats on dev, shared read-only by every backward-data conv (56 per training step;
+    scale: the power of two an H2 layer's accumulator is multiplied with)"""
+    key = (n, str(dev), float(scale))
     v = _UNIT.get(key)
     if v is None:
-        v = _UNIT[key] = (torch.ones(n, dtype=torch.float32, device=dev), torch.zeros(n, dtype=torch.float32, device=dev))
+        v = _UNIT[key] = (torch.full((n,), float(scale), dtype=torch.float32, device=dev),
+                          torch.zeros(n, dtype=torch.float32, device=dev))
     return v
 
 
@@ -188,7 +190,7 @@ class PackedConv:
     order = None   # LaunchOrder of the owning engine (set by the engine); None = always forward
 
     def __init__(self, weight, bias, bn, ksize, c0, c1=0, relu=True, transposed=False, stride=1,
-                 stem_cin=0, tag="conv", s3=False, fmt=None):
+                 stem_cin=0, tag="conv", s3=False, fmt=None, wexp=None):
         """fmt="s3" (or s3=True): sources are split-bf16 (S3) tensors and the contraction runs as six bf16 MFMAs
         per product; fmt="h2": two-plane fp16 (H2) sources, three fp16 MFMAs per product (both sfh_conv_s3_fwd);
         otherwise fp32 sources and fp32 MFMA (sfh_conv_fwd)."""
@@ -231,7 +233,7 @@ class PackedConv:
         elif self.s3:
             if stem_cin:
                 mode, aux = 2, stem_cin
-            self._pack_split(w, ksize, c0, c1, mode, aux)
+            self._pack_split(w, ksize, c0, c1, mode, aux, wexp)
         else:
             n = lib.sfh_packed_weight_floats(ksize, c0, c1, self.cout)
             if n <= 0:
@@ -252,9 +254,10 @@ class PackedConv:
         if self.escale != 1.0:
             self.scale.mul_(self.escale)     # a power of two: exact
 
-    def _pack_split(self, w, ksize, c0, c1, mode, aux):
+    def _pack_split(self, w, ksize, c0, c1, mode, aux, wexp=None):
         """Pack w for the split-operand kernel in this layer's format.  H2: planes of w * 2^wexp with
-        max |w| * 2^wexp in [2^13, 2^14); self.escale = 2^-(wexp + H2_ACT_EXP) is what the accumulator has to be
+        max |w| * 2^wexp in [2^13, 2^14) (wexp given by a caller that has the maximum already, else one
+        device read-back here); self.escale = 2^-(wexp + H2_ACT_EXP) is what the accumulator has to be
         multiplied with (the caller folds it into `scale`)."""
         lib = _lib.load()
         if self.fmt == "h2":
@@ -266,11 +269,12 @@ class PackedConv:
         self.wpacked = torch.empty(n, dtype=torch.uint8, device=w.device)
         if self.fmt == "h2":
             import math
-            wmax = float(w.abs().max())
-            if not math.isfinite(wmax):
-                raise ValueError("conv weight holds non-finite values")
-            wexp = 13 - math.frexp(wmax)[1] + 1 if wmax > 0 else 0    # frexp: wmax = m * 2^e, 0.5 <= m < 1
-            wexp = max(-100, min(100, wexp))
+            if wexp is None:
+                wmax = float(w.abs().max())
+                if not math.isfinite(wmax):
+                    raise ValueError("conv weight holds non-finite values")
+                wexp = 13 - math.frexp(wmax)[1] + 1 if wmax > 0 else 0    # frexp: wmax = m * 2^e, 0.5 <= m < 1
+            wexp = max(-100, min(100, int(wexp)))
             self.escale = 2.0 ** -(wexp + _lib.H2_ACT_EXP)
             _lib.check(lib.sfh_pack_h2_weights(_ptr(w), _ptr(self.wpacked), ksize, c0, c1, self.cout, mode, aux, wexp,
                                                _stream()), "pack_h2_weights")
@@ -318,7 +322,7 @@ class PackedConv:
         return self
 
     @classmethod
-    def backward_data(cls, weight, ksize, transposed=False, tag="bwd_data", s3=False):
+    def backward_data(cls, weight, ksize, transposed=False, tag="bwd_data", s3=False, fmt=None, wexp=None):
         """The conv that maps dz -> dx for a stride-1 nn.Conv2d (OIHW weight; taps flipped, channels
         swapped: pack mode 3) or for nn.ConvTranspose2d k2 s2 (IOHW weight; a 1x1 conv over
         space_to_depth2(dY): pack mode 4).  fp32 kernel; output channels padded to a multiple of 64."""
@@ -334,19 +338,16 @@ class PackedConv:
             cout, cin = w.shape[0], w.shape[1]
             assert tuple(w.shape[2:]) == (ksize, ksize) and ksize in (1, 3)
             c0, mode, aux = cout, 3, cin
-        self.tag, self.s3, self.c4, self.stem_cin = tag, bool(s3), False, 0
-        self.fmt, self.escale = ("s3" if s3 else None), 1.0
+        self.fmt = fmt if fmt is not None else ("s3" if s3 else None)
+        s3 = self.fmt is not None
+        self.tag, self.s3, self.c4, self.stem_cin = tag, s3, False, 0
+        self.escale = 1.0
         self.ksize, self.c0, self.c1, self.relu, self.stride, self.transposed = ksize, c0, 0, False, 1, False
         if cin % 64:
             raise ValueError(f"backward-data conv needs a multiple of 64 input channels, got {cin}")
         self.cout = self.cout_real = cin
         if s3:
-            n = lib.sfh_packed_s3_weight_bytes(ksize, c0, 0, self.cout)
-            if n <= 0:
-                raise ValueError(f"unsupported S3 backward-data geometry ksize={ksize} c0={c0} cout={self.cout}")
-            self.wpacked = torch.empty(n, dtype=torch.uint8, device=dev)
-            _lib.check(lib.sfh_pack_s3_weights(_ptr(w), _ptr(self.wpacked), ksize, c0, 0, self.cout, mode, aux,
-                                               _stream()), "pack_s3_weights")
+            self._pack_split(w, ksize, c0, 0, mode, aux, wexp)
         else:
             n = lib.sfh_packed_weight_floats(ksize, c0, 0, self.cout)
             if n <= 0:
@@ -354,7 +355,7 @@ class PackedConv:
             self.wpacked = torch.empty(n, dtype=torch.float32, device=dev)
             _lib.check(lib.sfh_pack_conv_weights(_ptr(w), _ptr(self.wpacked), ksize, c0, 0, self.cout, mode, aux,
                                                  _stream()), "pack_conv_weights")
-        self.scale, self.shift = _unit_epilogue(self.cout, dev)
+        self.scale, self.shift = _unit_epilogue(self.cout, dev, self.escale)
         return self
 
     def run(self, src0, batch, H, W, dst, src1=None, pool0=False, pad1=(0, 0), residual=None, tile=None,

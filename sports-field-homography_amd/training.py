@@ -5,13 +5,17 @@ What ``net.train(); preds = net(imgs); loss.backward()`` does in the reference (
 the backward pass, and gradients for every parameter.  The losses, ``clip_grad_value_`` and the
 optimizer stay with the caller (train.py:181-237), exactly as in the reference.
 
-Activations are kept in fp32 NHWC.  Forward and backward-data convolutions run on the split-bf16
-kernel (``sfh_conv_s3_fwd``: fp32-equivalent, the sources are converted to the S3 format once per
-tensor) unless ``SFH_TRAIN_PRECISION=fp32`` selects the fp32 MFMA kernel; the first layer, the stem
-and the backward-filter (``sfh_conv_wgrad``) are fp32 MFMA.  A tape of closures records the backward
-of each layer; gradients of activations are keyed by tensor identity and accumulated with
-``sfh_slice_add``.  PyTorch provides memory, streams and the autograd hook
-(``torch.autograd.Function``) only.
+Activations are kept in fp32 NHWC.  Forward, backward-data and 3x3 backward-filter convolutions run on the
+split-operand kernels (``sfh_conv_s3_fwd`` / ``sfh_conv_wgrad_s3``); the split copies of activations and
+pre-activation gradients are written by the BatchNorm kernels in the same pass.  ``SFH_TRAIN_PRECISION``:
+``f16x3`` (default) - two fp16 planes per operand, three MFMA products; the backward pass is carried at a power of
+two chosen from the largest output gradient of the step, so that the gradients (~1e-7 for losses that are means over
+B*H*W pixels) fit fp16's exponent range, and a step whose activations or gradients still leave it is repeated with
+bf16x6 from the same BatchNorm statistics (TrainStep; under the autograd node a gradient overflow raises
+FP16RangeError); ``bf16x6`` - three bf16 planes, six products; ``fp32`` - fp32 MFMA kernels throughout.  The first
+layer, the stem and the other backward-filter shapes (``sfh_conv_wgrad``) are fp32 MFMA in every mode.  A tape of
+closures records the backward of each layer; gradients of activations are keyed by tensor identity and accumulated
+with ``sfh_slice_add``.  PyTorch provides memory, streams and the autograd hook (``torch.autograd.Function``) only.
 """
 import ctypes
 import os
@@ -25,11 +29,12 @@ from .engine import PackedConv, _ptr, _stream
 BN_MOMENTUM = 0.1  # nn.BatchNorm2d default, unchanged by the reference
 
 
-def _use_s3():
-    p = os.environ.get("SFH_TRAIN_PRECISION", "bf16x6")
-    if p not in ("bf16x6", "fp32"):
-        raise ValueError(f"SFH_TRAIN_PRECISION={p!r}: expected 'bf16x6' or 'fp32'")
-    return p == "bf16x6"
+def _train_fmt():
+    """split format of the training convs: "h2" (f16x3, default), "s3" (bf16x6) or None (fp32 MFMA)"""
+    p = os.environ.get("SFH_TRAIN_PRECISION", "f16x3")
+    if p not in E.PRECISIONS:
+        raise ValueError(f"SFH_TRAIN_PRECISION={p!r}: expected one of {sorted(E.PRECISIONS)}")
+    return E.PRECISIONS[p]
 
 
 def _empty(shape, like, dtype=torch.float32):
@@ -40,16 +45,59 @@ def _zeros(shape, like, dtype=torch.float32):
     return torch.zeros(shape, dtype=dtype, device=like.device)
 
 
+class FP16RangeError(RuntimeError):
+    """an activation or gradient of a training step did not fit the two-plane fp16 (H2) format"""
+
+
+class _BNSnapshot:
+    """Copies of a model's buffers (BatchNorm running statistics), so that a training step that has to be repeated
+    in another precision starts from the same statistics: two multi-tensor copies, no allocation after the first use."""
+
+    def __init__(self, net):
+        self.bufs = [b for b in net.buffers() if b.is_cuda]
+        self.snap = [torch.empty_like(b) for b in self.bufs]
+
+    def save(self):
+        if self.bufs:
+            torch._foreach_copy_(self.snap, self.bufs)
+
+    def restore(self):
+        if self.bufs:
+            torch._foreach_copy_(self.bufs, self.snap)
+
+
+_RANGE_WARNED = []
+
+
+def _warn_range_fallback():
+    if not _RANGE_WARNED:
+        _RANGE_WARNED.append(1)
+        import warnings
+        warnings.warn("sfh_amd training: a value left the fp16 range of SFH_TRAIN_PRECISION=f16x3; the step was repeated "
+                      "with bf16x6 (set SFH_TRAIN_PRECISION=bf16x6 to avoid the double work)")
+
+
 class Tape:
     """Backward closures in forward order + gradients of activations by tensor identity."""
 
-    def __init__(self):
+    def __init__(self, fmt="env"):
         self.ops = []
         self.grads = {}
         self.param_grads = {}
         self.lib = _lib.load()
-        self.use_s3 = _use_s3()
+        self.fmt = _train_fmt() if fmt == "env" else fmt            # "s3" | "h2" | None
+        self.use_s3 = self.fmt is not None
+        self.fmt_code = {"s3": _lib.FMT_S3, "h2": _lib.FMT_H2}.get(self.fmt, _lib.FMT_F32)
         self._s3 = {}
+        # f16x3 (H2 copies of activations and gradients): fp16's exponent range has to hold them.
+        #   overflow - device word the kernels raise when a value does not fit (checked at the end of the backward pass);
+        #   gscale   - power of two all gradients are carried with (the losses are means over B*H*W pixels, their
+        #              gradients ~1e-7: far below fp16's range); chosen by run_backward from the largest seed gradient
+        #              (one read-back per step) and divided out of the parameter gradients at its end;
+        #   wexp     - per conv weight: exponent of its H2 planes, from ONE batched max over the parameters per step
+        self.overflow = None
+        self.gscale = 1.0
+        self.wexp = {}
         self.order = E.LaunchOrder()
         self._arena = {}      # dtype -> [zero-filled buffer, next free element]
 
@@ -71,11 +119,28 @@ class Tape:
         return out
 
     def s3(self, t):
-        """split-bf16 copy of an NHWC activation (converted once, kept while the tape lives)"""
+        """split copy (S3 or H2, the tape's format) of an NHWC activation (converted once, kept while the tape lives)"""
         v = self._s3.get(id(t))
         if v is None:
-            v = self._s3[id(t)] = (t, E.f32_to_s3(t))
+            v = self._s3[id(t)] = (t, E.f32_to_split(t, self.fmt, self.overflow))
         return v[1]
+
+    def prepare_h2(self, net, n_pixels):
+        """H2 mode: gradient scale for n_pixels = B*H*W and the weight exponents of all conv weights (one sync)."""
+        if self.fmt != "h2":
+            return
+        import math
+        dev = next(net.parameters()).device
+        self.overflow = torch.zeros(1, dtype=torch.int32, device=dev)
+        ws = [p for p in net.parameters() if p.dim() == 4]
+        mx = torch.stack(torch._foreach_norm([w.detach() for w in ws], float("inf"))).cpu().tolist()
+        for w, m in zip(ws, mx):
+            if not math.isfinite(m):
+                raise ValueError("a conv weight holds non-finite values")
+            self.wexp[id(w)] = (14 - math.frexp(m)[1]) if m > 0 else 0
+
+    def wexp_of(self, param):
+        return self.wexp.get(id(param)) if self.fmt == "h2" else None
 
     def push(self, fn):
         self.ops.append(fn)
@@ -114,9 +179,10 @@ def _bn_forward(lib, z, bn, relu, residual, tape, want_s3=True):
                                    _ptr(bn.running_var), _ptr(mi), _stream()), "bn_finalize")
     bn.num_batches_tracked += 1
     y = _empty(z.shape, z)
-    y_s3 = E.s3_empty(B, H, W, C, z.device) if (want_s3 and tape.use_s3 and C % 32 == 0) else None
+    y_s3 = E.split_empty(tape.fmt, B, H, W, C, z.device) if (want_s3 and tape.use_s3 and C % 32 == 0) else None
     _lib.check(lib.sfh_bn_apply(_ptr(z), _ptr(mi), _ptr(bn.weight.detach()), _ptr(bn.bias.detach()),
-                                _ptr(residual), 1 if relu else 0, npix, C, _ptr(y), _ptr(y_s3), W, _stream()), "bn_apply")
+                                _ptr(residual), 1 if relu else 0, npix, C, _ptr(y), _ptr(y_s3), W, tape.fmt_code,
+                                _ptr(tape.overflow), _stream()), "bn_apply")
     if y_s3 is not None:
         tape._s3[id(y)] = (y, y_s3)
     return y, mi
@@ -130,10 +196,10 @@ def _bn_backward(lib, tape, dy, y, z, mi, bn, relu, want_dres, want_s3=False):
                                      _stream()), "bn_bwd_reduce")
     dz = _empty(z.shape, z)
     dres = _empty(z.shape, z) if want_dres else None
-    dz_s3 = E.s3_empty(B, H, W, C, z.device) if (want_s3 and C % 32 == 0) else None
+    dz_s3 = E.split_empty(tape.fmt, B, H, W, C, z.device) if (want_s3 and C % 32 == 0) else None
     _lib.check(lib.sfh_bn_bwd_apply(_ptr(dy), _ptr(y), _ptr(z), _ptr(mi), _ptr(bn.weight.detach()), _ptr(acc),
-                                    1 if relu else 0, npix, C, _ptr(dz), _ptr(dres), _ptr(dz_s3), W, _stream()),
-               "bn_bwd_apply")
+                                    1 if relu else 0, npix, C, _ptr(dz), _ptr(dres), _ptr(dz_s3), W, tape.fmt_code,
+                                    _ptr(tape.overflow), _stream()), "bn_bwd_apply")
     a = acc.to(torch.float32)
     return dz, a[C:], a[:C], dres, dz_s3   # dz, dgamma, dbeta, dresidual, S3 copy of dz
 
@@ -160,7 +226,7 @@ def _wgrad_s3(lib, tape, dz_s3, M, srcs, B, H, W, cin_store):
     for (t, n, n_off, pt, pl) in srcs:
         xs = tape.s3(t)
         _lib.check(lib.sfh_conv_wgrad_s3(_ptr(dz_s3), M, _ptr(xs), t.shape[3], t.shape[1], t.shape[2], n, pt, pl,
-                                         B, H, W, _ptr(raw), cin_store, n_off, _stream()), "conv_wgrad_s3")
+                                         B, H, W, _ptr(raw), cin_store, n_off, tape.fmt_code, _stream()), "conv_wgrad_s3")
     return raw
 
 
@@ -198,8 +264,10 @@ def conv_bn_act(tape, names, conv, bn, srcs, B, H, W, relu=True, residual=None, 
     t0, c0 = srcs[0][0], srcs[0][1]
     t1, c1 = (srcs[1][0], srcs[1][1]) if len(srcs) > 1 else (None, 0)
     s3 = tape.use_s3 and c0 % 32 == 0 and c1 % 32 == 0 and c0 == t0.shape[3] and (t1 is None or c1 == t1.shape[3])
-    pc = PackedConv(w, conv.bias, None, ks, c0, c1, relu=False, stride=stride, tag="train_fwd", s3=s3)
+    pc = PackedConv(w, conv.bias, None, ks, c0, c1, relu=False, stride=stride, tag="train_fwd",
+                    fmt=tape.fmt if s3 else None, wexp=tape.wexp_of(conv.weight))
     pc.order = tape.order
+    pc.overflow = tape.overflow
     ho, wo = (H - 1) // stride + 1, (W - 1) // stride + 1
     z = _empty((B, ho, wo, cout), t0)
     pc.run(tape.s3(t0) if s3 else t0, B, H, W, z, src1=(tape.s3(t1) if s3 else t1) if t1 is not None else None,
@@ -237,10 +305,10 @@ def conv_bn_act(tape, names, conv, bn, srcs, B, H, W, relu=True, residual=None, 
         g[names(conv.weight)] = raw.view(cout, ks, ks, cin_store)[..., :c0 + c1].permute(0, 3, 1, 2)
         if not need_dx:
             return
-        bd = PackedConv.backward_data(w, ks, s3=s3)
+        bd = PackedConv.backward_data(w, ks, fmt=tape.fmt if s3 else None, wexp=tape.wexp_of(conv.weight))
         bd.order = tape.order
         dx = _empty((B, H, W, bd.cout), dz)
-        bd.run((dz_s3 if dz_s3 is not None else E.f32_to_s3(dz)) if s3 else dz, B, H, W, dx)
+        bd.run((dz_s3 if dz_s3 is not None else E.f32_to_split(dz, tape.fmt, tape.overflow)) if s3 else dz, B, H, W, dx)
         if t1 is None:
             tape.add_grad(t0, dx)
             return
@@ -286,7 +354,8 @@ def conv_transpose2x2(tape, names, up, x):
     wt = up.weight.detach()
     cout = wt.shape[1]
     s3 = tape.use_s3 and cin % 32 == 0
-    pc = PackedConv(wt, up.bias, None, 1, cin, relu=False, transposed=True, tag="train_fwd", s3=s3)
+    pc = PackedConv(wt, up.bias, None, 1, cin, relu=False, transposed=True, tag="train_fwd",
+                    fmt=tape.fmt if s3 else None, wexp=tape.wexp_of(up.weight))
     u = _empty((B, 2 * h, 2 * w, cout), x)
     pc.run(tape.s3(x) if s3 else x, B, h, w, u)
 
@@ -298,9 +367,9 @@ def conv_transpose2x2(tape, names, up, x):
         _lib.check(lib.sfh_space_to_depth2(_ptr(du), _ptr(s), B, 2 * h, 2 * w, cout, _stream()), "space_to_depth2")
         raw = _wgrad(lib, s, [(x, cin, 0, 0, 0)], B, h, w, 1, cin, tape)      # (4*cout, 1, cin)
         g[names(up.weight)] = raw.view(2, 2, cout, cin).permute(3, 2, 0, 1)
-        bd = PackedConv.backward_data(wt, 1, transposed=True, s3=s3)
+        bd = PackedConv.backward_data(wt, 1, transposed=True, fmt=tape.fmt if s3 else None, wexp=tape.wexp_of(up.weight))
         dx = _empty((B, h, w, bd.cout), x)
-        bd.run(E.f32_to_s3(s) if s3 else s, B, h, w, dx)
+        bd.run(E.f32_to_split(s, tape.fmt, tape.overflow) if s3 else s, B, h, w, dx)
         tape.add_grad(x, dx)
 
     tape.push(backward)
@@ -521,6 +590,7 @@ def run_forward(net, tape, x):
     """Reconstructor.forward (models/reconstructor.py:160-194) on the training kernels.
     -> dict: logits / uv / theta (B,9) / poi / warp_mask tensors, `heads` [(NCHW output, backward fn)]."""
     B, _, H, W = x.shape
+    tape.prepare_h2(net, B * H * W)
     mode = net.resnet_input.name
     nc = net.mask_classes
     f = {"logits": None, "uv": None, "theta": None, "poi": None, "warp_mask": None, "heads": [], "shared": False}
@@ -581,6 +651,28 @@ def run_backward(net, tape, f, dheads, dtheta):
     """dheads: gradients of the head outputs in the order of f['heads'] (None = zero); dtheta (B,9) or None.
     -> {state_dict key: gradient}.  ResNet closures run first (pushed last) and add the stem's gradient
     into the head gradients; then the heads; then the UNet."""
+    S = 1.0
+    if tape.fmt == "h2":
+        # the whole backward pass is linear in its seeds: carry it at a scale the H2 copies of the gradients can hold.
+        # The dense per-pixel gradient of the heads sets it: its largest element -> [2, 4); the pre-activation
+        # gradients of this model then peak at 1e2..1e3 (two to three orders of magnitude above the seeds at the last
+        # decoder layers, below them in the ResNet: tests/probes/train_grad_range_probe.py), inside the format's
+        # window (16376 down to an absolute floor of 2^-27).  Without a head (ResNet-only models) the gradient of
+        # theta does: -> [2^12, 2^13), the average pool divides it by the pixels of layer4 first.
+        import math
+        heads = [d for d in dheads if d is not None]
+        if heads:
+            m, target = max(float(d.abs().max()) for d in heads), 2
+        else:
+            m, target = (float(dtheta.abs().max()) if dtheta is not None else 0.0), 13
+        if not math.isfinite(m):
+            raise FP16RangeError("non-finite gradient at the outputs of the model")
+        if m > 0.0:
+            S = 2.0 ** (target - math.frexp(m)[1])       # m = f * 2^e, 0.5 <= f < 1  ->  m * S in [2^(target-1), 2^target)
+        tape.gscale = S
+    if S != 1.0:
+        dtheta = None if dtheta is None else dtheta * S
+        dheads = [None if d is None else d.mul_(S) for d in dheads]
     if f["theta"] is not None:
         tape.grads[id(f["theta"])] = dtheta if dtheta is not None else torch.zeros_like(f["theta"])
     for (t, _), d in zip(f["heads"], dheads):
@@ -594,6 +686,14 @@ def run_backward(net, tape, f, dheads, dtheta):
     for fn in reversed(ops[:k]):
         fn()
     g = tape.param_grads
+    if S != 1.0:
+        torch._foreach_mul_([t for t in g.values() if t is not None], 1.0 / S)
+    if tape.overflow is not None and int(tape.overflow.item()):
+        tape.ops, tape.param_grads = [], {}
+        tape.grads.clear()
+        tape._s3.clear()
+        raise FP16RangeError("training step with SFH_TRAIN_PRECISION=f16x3: an activation or gradient left the range of "
+                             "the two-plane fp16 format (or was not finite); use SFH_TRAIN_PRECISION=bf16x6 for this model")
     # the closures reference the tape and the tape the closures: break the cycle so the activations
     # are released now rather than at the next garbage collection
     tape.param_grads = {}
@@ -629,7 +729,22 @@ class _TrainForward(torch.autograd.Function):
     def forward(ctx, net, info, x, *params):
         tape = Tape()
         x = E._f32c(x.detach(), "input frames")
-        f = run_forward(net, tape, x)
+        if tape.fmt == "h2":
+            # the forward pass updates the BatchNorm statistics: keep a copy, so that a pass whose activations leave
+            # the fp16 range can be repeated with bf16x6 operands (a gradient that leaves it later, in backward(),
+            # raises FP16RangeError: the statistics of this step are then already the caller's)
+            snap = net.__dict__.get("_bn_snapshot")
+            if snap is None:
+                snap = net.__dict__["_bn_snapshot"] = _BNSnapshot(net)
+            snap.save()
+            f = run_forward(net, tape, x)
+            if int(tape.overflow.item()):
+                snap.restore()
+                _warn_range_fallback()
+                tape = Tape(fmt="s3")
+                f = run_forward(net, tape, x)
+        else:
+            f = run_forward(net, tape, x)
         B = x.shape[0]
         keys = [k for k in _OUT_KEYS if f[k] is not None]
         outs = [f[k].view(B, 1, 3, 3) if k == "theta" else f[k] for k in keys]
@@ -695,6 +810,8 @@ class TrainStep:
         self.rec_mse = 1 if rec_loss == "MSE" else 0
         self.consist_start_iter = consist_start_iter
         self.global_step = 0
+        self._bn_snapshot = None     # f16x3 only: copies of the BatchNorm statistics for a repeated step
+        self.range_fallbacks = 0     # steps repeated with bf16x6 because a value left the fp16 range
         self._init_optimizer([p for p in net.parameters()])
 
     def _init_optimizer(self, params):
@@ -781,14 +898,29 @@ class TrainStep:
     def loss_and_grads(self, x, batch):
         """forward + losses + backward; fills self.grads, returns a float64 device tensor of 4 values in the
         order [seg, rec, consist, reproj] (each already times its lambda).  batch: mask (B,H,W) int64, weight (B), poi (B,N,2),
-        nonzeros (B,N), num_nonzero (B)."""
+        nonzeros (B,N), num_nonzero (B).  With SFH_TRAIN_PRECISION=f16x3 a step whose activations or gradients leave
+        the fp16 range is repeated with bf16x6 operands from the same BatchNorm statistics (range_fallbacks counts)."""
+        if _train_fmt() != "h2":
+            return self._loss_and_grads(x, batch, "env")
+        if self._bn_snapshot is None:
+            self._bn_snapshot = _BNSnapshot(self.net)
+        self._bn_snapshot.save()
+        try:
+            return self._loss_and_grads(x, batch, "h2")
+        except FP16RangeError:
+            self._bn_snapshot.restore()
+            self.range_fallbacks += 1
+            _warn_range_fallback()
+            return self._loss_and_grads(x, batch, "s3")
+
+    def _loss_and_grads(self, x, batch, fmt):
         net, lib = self.net, _lib.load()
         if not net.training:
             raise RuntimeError("TrainStep: call net.train() first")
         if net.unet_uv or net.resnet_input.name != "IMG_AND_MASK" or not (net.use_unet and net.use_resnet and net.warper):
             raise NotImplementedError("TrainStep covers the reference's training configuration "
                                       "(UNet + ResNetSTN + warper, resnet_input='img+mask', no uv head)")
-        tape = Tape()
+        tape = Tape(fmt=fmt)
         B, _, H, W = x.shape
         x = E._f32c(x, "input frames")
         f = run_forward(net, tape, x)

@@ -234,7 +234,7 @@ def test_public_methods_direct():
     assert float((wb.cpu() - warp_ref.homography_warp(th, court, 360, 640, "bilinear")).abs().max()) < 1e-6
 
 
-@pytest.mark.parametrize("precision", ["bf16x6", "fp32"])  # training precisions
+@pytest.mark.parametrize("precision", ["f16x3", "bf16x6", "fp32"])  # training precisions
 def test_c3_training_step_640x360_vs_fp64_reference(precision, monkeypatch):
     """BASELINE config 3 at 640x360 (2 of the 16 frames): the reference classes under train() + autograd
     produced loss values and gradients in fp32 and in fp64 (oracle/make_fixtures.py:make_c3_golden).  The HIP

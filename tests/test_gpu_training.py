@@ -66,11 +66,13 @@ def test_wgrad_kernel_vs_autograd(T):
         assert _relerr(got, w.grad) < 2e-5
 
 
+@pytest.mark.parametrize("prec", ["bf16x6", "f16x3"])
 @pytest.mark.parametrize("shape", [(2, 11, 37), (1, 6, 70), (3, 9, 20), (2, 12, 8), (1, 40, 10)])
-def test_wgrad_s3_kernel_vs_fp64(T, shape):
+def test_wgrad_s3_kernel_vs_fp64(T, shape, prec, monkeypatch):
     """backward-filter on the bf16 matrix cores (split-bf16 operands, transposing LDS reads): two-source
     (concat + pad), all three tile shapes, partial tiles, against an fp64 reference and the fp32-MFMA kernel."""
     from sfh_amd import _lib, engine as E
+    monkeypatch.setenv("SFH_TRAIN_PRECISION", prec)
     lib = _lib.load()
     B, H, W = shape
     g = torch.Generator().manual_seed(5 + H)
@@ -86,7 +88,7 @@ def test_wgrad_s3_kernel_vs_fp64(T, shape):
     t0, t1, dzc = nh(x0), nh(x1), nh(dz)
     srcs = [(t0, 64, 0, 0, 0), (t1, 32, 64, pt, pl)]
     assert T.wgrad_s3_ok(3, 1, 128, srcs)
-    raw = T._wgrad_s3(lib, tape, E.f32_to_s3(dzc), 128, srcs, B, H, W, 96)
+    raw = T._wgrad_s3(lib, tape, E.f32_to_split(dzc, tape.fmt), 128, srcs, B, H, W, 96)
     ref32 = T._wgrad(lib, dzc, srcs, B, H, W, 3, 96)
     torch.cuda.synchronize()
     got = raw.view(128, 3, 3, 96).permute(0, 3, 1, 2)
@@ -151,7 +153,8 @@ def _nchw(t):
 @pytest.mark.parametrize("stride,ks,res", [(1, 3, False), (1, 3, True), (2, 3, False), (2, 1, False), (1, 1, True)])
 @pytest.mark.parametrize("shape", [(2, 13, 18), (3, 8, 40)])
 @pytest.mark.parametrize("seed", [20240917, 1063, 1092, 1094])
-def test_conv_bn_act_backward(T, stride, ks, res, shape, seed):
+@pytest.mark.parametrize("prec", ["bf16x6", "f16x3"])
+def test_conv_bn_act_backward(T, stride, ks, res, shape, seed, prec, monkeypatch):
     """conv (+bias) -> BatchNorm(train) (+residual) -> ReLU: outputs, input and parameter gradients.
 
     The conv's default initialisation draws from torch's global generator.  Round 1 saw this test fail once and
@@ -164,6 +167,7 @@ def test_conv_bn_act_backward(T, stride, ks, res, shape, seed):
     1e-4, and the three seeds that hit such an element stay in the parametrisation.  Every other run of the sweep
     was below 1.6e-6 against the 2e-5 bound."""
     B, H, W = shape
+    monkeypatch.setenv("SFH_TRAIN_PRECISION", prec)
     torch.manual_seed(seed)
     g = torch.Generator().manual_seed(11 + stride + ks)
     conv = torch.nn.Conv2d(64, 128, ks, stride=stride, padding=ks // 2, bias=(stride == 1))
@@ -210,9 +214,11 @@ def test_conv_bn_act_backward(T, stride, ks, res, shape, seed):
 
 
 
-def test_concat_pool_convT_backward(T):
+@pytest.mark.parametrize("prec", ["bf16x6", "f16x3"])
+def test_concat_pool_convT_backward(T, prec, monkeypatch):
     """One UNet level: skip -> max-pool -> conv/BN/ReLU -> transposed conv -> pad -> cat([skip, up]) ->
     conv/BN/ReLU, odd sizes (pad bottom 1), gradients of the skip tensor from both of its consumers."""
+    monkeypatch.setenv("SFH_TRAIN_PRECISION", prec)
     B, H, W = 2, 13, 22
     g = torch.Generator().manual_seed(23)
 
@@ -278,7 +284,8 @@ def test_warp_and_poi_backward_theta(T):
 
 
 # --------------------------------------------------------------------------------- whole model
-def test_full_training_forward_backward(T):
+@pytest.mark.parametrize("prec", ["bf16x6", "f16x3"])
+def test_full_training_forward_backward(T, prec, monkeypatch):
     """net.train(); preds = net(x); losses (train.py:181-224); loss.backward(): outputs, loss values and
     parameter gradients against torch autograd over the CPU oracle.  With batch-statistics BatchNorm the
     gradient is discontinuous in the forward rounding (a ReLU / max-pool decision that flips in a layer
@@ -286,6 +293,7 @@ def test_full_training_forward_backward(T):
     fp64 run on a few tensors; the per-tensor check is therefore statistical, and the exact per-layer
     checks above carry the tight tolerances."""
     from sfh_amd.reconstructor import Reconstructor
+    monkeypatch.setenv("SFH_TRAIN_PRECISION", prec)
     B, H, W = 4, 96, 128
     court = synth.load_court_template("ncaa_nc4_640x360", 4, B)[:, :, :H, :W].contiguous()
     poi = synth.load_court_poi("pitch", B)
@@ -375,7 +383,9 @@ def _dconv(T, tape, names, block, srcs, B, h, w):
     return T.conv_bn_act(tape, names, cv2, bn2, [(y1, y1.shape[3], 0, 0)], B, h, w)
 
 
-def test_training_blocks_vs_reference_golden(T, golden_train):
+@pytest.mark.parametrize("prec", ["bf16x6", "f16x3"])
+def test_training_blocks_vs_reference_golden(T, golden_train, prec, monkeypatch):
+    monkeypatch.setenv("SFH_TRAIN_PRECISION", prec)
     g = golden_train
 
     def dc(tape, names, m, xs):
@@ -489,10 +499,12 @@ def test_rmsprop_kernel_vs_torch(T):
         assert (p.detach().cpu() - r.detach()).abs().max().item() < 2e-6
 
 
-def test_train_step_on_hip_matches_autograd_path(T):
+@pytest.mark.parametrize("prec", ["bf16x6", "f16x3"])
+def test_train_step_on_hip_matches_autograd_path(T, prec, monkeypatch):
     """TrainStep (losses + backward without torch autograd) against net(x) + torch losses + autograd -
     both on the same HIP forward/backward kernels - and the loss goes down over a few steps."""
     from sfh_amd.reconstructor import Reconstructor
+    monkeypatch.setenv("SFH_TRAIN_PRECISION", prec)
     B, H, W = 4, 96, 128
     court = synth.load_court_template("ncaa_nc4_640x360", 4, B)[:, :, :H, :W].contiguous().cuda()
     poi = synth.load_court_poi("pitch", B).cuda()
@@ -783,3 +795,43 @@ def test_predict_after_train_steps_uses_fresh_weights(T):
     ts.step(x, batch)
     torch.cuda.synchronize()
     assert not torch.equal(p0.detach(), w_before)             # the NEW storage was updated
+
+
+def test_train_step_f16x3_range_fallback(T, monkeypatch):
+    """SFH_TRAIN_PRECISION=f16x3: a step whose activations leave the fp16 range (first BatchNorm scaled by 2^16, the
+    next conv divided by it) is repeated with bf16x6 operands FROM THE SAME BatchNorm statistics: losses, gradients
+    and running statistics equal those of a plain bf16x6 step; an ordinary model does not fall back."""
+    from sfh_amd.reconstructor import Reconstructor
+    B, H, W = 2, 64, 96
+    court = synth.load_court_template("ncaa_nc4_640x360", 4, B)[:, :, :H, :W].contiguous().cuda()
+    poi = synth.load_court_poi("pitch", B).cuda()
+    g = torch.Generator().manual_seed(7)
+    x = synth.frames_to_float(synth.synth_frames_u8(B, H, W, seed=7)).cuda()
+    batch = {"mask": torch.randint(0, 4, (B, H, W), generator=g).cuda(), "weight": torch.ones(B).cuda(),
+             "poi": torch.rand(B, poi.shape[1], 2, generator=g).cuda(), "nonzeros": torch.ones(B, poi.shape[1]).cuda()}
+    batch["num_nonzero"] = batch["nonzeros"].sum(1)
+
+    def run(prec, blow_up):
+        monkeypatch.setenv("SFH_TRAIN_PRECISION", prec)
+        net = Reconstructor(court, poi, target_size=(W, H), unet_size=(W, H), warp_size=(W, H))
+        sd = synth.synth_state_dict(net.state_dict(), 7)
+        if blow_up:
+            sd["inc.double_conv.1.weight"] = sd["inc.double_conv.1.weight"] * 65536.0
+            sd["inc.double_conv.1.bias"] = sd["inc.double_conv.1.bias"] * 65536.0
+        net.load_state_dict(sd)
+        net.cuda().train()
+        ts = T.TrainStep(net, lr=1e-5, weight_decay=1e-8, seg_lambda=1.0, rec_lambda=1.0, reproj_lambda=1.0, consist_lambda=1.0)
+        losses = ts.loss_and_grads(x, batch)
+        torch.cuda.synchronize()
+        return losses.clone(), ts.gflat.clone(), {k: v.clone() for k, v in net.state_dict().items() if "running" in k or "tracked" in k}, ts
+
+    l0, g0, b0, ts0 = run("f16x3", False)
+    assert ts0.range_fallbacks == 0
+    with pytest.warns(UserWarning, match="fp16 range"):
+        l1, g1, b1, ts1 = run("f16x3", True)
+    assert ts1.range_fallbacks == 1
+    l2, g2, b2, _ = run("bf16x6", True)
+    # (split-K / reduction atomics make two runs of the same step differ in the last bits)
+    assert torch.allclose(l1, l2, rtol=1e-6, atol=0) and _relerr(g1, g2) < 1e-4
+    for k in b1:      # a step repeated WITHOUT the restored statistics would have moved them twice (momentum 0.1)
+        assert torch.allclose(b1[k].double(), b2[k].double(), rtol=1e-5, atol=1e-7), k
