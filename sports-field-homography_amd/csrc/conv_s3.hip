@@ -543,10 +543,10 @@ __global__ void pack_s3_weights_kernel(const float* __restrict__ w, unsigned sho
 // OIHW, mode 3: backward-data = channels swapped + taps flipped), 3x3 and 1x1: one thread = (cout, 8 cins) for
 // ALL taps, so that it reads whole contiguous runs of the checkpoint tensor (72 floats in mode 0, nine floats
 // per cin in mode 3) instead of one float every 36 bytes (the per-tap kernel above moved 0.5 TB/s).
-template <int KS, int MODE>
+template <int KS, int MODE, int NP>
 __global__ __launch_bounds__(256) void pack_s3_weights_alltaps_kernel(const float* __restrict__ w,
                                                                       unsigned short* __restrict__ packed, int c0, int c1,
-                                                                      int coutv, int aux, long total) {
+                                                                      int coutv, int aux, long total, float wscale) {
   constexpr int NT = KS * KS;
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;  // (nb, st, ng, lane)
   if (idx >= total) return;
@@ -584,18 +584,26 @@ __global__ __launch_bounds__(256) void pack_s3_weights_alltaps_kernel(const floa
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const float x = v[j][t];
-      const __bf16 v0 = (__bf16)x;
-      const float r1 = x - (float)v0;
-      const __bf16 v1 = (__bf16)r1;
-      const __bf16 v2 = (__bf16)(r1 - (float)v1);
-      p0[j] = __builtin_bit_cast(unsigned short, v0);
-      p1[j] = __builtin_bit_cast(unsigned short, v1);
-      p2[j] = __builtin_bit_cast(unsigned short, v2);
+      if constexpr (NP == 3) {
+        const __bf16 v0 = (__bf16)x;
+        const float r1 = x - (float)v0;
+        const __bf16 v1 = (__bf16)r1;
+        const __bf16 v2 = (__bf16)(r1 - (float)v1);
+        p0[j] = __builtin_bit_cast(unsigned short, v0);
+        p1[j] = __builtin_bit_cast(unsigned short, v1);
+        p2[j] = __builtin_bit_cast(unsigned short, v2);
+      } else {   // two fp16 planes of w * wscale (as pack_s3_weights_kernel<2>)
+        const float u = fminf(fmaxf(x * wscale, -65504.f), 65504.f);
+        const _Float16 h0 = (_Float16)u;
+        const _Float16 h1 = (_Float16)(u - (float)h0);
+        p0[j] = __builtin_bit_cast(unsigned short, h0);
+        p1[j] = __builtin_bit_cast(unsigned short, h1);
+      }
     }
-    const long base = ((((long)nb * nst + st) * NT + t) * 3) * 4096 + (long)ng * 1024 + lane * 16;  // bytes
+    const long base = ((((long)nb * nst + st) * NT + t) * NP) * 4096 + (long)ng * 1024 + lane * 16;  // bytes
     *reinterpret_cast<u16x8*>(packed + (base + 0 * 4096) / 2) = p0;
     *reinterpret_cast<u16x8*>(packed + (base + 1 * 4096) / 2) = p1;
-    *reinterpret_cast<u16x8*>(packed + (base + 2 * 4096) / 2) = p2;
+    if constexpr (NP == 3) *reinterpret_cast<u16x8*>(packed + (base + 2 * 4096) / 2) = p2;
   }
 }
 
@@ -776,9 +784,9 @@ extern "C" int sfh_pack_s3_weights(const float* w, void* packed, int ksize, int 
   if ((mode == 0 || mode == 3) && (ksize == 3 || ksize == 1)) {
     const long tot = n / 48 / (ksize * ksize);   // one thread per (cout, 8 cins), all taps
     const dim3 grid((unsigned)((tot + 255) / 256));
-#define SFH_PACK_AT(KS_, M_)                                                                                  \
-  hipLaunchKernelGGL((pack_s3_weights_alltaps_kernel<KS_, M_>), grid, dim3(256), 0, (hipStream_t)stream, w,   \
-                     (unsigned short*)packed, c0, c1, cout_virtual, aux, tot)
+#define SFH_PACK_AT(KS_, M_)                                                                                     \
+  hipLaunchKernelGGL((pack_s3_weights_alltaps_kernel<KS_, M_, 3>), grid, dim3(256), 0, (hipStream_t)stream, w,   \
+                     (unsigned short*)packed, c0, c1, cout_virtual, aux, tot, 1.f)
     if (ksize == 3 && mode == 0) SFH_PACK_AT(3, 0);
     else if (ksize == 3) SFH_PACK_AT(3, 3);
     else if (mode == 0) SFH_PACK_AT(1, 0);
@@ -808,6 +816,20 @@ extern "C" int sfh_pack_h2_weights(const float* w, void* packed, int ksize, int 
                   (mode == 3 && c1 == 0 && (ksize == 1 || ksize == 3) && aux > 0 && aux <= cout_virtual) ||
                   (mode == 4 && ksize == 1 && c1 == 0 && aux > 0 && c0 == 4 * aux),
               "pack_h2_weights: bad mode/geometry (mode %d, ksize %d)", mode, ksize);
+  if ((mode == 0 || mode == 3) && (ksize == 3 || ksize == 1)) {   // whole runs of the checkpoint tensor per thread
+    const long tot = n / 32 / (ksize * ksize);
+    const dim3 grid((unsigned)((tot + 255) / 256));
+    const float wscale = ldexpf(1.f, wexp);
+#define SFH_PACK_AT(KS_, M_)                                                                                     \
+  hipLaunchKernelGGL((pack_s3_weights_alltaps_kernel<KS_, M_, 2>), grid, dim3(256), 0, (hipStream_t)stream, w,   \
+                     (unsigned short*)packed, c0, c1, cout_virtual, aux, tot, wscale)
+    if (ksize == 3 && mode == 0) SFH_PACK_AT(3, 0);
+    else if (ksize == 3) SFH_PACK_AT(3, 3);
+    else if (mode == 0) SFH_PACK_AT(1, 0);
+    else SFH_PACK_AT(1, 3);
+#undef SFH_PACK_AT
+    return sfh_check_launch("pack_h2_weights_alltaps_kernel");
+  }
   const long total = n / 32;  // one thread per (lane, 8 channels) of both planes
   hipLaunchKernelGGL(pack_s3_weights_kernel<2>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
                      (hipStream_t)stream, w, (unsigned short*)packed, ksize, c0, c1, cout_virtual, mode, aux, total,

@@ -190,7 +190,7 @@ class PackedConv:
     order = None   # LaunchOrder of the owning engine (set by the engine); None = always forward
 
     def __init__(self, weight, bias, bn, ksize, c0, c1=0, relu=True, transposed=False, stride=1,
-                 stem_cin=0, tag="conv", s3=False, fmt=None, wexp=None):
+                 stem_cin=0, tag="conv", s3=False, fmt=None, wexp=None, shared_unit_scale=False):
         """fmt="s3" (or s3=True): sources are split-bf16 (S3) tensors and the contraction runs as six bf16 MFMAs
         per product; fmt="h2": two-plane fp16 (H2) sources, three fp16 MFMAs per product (both sfh_conv_s3_fwd);
         otherwise fp32 sources and fp32 MFMA (sfh_conv_fwd)."""
@@ -241,9 +241,16 @@ class PackedConv:
             self.wpacked = torch.empty(n, dtype=torch.float32, device=dev)
             _lib.check(lib.sfh_pack_conv_weights(_ptr(w), _ptr(self.wpacked), ksize, c0, c1, self.cout,
                                                  mode, aux, _stream()), "pack_conv_weights")
+        b = _f32c(bias.detach(), "conv bias") if bias is not None else None
+        if shared_unit_scale and bn is None:
+            # training convs (one PackedConv per layer and step): no BatchNorm to fold - the scale is the layer's
+            # power-of-two factor times ones, shared read-only between all layers of that size, the shift the bias
+            # itself: no kernel launch here (a step builds 114 of these objects)
+            self.scale, zeros = _unit_epilogue(self.cout, dev, self.escale)
+            self.shift = zeros if b is None else (b if rep == 1 else b.repeat(rep))
+            return
         self.scale = torch.empty(self.cout, dtype=torch.float32, device=dev)
         self.shift = torch.empty(self.cout, dtype=torch.float32, device=dev)
-        b = _f32c(bias.detach(), "conv bias") if bias is not None else None
         if bn is not None:
             args = [_f32c(t.detach(), "bn tensor") for t in (bn.weight, bn.bias, bn.running_mean, bn.running_var)]
             eps = float(bn.eps)

@@ -265,7 +265,7 @@ def conv_bn_act(tape, names, conv, bn, srcs, B, H, W, relu=True, residual=None, 
     t1, c1 = (srcs[1][0], srcs[1][1]) if len(srcs) > 1 else (None, 0)
     s3 = tape.use_s3 and c0 % 32 == 0 and c1 % 32 == 0 and c0 == t0.shape[3] and (t1 is None or c1 == t1.shape[3])
     pc = PackedConv(w, conv.bias, None, ks, c0, c1, relu=False, stride=stride, tag="train_fwd",
-                    fmt=tape.fmt if s3 else None, wexp=tape.wexp_of(conv.weight))
+                    fmt=tape.fmt if s3 else None, wexp=tape.wexp_of(conv.weight), shared_unit_scale=True)
     pc.order = tape.order
     pc.overflow = tape.overflow
     ho, wo = (H - 1) // stride + 1, (W - 1) // stride + 1
@@ -355,7 +355,7 @@ def conv_transpose2x2(tape, names, up, x):
     cout = wt.shape[1]
     s3 = tape.use_s3 and cin % 32 == 0
     pc = PackedConv(wt, up.bias, None, 1, cin, relu=False, transposed=True, tag="train_fwd",
-                    fmt=tape.fmt if s3 else None, wexp=tape.wexp_of(up.weight))
+                    fmt=tape.fmt if s3 else None, wexp=tape.wexp_of(up.weight), shared_unit_scale=True)
     u = _empty((B, 2 * h, 2 * w, cout), x)
     pc.run(tape.s3(x) if s3 else x, B, h, w, u)
 
