@@ -306,16 +306,16 @@ int sfh_bn_finalize(const double* acc, int64_t npix, int C, float eps, float mom
 int sfh_bn_apply(const float* z, const float* mean_invstd, const float* gamma, const float* beta,
                  const float* residual, int relu, int64_t npix, int C, float* y, void* y_s3, int W,
                  int split_fmt, uint32_t* overflow, void* stream);
-/* backward of bn_apply: with g = dy * (y > 0) (or dy when relu == 0), acc[0][c] += sum g,
+/* backward of bn_apply: with g = dy * (y > 0) (or dy when relu == 0; y == NULL with relu: the layer has no residual and
+ * the sign of y is recomputed from z, gamma, beta - 8 instead of 12 bytes read per element), acc[0][c] += sum g,
  * acc[1][c] += sum g * xhat  (= dbeta, dgamma);  then
  * dz = gamma * invstd * (g - acc[0]/N - xhat * acc[1]/N), and dres = g (gradient of the residual
  * branch, optional).                                                                              */
-int sfh_bn_bwd_reduce(const float* dy, const float* y, const float* z, const float* mean_invstd, int relu,
-                      int64_t npix, int C, double* acc, void* stream);
+int sfh_bn_bwd_reduce(const float* dy, const float* y, const float* z, const float* mean_invstd,
+                      const float* gamma, const float* beta, int relu, int64_t npix, int C, double* acc, void* stream);
 int sfh_bn_bwd_apply(const float* dy, const float* y, const float* z, const float* mean_invstd,
-                     const float* gamma, const double* acc, int relu, int64_t npix, int C, float* dz,
-                     float* dres, void* dz_s3, int W, int split_fmt, uint32_t* overflow,
-                     void* stream);   /* dz_s3: optional split copy of dz (split_fmt, overflow: as sfh_bn_apply) */
+                     const float* gamma, const float* beta, const double* acc, int relu, int64_t npix, int C,
+                     float* dz, float* dres, void* dz_s3, int W, int split_fmt, uint32_t* overflow, void* stream);   /* dz_s3: optional split copy of dz (split_fmt, overflow: as sfh_bn_apply) */
 /* acc[c] += sum_p x[p][c] over a channel slice of a (npix, cs) tensor: conv / transposed-conv bias
  * gradients.                                                                                       */
 int sfh_colsum(const float* x, int64_t npix, int C, int cs, double* acc, void* stream);

@@ -77,9 +77,9 @@ SIGNATURES = {
     "sfh_bn_stats": (C.c_int, [_p, C.c_int64, C.c_int, _p, _p]),
     "sfh_bn_finalize": (C.c_int, [_p, C.c_int64, C.c_int, C.c_float, C.c_float, _p, _p, _p, _p]),
     "sfh_bn_apply": (C.c_int, [_p, _p, _p, _p, _p, C.c_int, C.c_int64, C.c_int, _p, _p, C.c_int, C.c_int, _p, _p]),
-    "sfh_bn_bwd_reduce": (C.c_int, [_p, _p, _p, _p, C.c_int, C.c_int64, C.c_int, _p, _p]),
-    "sfh_bn_bwd_apply": (C.c_int, [_p, _p, _p, _p, _p, _p, C.c_int, C.c_int64, C.c_int, _p, _p, _p, C.c_int, C.c_int, _p,
-                                   _p]),
+    "sfh_bn_bwd_reduce": (C.c_int, [_p, _p, _p, _p, _p, _p, C.c_int, C.c_int64, C.c_int, _p, _p]),
+    "sfh_bn_bwd_apply": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, C.c_int, C.c_int64, C.c_int, _p, _p, _p, C.c_int, C.c_int,
+                                   _p, _p]),
     "sfh_colsum": (C.c_int, [_p, C.c_int64, C.c_int, C.c_int, _p, _p]),
     "sfh_maxpool2_fwd": (C.c_int, [_p, _p, C.c_int, C.c_int, C.c_int, C.c_int, _p]),
     "sfh_maxpool2_bwd": (C.c_int, [_p, _p, _p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _p]),

@@ -159,9 +159,14 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
 }
 
 // g = dy * (y > 0 if relu); sums: [0] = sum g, [1] = sum g * xhat
+// relu with y == nullptr: the layer has no residual, so the ReLU decision y > 0 is recomputed from z with the
+// arithmetic of bn_apply ((z - mean) * invstd * gamma + beta, same operation order => same bits) instead of
+// reading y: 8 instead of 12 bytes per element.
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ dy, const float* __restrict__ y,
                                                             const float* __restrict__ z, const float* __restrict__ mi,
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
                                                             int relu, long npix, int C, double* __restrict__ acc) {
+  const bool sign_from_z = relu && !y;
   __shared__ double sh[256];
   for (int c0 = 0; c0 < C; c0 += 1024) {
     const int cq = min(1024, C - c0) >> 2;
@@ -171,16 +176,21 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
     if (pl < lanes) {
       const long stride = (long)gridDim.x * lanes;
       long p = (long)blockIdx.x * lanes + pl;
-      float mean[4], invstd[4];
+      float mean[4], invstd[4], gam[4] = {1.f, 1.f, 1.f, 1.f}, bet[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         mean[j] = mi[c0 + 4 * q + j];
         invstd[j] = mi[C + c0 + 4 * q + j];
+        if (sign_from_z) {
+          gam[j] = gamma[c0 + 4 * q + j];
+          bet[j] = beta[c0 + 4 * q + j];
+        }
       }
       auto add = [&](const f32x4& g, const f32x4& zz, const f32x4& yy) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          const float gj = yy[j] > 0.f ? g[j] : 0.f;
+          const float yv = sign_from_z ? (zz[j] - mean[j]) * invstd[j] * gam[j] + bet[j] : yy[j];
+          const float gj = yv > 0.f ? g[j] : 0.f;
           const float xh = (zz[j] - mean[j]) * invstd[j];
           s0[j] += (double)gj;
           s1[j] += (double)gj * (double)xh;
@@ -192,7 +202,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
         const f32x4 g0 = *reinterpret_cast<const f32x4*>(dy + o0), g1 = *reinterpret_cast<const f32x4*>(dy + o1);
         const f32x4 z0 = *reinterpret_cast<const f32x4*>(z + o0), z1 = *reinterpret_cast<const f32x4*>(z + o1);
         f32x4 y0 = {1.f, 1.f, 1.f, 1.f}, y1 = {1.f, 1.f, 1.f, 1.f};
-        if (relu) {
+        if (relu && y) {
           y0 = *reinterpret_cast<const f32x4*>(y + o0);
           y1 = *reinterpret_cast<const f32x4*>(y + o1);
         }
@@ -202,7 +212,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
       for (; p < npix; p += stride) {
         const long o = p * C + c0 + 4 * q;
         f32x4 yy = {1.f, 1.f, 1.f, 1.f};
-        if (relu) yy = *reinterpret_cast<const f32x4*>(y + o);
+        if (relu && y) yy = *reinterpret_cast<const f32x4*>(y + o);
         add(*reinterpret_cast<const f32x4*>(dy + o), *reinterpret_cast<const f32x4*>(z + o), yy);
       }
     }
@@ -225,14 +235,19 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                                                            const float* __restrict__ z, const float* __restrict__ mi,
                                                            const float* __restrict__ gamma, const double* __restrict__ acc,
                                                            int relu, long npix, long total4, int C,
-                                                           float* __restrict__ dz, float* __restrict__ dres) {
+                                                           float* __restrict__ dz, float* __restrict__ dres,
+                                                           const float* __restrict__ beta) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   if (i >= total4) return;
   const int c = (int)((i * 4) % C);
   const f32x4 g4 = reinterpret_cast<const f32x4*>(dy)[i];
   const f32x4 zz = reinterpret_cast<const f32x4*>(z)[i];
   f32x4 yy = {1.f, 1.f, 1.f, 1.f};
-  if (relu) yy = reinterpret_cast<const f32x4*>(y)[i];
+  if (relu && y) yy = reinterpret_cast<const f32x4*>(y)[i];
+  if (relu && !y) {   // sign recomputed from z (see bn_bwd_reduce_kernel)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) yy[j] = (zz[j] - mi[c + j]) * mi[C + c + j] * gamma[c + j] + beta[c + j];
+  }
   const float inv_n = 1.0f / (float)npix;
   f32x4 o, gg;
 #pragma unroll
@@ -346,7 +361,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_s3_kernel(const float* __res
                                                               const float* __restrict__ gamma, const double* __restrict__ acc,
                                                               int relu, long npix, int W, int C, int xchunks, long total,
                                                               float* __restrict__ dz, float* __restrict__ dres,
-                                                              unsigned short* __restrict__ dz_s3, unsigned* __restrict__ overflow) {
+                                                              unsigned short* __restrict__ dz_s3, unsigned* __restrict__ overflow,
+                                                              const float* __restrict__ beta) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   if (i >= total) return;
   long row; int x, c0;
@@ -359,7 +375,14 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_s3_kernel(const float* __res
     const f32x4 g4 = *reinterpret_cast<const f32x4*>(dy + o + 4 * h);
     const f32x4 zz = *reinterpret_cast<const f32x4*>(z + o + 4 * h);
     f32x4 yy = {1.f, 1.f, 1.f, 1.f};
-    if (relu) yy = *reinterpret_cast<const f32x4*>(y + o + 4 * h);
+    if (relu && y) yy = *reinterpret_cast<const f32x4*>(y + o + 4 * h);
+    if (relu && !y) {   // sign recomputed from z (see bn_bwd_reduce_kernel)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int c = c0 + 4 * h + j;
+        yy[j] = (zz[j] - mi[c]) * mi[C + c] * gamma[c] + beta[c];
+      }
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int c = c0 + 4 * h + j;
@@ -1015,20 +1038,22 @@ extern "C" int sfh_bn_apply(const float* z, const float* mean_invstd, const floa
 }
 
 extern "C" int sfh_bn_bwd_reduce(const float* dy, const float* y, const float* z, const float* mean_invstd,
-                                 int relu, int64_t npix, int C, double* acc, void* stream) {
-  SFH_REQUIRE(dy && z && mean_invstd && acc && (y || !relu) && npix > 0 && C > 0 && C % 4 == 0,
-              "bn_bwd_reduce: bad argument");
+                                 const float* gamma, const float* beta, int relu, int64_t npix, int C, double* acc,
+                                 void* stream) {
+  SFH_REQUIRE(dy && z && mean_invstd && acc && (y || !relu || (gamma && beta)) && npix > 0 && C > 0 && C % 4 == 0,
+              "bn_bwd_reduce: bad argument (relu needs y, or gamma and beta to recompute its sign from z)");
   const unsigned nb = red_grid((long)npix);
-  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, dy, y, z, mean_invstd, relu,
-                     (long)npix, C, acc);
+  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, dy, y, z, mean_invstd, gamma,
+                     beta, relu, (long)npix, C, acc);
   return sfh_check_launch("bn_bwd_reduce_kernel");
 }
 
 extern "C" int sfh_bn_bwd_apply(const float* dy, const float* y, const float* z, const float* mean_invstd,
-                                const float* gamma, const double* acc, int relu, int64_t npix, int C, float* dz,
-                                float* dres, void* dz_s3, int W, int split_fmt, uint32_t* overflow, void* stream) {
-  SFH_REQUIRE(dy && z && mean_invstd && gamma && acc && dz && (y || !relu) && npix > 0 && C > 0 && C % 4 == 0,
-              "bn_bwd_apply: bad argument");
+                                const float* gamma, const float* beta, const double* acc, int relu, int64_t npix, int C,
+                                float* dz, float* dres, void* dz_s3, int W, int split_fmt, uint32_t* overflow,
+                                void* stream) {
+  SFH_REQUIRE(dy && z && mean_invstd && gamma && acc && dz && (y || !relu || beta) && npix > 0 && C > 0 && C % 4 == 0,
+              "bn_bwd_apply: bad argument (relu needs y, or beta to recompute its sign from z)");
   if (dz_s3) {
     SFH_REQUIRE(C % 32 == 0 && W > 0 && npix % W == 0, "bn_bwd_apply: the split copy needs C %% 32 == 0 and npix = rows * W");
     SFH_REQUIRE(split_fmt == SFH_FMT_S3 || split_fmt == SFH_FMT_H2, "bn_bwd_apply: split_fmt=%d (S3 or H2)", split_fmt);
@@ -1037,15 +1062,15 @@ extern "C" int sfh_bn_bwd_apply(const float* dy, const float* y, const float* z,
     const dim3 grid((unsigned)((total + 255) / 256));
     if (split_fmt == SFH_FMT_H2)
       hipLaunchKernelGGL(bn_bwd_apply_s3_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, dy, y, z, mean_invstd, gamma,
-                         acc, relu, (long)npix, W, C, xchunks, total, dz, dres, (unsigned short*)dz_s3, overflow);
+                         acc, relu, (long)npix, W, C, xchunks, total, dz, dres, (unsigned short*)dz_s3, overflow, beta);
     else
       hipLaunchKernelGGL(bn_bwd_apply_s3_kernel<3>, grid, dim3(256), 0, (hipStream_t)stream, dy, y, z, mean_invstd, gamma,
-                         acc, relu, (long)npix, W, C, xchunks, total, dz, dres, (unsigned short*)dz_s3, overflow);
+                         acc, relu, (long)npix, W, C, xchunks, total, dz, dres, (unsigned short*)dz_s3, overflow, beta);
     return sfh_check_launch("bn_bwd_apply_s3_kernel");
   }
   const long total4 = (long)npix * C / 4;
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                     dy, y, z, mean_invstd, gamma, acc, relu, (long)npix, total4, C, dz, dres);
+                     dy, y, z, mean_invstd, gamma, acc, relu, (long)npix, total4, C, dz, dres, beta);
   return sfh_check_launch("bn_bwd_apply_kernel");
 }
 

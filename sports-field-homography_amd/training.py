@@ -189,15 +189,20 @@ def _bn_forward(lib, z, bn, relu, residual, tape, want_s3=True):
 
 
 def _bn_backward(lib, tape, dy, y, z, mi, bn, relu, want_dres, want_s3=False):
+    """want_dres: the layer added a residual before its ReLU (its gradient is returned as dres)."""
     B, H, W, C = z.shape
     npix = B * H * W
     acc = tape.zeros((2 * C,), z, torch.float64)
-    _lib.check(lib.sfh_bn_bwd_reduce(_ptr(dy), _ptr(y), _ptr(z), _ptr(mi), 1 if relu else 0, npix, C, _ptr(acc),
-                                     _stream()), "bn_bwd_reduce")
+    # without a residual the ReLU decision y > 0 is a function of z alone: the kernels recompute it (same arithmetic as
+    # bn_apply) instead of reading y - 8 instead of 12 bytes per element in the reduction, 16 instead of 20 in the apply
+    ysign = y if (relu and want_dres) else None
+    gam, bet = bn.weight.detach(), bn.bias.detach()
+    _lib.check(lib.sfh_bn_bwd_reduce(_ptr(dy), _ptr(ysign), _ptr(z), _ptr(mi), _ptr(gam), _ptr(bet), 1 if relu else 0,
+                                     npix, C, _ptr(acc), _stream()), "bn_bwd_reduce")
     dz = _empty(z.shape, z)
     dres = _empty(z.shape, z) if want_dres else None
     dz_s3 = E.split_empty(tape.fmt, B, H, W, C, z.device) if (want_s3 and C % 32 == 0) else None
-    _lib.check(lib.sfh_bn_bwd_apply(_ptr(dy), _ptr(y), _ptr(z), _ptr(mi), _ptr(bn.weight.detach()), _ptr(acc),
+    _lib.check(lib.sfh_bn_bwd_apply(_ptr(dy), _ptr(ysign), _ptr(z), _ptr(mi), _ptr(gam), _ptr(bet), _ptr(acc),
                                     1 if relu else 0, npix, C, _ptr(dz), _ptr(dres), _ptr(dz_s3), W, tape.fmt_code,
                                     _ptr(tape.overflow), _stream()), "bn_bwd_apply")
     a = acc.to(torch.float32)
