@@ -189,7 +189,8 @@ def extra_configs(args):
     a.batch, a.width, a.height, a.steps, a.warmup, a.train_autograd = 16, 640, 360, 4, 2, False
     t = train_bench(a)
     res["C3_train_step_640x360_batch16"] = {k: t[k] for k in ("value", "unit", "ms_per_step", "steps", "warmup", "dtype",
-                                                              "losses_and_optimizer", "peak_mem_gib", "final_loss")}
+                                                              "losses_and_optimizer", "peak_mem_gib", "final_loss",
+                                                              "range_fallbacks")}
     res["C3_train_step_640x360_batch16"]["workload"] = t["config"]["workload"]
     return res
 
