@@ -953,9 +953,11 @@ class TrainStep:
                                        self.lam["reproj"], _ptr(dpoi), ctypes.c_void_p(losses.data_ptr() + 24), st),
                    "reproj_loss")
         g = run_backward(net, tape, f, [dlogits], theta_gradient(net, f, None, dpoi, dwarp))
+        srcs = []
         for p, dst in zip(self.params, self.grads):
             src = g[self.names(p)]
-            dst.copy_(src if tuple(src.shape) == tuple(dst.shape) else src.reshape(dst.shape))   # strided views copy in one pass
+            srcs.append(src if tuple(src.shape) == tuple(dst.shape) else src.reshape(dst.shape))
+        torch._foreach_copy_(self.grads, srcs)     # multi-tensor copy instead of 182 launches
         return losses
 
     def step(self, x, batch):
