@@ -1,8 +1,10 @@
 """Per-layer table from a rocprofv3 --kernel-trace CSV of bench.py (last step of the run).
 usage: python profiles/layer_table.py <kernel_trace.csv> [batch]"""
-import csv, re, sys
-rows = list(csv.DictReader(open(sys.argv[1])))
-B = int(sys.argv[2]) if len(sys.argv) > 2 and sys.argv[2].isdigit() else 16
+import csv, os, re, sys
+# several traces may be given (gpurun merges every call's files into the local directory): the newest one counts
+paths = [a for a in sys.argv[1:] if a.endswith(".csv")]
+rows = list(csv.DictReader(open(max(paths, key=os.path.getmtime))))
+B = int(sys.argv[-1]) if len(sys.argv) > 2 and sys.argv[-1].isdigit() else 16
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
 idx = [i for i, r in enumerate(rows) if 'nchw_to_nhwc' in r['Kernel_Name']]
 step = rows[idx[-1]:]

@@ -7,7 +7,8 @@ import sys
 
 tag = sys.argv[1] if len(sys.argv) > 1 else "r02h"
 nsteps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
-f = glob.glob(f"gpurun_out/{tag}_train_trace/*/*_kernel_trace.csv")[0]
+import os
+f = max(glob.glob(f"gpurun_out/{tag}_train_trace/*/*_kernel_trace.csv"), key=os.path.getmtime)   # newest (gpurun merges)
 rows = list(csv.DictReader(open(f)))
 agg = collections.OrderedDict()
 for r in rows:
@@ -24,7 +25,7 @@ for k, (n, ms) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:32]:
 g = glob.glob(f"gpurun_out/{tag}_train_mfma/*/*_counter_collection.csv")
 if g:
     c = collections.defaultdict(lambda: collections.defaultdict(float))
-    for r in csv.DictReader(open(g[0])):
+    for r in csv.DictReader(open(max(g, key=os.path.getmtime))):
         n = r["Kernel_Name"]
         key = "conv_s3_kernel" if "conv_s3_kernel" in n else "wgrad_s3_kernel" if "wgrad_s3_kernel" in n else "wgrad_kernel (fp32)" if "wgrad_kernel" in n else "conv_mfma_kernel (fp32)" if "conv_mfma" in n else None
         if key:
