@@ -224,6 +224,7 @@ class Reconstructor(nn.Module):
         st = self.__dict__.copy()
         st["_engines"] = st["_engine_stamp"] = st["_tmpl_shared"] = st["_h2_overflow"] = None
         st.pop("_stamp_tensors", None)
+        st.pop("_bn_snapshot", None)       # training: copies of the BatchNorm statistics (training._BNSnapshot)
         st["_engines_by_precision"] = {}
         return st
 
