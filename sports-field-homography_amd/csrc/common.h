@@ -30,6 +30,11 @@ static inline int sfh_check_launch(const char* what) {
 
 static inline int sfh_cdiv(int a, int b) { return (a + b - 1) / b; }
 
+// ReLU and max with torch's NaN behaviour (relu(NaN) = NaN, max_pool propagates NaN): v_max_f32 would return the other
+// operand.  A non-finite input frame then produces non-finite outputs, as it does in the reference.
+__device__ __forceinline__ float sfh_relu(float v) { return v < 0.f ? 0.f : v; }
+__device__ __forceinline__ float sfh_max_nan(float a, float b) { return (a > b || a != a) ? a : b; }
+
 // Kernels that use more than 64 KB of dynamic LDS need hipFuncAttributeMaxDynamicSharedMemorySize raised once
 // per (kernel instance, device).  The template parameter gives every call site its own flag word; bit d of it
 // records device d.  The only process-wide state of the library besides the last-error string: idempotent,

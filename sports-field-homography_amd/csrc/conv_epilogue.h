@@ -228,7 +228,7 @@ __device__ __forceinline__ void sfh_conv_epilogue(const sfh_conv_desc& d, const 
       }
       if (d.relu) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
+        for (int j = 0; j < 4; ++j) v[j] = sfh_relu(v[j]);
       }
       acc[ni][mi] = v;
       if (h2) {
@@ -283,14 +283,14 @@ __device__ __forceinline__ void sfh_conv_epilogue(const sfh_conv_desc& d, const 
         f32x4 m = acc[ni][mi];
         if (CFG::SH == 2) {
 #pragma unroll
-          for (int j = 0; j < 4; ++j) m[j] = fmaxf(m[j], __shfl_xor(m[j], 8));
+          for (int j = 0; j < 4; ++j) m[j] = sfh_max_nan(m[j], __shfl_xor(m[j], 8));
         } else {
           const f32x4 o = acc[ni][mi + VSTEP < MT ? mi + VSTEP : mi];
 #pragma unroll
-          for (int j = 0; j < 4; ++j) m[j] = fmaxf(m[j], o[j]);
+          for (int j = 0; j < 4; ++j) m[j] = sfh_max_nan(m[j], o[j]);
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) m[j] = fmaxf(m[j], __shfl_xor(m[j], 1));
+        for (int j = 0; j < 4; ++j) m[j] = sfh_max_nan(m[j], __shfl_xor(m[j], 1));
         const unsigned nioff = pni_off(ni);
         if (h2) {
           if constexpr ((FMTS & 2) != 0) {

@@ -237,7 +237,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const sfh_conv_desc d
           const f32x4 a2 = bload(rs0, hoff[i], cb + pd2), a3 = bload(rs0, hoff[i], cb + pd2 + pd1);
           f32x4 v;
 #pragma unroll
-          for (int j = 0; j < 4; ++j) v[j] = fmaxf(fmaxf(a0[j], a1[j]), fmaxf(a2[j], a3[j]));
+          for (int j = 0; j < 4; ++j) v[j] = sfh_max_nan(sfh_max_nan(a0[j], a1[j]), sfh_max_nan(a2[j], a3[j]));
           hreg[i] = v;
         }
       } else if (first) {

@@ -469,7 +469,7 @@ __global__ void maxpool3x3s2_kernel(const float* __restrict__ x, float* __restri
       if (xx < 0 || xx >= W) continue;
       const f32x4 v = *reinterpret_cast<const f32x4*>(x + ((b * H + yy) * W + xx) * C + 4 * c4);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) m[j] = fmaxf(m[j], v[j]);
+      for (int j = 0; j < 4; ++j) m[j] = sfh_max_nan(m[j], v[j]);
     }
   }
   *reinterpret_cast<f32x4*>(y + idx * 4) = m;

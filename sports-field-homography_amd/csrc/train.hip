@@ -153,7 +153,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
   }
   if (relu) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) o[j] = fmaxf(o[j], 0.f);
+    for (int j = 0; j < 4; ++j) o[j] = sfh_relu(o[j]);
   }
   reinterpret_cast<f32x4*>(y)[i] = o;
 }
@@ -342,7 +342,7 @@ __global__ __launch_bounds__(256) void bn_apply_s3_kernel(const float* __restric
   }
   if (relu) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
+    for (int j = 0; j < 8; ++j) v[j] = sfh_relu(v[j]);
   }
   *reinterpret_cast<f32x4*>(y + o) = (f32x4){v[0], v[1], v[2], v[3]};
   *reinterpret_cast<f32x4*>(y + o + 4) = (f32x4){v[4], v[5], v[6], v[7]};
@@ -425,7 +425,7 @@ __global__ __launch_bounds__(256) void maxpool2_fwd_kernel(const float* __restri
   const f32x4 c = *reinterpret_cast<const f32x4*>(p + (long)W * C), d = *reinterpret_cast<const f32x4*>(p + (long)W * C + C);
   f32x4 o;
 #pragma unroll
-  for (int j = 0; j < 4; ++j) o[j] = fmaxf(fmaxf(a[j], bq[j]), fmaxf(c[j], d[j]));
+  for (int j = 0; j < 4; ++j) o[j] = sfh_max_nan(sfh_max_nan(a[j], bq[j]), sfh_max_nan(c[j], d[j]));
   reinterpret_cast<f32x4*>(y)[i] = o;
 }
 

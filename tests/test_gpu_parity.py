@@ -2,6 +2,7 @@
 committed golden vectors.  Tolerances (BASELINE.json north_star): homography and warp
 within 1e-4 abs, nearest-mode warp / argmax / POI pixel integer-exact."""
 import os
+import warnings
 
 import numpy as np
 import pytest
@@ -606,6 +607,41 @@ def test_f16x3_range_guard_falls_back(E):
     with torch.no_grad():
         lg, _, _ = net.forward_unet(x)
     assert net.range_fallbacks == 2 and torch.equal(lg, want["logits"])
+
+
+@pytest.mark.parametrize("precision", ["f16x3", "bf16x6", "fp32"])
+def test_non_finite_frame_gives_non_finite_outputs_like_torch(E, precision):
+    """torch propagates a NaN through conv / BatchNorm / ReLU / max-pool, so the reference answers a frame that
+    holds one with NaN logits and a NaN theta; the HIP path must not launder it into finite numbers (ReLU and the
+    pooling maxima keep NaNs; the H2 conversions flag them and the batch is repeated in bf16x6).  The other frame of
+    the batch is untouched."""
+    from sfh_amd.reconstructor import Reconstructor
+    B, H, W = 2, 48, 64
+    court = synth.load_court_template("ncaa_nc4_640x360", 4, B)[:, :, :H, :W].contiguous()
+    poi = synth.load_court_poi("pitch", B)
+    net = Reconstructor(court.cuda(), poi.cuda(), target_size=(W, H), unet_size=(W, H), warp_size=(W, H),
+                        warp_with_nearest=True)
+    sd = synth.synth_state_dict(net.state_dict(), 47)
+    net.load_state_dict(sd)
+    net.cuda().eval()
+    net.precision = precision
+    x = synth.smooth_frames(B, H, W, seed=47)
+    with torch.no_grad():
+        clean = net.predict(x.cuda(), consistency=False)
+    xn = x.clone()
+    xn[1, 2, 20, 30] = float("nan")
+    with torch.no_grad(), warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        got = net.predict(xn.cuda(), consistency=False)
+        want = torch_ref.predict(xn, sd, court, poi, warp_size=(W, H), unet_size=(W, H), target_size=(W, H))
+    assert torch.isnan(want["theta"][1]).all() and torch.isnan(got["theta"][1].cpu()).all()
+    assert torch.isnan(got["logits"][1]).any()
+    # where the reference's logits are NaN ours are too (the receptive field of the bad pixel)
+    assert bool((torch.isnan(got["logits"][1].cpu()) | ~torch.isnan(want["logits"][1])).all())
+    assert not torch.isnan(got["theta"][0]).any() and not torch.isnan(got["logits"][0]).any()
+    assert _maxerr(got["theta"][0].cpu(), clean["theta"][0].cpu()) < 1e-5
+    if precision == "f16x3":
+        assert net.range_fallbacks == 1
 
 
 @pytest.mark.parametrize("precision", ["f16x3", "bf16x6"])
