@@ -127,6 +127,9 @@ typedef struct sfh_conv_desc {
    * buffers; needs stride 1, ksize 3 or 2, cout % 128 == 0 - per quadrant for the up-scatter conv -, at least 128
    * input channels, no fused head). */
   int32_t wg_couts;
+  /* kernels that split an fp32 source themselves (sfh_stem7x7_fwd): 0 or SFH_FMT_S3 = three bf16 planes, six products;
+   * SFH_FMT_H2 = two fp16 planes, three products (weights from sfh_pack_stem_weights with the same format). */
+  int32_t split_arith;
 } sfh_conv_desc;
 
 const char* sfh_last_error(void);
@@ -427,7 +430,8 @@ int sfh_compose_up_weights(const float* wconv, int cout, int c0, int c1, const f
  * fields must describe a plain single-source launch.                                                    */
 int sfh_stem7x7_fwd(const sfh_conv_desc* d, void* stream);
 int64_t sfh_packed_stem_weight_bytes(void);
-int sfh_pack_stem_weights(const float* w, void* packed, int cin, void* stream);
+int sfh_pack_stem_weights(const float* w, void* packed, int cin, int fmt, int wexp, void* stream);   /* fmt: SFH_FMT_S3, or
+    SFH_FMT_H2 (planes of w * 2^wexp; the caller folds 2^-(wexp + SFH_H2_ACT_EXP) into the layer's scale) */
 
 #ifdef __cplusplus
 }

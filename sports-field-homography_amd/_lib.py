@@ -33,7 +33,7 @@ class ConvDesc(C.Structure):
         ("reverse_tiles", _i),
         ("head_w", _p), ("head_b", _p), ("head_nc", _i), ("head_skip_dst", _i),
         ("head_logits", _p), ("head_stn", _p), ("head_frame", _p),
-        ("h2_overflow", _p), ("wg_couts", _i),
+        ("h2_overflow", _p), ("wg_couts", _i), ("split_arith", _i),
     ]
 
 
@@ -107,7 +107,7 @@ SIGNATURES = {
     "sfh_compose_up_weights": (C.c_int, [_p, C.c_int, C.c_int, C.c_int, _p, C.c_int, _p, _p, _p, _p, _p, _p]),
     "sfh_stem7x7_fwd": (C.c_int, [C.POINTER(ConvDesc), _p]),
     "sfh_packed_stem_weight_bytes": (C.c_int64, []),
-    "sfh_pack_stem_weights": (C.c_int, [_p, _p, C.c_int, _p]),
+    "sfh_pack_stem_weights": (C.c_int, [_p, _p, C.c_int, C.c_int, C.c_int, _p]),
     "sfh_maxpool3x3s2_fwd": (C.c_int, [_p, _p, C.c_int, C.c_int, C.c_int, C.c_int, _p]),
     "sfh_avgpool_linear_fwd": (C.c_int, [_p, _p, _p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _p, _p, _p]),
 }

@@ -14,6 +14,7 @@
 
 typedef unsigned int st_u32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 st_bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 st_f16x8 __attribute__((ext_vector_type(8)));
 
 namespace {
 
@@ -22,7 +23,7 @@ struct StemCfg {  // what the shared epilogue needs to know about the tile
   static constexpr bool FLATROWS = false;
   static constexpr int HH = 2 * (TH - 1) + 7, HW = 2 * (TW - 1) + 7;  // 21 x 69 input pixels
   static constexpr int HPIX = HH * HW, HPIXP = (HPIX + 15) / 16 * 16;
-  static constexpr int LDS_BYTES = 3 * HPIXP * 16;
+  static constexpr int LDS_BYTES = 3 * HPIXP * 16;   // three planes; the two-plane instance uses two thirds of it
   static constexpr int NSTEP = 13;  // ceil(49 taps / 4 per MFMA)
 };
 
@@ -34,6 +35,9 @@ struct StemGeom {
 
 __device__ __forceinline__ st_bf16x8 st_bf(const st_u32x4& v) { return __builtin_bit_cast(st_bf16x8, v); }
 
+// NP = 3: the input is split into three bf16 planes, six products (bf16x6); NP = 2: two fp16 planes of v * 2^2, three
+// products (f16x3: weights packed as planes of w * 2^wexp, the caller folds 2^-(wexp + 2) into `scale`)
+template <int NP>
 __global__ __launch_bounds__(256, 2) void stem7x7_kernel(const sfh_conv_desc d, const StemGeom g) {
   using C = StemCfg;
   extern __shared__ __attribute__((aligned(16))) float smem_f[];
@@ -50,6 +54,7 @@ __global__ __launch_bounds__(256, 2) void stem7x7_kernel(const sfh_conv_desc d, 
 
   // ---- stage the input halo: fp32 (8 channels) -> three bf16 planes, zeros outside the frame
   const float* src = d.src0 + (long)img * d.H * d.W * 8;
+  unsigned over = 0u;   // NP = 2: see sfh_split4_h2
   for (int p = tid; p < C::HPIX; p += 256) {
     const int hy = p / C::HW, hx = p - hy * C::HW;
     const int y = 2 * y0 - 3 + hy, x = 2 * x0 - 3 + hx;
@@ -59,32 +64,43 @@ __global__ __launch_bounds__(256, 2) void stem7x7_kernel(const sfh_conv_desc d, 
       const f32x4 b = *reinterpret_cast<const f32x4*>(src + ((long)y * d.W + x) * 8 + 4);
       v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3]; v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
     }
-    st_u32x4 pl[3];
-    float r[8];
+    if constexpr (NP == 3) {
+      st_u32x4 pl[3];
+      float r[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) r[j] = v[j];
+      for (int j = 0; j < 8; ++j) r[j] = v[j];
 #pragma unroll
-    for (int q = 0; q < 3; ++q) {
+      for (int q = 0; q < 3; ++q) {
 #pragma unroll
-      for (int h = 0; h < 4; ++h) {
-        const unsigned w = sfh_cvt_pk(r[2 * h], r[2 * h + 1]);
-        pl[q][h] = w;
-        r[2 * h] -= __builtin_bit_cast(float, w << 16);
-        r[2 * h + 1] -= __builtin_bit_cast(float, w & 0xFFFF0000u);
+        for (int h = 0; h < 4; ++h) {
+          const unsigned w = sfh_cvt_pk(r[2 * h], r[2 * h + 1]);
+          pl[q][h] = w;
+          r[2 * h] -= __builtin_bit_cast(float, w << 16);
+          r[2 * h + 1] -= __builtin_bit_cast(float, w & 0xFFFF0000u);
+        }
+        lds[q * C::HPIXP + p] = pl[q];
       }
-      lds[q * C::HPIXP + p] = pl[q];
+    } else {
+      sfh_u32x2 pa[2], pb[2];
+      sfh_split4_h2((f32x4){v[0], v[1], v[2], v[3]}, pa, over);
+      sfh_split4_h2((f32x4){v[4], v[5], v[6], v[7]}, pb, over);
+      lds[p] = (st_u32x4){pa[0][0], pa[0][1], pb[0][0], pb[0][1]};
+      lds[C::HPIXP + p] = (st_u32x4){pa[1][0], pa[1][1], pb[1][0], pb[1][1]};
     }
   }
+  if constexpr (NP == 2) {
+    if (d.h2_overflow && sfh_h2_out_of_range(over)) atomicOr(d.h2_overflow, 1u);
+  }
 
-  // ---- weights: packed [step 13][plane 3][cout subtile 4][lane 64] x 16 B; this wave: subtiles 2*wn, 2*wn+1
+  // ---- weights: packed [step 13][plane NP][cout subtile 4][lane 64] x 16 B; this wave: subtiles 2*wn, 2*wn+1
   const st_u32x4* wp = reinterpret_cast<const st_u32x4*>(d.wpacked) + (2 * wn) * 64 + lane;
-  auto load_w = [&](st_u32x4 (&w)[3][2], int s) {
+  auto load_w = [&](st_u32x4 (&w)[NP][2], int s) {
 #pragma unroll
-    for (int p = 0; p < 3; ++p)
+    for (int p = 0; p < NP; ++p)
 #pragma unroll
-      for (int ni = 0; ni < 2; ++ni) w[p][ni] = wp[((s * 3 + p) * 4 + ni) * 64];
+      for (int ni = 0; ni < 2; ++ni) w[p][ni] = wp[((s * NP + p) * 4 + ni) * 64];
   };
-  st_u32x4 wa[3][2], wb[3][2];
+  st_u32x4 wa[NP][2], wb[NP][2];
   load_w(wa, 0);
 
   f32x4 acc[2][8];
@@ -97,11 +113,12 @@ __global__ __launch_bounds__(256, 2) void stem7x7_kernel(const sfh_conv_desc d, 
   // lane's pixel in pixel group mi of this wave: row wm*4 + mi/2, col 16*(mi%2) + lq; halo pixel of tap
   // (ky,kx): (2*row + ky) * HW + 2*col + kx.  The tap of a lane is 4*s + lg.
   const int pix0 = (2 * (wm * 4)) * C::HW + 2 * lq;
-  constexpr int PW[6] = {0, 1, 2, 0, 1, 0}, PX[6] = {2, 1, 0, 1, 0, 0};
+  constexpr int NPROD = NP == 3 ? 6 : 3;
+  constexpr int PW[6] = {0, 1, NP == 3 ? 2 : 0, 0, 1, 0}, PX[6] = {NP == 3 ? 2 : 1, NP == 3 ? 1 : 0, 0, 1, 0, 0};
 #pragma unroll
   for (int s = 0; s < C::NSTEP; ++s) {
-    st_u32x4 (&wc)[3][2] = (s & 1) ? wb : wa;
-    st_u32x4 (&wn_)[3][2] = (s & 1) ? wa : wb;
+    st_u32x4 (&wc)[NP][2] = (s & 1) ? wb : wa;
+    st_u32x4 (&wn_)[NP][2] = (s & 1) ? wa : wb;
     if (s + 1 < C::NSTEP) load_w(wn_, s + 1);
     int t = 4 * s + lg;
     if (t > 48) t = 48;                      // padding taps carry zero weights: any valid address will do
@@ -109,22 +126,28 @@ __global__ __launch_bounds__(256, 2) void stem7x7_kernel(const sfh_conv_desc d, 
 #pragma unroll
     for (int mi = 0; mi < 8; ++mi) {
       const int moff = (2 * (mi >> 1)) * C::HW + 32 * (mi & 1);
-      st_u32x4 xq[3];
+      st_u32x4 xq[NP];
 #pragma unroll
-      for (int p = 0; p < 3; ++p) xq[p] = lds[p * C::HPIXP + pix0 + moff + toff];
+      for (int p = 0; p < NP; ++p) xq[p] = lds[p * C::HPIXP + pix0 + moff + toff];
 #pragma unroll
-      for (int k6 = 0; k6 < 6; ++k6)
+      for (int k6 = 0; k6 < NPROD; ++k6)
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
-          acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(st_bf(wc[PW[k6]][ni]), st_bf(xq[PX[k6]]), acc[ni][mi], 0, 0, 0);
+        for (int ni = 0; ni < 2; ++ni) {
+          if constexpr (NP == 3)
+            acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(st_bf(wc[PW[k6]][ni]), st_bf(xq[PX[k6]]), acc[ni][mi], 0, 0, 0);
+          else
+            acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(st_f16x8, wc[PW[k6]][ni]),
+                                                                __builtin_bit_cast(st_f16x8, xq[PX[k6]]), acc[ni][mi], 0, 0, 0);
+        }
     }
   }
   sfh_conv_epilogue<C, 2, 8>(d, g, acc, 32 * wn, wm * 8, (img << 16) | y0, x0, lq, lg);
 }
 
 // packed[s][plane][subtile][lane][j]: cout = subtile*16 + (lane & 15), tap = 4*s + (lane >> 4), channel j
+template <int NP>
 __global__ void pack_stem_weights_kernel(const float* __restrict__ w, unsigned short* __restrict__ packed, int cin,
-                                         int total) {
+                                         int total, float wscale) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;   // one (s, subtile, lane)
   if (idx >= total) return;
   const int lane = idx & 63, sub = (idx >> 6) & 3, s = idx >> 8;
@@ -132,14 +155,22 @@ __global__ void pack_stem_weights_kernel(const float* __restrict__ w, unsigned s
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     const float v = (t < 49 && j < cin) ? w[((long)co * cin + j) * 49 + t] : 0.f;
-    const __bf16 v0 = (__bf16)v;
-    const float r1 = v - (float)v0;
-    const __bf16 v1 = (__bf16)r1;
-    const __bf16 v2 = (__bf16)(r1 - (float)v1);
-    const long base = ((long)(s * 3) * 4 + sub) * 64 + lane;   // plane 0 element index (16-byte units)
-    packed[(base + 0 * 256) * 8 + j] = __builtin_bit_cast(unsigned short, v0);
-    packed[(base + 1 * 256) * 8 + j] = __builtin_bit_cast(unsigned short, v1);
-    packed[(base + 2 * 256) * 8 + j] = __builtin_bit_cast(unsigned short, v2);
+    const long base = ((long)(s * NP) * 4 + sub) * 64 + lane;   // plane 0 element index (16-byte units)
+    if constexpr (NP == 3) {
+      const __bf16 v0 = (__bf16)v;
+      const float r1 = v - (float)v0;
+      const __bf16 v1 = (__bf16)r1;
+      const __bf16 v2 = (__bf16)(r1 - (float)v1);
+      packed[(base + 0 * 256) * 8 + j] = __builtin_bit_cast(unsigned short, v0);
+      packed[(base + 1 * 256) * 8 + j] = __builtin_bit_cast(unsigned short, v1);
+      packed[(base + 2 * 256) * 8 + j] = __builtin_bit_cast(unsigned short, v2);
+    } else {
+      const float u = fminf(fmaxf(v * wscale, -65504.f), 65504.f);
+      const _Float16 h0 = (_Float16)u;
+      const _Float16 h1 = (_Float16)(u - (float)h0);
+      packed[(base + 0 * 256) * 8 + j] = __builtin_bit_cast(unsigned short, h0);
+      packed[(base + 1 * 256) * 8 + j] = __builtin_bit_cast(unsigned short, h1);
+    }
   }
 }
 
@@ -147,11 +178,17 @@ __global__ void pack_stem_weights_kernel(const float* __restrict__ w, unsigned s
 
 extern "C" int64_t sfh_packed_stem_weight_bytes(void) { return (int64_t)StemCfg::NSTEP * 3 * 4 * 64 * 16; }
 
-extern "C" int sfh_pack_stem_weights(const float* w, void* packed, int cin, void* stream) {
+extern "C" int sfh_pack_stem_weights(const float* w, void* packed, int cin, int fmt, int wexp, void* stream) {
   SFH_REQUIRE(w && packed && cin >= 1 && cin <= 8, "pack_stem_weights: 1..8 input channels");
+  SFH_REQUIRE(fmt == SFH_FMT_S3 || (fmt == SFH_FMT_H2 && wexp >= -100 && wexp <= 100), "pack_stem_weights: fmt=%d wexp=%d", fmt, wexp);
   const int total = StemCfg::NSTEP * 4 * 64;
-  hipLaunchKernelGGL(pack_stem_weights_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w,
-                     (unsigned short*)packed, cin, total);
+  const dim3 grid((unsigned)((total + 255) / 256));
+  if (fmt == SFH_FMT_H2)
+    hipLaunchKernelGGL(pack_stem_weights_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, w, (unsigned short*)packed, cin,
+                       total, ldexpf(1.f, wexp));
+  else
+    hipLaunchKernelGGL(pack_stem_weights_kernel<3>, grid, dim3(256), 0, (hipStream_t)stream, w, (unsigned short*)packed, cin,
+                       total, 1.f);
   return sfh_check_launch("pack_stem_weights_kernel");
 }
 
@@ -172,7 +209,13 @@ extern "C" int sfh_stem7x7_fwd(const sfh_conv_desc* dp, void* stream) {
   g.tiles_y = sfh_cdiv(g.Ho, StemCfg::TH);
   g.ntiles = g.tiles_x * g.tiles_y * d.batch;
   SFH_REQUIRE((unsigned long long)d.batch * g.Ho * g.Wo * d.dst_cs * 4ULL < 0xFFFFFFF0ULL, "stem7x7_fwd: destination exceeds 4 GiB");
-  sfh_allow_big_lds(reinterpret_cast<const void*>(&stem7x7_kernel));
-  hipLaunchKernelGGL(stem7x7_kernel, dim3((unsigned)g.ntiles), dim3(256), StemCfg::LDS_BYTES, (hipStream_t)stream, d, g);
+  SFH_REQUIRE(d.split_arith == 0 || d.split_arith == SFH_FMT_S3 || d.split_arith == SFH_FMT_H2, "stem7x7_fwd: split_arith=%d", d.split_arith);
+  if (d.split_arith == SFH_FMT_H2) {
+    sfh_allow_big_lds(reinterpret_cast<const void*>(&stem7x7_kernel<2>));
+    hipLaunchKernelGGL(stem7x7_kernel<2>, dim3((unsigned)g.ntiles), dim3(256), StemCfg::LDS_BYTES / 3 * 2, (hipStream_t)stream, d, g);
+  } else {
+    sfh_allow_big_lds(reinterpret_cast<const void*>(&stem7x7_kernel<3>));
+    hipLaunchKernelGGL(stem7x7_kernel<3>, dim3((unsigned)g.ntiles), dim3(256), StemCfg::LDS_BYTES, (hipStream_t)stream, d, g);
+  }
   return sfh_check_launch("stem7x7_kernel");
 }

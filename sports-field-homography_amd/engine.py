@@ -664,20 +664,35 @@ class StemConv:
     """ResNetSTN stem (7x7 s2 conv + BatchNorm + ReLU) on the tap-packed split-bf16 kernel (csrc/stem.hip):
     reads the fp32 NHWC STN input (8 stored channels) directly, no space-to-depth copy."""
 
-    def __init__(self, conv, bn, cin, tag="resnet"):
+    def __init__(self, conv, bn, cin, tag="resnet", fmt="s3", overflow=None):
+        """fmt: arithmetic of the kernel - "s3": the input is split into three bf16 planes, six products; "h2": two
+        fp16 planes, three products (overflow: the engine's fp16-range word)."""
         lib = _lib.load()
         w = _f32c(conv.weight.detach(), "stem weight")
         if tuple(w.shape) != (64, cin, 7, 7) or cin > 8:
             raise ValueError(f"stem kernel needs a (64, <=8, 7, 7) weight, got {tuple(w.shape)}")
+        if fmt not in ("s3", "h2"):
+            raise ValueError(f"fmt={fmt!r}: expected 's3' or 'h2'")
         dev = w.device
-        self.tag, self.cin = tag, cin
+        self.tag, self.cin, self.fmt, self.overflow = tag, cin, fmt, overflow
         self.wpacked = torch.empty(lib.sfh_packed_stem_weight_bytes(), dtype=torch.uint8, device=dev)
-        _lib.check(lib.sfh_pack_stem_weights(_ptr(w), _ptr(self.wpacked), cin, _stream()), "pack_stem_weights")
+        wexp, self.escale = 0, 1.0
+        if fmt == "h2":
+            import math
+            wmax = float(w.abs().max())
+            if not math.isfinite(wmax):
+                raise ValueError("stem weight holds non-finite values")
+            wexp = max(-100, min(100, 14 - math.frexp(wmax)[1])) if wmax > 0 else 0
+            self.escale = 2.0 ** -(wexp + _lib.H2_ACT_EXP)
+        _lib.check(lib.sfh_pack_stem_weights(_ptr(w), _ptr(self.wpacked), cin, _SPLIT[fmt][2], wexp, _stream()),
+                   "pack_stem_weights")
         self.scale = torch.empty(64, dtype=torch.float32, device=dev)
         self.shift = torch.empty(64, dtype=torch.float32, device=dev)
         args = [_f32c(t.detach(), "bn tensor") for t in (bn.weight, bn.bias, bn.running_mean, bn.running_var)]
         _lib.check(lib.sfh_fold_bn(None, *[_ptr(a) for a in args], float(bn.eps), 64, 1, _ptr(self.scale),
                                    _ptr(self.shift), _stream()), "fold_bn")
+        if self.escale != 1.0:
+            self.scale.mul_(self.escale)
 
     def run(self, x_nhwc8, B, H, W, dst):
         lib = _lib.load()
@@ -688,6 +703,8 @@ class StemConv:
         d.cout, d.relu = 64, 1
         d.dst, d.dst_cs, d.out_mode = dst.data_ptr(), dst.shape[3], _lib.OUT_NHWC
         d.src_fmt = d.dst_fmt = _lib.FMT_F32
+        d.split_arith = _SPLIT[self.fmt][2]
+        d.h2_overflow = self.overflow.data_ptr() if (self.overflow is not None and self.fmt == "h2") else None
         ho, wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
         if tuple(dst.shape) != (B, ho, wo, 64) or tuple(x_nhwc8.shape) != (B, H, W, 8):
             raise ValueError(f"stem: shapes {tuple(x_nhwc8.shape)} -> {tuple(dst.shape)} do not match {(B, ho, wo, 64)}")
@@ -726,7 +743,8 @@ class ResNetEngine:
         # measured 1.59 ms against 0.55 ms
         L["stem"] = PackedConv(rn.conv0.weight, None, rn.bn1, 4, 4 * self.cs_in, stem_cin=in_channels, tag="resnet")
         # bf16x6 mode with <= 8 input channels (every resnet_input mode but img+mask+uv): the tap-packed stem kernel
-        self.stem7 = (StemConv(rn.conv0, rn.bn1, in_channels) if (s3 and self.cs_in == 8 and rn.conv0.out_channels == 64
+        self.stem7 = (StemConv(rn.conv0, rn.bn1, in_channels, fmt=fmt, overflow=self.overflow)
+                      if (s3 and self.cs_in == 8 and rn.conv0.out_channels == 64
                                                                   and os.environ.get("SFH_STEM7", "1") != "0") else None)
         self.blocks = []
         for li in range(1, 5):

@@ -711,9 +711,10 @@ def test_fused_outconv_head_vs_outconv_kernel(E, monkeypatch, size, precision):
     assert _maxerr(res["1"][0].cpu(), logits) < 3e-4
 
 
+@pytest.mark.parametrize("fmt", ["s3", "h2"])
 @pytest.mark.parametrize("shape", [(3, 45, 83), (1, 16, 16), (2, 90, 112), (2, 23, 70)])
 @pytest.mark.parametrize("cin", [7, 5, 8])
-def test_stem_kernel_vs_torch(E, shape, cin):
+def test_stem_kernel_vs_torch(E, shape, cin, fmt):
     """7x7 stride-2 pad-3 conv + BatchNorm(eval) + ReLU (models/resnet.py:172,241-243) on the tap-packed
     split-bf16 kernel: odd sizes, partial tiles, fewer than 8 real channels."""
     B, H, W = shape
@@ -732,7 +733,7 @@ def test_stem_kernel_vs_torch(E, shape, cin):
             torch.nn.functional.conv2d(x.double(), conv.weight.double(), None, 2, 3), bn.running_mean.double(),
             bn.running_var.double(), bn.weight.double(), bn.bias.double(), False, 0.0, bn.eps))
     conv.cuda(); bn.cuda()
-    st = E.StemConv(conv, bn, cin)
+    st = E.StemConv(conv, bn, cin, fmt=fmt)
     xin = E.nchw_to_nhwc(x.cuda(), 8)
     ho, wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
     out = torch.empty((B, ho, wo, 64), device="cuda")
