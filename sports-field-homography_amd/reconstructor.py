@@ -344,6 +344,8 @@ class Reconstructor(nn.Module):
         if self.training:
             from . import training
             return training.train_forward(self, x)
+        if x.shape[0] == 0:
+            return self._empty_outputs(x, predict=False)
         return self._chunked(self._forward_one, x)
 
     def _forward_one(self, x, off):
@@ -368,7 +370,31 @@ class Reconstructor(nn.Module):
     def predict(self, x, consistency=True, project_poi=False):
         """Reference: models/reconstructor.py:196-247."""
         self._require_eval("predict")
+        if x.shape[0] == 0:
+            return self._empty_outputs(x, predict=True, consistency=consistency, project_poi=project_poi)
         return self._chunked(self._predict_one, x, consistency, project_poi)
+
+    def _empty_outputs(self, x, predict, consistency=False, project_poi=False):
+        """A batch of zero frames: the reference's torch ops return empty tensors of the usual trailing shapes."""
+        if not x.is_cuda:
+            raise RuntimeError("input frames are on the CPU: the HIP path has no CPU fallback")
+        dev, f32 = x.device, torch.float32
+        tw, th = self.target_size
+        h, w = self._warp_hw
+        ret = {}
+        if self.use_unet:
+            ret["logits"] = torch.empty((0, self.mask_classes, th, tw), dtype=f32, device=dev)
+            if not predict and self.unet_uv:
+                ret["uv"] = torch.empty((0, 2, th, tw), dtype=f32, device=dev)
+        if self.use_resnet:
+            ret["theta"] = torch.empty((0, 1, 3, 3), dtype=f32, device=dev)
+            if self.warper:
+                ret["warp_mask"] = torch.empty((0, h, w), dtype=torch.int32 if predict else f32, device=dev)
+                if predict and consistency and self.use_unet:
+                    ret["consist_score"] = torch.empty((0,), dtype=f32, device=dev)
+            if project_poi or not predict:
+                ret["poi"] = torch.empty((0,) + tuple(self.court_poi.shape[1:]), dtype=f32, device=dev)
+        return ret
 
     def _predict_one(self, x, off, consistency, project_poi):
         return self._range_guarded(self._predict_one_unguarded, x, off, consistency, project_poi)

@@ -609,6 +609,37 @@ def test_f16x3_range_guard_falls_back(E):
     assert net.range_fallbacks == 2 and torch.equal(lg, want["logits"])
 
 
+@pytest.mark.parametrize("B,size", [(1, (50, 70)), (3, (33, 47)), (1, (16, 16)), (5, (64, 48))])
+def test_ragged_batches_and_sizes_vs_oracle(E, B, size):
+    """Batch sizes 1 / 3 / 5, odd and minimal frame sizes (16x16 is the smallest frame four 2x2 poolings allow),
+    default arithmetic, against the CPU restatement; and a batch of zero frames gives empty tensors like torch."""
+    from sfh_amd.reconstructor import Reconstructor
+    H, W = size
+    court = synth.load_court_template("ncaa_nc4_640x360", 4, B)[:, :, :H, :W].contiguous()
+    poi = synth.load_court_poi("pitch", B)
+    net = Reconstructor(court.cuda(), poi.cuda(), target_size=(W, H), unet_size=(W, H), warp_size=(W, H),
+                        warp_with_nearest=True)
+    sd = synth.synth_state_dict(net.state_dict(), 53)
+    net.load_state_dict(sd)
+    net.cuda().eval()
+    x = synth.smooth_frames(B, H, W, seed=53)
+    with torch.no_grad():
+        out = net.predict(x.cuda(), consistency=True, project_poi=True)
+        want = torch_ref.predict(x, sd, court, poi, warp_size=(W, H), unet_size=(W, H), target_size=(W, H), project_poi=True)
+    assert _maxerr(out["theta"].cpu(), want["theta"]) < 1e-4
+    assert _maxerr(out["logits"].cpu(), want["logits"]) < 5e-4
+    assert _maxerr(out["poi"].cpu(), want["poi"]) < 1e-4
+    wm = (warp_ref.homography_warp(out["theta"].cpu(), court, H, W, "nearest") * 4).to(torch.int32)
+    assert torch.equal(out["warp_mask"].cpu(), wm)
+    with torch.no_grad():
+        e = net.predict(x[:0].cuda(), consistency=True, project_poi=True)
+        f = net(x[:0].cuda())
+    assert tuple(e["logits"].shape) == (0, 4, H, W) and tuple(e["theta"].shape) == (0, 1, 3, 3)
+    assert tuple(e["warp_mask"].shape) == (0, H, W) and e["warp_mask"].dtype == torch.int32
+    assert tuple(e["consist_score"].shape) == (0,) and tuple(e["poi"].shape) == (0, poi.shape[1], 2)
+    assert tuple(f["logits"].shape) == (0, 4, H, W) and f["warp_mask"].dtype == torch.float32
+
+
 @pytest.mark.parametrize("precision", ["f16x3", "bf16x6", "fp32"])
 def test_non_finite_frame_gives_non_finite_outputs_like_torch(E, precision):
     """torch propagates a NaN through conv / BatchNorm / ReLU / max-pool, so the reference answers a frame that
