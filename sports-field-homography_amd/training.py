@@ -652,7 +652,7 @@ def run_forward(net, tape, x):
     return f
 
 
-def run_backward(net, tape, f, dheads, dtheta):
+def run_backward(net, tape, f, dheads, dtheta, unscale=True):
     """dheads: gradients of the head outputs in the order of f['heads'] (None = zero); dtheta (B,9) or None.
     -> {state_dict key: gradient}.  ResNet closures run first (pushed last) and add the stem's gradient
     into the head gradients; then the heads; then the UNet."""
@@ -691,7 +691,7 @@ def run_backward(net, tape, f, dheads, dtheta):
     for fn in reversed(ops[:k]):
         fn()
     g = tape.param_grads
-    if S != 1.0:
+    if S != 1.0 and unscale:     # (unscale=False: the caller divides tape.gscale out itself, e.g. once over a flat buffer)
         torch._foreach_mul_([t for t in g.values() if t is not None], 1.0 / S)
     if tape.overflow is not None and int(tape.overflow.item()):
         tape.ops, tape.param_grads = [], {}
@@ -952,12 +952,14 @@ class TrainStep:
                                        _ptr(E._f32c(batch["num_nonzero"], "num_nonzero")), B, poi.shape[1],
                                        self.lam["reproj"], _ptr(dpoi), ctypes.c_void_p(losses.data_ptr() + 24), st),
                    "reproj_loss")
-        g = run_backward(net, tape, f, [dlogits], theta_gradient(net, f, None, dpoi, dwarp))
+        g = run_backward(net, tape, f, [dlogits], theta_gradient(net, f, None, dpoi, dwarp), unscale=False)
         srcs = []
         for p, dst in zip(self.params, self.grads):
             src = g[self.names(p)]
             srcs.append(src if tuple(src.shape) == tuple(dst.shape) else src.reshape(dst.shape))
         torch._foreach_copy_(self.grads, srcs)     # multi-tensor copy instead of 182 launches
+        if tape.gscale != 1.0:
+            self.gflat.mul_(1.0 / tape.gscale)     # the power of two the backward pass was carried with (one pass, exact)
         return losses
 
     def step(self, x, batch):
