@@ -6,7 +6,7 @@ from sfh_amd import synth
 from sfh_amd.reconstructor import Reconstructor
 
 dev = torch.device("cuda", 0)
-B, W, H = 16, 640, 360
+B, W, H = (int(sys.argv[1]) if len(sys.argv) > 1 else 16), 640, 360
 court = synth.load_court_template("ncaa_nc4_640x360", 4, B).to(dev)
 poi = synth.load_court_poi("pitch", B).to(dev)
 net = Reconstructor(court, poi, target_size=(W, H), unet_size=(W, H), warp_size=(W, H), warp_with_nearest=True)
@@ -40,5 +40,5 @@ with torch.no_grad():
     graph = bench(g.replay)
     g.replay()
     torch.cuda.synchronize()
-    print("precision %s: eager with range guard %.3f ms  eager %.3f ms  graph %.3f ms  same theta %s same mask %s overflow %s" % (
+    print("B=%d " % B + "precision %s: eager with range guard %.3f ms  eager %.3f ms  graph %.3f ms  same theta %s same mask %s overflow %s" % (
         net.precision, eager_guard, eager, graph, torch.equal(out["theta"], ref["theta"]), torch.equal(out["warp_mask"], ref["warp_mask"]), net.range_overflowed()))
