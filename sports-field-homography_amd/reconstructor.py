@@ -36,6 +36,21 @@ class Input(Enum):
         return table[input]
 
 
+# Parameter / buffer / sub-module registrations anywhere in the process (torch.nn global hooks): Reconstructor caches the
+# list of its tensors for the engine stamp and rebuilds it when this counter moved.
+_REGISTRATIONS = [0]
+
+
+def _count_registration(module, name, value):
+    _REGISTRATIONS[0] += 1
+    return None
+
+
+torch.nn.modules.module.register_module_parameter_registration_hook(_count_registration)
+torch.nn.modules.module.register_module_buffer_registration_hook(_count_registration)
+torch.nn.modules.module.register_module_module_registration_hook(_count_registration)
+
+
 class Reconstructor(nn.Module):
     """UNet segmentation + ResNet-STN homography regression + court-template warp."""
 
@@ -132,11 +147,13 @@ class Reconstructor(nn.Module):
     def _param_stamp(self):
         # walking the module tree costs ~1 ms per call (354 tensors behind ~200 modules), more than enqueueing the
         # whole UNet: the tensor list is collected once.  load_state_dict(), .to() and optimizers change these
-        # tensors in place (their torch _version moves); code that REPLACES a Parameter object calls
-        # invalidate_engines().
+        # tensors in place (their torch _version moves); a Parameter / buffer / sub-module that is REPLACED anywhere
+        # in the process registers with torch's module hooks, which advance _REGISTRATIONS: the list is rebuilt then.
         lst = self.__dict__.get("_stamp_tensors")
-        if lst is None:
+        if lst is None or self.__dict__.get("_stamp_regs") != _REGISTRATIONS[0]:
             lst = self.__dict__["_stamp_tensors"] = list(self.parameters()) + list(self.buffers())
+            self.__dict__["_stamp_regs"] = _REGISTRATIONS[0]
+            self._weights_generation += 1          # a replaced tensor may carry any _version: force a new stamp
         dev = None
         ver = 0
         for t in lst:

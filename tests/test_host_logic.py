@@ -112,3 +112,21 @@ def test_precision_names():
     assert E.split_shape("s3", 2, 5, 7, 64) == (2, 5, 2, 3, 4, 7, 8)
     with pytest.raises(ValueError):
         E.split_shape("h2", 1, 4, 4, 48)
+
+
+def test_engine_stamp_notices_in_place_updates_and_replaced_parameters():
+    """The packed-weight engines are rebuilt when the stamp moves: in-place writes move a tensor's torch _version; a
+    Parameter object that is replaced (anywhere under the model) registers with torch's module hooks."""
+    net = Reconstructor(synth.load_court_template(batch_size=1), synth.load_court_poi(batch_size=1)).eval()
+    s1 = net._param_stamp()
+    assert net._param_stamp() == s1                                   # stable while nothing changes
+    with torch.no_grad():
+        net.inc.double_conv[0].weight.mul_(1.0)
+    s2 = net._param_stamp()
+    assert s2 != s1
+    net.inc.double_conv[0].weight = torch.nn.Parameter(torch.zeros_like(net.inc.double_conv[0].weight))
+    s3 = net._param_stamp()
+    assert s3 != s2
+    assert any(t is net.inc.double_conv[0].weight for t in net.__dict__["_stamp_tensors"])
+    net.load_state_dict(net.state_dict())
+    assert net._param_stamp() != s3
