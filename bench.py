@@ -33,6 +33,9 @@ BF16X6_PEAK_TFLOPS = BF16_MFMA_PEAK_TFLOPS / 6.0
 # f16x3 mode (default): two fp16 planes per operand, 3 fp16 MFMA products per product (fp16 and bf16 MFMA have the
 # same dense peak)
 F16X3_PEAK_TFLOPS = BF16_MFMA_PEAK_TFLOPS / 3.0
+HBM_PEAK_TBS = 8.0              # MI355X_MICROARCH.md: HBM3E peak
+# algorithmic work of one frame of the hot path at 640x360 (UNet 338.1 + ResNet34-STN 35.75)
+STEP_GFLOP_PER_FRAME_640x360 = 338.1 + 35.75
 
 
 def usable_cores():
@@ -156,13 +159,42 @@ def train_bench(args):
 def extra_configs(args):
     """BASELINE configs 3 and 5 on this GPU, a few steps each (driver-observed numbers for every
     single-GPU config in one default run): C5 = predict() with consistency + POI on 16 frames of
-    1280x720 against the 4-class pitch template; C3 = one training step per batch of 16 at 640x360."""
+    1280x720 against the 4-class pitch template; C3 = one training step per batch of 16 at 640x360; and C2 again
+    in the two other arithmetic modes (exact three-plane bf16 operands, fp32 MFMA)."""
     import copy
     import torch
     from sfh_amd import synth
     from sfh_amd.reconstructor import Reconstructor
     res = {}
     dev = torch.device("cuda", 0)
+    # C2 (the headline workload) in the other two arithmetic modes: "bf16x6" carries every fp32 operand exactly
+    # (six bf16 MFMA products), "fp32" is the fp32 MFMA throughout
+    B, W, H = 16, 640, 360
+    court = synth.load_court_template("ncaa_nc4_640x360", 4, B).to(dev)
+    poi = synth.load_court_poi("pitch", B).to(dev)
+    net = Reconstructor(court, poi, target_size=(W, H), unet_size=(W, H), warp_size=(W, H), warp_with_nearest=True)
+    net.load_state_dict(synth.synth_state_dict(net.state_dict(), 0))
+    net.to(dev).eval()
+    x = synth.frames_to_float(synth.synth_frames_u8(B, H, W, seed=0)).to(dev)
+    for prec in ("bf16x6", "fp32"):
+        net.precision = prec
+        with torch.no_grad():
+            for _ in range(2):
+                net.predict(x, consistency=False)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            n = 4
+            for _ in range(n):
+                net.predict(x, consistency=False)
+            torch.cuda.synchronize()
+            el = time.perf_counter() - t0
+        res[f"C2_640x360_batch16_{prec}"] = {
+            "value": round(B * n / el, 2), "unit": "frames/s", "ms_per_step": round(el / n * 1e3, 2), "steps": n, "warmup": 2,
+            "precision": prec, "workload": "the headline workload (predict(), 640x360, batch 16, theta + warp_mask) in this arithmetic mode"}
+        net.invalidate_engines()
+        torch.cuda.empty_cache()
+    del net, x, court, poi
+    torch.cuda.empty_cache()
     B, W, H = 16, 1280, 720
     court = synth.load_court_template("pitch_v3_nc4_1280x720", 4, B).to(dev)
     poi = synth.load_court_poi("pitch", B).to(dev)
@@ -266,12 +298,14 @@ def main():
     nbatches = 2
     frames = [synth.frames_to_float(synth.synth_frames_u8(B, H, W, seed=1000 * rank + k)).to(dev)
               for k in range(nbatches)]
-    gbuf = [torch.empty((B, 10), device=dev) for _ in range(world)] if world > 1 else None
+    # the one exchange step of the sharded path: theta (+score) rows to every rank, all-gathered on a side stream
+    # while the next batch's kernels run (sharding.ResultGather; the final device synchronize covers it)
+    gather = sharding.ResultGather(world, B, dev, depth=2) if world > 1 else None
 
     def step(k):
         out = net.predict(frames[k % nbatches], consistency=args.consistency, project_poi=args.consistency)
-        if world > 1:  # the one exchange step of the sharded path: theta (+score) rows to every rank
-            dist.all_gather(gbuf, sharding.pack_results(out["theta"], out.get("consist_score")))
+        if gather is not None:
+            gather.submit(out["theta"], out.get("consist_score"))
         return out
 
     with torch.no_grad():
@@ -320,8 +354,21 @@ def main():
                 "avg_launch_ms": round(ms / max(n, 1), 4),
                 "algorithmic_gflop_per_launch": round(fl / max(n, 1) / 1e9, 2),
                 "share_of_step_time": round(ms * 1e-3 / elapsed, 4)}
-    other = {t: {"launches": v[0], "tflops": round(v[1] / (v[2] * 1e-3) / 1e12, 2), "ms_per_step": round(v[2] / args.steps, 3)}
-             for t, v in summ.items()}
+    # every timed kernel group against the roofline that bounds it: conv groups against the matrix peak of the mode
+    # (algorithmic FLOPs), the homography warp against HBM (algorithmic bytes, SURVEY 8d: B*h*w*4 + Ht*Wt*4 + 36*B)
+    other = {}
+    for t, v in summ.items():
+        if t == "warp":
+            tbs = v[1] / (v[2] * 1e-3) / 1e12
+            other[t] = {"launches": v[0], "bound": "hbm", "us_per_launch": round(v[2] * 1e3 / v[0], 2),
+                        "algorithmic_bytes_per_launch": int(v[1] / v[0]), "tb_per_s": round(tbs, 3),
+                        "frac": round(tbs / HBM_PEAK_TBS, 4), "ms_per_step": round(v[2] / args.steps, 4)}
+        else:
+            tf = v[1] / (v[2] * 1e-3) / 1e12
+            other[t] = {"launches": v[0], "bound": "mfma", "tflops": round(tf, 2), "frac": round(tf / peak, 4),
+                        "ms_per_step": round(v[2] / args.steps, 3)}
+    step_gflop = STEP_GFLOP_PER_FRAME_640x360 * (W * H) / (640.0 * 360.0) * B
+    whole_tf = step_gflop * 1e9 * args.steps / elapsed / 1e12    # per GPU: every rank runs its own batch per step
 
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -379,10 +426,14 @@ def main():
                                    + (",consistency,poi" if args.consistency else ""),
                        "frames_per_gpu_per_step": B, "global_batch": B * world,
                        "precision": prec, "range_fallbacks": int(getattr(net, "range_fallbacks", 0)),
+                       "range_rescales": int(getattr(net, "range_rescales", 0)),
                        "parallelism": (f"frame-sharded x{world}, all_gather(theta) over "
                                        + ("RCCL" if args.dist_backend == "nccl" else "gloo (REHEARSAL, ranks share a GPU)" if args.share_gpu else "gloo")
                                        if world > 1 else "single GPU")},
             "roofline": roofline,
+            "whole_step": {"algorithmic_gflop_per_step_per_gpu": round(step_gflop, 1), "tflops_per_gpu": round(whole_tf, 2),
+                           "frac": round(whole_tf / peak, 4),
+                           "note": "UNet + ResNet34-STN algorithmic FLOPs of a batch / ms_per_step, against the matrix peak of the mode"},
             "cpu_baseline": cpu_baseline,
             "kernel_groups": other,
             "other_configs": other_configs,

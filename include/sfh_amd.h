@@ -45,13 +45,16 @@ extern "C" {
  *      pixel (y, x) lives in block c/32, group (c%32)/8, lane c%8 - each (block, plane, group) of an
  *      image row is W x 16 contiguous bytes.
  * H2 : "split-2" fp16 (B, H, cs/32, 2 planes, 4 groups, W, 8), the same layout with two planes:
- *      u = v * 2^SFH_H2_ACT_EXP saturated to +-65504, plane0 = f16(u), plane1 = f16(u - plane0) (both RNE):
- *      22 significand bits of v while plane1 is a normal fp16 number (|v| >= 2^-5), an absolute error
- *      <= 2^-27 below that (fp16 subnormals are honoured by the conversions and by the MFMA).  |v| must stay
- *      below 16376: the producing kernel saturates and raises sfh_conv_desc.h2_overflow.  The exponent trades
- *      range against the absolute error floor; end to end the result does not depend on it between 0 and 6
- *      (tests/probes/f16x3_error_probe.py), 2 leaves 4x the range of the largest activation the synthetic
- *      ResNet-STN checkpoints of the tests produce. */
+ *      u = v * 2^e saturated to +-65504, plane0 = f16(u), plane1 = f16(u - plane0) (both RNE):
+ *      22 significand bits of v while plane1 is a normal fp16 number (|u| >= 2^-3), an absolute error
+ *      <= 2^-25 * 2^-e below that (fp16 subnormals are honoured by the conversions and by the MFMA).  The
+ *      exponent e belongs to the TENSOR and is chosen by the caller (sfh_conv_desc.h2_exp_dst of the producer =
+ *      h2_exp_src / h2_exp_res of its consumers); |v| must stay below 65504 * 2^-e: the producing kernel
+ *      saturates, raises sfh_conv_desc.h2_overflow and records the largest |u| it saw in sfh_conv_desc.h2_range,
+ *      from which the caller picks a smaller exponent.  The exponent trades range against the absolute error
+ *      floor; end to end the result does not depend on it over a span of 2^6 (tests/probes/f16x3_error_probe.py).
+ *      SFH_H2_ACT_EXP (2: |v| < 16376) is the conventional default - 4x the largest activation the synthetic
+ *      ResNet-STN checkpoints of the tests produce - and what the training kernels use throughout. */
 #define SFH_FMT_F32 0
 #define SFH_FMT_S3 1
 #define SFH_FMT_H2 2
@@ -122,6 +125,16 @@ typedef struct sfh_conv_desc {
   /* H2 destinations: device word that is OR-ed with 1 when a value had to be saturated to the fp16 range
    * (optional).  The caller zeroes it and reads it back after the last launch of a forward pass. */
   uint32_t* h2_overflow;
+  /* Exponents of the H2 tensors of this launch (see SFH_FMT_H2; every H2 tensor stores v * 2^e):
+   * h2_exp_src - both sources (folded by the CALLER into `scale` together with the weight exponent; the
+   *              kernels that split an fp32 source themselves, sfh_stem7x7_fwd, read it);
+   * h2_exp_dst - dst and dst_pool;  h2_exp_res - an H2 residual.  Range -64 .. 64. */
+  int32_t h2_exp_src, h2_exp_dst, h2_exp_res;
+  /* H2 destinations (optional): device word that receives, by atomic max, the largest bit pattern of
+   * |v * 2^h2_exp_dst| this launch produced BEFORE saturation (bit patterns of non-negative floats order like
+   * the floats; an Inf / NaN reads >= 0x7F800000).  > 0x477FE000 (65504.f) means the tensor was saturated; the
+   * value tells the caller which exponent would have fitted.  Never reset by the library. */
+  uint32_t* h2_range;
   /* sfh_conv_s3_fwd, H2 sources: couts per workgroup. 0 = chosen by the launcher, 64 = the 4-wave workgroup
    * (256 pixels x 64 couts, two per CU), 128 = the 8-wave workgroup (256 pixels x 128 couts, one per CU, two LDS
    * buffers; needs stride 1, ksize 3 or 2, cout % 128 == 0 - per quadrant for the up-scatter conv -, at least 128
@@ -163,14 +176,16 @@ int sfh_s3_to_f32(const void* src, float* dst, int64_t rows, int W, int cs, void
  * end to end (tests/probes/f16x3_error_probe.py) the representation error is below half of what the fp32
  * accumulation order already costs.  Weights are packed as planes of w * 2^wexp (wexp chosen by the caller so
  * that max |w| * 2^wexp lies in [2^13, 2^14)): the caller multiplies the layer's `scale` by 2^-(wexp +
- * SFH_H2_ACT_EXP).  Modes and geometry as sfh_pack_s3_weights; packed size = 2/3 of the S3 size. */
+ * h2_exp_src).  Modes and geometry as sfh_pack_s3_weights; packed size = 2/3 of the S3 size. */
 int64_t sfh_packed_h2_weight_bytes(int ksize, int c0, int c1, int cout_virtual);
 int sfh_pack_h2_weights(const float* w, void* packed, int ksize, int c0, int c1, int cout_virtual,
                         int mode, int aux, int wexp, void* stream);
-/* fp32 NHWC (rows = B*H, W, cs) <-> H2 (rows, cs/32, 2, 4, W, 8); overflow: optional device word, OR-ed with 1
- * when a value was saturated. */
-int sfh_f32_to_h2(const float* src, void* dst, int64_t rows, int W, int cs, uint32_t* overflow, void* stream);
-int sfh_h2_to_f32(const void* src, float* dst, int64_t rows, int W, int cs, void* stream);
+/* fp32 NHWC (rows = B*H, W, cs) <-> H2 (rows, cs/32, 2, 4, W, 8) with the tensor's exponent act_exp (-64 .. 64);
+ * overflow: optional device word, OR-ed with 1 when a value was saturated; range: optional device word, atomic
+ * max of the bit patterns of |v * 2^act_exp| (as sfh_conv_desc.h2_range). */
+int sfh_f32_to_h2(const float* src, void* dst, int64_t rows, int W, int cs, int act_exp, uint32_t* overflow,
+                  uint32_t* range, void* stream);
+int sfh_h2_to_f32(const void* src, float* dst, int64_t rows, int W, int cs, int act_exp, void* stream);
 
 /* First UNet layer (inc.double_conv.0, unet/unet_parts.py:15; 3 input channels stored as 4):
  * tap-packed fp32 MFMA kernel, k = channel, one MFMA k-step per tap.  Same descriptor/epilogue as
@@ -431,7 +446,7 @@ int sfh_compose_up_weights(const float* wconv, int cout, int c0, int c1, const f
 int sfh_stem7x7_fwd(const sfh_conv_desc* d, void* stream);
 int64_t sfh_packed_stem_weight_bytes(void);
 int sfh_pack_stem_weights(const float* w, void* packed, int cin, int fmt, int wexp, void* stream);   /* fmt: SFH_FMT_S3, or
-    SFH_FMT_H2 (planes of w * 2^wexp; the caller folds 2^-(wexp + SFH_H2_ACT_EXP) into the layer's scale) */
+    SFH_FMT_H2 (planes of w * 2^wexp; the caller folds 2^-(wexp + h2_exp_src) into the layer's scale) */
 
 #ifdef __cplusplus
 }

@@ -14,7 +14,7 @@ Two kinds of output:
    deterministic synthetic weights of ``sfh_amd.synth``.  These pin ``oracle/torch_ref.py``.
 
 Usage:  python oracle/make_fixtures.py [--full]     (--full adds the 640x360 end-to-end vector)
-        python oracle/make_fixtures.py --configs c2,c5,c3   (BASELINE configs at their stated sizes)
+        python oracle/make_fixtures.py --configs c2,c5,c3,c3b16   (BASELINE configs at their stated sizes)
 """
 import argparse
 import importlib.util
@@ -289,17 +289,51 @@ def make_c2_golden(up_mod, rn_mod):
 
 
 def make_c5_golden(up_mod, rn_mod):
-    """BASELINE config 5: 1280x720 frames, 4-class pitch template (pitch_mask_v3_nc4_hd), 33-point POI
-    (predict.py:151-155,186-192); first 2 frames of the batch of 16 the GPU test runs."""
+    """BASELINE config 5 at its stated batch: 16 frames of 1280x720, 4-class pitch template
+    (pitch_mask_v3_nc4_hd), 33-point POI (predict.py:151-155,186-192).  About ten minutes on 8 host cores."""
     torch.set_num_threads(os.cpu_count())
-    B = 2
+    B = 16
     with torch.no_grad():
         x = synth.frames_to_float(synth.synth_frames_u8(B, 720, 1280, seed=0))
         court = synth.load_court_template("pitch_v3_nc4_1280x720", 4, B)
         poi = synth.load_court_poi("pitch", B)
         out = _predict_golden(up_mod, rn_mod, x, court, poi, (1280, 720), 1)
-    np.savez_compressed(os.path.join(GOLD, "c5_1280x720_b2.npz"), **out)
-    print("c5 golden: theta", out["theta"].reshape(B, 9), "consist", out["consist"])
+    np.savez_compressed(os.path.join(GOLD, "c5_1280x720_b16.npz"), **out)
+    print("c5 golden: theta", out["theta"].reshape(B, 9)[:2], "consist", out["consist"])
+
+
+def make_c3_b16_golden(up_mod, rn_mod):
+    """BASELINE config 3 at its stated batch (train.py:155-225: batch 16, batch-statistics BatchNorm depends on
+    it): the reference's own classes under ``net.train()``, FORWARD ONLY (fp32, no_grad - the backward of 16
+    frames does not fit this container), losses of train.py:181-224 through oracle/train_ref.losses.  Stored:
+    the loss values, theta, sub-sampled logits, and every BatchNorm layer's running_mean / running_var /
+    num_batches_tracked AFTER the step (momentum 0.1, unbiased variance)."""
+    from oracle import train_ref
+    torch.set_num_threads(os.cpu_count())
+    B, H, W = 16, 360, 640
+    x = synth.frames_to_float(synth.synth_frames_u8(B, H, W, seed=0))
+    court = synth.load_court_template("ncaa_nc4_640x360", 4, B)
+    poi = synth.load_court_poi("pitch", B)
+    batch = c3_batch(B, H, W, poi.shape[1])
+    net = _loaded(_RefNet(up_mod, rn_mod), 0).train()
+    with torch.no_grad():
+        logits, _, _ = net.unet(x)
+        theta = net.resnet_reg(torch.cat((logits, x), 1))
+        preds = {"logits": logits, "theta": theta, "poi": torch_ref.transform_poi(theta, poi),
+                 "warp_mask": torch_ref.warp(theta, court, (W, H), nearest=False)}
+        ls = train_ref.losses(preds, batch)
+    out = {"theta": theta.numpy(), "logits_sub": logits[:, :, 4::16, 4::16].numpy().copy(),
+           "poi": preds["poi"].numpy(), "warp_mask_sub": preds["warp_mask"][:, 4::16, 4::16].numpy().copy()}
+    for k, v in ls.items():
+        out[f"loss.{k}"] = np.float64(float(v))
+    names = []
+    for k, b in net.named_buffers():
+        if k.endswith(("running_mean", "running_var", "num_batches_tracked")):
+            names.append(k)
+            out[f"buf.{k}"] = b.numpy().copy()
+    out["buffers"] = np.array(names)
+    np.savez_compressed(os.path.join(GOLD, "c3_fwd_640x360_b16.npz"), **out)
+    print("c3 b16 golden:", {k: float(v) for k, v in ls.items()}, len(names), "BatchNorm buffers")
 
 
 def make_c3_golden(up_mod, rn_mod):
@@ -355,7 +389,7 @@ if __name__ == "__main__":
     ap.add_argument("--full", action="store_true")
     ap.add_argument("--data-only", action="store_true")
     ap.add_argument("--train-only", action="store_true", help="only tests/golden/train_blocks.npz")
-    ap.add_argument("--configs", default="", help="comma list of c2,c5,c3: only the full-size BASELINE-config vectors")
+    ap.add_argument("--configs", default="", help="comma list of c2,c5,c3,c3b16: only the full-size BASELINE-config vectors")
     a = ap.parse_args()
     os.makedirs(GOLD, exist_ok=True)
     make_data()
@@ -364,7 +398,7 @@ if __name__ == "__main__":
         rn_mod = _load("ref_resnet", "models/resnet.py")
         if a.configs:
             for c in a.configs.split(","):
-                {"c2": make_c2_golden, "c5": make_c5_golden, "c3": make_c3_golden}[c](up_mod, rn_mod)
+                {"c2": make_c2_golden, "c5": make_c5_golden, "c3": make_c3_golden, "c3b16": make_c3_b16_golden}[c](up_mod, rn_mod)
             raise SystemExit(0)
         if a.train_only:
             make_train_goldens(up_mod, rn_mod)

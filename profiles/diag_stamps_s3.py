@@ -41,10 +41,12 @@ def run(name, cin, cout, h, w, B=16, pool=False, residual=False, reps=3):
     torch.cuda.synchronize()
     rd(buf, 1)
     seg = [buf[8 + i] for i in range(5)]
-    tot = sum(seg)
+    tot = sum(seg) or 1   # the clock-only build (libsfh_amd_clock.so) stamps no phases
     ms = e0.elapsed_time(e1) / reps
     tf = 2.0 * B * h * w * cout * 9 * cin / (ms * 1e-3) / 1e12
-    print(f"{name:34s} {ms:7.3f} ms {tf:6.1f} TF(diag) | " + "  ".join(f"{SEG[i]} {100.0 * seg[i] / tot:5.1f}%" for i in range(5)), flush=True)
+    ghz = 0.1 * buf[14] / buf[15] if buf[15] else float("nan")   # shader cycles per 100 MHz tick, over the stamped waves
+    print(f"{name:34s} {ms:7.3f} ms {tf:6.1f} TF(diag) in-kernel clock {ghz:4.2f} GHz | "
+          + "  ".join(f"{SEG[i]} {100.0 * seg[i] / tot:5.1f}%" for i in range(5)), flush=True)
 
 
 if __name__ == "__main__":
@@ -55,3 +57,4 @@ if __name__ == "__main__":
     run("d2.3   256->256  90x160 +pool", 256, 256, 90, 160, pool=True)
     run("d3.3   512->512  45x80", 512, 512, 45, 80)
     run("d4.3 1024->1024  22x40", 1024, 1024, 22, 40)
+    run("     512->512   360x80 (14 rounds)", 512, 512, 360, 80)

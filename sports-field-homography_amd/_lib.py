@@ -13,7 +13,8 @@ LIB_PATH = os.environ.get("SFH_AMD_LIB") or os.path.join(_HERE, "libsfh_amd.so")
 TILE_8x32, TILE_16x16, TILE_32x8, TILE_8x16, TILE_16x8 = 0, 1, 2, 3, 4
 OUT_NHWC, OUT_UPSCATTER2 = 0, 1
 FMT_F32, FMT_S3, FMT_H2 = 0, 1, 2
-H2_ACT_EXP = 2   # SFH_H2_ACT_EXP
+H2_ACT_EXP = 2   # SFH_H2_ACT_EXP: the default exponent of an H2 tensor
+H2_LIMIT_BITS = 0x477FE000   # bit pattern of 65504.f: sfh_conv_desc.h2_range words above it mean saturation
 
 _p = C.c_void_p
 _i = C.c_int32
@@ -33,8 +34,16 @@ class ConvDesc(C.Structure):
         ("reverse_tiles", _i),
         ("head_w", _p), ("head_b", _p), ("head_nc", _i), ("head_skip_dst", _i),
         ("head_logits", _p), ("head_stn", _p), ("head_frame", _p),
-        ("h2_overflow", _p), ("wg_couts", _i), ("split_arith", _i),
+        ("h2_overflow", _p), ("h2_exp_src", _i), ("h2_exp_dst", _i), ("h2_exp_res", _i), ("h2_range", _p),
+        ("wg_couts", _i), ("split_arith", _i),
     ]
+
+    def __init__(self, *args, **kw):
+        super().__init__(*args, **kw)
+        # H2 tensors of a launch carry v * 2^e; callers that do not manage exponents (the training kernels) get the
+        # conventional default for every tensor
+        if "h2_exp_src" not in kw:
+            self.h2_exp_src = self.h2_exp_dst = self.h2_exp_res = H2_ACT_EXP
 
 
 # name -> (restype, argtypes); every symbol declared in include/sfh_amd.h
@@ -49,8 +58,8 @@ SIGNATURES = {
     "sfh_s3_to_f32": (C.c_int, [_p, _p, C.c_int64, C.c_int, C.c_int, _p]),
     "sfh_packed_h2_weight_bytes": (C.c_int64, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "sfh_pack_h2_weights": (C.c_int, [_p, _p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _p]),
-    "sfh_f32_to_h2": (C.c_int, [_p, _p, C.c_int64, C.c_int, C.c_int, _p, _p]),
-    "sfh_h2_to_f32": (C.c_int, [_p, _p, C.c_int64, C.c_int, C.c_int, _p]),
+    "sfh_f32_to_h2": (C.c_int, [_p, _p, C.c_int64, C.c_int, C.c_int, C.c_int, _p, _p, _p]),
+    "sfh_h2_to_f32": (C.c_int, [_p, _p, C.c_int64, C.c_int, C.c_int, C.c_int, _p]),
     "sfh_conv3x3_c4_fwd": (C.c_int, [C.POINTER(ConvDesc), _p]),
     "sfh_pack_c4_weights": (C.c_int, [_p, _p, C.c_int, C.c_int, _p]),
     "sfh_packed_weight_floats": (C.c_int64, [C.c_int, C.c_int, C.c_int, C.c_int]),

@@ -56,13 +56,15 @@ def build(force=False, verbose=True):
     return LIB
 
 
-def build_diag(verbose=True):
+def build_diag(verbose=True, clock_only=False):
     """Diagnostic variant with in-kernel s_memtime stamps (profiles/diag_stamps.py); never loaded
-    by the product path."""
+    by the product path.  clock_only: no phase stamps (they fence the schedule), only the in-kernel clock probe
+    of conv_s3_kernel (libsfh_amd_clock.so)."""
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    out = os.path.join(_HERE, "libsfh_amd_diag.so")
+    out = os.path.join(_HERE, "libsfh_amd_clock.so" if clock_only else "libsfh_amd_diag.so")
     # -fgpu-rdc: the stamp accumulator (conv_mfma.hip) is referenced from other translation units
-    cmd = [hipcc] + FLAGS + _NO_SLP + ["-DSFH_DIAG_STAMPS", "-fgpu-rdc", "-shared", "-o", out] + [os.path.join(CSRC, s) for s in SOURCES]
+    cmd = [hipcc] + FLAGS + _NO_SLP + ["-DSFH_DIAG_STAMPS"] + (["-DSFH_DIAG_CLOCK_ONLY"] if clock_only else []) + [
+        "-fgpu-rdc", "-shared", "-o", out] + [os.path.join(CSRC, s) for s in SOURCES]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
@@ -72,5 +74,7 @@ def build_diag(verbose=True):
 if __name__ == "__main__":
     if "--diag" in sys.argv:
         build_diag()
+    elif "--clock" in sys.argv:
+        build_diag(clock_only=True)
     else:
         build(force="--force" in sys.argv)

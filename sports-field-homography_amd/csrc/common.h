@@ -60,6 +60,9 @@ static inline void sfh_allow_big_lds_impl(const void* fn, std::atomic<unsigned l
 // SFH_STAMP(i) closes segment i; BASE offsets a kernel's segments inside the 16 counters.
 #ifdef SFH_DIAG_STAMPS
 extern __device__ unsigned long long g_stamps[16];
+#ifdef SFH_DIAG_CLOCK_ONLY   // only the in-kernel clock of SFH_CLOCK_BEGIN / END: no phase stamp fences the schedule
+#define SFH_STAMP(i) do {} while (0)
+#else
 #define SFH_STAMP(i)                                                                         \
   do {                                                                                       \
     unsigned long long t_;                                                                   \
@@ -69,6 +72,7 @@ extern __device__ unsigned long long g_stamps[16];
     seg_[i] += t_ - tprev_;                                                                  \
     tprev_ = t_;                                                                             \
   } while (0)
+#endif
 #define SFH_STAMP_INIT()                                                                     \
   unsigned long long seg_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev_;                             \
   asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tprev_)::"memory")
@@ -80,7 +84,21 @@ extern __device__ unsigned long long g_stamps[16];
       for (int i_ = 0; i_ < 8; ++i_) atomicAdd(&g_stamps[(BASE) + i_], seg_[i_]);            \
   } while (0)
 #define SFH_STAMP_FLUSH() SFH_STAMP_FLUSH_AT(0)
+// in-kernel clock (MI355X_MICROARCH.md, DVFS give-back (6)): shader cycles (s_memtime) and 100 MHz ticks (s_memrealtime)
+// over the life of the wave go to segments 6 and 7: clock = 100 MHz * sum[6] / sum[7]
+#define SFH_CLOCK_BEGIN()                                                                    \
+  unsigned long long ck0_, rt0_;                                                             \
+  asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(ck0_), "=s"(rt0_)::"memory")
+#define SFH_CLOCK_END()                                                                      \
+  do {                                                                                       \
+    unsigned long long ck1_, rt1_;                                                           \
+    asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(ck1_), "=s"(rt1_)::"memory"); \
+    seg_[6] += ck1_ - ck0_;                                                                  \
+    seg_[7] += rt1_ - rt0_;                                                                  \
+  } while (0)
 #else
+#define SFH_CLOCK_BEGIN() do {} while (0)
+#define SFH_CLOCK_END() do {} while (0)
 #define SFH_STAMP(i) do {} while (0)
 #define SFH_STAMP_INIT() do {} while (0)
 #define SFH_STAMP_FLUSH() do {} while (0)

@@ -35,17 +35,20 @@ __device__ __forceinline__ void sfh_split4(const f32x4& v, sfh_u32x2 (&out)[3]) 
   }
 }
 
-// two-plane fp16 split ("H2", include/sfh_amd.h) of 4 fp32 values: u = clamp(v * 2^SFH_H2_ACT_EXP) so that the
-// low plane of ordinary activations stays a NORMAL fp16 number (22 significand bits kept), plane0 = f16(u),
-// plane1 = f16(u - plane0), both round-to-nearest-even (v_cvt_pk_f16_f32).  Values beyond the fp16 range
-// saturate (a NaN becomes -65504); `over` collects max |u| - or a NaN - so that the caller can report it with
-// sfh_h2_out_of_range(over): the host then repeats the work in a format with fp32's range, where NaN / Inf propagate.
+// two-plane fp16 split ("H2", include/sfh_amd.h) of 4 fp32 values: u = clamp(v * scale), scale = 2^e the tensor's
+// power-of-two factor (2^SFH_H2_ACT_EXP by default: the low plane of ordinary activations stays a NORMAL fp16
+// number, 22 significand bits kept), plane0 = f16(u), plane1 = f16(u - plane0), both round-to-nearest-even
+// (v_cvt_pk_f16_f32).  Values beyond the fp16 range saturate (a NaN becomes -65504); `over` collects max |u| - or a
+// NaN - BEFORE saturation so that the caller can report it (sfh_h2_report): the host then picks a smaller exponent
+// for the tensor or, for a non-finite value, repeats the work in a format with fp32's range, where NaN / Inf propagate.
 typedef _Float16 sfh_f16x2 __attribute__((ext_vector_type(2)));
 constexpr float kSfhH2Scale = (float)(1 << SFH_H2_ACT_EXP), kSfhH2InvScale = 1.f / (float)(1 << SFH_H2_ACT_EXP);
 constexpr float kSfhH2Max = 65504.f;
 // `over` is the running UNSIGNED-INTEGER maximum of the bit patterns of |u|: ordered like the floats, with Inf and every
 // NaN above all finite values, so a NaN sticks (fmaxf would drop it)
 __device__ __forceinline__ bool sfh_h2_out_of_range(unsigned over) { return over > 0x477FE000u; }   // bits of 65504.f
+// 2^e for a tensor exponent -64 <= e <= 64 (exact: the bit pattern of the power of two)
+__device__ __forceinline__ float sfh_h2_pow2(int e) { return __builtin_bit_cast(float, (unsigned)(127 + e) << 23); }
 
 __device__ __forceinline__ unsigned sfh_cvt_pk_h(float a, float b) {  // v_cvt_pk_f16_f32 (RNE)
   return __builtin_bit_cast(unsigned, __builtin_convertvector((sfh_f32x2){a, b}, sfh_f16x2));
@@ -54,11 +57,11 @@ __device__ __forceinline__ sfh_f32x2 sfh_unpack_h(unsigned w) {
   return __builtin_convertvector(__builtin_bit_cast(sfh_f16x2, w), sfh_f32x2);
 }
 
-__device__ __forceinline__ void sfh_split4_h2(const f32x4& v, sfh_u32x2 (&out)[2], unsigned& over) {
+__device__ __forceinline__ void sfh_split4_h2(const f32x4& v, float scale, sfh_u32x2 (&out)[2], unsigned& over) {
   f32x4 u;
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    const float t = v[j] * kSfhH2Scale;
+    const float t = v[j] * scale;
     const unsigned ab = __builtin_bit_cast(unsigned, t) & 0x7FFFFFFFu;
     over = ab > over ? ab : over;
     u[j] = fminf(fmaxf(t, -kSfhH2Max), kSfhH2Max);
@@ -69,6 +72,23 @@ __device__ __forceinline__ void sfh_split4_h2(const f32x4& v, sfh_u32x2 (&out)[2
   out[0][1] = w1;
   out[1][0] = sfh_cvt_pk_h(u[0] - b0[0], u[1] - b0[1]);
   out[1][1] = sfh_cvt_pk_h(u[2] - b1[0], u[3] - b1[1]);
+}
+
+// End of a kernel that produced H2 values, reached by ALL 64 lanes of the wave (the butterfly reads every lane):
+// `over` = the lane's running maximum (sfh_split4_h2).  overflow (optional): OR-ed with 1 when a value was saturated;
+// range (optional): atomic max of the wave's maximum - only when it exceeds what the word already holds, so that a
+// steady-state launch (the word carries the maximum of the earlier batches) issues no atomic at all.
+__device__ __forceinline__ void sfh_h2_report(unsigned over, unsigned* overflow, unsigned* range) {
+  if (!overflow && !range) return;
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) {
+    const unsigned o = (unsigned)__shfl_xor((int)over, m);
+    over = o > over ? o : over;
+  }
+  if ((threadIdx.x & 63) == 0) {
+    if (overflow && sfh_h2_out_of_range(over)) atomicOr(overflow, 1u);
+    if (range && over > *reinterpret_cast<volatile unsigned*>(range)) atomicMax(range, over);
+  }
 }
 
 constexpr unsigned kSfhOOB = 0xFFFFFFF0u;  // byte offset that the buffer range check rejects
@@ -86,6 +106,8 @@ __device__ __forceinline__ void sfh_conv_epilogue(const sfh_conv_desc& d, const 
   const bool s3 = h2 || ((FMTS & 1) && d.dst_fmt == SFH_FMT_S3);  // a split (plane) format
   const unsigned np4 = h2 ? 8u : 12u;                              // (plane, group) runs per 32-channel block
   unsigned over = 0u;
+  // H2 tensors carry v * 2^e with a per-tensor exponent (include/sfh_amd.h): destination / pooled output, residual
+  const float h2_dst_scale = sfh_h2_pow2(d.h2_exp_dst), h2_res_inv = sfh_h2_pow2(-d.h2_exp_res);
   // S3 layout (B, H, cs/32, 3 planes, 4 groups of 8 ch, W, 8) bf16: for one image row every
   // (channel block, plane, group) is a contiguous run of W x 16 bytes, so that 16 consecutive pixels
   // of a lane group are 256 contiguous bytes (lane groups lg and lg^1 hold the two 8-byte halves of
@@ -196,7 +218,7 @@ __device__ __forceinline__ void sfh_conv_epilogue(const sfh_conv_desc& d, const 
               q[0] += a[0]; q[1] += a[1]; q[2] += b[0]; q[3] += b[1];
             }
 #pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] += q[j] * kSfhH2InvScale;
+            for (int j = 0; j < 4; ++j) v[j] += q[j] * h2_res_inv;
           }
         } else if (res_s3) {
 #pragma unroll
@@ -234,7 +256,7 @@ __device__ __forceinline__ void sfh_conv_epilogue(const sfh_conv_desc& d, const 
       if (h2) {
         if constexpr ((FMTS & 2) != 0) {
           sfh_u32x2 pl[2];
-          sfh_split4_h2(v, pl, over);
+          sfh_split4_h2(v, h2_dst_scale, pl, over);
 #pragma unroll
           for (int p = 0; p < 2; ++p)
             __builtin_amdgcn_raw_buffer_store_b64(pl[p], rd, (int)voff[mi], (int)(nioff + p * planeb), 0);
@@ -296,7 +318,7 @@ __device__ __forceinline__ void sfh_conv_epilogue(const sfh_conv_desc& d, const 
           if constexpr ((FMTS & 2) != 0) {
             sfh_u32x2 pl[2];
             unsigned dummy = 0u;   // the pooled values are a subset of the values checked above
-            sfh_split4_h2(m, pl, dummy);
+            sfh_split4_h2(m, h2_dst_scale, pl, dummy);
 #pragma unroll
             for (int p = 0; p < 2; ++p)
               __builtin_amdgcn_raw_buffer_store_b64(pl[p], rp, (int)pv, (int)(nioff + p * pplaneb), 0);
@@ -313,9 +335,10 @@ __device__ __forceinline__ void sfh_conv_epilogue(const sfh_conv_desc& d, const 
       }
     }
   }
-  // H2 destination: a value beyond the fp16 range was saturated - leave a mark for the host (the engine
-  // re-runs such a batch with the three-plane bf16 format, which has fp32's exponent range)
+  // H2 destination: leave the largest |u| for the host - beyond the fp16 range the value was saturated: the engine
+  // lowers the tensor's exponent and re-runs from this layer (non-finite: the batch goes through the three-plane
+  // bf16 format, which has fp32's exponent range)
   if constexpr ((FMTS & 2) != 0) {
-    if (h2 && d.h2_overflow && sfh_h2_out_of_range(over)) atomicOr(d.h2_overflow, 1u);
+    if (h2) sfh_h2_report(over, d.h2_overflow, d.h2_range);
   }
 }

@@ -583,6 +583,7 @@ extern "C" int sfh_conv3x3_c4_fwd(const sfh_conv_desc* dp, void* stream_) {
                   d.src_fmt == SFH_FMT_F32 && d.out_mode == SFH_OUT_NHWC && d.h0 == d.H && d.w0 == d.W,
               "conv3x3_c4_fwd: needs a single fp32 NHWC source with 4 stored channels, 3x3 stride 1");
   SFH_REQUIRE(d.cout > 0 && d.cout % 64 == 0 && d.batch > 0 && d.H > 0 && d.W > 0, "conv3x3_c4_fwd: bad geometry");
+  SFH_REQUIRE(d.h2_exp_dst >= -64 && d.h2_exp_dst <= 64, "conv3x3_c4_fwd: h2_exp_dst=%d out of range (-64 .. 64)", d.h2_exp_dst);
   ConvGeom g;
   g.Ho = d.H;
   g.Wo = d.W;

@@ -2,13 +2,13 @@
 //
 // Two operand formats, one kernel source (S3Cfg::NP = planes per operand):
 //   * H2 ("f16x3", the default of the engines): every value is two fp16 planes of u = v * 2^e,
-//     p0 = f16(u), p1 = f16(u - p0) - 22 significand bits; e = 2 for activations, per layer for weights
+//     p0 = f16(u), p1 = f16(u - p0) - 22 significand bits; e per tensor for activations (default 2), per layer for weights
 //     (max |w| 2^e in [2^13, 2^14), folded into the epilogue scale).  A product is accumulated from
 //            w*x  ~=  w0x1 + w1x0 + w0x0                                  (dropped term <= 2^-22)
 //     by v_mfma_f32_16x16x32_f16 in fp32: 3 MFMAs per 32 k, ceiling 2.5 PFLOP/s / 3 = 833 TFLOP/s of fp32-grade
 //     work.  The operand representation perturbs a whole forward pass less than the accumulation order of an
 //     fp32 run does (tests/test_oracle.py::test_f16x3_operand_representation_...); values beyond fp16's range
-//     raise sfh_conv_desc.h2_overflow and the host repeats the batch in the other format.
+//     raise sfh_conv_desc.h2_overflow / h2_range: the host lowers the tensor's exponent and repeats from that layer.
 //   * S3 ("bf16x6"): three bf16 planes v = v0 + v1 + v2 (v0 = bf16(v), v1 = bf16(v - v0), v2 = bf16(v - v0 - v1):
 //     exact, 3 x 8 significand bits, fp32's exponent range), six partial products
 //            w*x  ~=  w0x2 + w1x1 + w2x0 + w0x1 + w1x0 + w0x0            (dropped terms <= 2^-24)
@@ -164,6 +164,7 @@ __global__ __launch_bounds__(C::NT, (C::NP == 2 && !DB) ? SFH_H2_WAVES_PER_SIMD 
   u32x4* const lds = reinterpret_cast<u32x4*>(smem_f);
   typedef __attribute__((address_space(3))) void* lds_ptr_t;
   SFH_STAMP_INIT();
+  SFH_CLOCK_BEGIN();
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -421,6 +422,7 @@ __global__ __launch_bounds__(C::NT, (C::NP == 2 && !DB) ? SFH_H2_WAVES_PER_SIMD 
   sfh_conv_epilogue<C, 2, C::MT_M, (NP == 3 ? 1 : 2)>(d, g, acc, n0 + 32 * wn, wm * C::MT_M, r0, x0, lq, lg);
   if (!DB) {
     SFH_STAMP(4);
+    SFH_CLOCK_END();
     SFH_STAMP_FLUSH_AT(8);
   }
 
@@ -663,32 +665,34 @@ __global__ void s3_to_f32_kernel(const unsigned short* __restrict__ src, float* 
 }
 
 // fp32 NHWC <-> H2 (rows, cs/32, 2, 4, W, 8) fp16 (format: include/sfh_amd.h); thread mapping as f32_to_s3_kernel
+// (no early exit: every lane reaches sfh_h2_report)
 __global__ __launch_bounds__(256) void f32_to_h2_kernel(const float* __restrict__ src, unsigned short* __restrict__ dst,
-                                                        int W, int cs, int xchunks, long total, unsigned* overflow) {
+                                                        int W, int cs, int xchunks, long total, float scale,
+                                                        unsigned* overflow, unsigned* range) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
-  if (i >= total) return;
   const int g = (int)(i & 3), px = (int)((i >> 2) & 15);
   long r = i >> 6;
   const int xc = (int)(r % xchunks); r /= xchunks;
   const int cb = (int)(r % (cs >> 5));
   const long row = r / (cs >> 5);
   const int x = xc * 16 + px;
-  if (x >= W) return;
-  const float* sp = src + (row * W + x) * cs + cb * 32 + g * 8;
-  const f32x4 a = *reinterpret_cast<const f32x4*>(sp), b = *reinterpret_cast<const f32x4*>(sp + 4);
-  sfh_u32x2 pa[2], pb[2];
   unsigned over = 0u;
-  sfh_split4_h2(a, pa, over);
-  sfh_split4_h2(b, pb, over);
-  const long e = ((((row * (cs >> 5) + cb) * 2) * 4 + g) * W + x) * 8;
-  const long ps = 4L * W * 8;  // plane stride in elements
-  *reinterpret_cast<u32x4*>(dst + e) = (u32x4){pa[0][0], pa[0][1], pb[0][0], pb[0][1]};
-  *reinterpret_cast<u32x4*>(dst + e + ps) = (u32x4){pa[1][0], pa[1][1], pb[1][0], pb[1][1]};
-  if (overflow && sfh_h2_out_of_range(over)) atomicOr(overflow, 1u);
+  if (i < total && x < W) {
+    const float* sp = src + (row * W + x) * cs + cb * 32 + g * 8;
+    const f32x4 a = *reinterpret_cast<const f32x4*>(sp), b = *reinterpret_cast<const f32x4*>(sp + 4);
+    sfh_u32x2 pa[2], pb[2];
+    sfh_split4_h2(a, scale, pa, over);
+    sfh_split4_h2(b, scale, pb, over);
+    const long e = ((((row * (cs >> 5) + cb) * 2) * 4 + g) * W + x) * 8;
+    const long ps = 4L * W * 8;  // plane stride in elements
+    *reinterpret_cast<u32x4*>(dst + e) = (u32x4){pa[0][0], pa[0][1], pb[0][0], pb[0][1]};
+    *reinterpret_cast<u32x4*>(dst + e + ps) = (u32x4){pa[1][0], pa[1][1], pb[1][0], pb[1][1]};
+  }
+  sfh_h2_report(over, overflow, range);
 }
 
 __global__ void h2_to_f32_kernel(const unsigned short* __restrict__ src, float* __restrict__ dst, int W, int cs,
-                                 long total) {
+                                 long total, float inv_scale) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total) return;
   const long pix = i / cs;
@@ -698,7 +702,7 @@ __global__ void h2_to_f32_kernel(const unsigned short* __restrict__ src, float* 
   const long e = ((((row * (cs >> 5) + (c >> 5)) * 2) * 4 + ((c & 31) >> 3)) * W + x) * 8 + (c & 7);
   const float lo = (float)__builtin_bit_cast(_Float16, src[e + 4L * W * 8]);
   const float hi = (float)__builtin_bit_cast(_Float16, src[e]);
-  dst[i] = (lo + hi) * kSfhH2InvScale;
+  dst[i] = (lo + hi) * inv_scale;
 }
 
 template <class C, bool DB>
@@ -854,20 +858,23 @@ extern "C" int sfh_s3_to_f32(const void* src, float* dst, int64_t rows, int W, i
   return sfh_check_launch("s3_to_f32_kernel");
 }
 
-extern "C" int sfh_f32_to_h2(const float* src, void* dst, int64_t rows, int W, int cs, uint32_t* overflow, void* stream) {
+extern "C" int sfh_f32_to_h2(const float* src, void* dst, int64_t rows, int W, int cs, int act_exp, uint32_t* overflow,
+                             uint32_t* range, void* stream) {
   SFH_REQUIRE(src && dst && rows > 0 && W > 0 && cs > 0 && cs % 32 == 0, "f32_to_h2: cs must be a multiple of 32");
+  SFH_REQUIRE(act_exp >= -64 && act_exp <= 64, "f32_to_h2: act_exp=%d out of range", act_exp);
   const int xchunks = (W + 15) / 16;
   const long total = rows * (cs / 32) * xchunks * 64;
   hipLaunchKernelGGL(f32_to_h2_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                     src, (unsigned short*)dst, W, cs, xchunks, total, overflow);
+                     src, (unsigned short*)dst, W, cs, xchunks, total, ldexpf(1.f, act_exp), overflow, range);
   return sfh_check_launch("f32_to_h2_kernel");
 }
 
-extern "C" int sfh_h2_to_f32(const void* src, float* dst, int64_t rows, int W, int cs, void* stream) {
+extern "C" int sfh_h2_to_f32(const void* src, float* dst, int64_t rows, int W, int cs, int act_exp, void* stream) {
   SFH_REQUIRE(src && dst && rows > 0 && W > 0 && cs > 0 && cs % 32 == 0, "h2_to_f32: cs must be a multiple of 32");
+  SFH_REQUIRE(act_exp >= -64 && act_exp <= 64, "h2_to_f32: act_exp=%d out of range", act_exp);
   const long total = rows * W * cs;
   hipLaunchKernelGGL(h2_to_f32_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                     (const unsigned short*)src, dst, W, cs, total);
+                     (const unsigned short*)src, dst, W, cs, total, ldexpf(1.f, -act_exp));
   return sfh_check_launch("h2_to_f32_kernel");
 }
 
@@ -880,6 +887,8 @@ extern "C" int sfh_conv_s3_fwd(const sfh_conv_desc* dp, void* stream_) {
   SFH_REQUIRE(d.dst_fmt == SFH_FMT_F32 || d.dst_fmt == d.src_fmt,
               "conv_s3_fwd: the destination is fp32 or the sources' own split format (src_fmt=%d, dst_fmt=%d)", d.src_fmt, d.dst_fmt);
   SFH_REQUIRE(d.batch > 0 && d.H > 0 && d.W > 0, "conv_s3_fwd: empty geometry");
+  SFH_REQUIRE(d.h2_exp_dst >= -64 && d.h2_exp_dst <= 64 && d.h2_exp_res >= -64 && d.h2_exp_res <= 64,
+              "conv_s3_fwd: h2_exp_dst=%d / h2_exp_res=%d out of range (-64 .. 64)", d.h2_exp_dst, d.h2_exp_res);
   SFH_REQUIRE(d.cout > 0 && d.cout % 64 == 0, "conv_s3_fwd: cout=%d must be a multiple of 64", d.cout);
   SFH_REQUIRE(d.c0 > 0 && d.c0 % 32 == 0 && d.cs0 >= d.c0, "conv_s3_fwd: c0=%d must be a multiple of 32 (cs0=%d)", d.c0, d.cs0);
   SFH_REQUIRE(!d.pool0, "conv_s3_fwd: pool-on-load is not available for S3 sources (use the producer's dst_pool)");

@@ -55,6 +55,7 @@ __global__ __launch_bounds__(256, 2) void stem7x7_kernel(const sfh_conv_desc d, 
   // ---- stage the input halo: fp32 (8 channels) -> three bf16 planes, zeros outside the frame
   const float* src = d.src0 + (long)img * d.H * d.W * 8;
   unsigned over = 0u;   // NP = 2: see sfh_split4_h2
+  const float in_scale = sfh_h2_pow2(d.h2_exp_src);   // the planes carry x * 2^h2_exp_src (folded into `scale` by the caller)
   for (int p = tid; p < C::HPIX; p += 256) {
     const int hy = p / C::HW, hx = p - hy * C::HW;
     const int y = 2 * y0 - 3 + hy, x = 2 * x0 - 3 + hx;
@@ -82,14 +83,14 @@ __global__ __launch_bounds__(256, 2) void stem7x7_kernel(const sfh_conv_desc d, 
       }
     } else {
       sfh_u32x2 pa[2], pb[2];
-      sfh_split4_h2((f32x4){v[0], v[1], v[2], v[3]}, pa, over);
-      sfh_split4_h2((f32x4){v[4], v[5], v[6], v[7]}, pb, over);
+      sfh_split4_h2((f32x4){v[0], v[1], v[2], v[3]}, in_scale, pa, over);
+      sfh_split4_h2((f32x4){v[4], v[5], v[6], v[7]}, in_scale, pb, over);
       lds[p] = (st_u32x4){pa[0][0], pa[0][1], pb[0][0], pb[0][1]};
       lds[C::HPIXP + p] = (st_u32x4){pa[1][0], pa[1][1], pb[1][0], pb[1][1]};
     }
   }
   if constexpr (NP == 2) {
-    if (d.h2_overflow && sfh_h2_out_of_range(over)) atomicOr(d.h2_overflow, 1u);
+    sfh_h2_report(over, d.h2_overflow, d.h2_range);   // (all lanes are back from the staging loop)
   }
 
   // ---- weights: packed [step 13][plane NP][cout subtile 4][lane 64] x 16 B; this wave: subtiles 2*wn, 2*wn+1
@@ -210,6 +211,7 @@ extern "C" int sfh_stem7x7_fwd(const sfh_conv_desc* dp, void* stream) {
   g.ntiles = g.tiles_x * g.tiles_y * d.batch;
   SFH_REQUIRE((unsigned long long)d.batch * g.Ho * g.Wo * d.dst_cs * 4ULL < 0xFFFFFFF0ULL, "stem7x7_fwd: destination exceeds 4 GiB");
   SFH_REQUIRE(d.split_arith == 0 || d.split_arith == SFH_FMT_S3 || d.split_arith == SFH_FMT_H2, "stem7x7_fwd: split_arith=%d", d.split_arith);
+  SFH_REQUIRE(d.h2_exp_src >= -64 && d.h2_exp_src <= 64, "stem7x7_fwd: h2_exp_src=%d out of range (-64 .. 64)", d.h2_exp_src);
   if (d.split_arith == SFH_FMT_H2) {
     sfh_allow_big_lds(reinterpret_cast<const void*>(&stem7x7_kernel<2>));
     hipLaunchKernelGGL(stem7x7_kernel<2>, dim3((unsigned)g.ntiles), dim3(256), StemCfg::LDS_BYTES / 3 * 2, (hipStream_t)stream, d, g);

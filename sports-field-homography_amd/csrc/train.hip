@@ -307,8 +307,8 @@ __device__ __forceinline__ long tr_s3_elem(long row, int x, int c, int W, int C,
 __device__ __forceinline__ void tr_split8_h2(const float (&v)[8], unsigned short* __restrict__ dst, long e, long ps,
                                              unsigned& over) {
   sfh_u32x2 pa[2], pb[2];
-  sfh_split4_h2((f32x4){v[0], v[1], v[2], v[3]}, pa, over);
-  sfh_split4_h2((f32x4){v[4], v[5], v[6], v[7]}, pb, over);
+  sfh_split4_h2((f32x4){v[0], v[1], v[2], v[3]}, kSfhH2Scale, pa, over);
+  sfh_split4_h2((f32x4){v[4], v[5], v[6], v[7]}, kSfhH2Scale, pb, over);
   typedef unsigned int tr_u32x4 __attribute__((ext_vector_type(4)));
   *reinterpret_cast<tr_u32x4*>(dst + e) = (tr_u32x4){pa[0][0], pa[0][1], pb[0][0], pb[0][1]};
   *reinterpret_cast<tr_u32x4*>(dst + e + ps) = (tr_u32x4){pa[1][0], pa[1][1], pb[1][0], pb[1][1]};

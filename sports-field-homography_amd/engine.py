@@ -5,7 +5,9 @@ PyTorch is used here for device memory (``torch.empty``), the current HIP stream
 parameter storage only; every arithmetic step is a call into ``libsfh_amd.so``.
 """
 import ctypes
+import math
 import os
+import threading
 
 import torch
 
@@ -18,23 +20,29 @@ BN_EPS = 1e-5
 _TILES = ((_lib.TILE_8x32, 8, 32), (_lib.TILE_16x16, 16, 16), (_lib.TILE_32x8, 32, 8))
 
 
-_STREAM_CACHE = []   # [c_void_p] while an engine's run() is on the stack (torch.cuda.current_stream() costs ~9 us)
+# the HIP stream of the engine run() on this THREAD's stack (torch.cuda.current_stream() costs ~9 us per launch);
+# thread-local: another thread's run() - another model, device or torch.cuda.stream() context - has its own
+_STREAM_TLS = threading.local()
 
 
 def _stream():
-    if _STREAM_CACHE:
-        return _STREAM_CACHE[-1]
+    stack = getattr(_STREAM_TLS, "stack", None)
+    if stack:
+        return stack[-1]
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
 class _stream_scope:
-    """Resolve the current HIP stream once for all launches of one engine run."""
+    """Resolve the current HIP stream once for all launches of one engine run (of the calling thread)."""
 
     def __enter__(self):
-        _STREAM_CACHE.append(ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+        stack = getattr(_STREAM_TLS, "stack", None)
+        if stack is None:
+            stack = _STREAM_TLS.stack = []
+        stack.append(ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
 
     def __exit__(self, *exc):
-        _STREAM_CACHE.pop()
+        _STREAM_TLS.stack.pop()
         return False
 
 
@@ -93,6 +101,127 @@ def s3_shape(b, h, w, c):
 def s3_empty(b, h, w, c, device):
     """uninitialised split-bf16 activation tensor for c channels (c multiple of 32)"""
     return torch.empty(s3_shape(b, h, w, c), dtype=torch.bfloat16, device=device)
+
+
+class H2Ranges:
+    """Exponents and range words of the H2 (two-plane fp16, "f16x3") activation tensors of one model.
+
+    An H2 tensor stores v * 2^e and saturates beyond |v| = 65504 * 2^-e (include/sfh_amd.h).  Every tensor NAME has
+    an exponent KEY - tensors that enter one conv as its two sources share a key, and so do a conv output and the
+    pooled copy its producer writes - and a device word that the producing kernels raise (atomic max) to the
+    largest bit pattern of |v * 2^e| they produced, before saturation.  After a forward pass the host reads the
+    words (`read`): a word above H2_LIMIT_BITS means its tensor was saturated, and how far it overshot gives the
+    exponent that fits (`lower`); the engines then repeat the pass from the first step that writes such a tensor.
+    Exponents start at the conventional 2 and only ever go down: the state is sticky, shared by the UNet and ResNet
+    engines of a Reconstructor and kept across engine rebuilds (same model, new weights)."""
+
+    LIMIT = _lib.H2_LIMIT_BITS
+    NONFINITE = 0x7F800000
+    DEFAULT = _lib.H2_ACT_EXP
+
+    def __init__(self, device, capacity=1024):
+        self.device = device
+        self.words = torch.zeros(capacity, dtype=torch.int32, device=device)
+        self.exps = {}     # key -> exponent (absent = DEFAULT)
+        self.slot = {}     # tensor name -> (key, word index)
+        self.peak = {}     # tensor name -> largest |v| seen so far (host side, from read())
+        self._nwords = 0
+
+    def register(self, name, key=None, word_of=None):
+        """name: tensor; key: name of an already registered tensor whose exponent it shares; word_of: name of a
+        tensor whose word it shares (a pooled copy: its values are a subset of the other tensor's)."""
+        cur = self.slot.get(name)
+        k = self.slot[key][0] if key is not None else name
+        if cur is not None:
+            if cur[0] != k:
+                raise ValueError(f"H2 tensor {name!r} is tied to exponent key {cur[0]!r}, not {k!r}")
+            return
+        if word_of is not None:
+            idx = self.slot[word_of][1]
+        else:
+            idx = self._nwords
+            self._nwords += 1
+            if idx >= self.words.numel():
+                raise RuntimeError("H2Ranges: out of range words")
+        self.slot[name] = (k, idx)
+
+    def exp(self, name):
+        s = self.slot.get(name)
+        return self.exps.get(s[0], self.DEFAULT) if s is not None else self.DEFAULT
+
+    def key(self, name):
+        return self.slot[name][0]
+
+    def word_ptr(self, name):
+        s = self.slot.get(name)
+        return self.words.data_ptr() + 4 * s[1] if s is not None else None
+
+    def args(self, src=None, dst=None, res=None):
+        """keyword arguments of PackedConv.run / StemConv.run for a launch reading `src`, writing `dst` (+ residual)"""
+        return {"exp_src": self.exp(src), "exp_dst": self.exp(dst), "exp_res": self.exp(res),
+                "range_word": self.word_ptr(dst)}
+
+    def read(self):
+        """One device read-back: {tensor name: bit pattern of the largest |v * 2^e| since the words were zeroed}."""
+        n = self._nwords
+        if n == 0:
+            return {}
+        vals = self.words[:n].cpu().numpy().view("uint32")
+        out = {}
+        for name, (key, idx) in self.slot.items():
+            b = int(vals[idx])
+            out[name] = b
+            if 0 < b < self.NONFINITE:
+                v = _bits_to_float(b) * 2.0 ** -self.exps.get(key, self.DEFAULT)
+                if v > self.peak.get(name, 0.0):
+                    self.peak[name] = v
+        return out
+
+    def saturated(self, bits):
+        """names whose tensor left the fp16 range, and whether any of them holds a non-finite value"""
+        bad = [n for n, b in bits.items() if b > self.LIMIT]
+        return bad, any(bits[n] >= self.NONFINITE for n in bad)
+
+    def lower(self, name, bits):
+        """Pick the exponent that puts the observed maximum into [2^12, 2^13) (8x headroom).  -> the key."""
+        key, _ = self.slot[name]
+        e = self.exps.get(key, self.DEFAULT)
+        vmax = _bits_to_float(bits) * 2.0 ** -e
+        new = 13 - math.frexp(vmax)[1]                 # frexp: vmax = m * 2^x, 0.5 <= m < 1
+        new = max(-64, min(new, e - 1))
+        self.exps[key] = new
+        return key
+
+    def reset_words(self):
+        self.words.zero_()
+
+    def headroom(self):
+        """{tensor name: 65504 * 2^-e / largest |v| seen} - how far each tensor is from saturating"""
+        return {n: 65504.0 * 2.0 ** -self.exp(n) / v for n, v in self.peak.items() if v > 0}
+
+
+def _bits_to_float(b):
+    import struct
+    return struct.unpack("<f", struct.pack("<I", b & 0xFFFFFFFF))[0]
+
+
+class _NoRanges:
+    """stands in for H2Ranges in the other precisions: default exponents, no words"""
+
+    def register(self, *a, **k):
+        pass
+
+    def exp(self, name):
+        return _lib.H2_ACT_EXP
+
+    def key(self, name):
+        return name
+
+    def word_ptr(self, name):
+        return None
+
+    def args(self, src=None, dst=None, res=None):
+        return {}
 
 
 # half-size tiles of the split-bf16 kernel (8 pixel groups): small maps and stride 2
@@ -188,6 +317,8 @@ class PackedConv:
 
     timer = None   # set to a ConvTimer to time every launch (bench.py / profiling only)
     order = None   # LaunchOrder of the owning engine (set by the engine); None = always forward
+    exp_src = _lib.H2_ACT_EXP   # H2 layers: exponent of the source tensors currently folded into `scale`
+    _shared_scale = False       # `scale` is a tensor shared with other layers (training): never rewritten in place
 
     def __init__(self, weight, bias, bn, ksize, c0, c1=0, relu=True, transposed=False, stride=1,
                  stem_cin=0, tag="conv", s3=False, fmt=None, wexp=None, shared_unit_scale=False):
@@ -248,6 +379,7 @@ class PackedConv:
             # itself: no kernel launch here (a step builds 114 of these objects)
             self.scale, zeros = _unit_epilogue(self.cout, dev, self.escale)
             self.shift = zeros if b is None else (b if rep == 1 else b.repeat(rep))
+            self._shared_scale = True
             return
         self.scale = torch.empty(self.cout, dtype=torch.float32, device=dev)
         self.shift = torch.empty(self.cout, dtype=torch.float32, device=dev)
@@ -363,14 +495,37 @@ class PackedConv:
             _lib.check(lib.sfh_pack_conv_weights(_ptr(w), _ptr(self.wpacked), ksize, c0, 0, self.cout, mode, aux,
                                                  _stream()), "pack_conv_weights")
         self.scale, self.shift = _unit_epilogue(self.cout, dev, self.escale)
+        self._shared_scale = True
         return self
 
+    def _fold_exp_src(self, e):
+        """H2 layer: its sources now carry v * 2^e.  `scale` holds the factor 2^-(wexp + exp_src) that takes the
+        accumulator back to real units: multiply the difference in (a power of two: exact)."""
+        if e == self.exp_src:
+            return
+        if self._shared_scale:
+            raise ValueError("this layer's epilogue scale is shared with other layers: its source exponent is fixed")
+        f = 2.0 ** (self.exp_src - e)
+        self.scale.mul_(f)
+        self.escale *= f
+        self.exp_src = e
+
     def run(self, src0, batch, H, W, dst, src1=None, pool0=False, pad1=(0, 0), residual=None, tile=None,
-            dst_pool=None, up_dst=None, head=None, wg_couts=0):
+            dst_pool=None, up_dst=None, head=None, wg_couts=0, exp_src=None, exp_dst=None, exp_res=None,
+            range_word=None):
         """src0/src1: NHWC float32 tensors, or split tensors of the layer's format (S3 bfloat16 / H2 float16);
-        dst/residual/dst_pool: float32 NHWC or the same split format (by dtype).  H, W: conv input frame."""
+        dst/residual/dst_pool: float32 NHWC or the same split format (by dtype).  H, W: conv input frame.
+        H2 tensors: exp_src / exp_dst / exp_res = exponents of the sources / dst and dst_pool / an H2 residual
+        (None: the conventional SFH_H2_ACT_EXP), range_word: device address of dst's range word (H2Ranges)."""
         lib = _lib.load()
         d = ConvDesc()
+        if self.fmt == "h2" and exp_src is not None:
+            self._fold_exp_src(int(exp_src))
+        d.h2_exp_src = self.exp_src
+        if exp_dst is not None:
+            d.h2_exp_dst = int(exp_dst)
+        if exp_res is not None:
+            d.h2_exp_res = int(exp_res)
         d.src0 = src0.data_ptr()
         d.c0, d.cs0 = self.c0, _chan(src0)
         d.h0, d.w0 = _hw(src0)
@@ -385,6 +540,7 @@ class PackedConv:
                 raise ValueError(f"dst_pool / residual of dtype {t.dtype} beside a {dst.dtype} destination")
         ovf = getattr(self, "overflow", None)
         d.h2_overflow = ovf.data_ptr() if (ovf is not None and _fmt_of(dst) == "h2") else None
+        d.h2_range = range_word if (range_word and _fmt_of(dst) == "h2") else None
         if dst_pool is not None:
             d.dst_pool, d.pool_cs = dst_pool.data_ptr(), _chan(dst_pool)
         d.pool0 = 1 if pool0 else 0
@@ -483,11 +639,12 @@ class _Workspace:
 class UNetEngine:
     """forward_unet (models/reconstructor.py:132-158) on the HIP kernels."""
 
-    def __init__(self, net, device, precision="bf16x6", overflow=None):
+    def __init__(self, net, device, precision="bf16x6", overflow=None, ranges=None):
         """precision: "bf16x6" - activations in split-bf16 (S3) format, contractions as six bf16
         MFMAs per product with fp32 accumulation (fp32-equivalent accuracy); "f16x3" - two-plane fp16 (H2)
-        activations, three fp16 MFMAs per product (22-bit operands; `overflow`: int32 device word that the kernels
-        raise when an activation leaves the fp16 range); "fp32" - fp32 activations and fp32 MFMA throughout."""
+        activations, three fp16 MFMAs per product (22-bit operands; `ranges`: the model's H2Ranges - per-tensor
+        exponents and the device words the kernels raise to the largest magnitude they produced; `overflow`:
+        optional int32 device word OR-ed with 1 on any saturation); "fp32" - fp32 activations and fp32 MFMA."""
         self.bilinear = bool(net.unet_bilinear)
         # fused Up levels where the composed 2x2 conv runs first (see run()): the two full-resolution-most
         # levels, where that conv is memory-heavy (measured per level: none 629, {4} 634, {3,4} 638, all 635
@@ -502,6 +659,9 @@ class UNetEngine:
         self.s3 = fmt is not None          # split-format activations
         s3 = self.s3
         self.overflow = overflow if fmt == "h2" else None
+        self.ranges = (ranges if ranges is not None else H2Ranges(device)) if fmt == "h2" else _NoRanges()
+        self.steps = []            # launches of the last run(), in order: [(names of the H2 tensors written, fn)]
+        self._last_out = None
         L = {}
 
         def dc(name, block, c0, c1=0, first_fmt=fmt):
@@ -545,9 +705,25 @@ class UNetEngine:
     def run(self, x, want_stn_in=False, want_argmax=False, want_uv=False):
         """x: (B,3,H,W) float32 NCHW on the GPU.  Returns dict with logits (NCHW, fresh),
         and optionally stn_in (NHWC8 workspace), argmax (B,H,W uint8), uv, plus the NHWC
-        workspace tensors x_top / y4 for callers that need them."""
+        workspace tensors x_top / y4 for callers that need them (x_top_exp: exponent of x_top if it is H2)."""
         with _stream_scope():
             return self._run(x, want_stn_in, want_argmax, want_uv)
+
+    def first_step(self, keys):
+        """index of the first launch of the last run() that writes an H2 tensor whose exponent key is in `keys`"""
+        rg = self.ranges
+        for i, (outs, _) in enumerate(self.steps):
+            if any(rg.key(n) in keys for n in outs):
+                return i
+        return None
+
+    def rerun(self, first):
+        """Repeat the launches of the last run() from index `first` on (same buffers, same output tensors) with the
+        exponents H2Ranges holds NOW: what the range guard does after lowering the exponent of a saturated tensor."""
+        with _stream_scope():
+            for _, fn in self.steps[first:]:
+                fn()
+        return self._last_out
 
     def _run(self, x, want_stn_in, want_argmax, want_uv):
         lib = _lib.load()
@@ -557,29 +733,42 @@ class UNetEngine:
             raise ValueError(f"expected 3 input channels, got {C}")
         if H < 16 or W < 16:
             raise ValueError("frames smaller than 16x16 cannot pass four 2x2 poolings")
-        ws, L, st = self.ws, self.L, _stream()
+        ws, L, rg = self.ws, self.L, self.ranges
+        steps = self.steps = []
+
+        def do(outs, fn):
+            """record + execute one launch; outs = names of the H2 tensors it writes; everything that depends on an
+            exponent is looked up inside fn, i.e. again when the step is repeated"""
+            steps.append((tuple(outs), fn))
+            fn()
+
         xin = ws.get("xin", (B, H, W, 4))
-        _lib.check(lib.sfh_nchw_to_nhwc(_ptr(x), _ptr(xin), B, 3, H, W, 4, st), "nchw_to_nhwc")
+        do((), lambda: _lib.check(lib.sfh_nchw_to_nhwc(_ptr(x), _ptr(xin), B, 3, H, W, 4, _stream()), "nchw_to_nhwc"))
 
         s3, fmt = self.s3, self.fmt
 
-        def act(name, shape_bhw, c, f32=False):
-            """activation workspace: the engine's split format (S3 bf16 / H2 fp16), else fp32 NHWC"""
+        def act(name, shape_bhw, c, f32=False, key=None, word_of=None):
+            """activation workspace: the engine's split format (S3 bf16 / H2 fp16), else fp32 NHWC -> (tensor, name)"""
             if s3 and not f32:
-                return ws.get(name, split_shape(fmt, *shape_bhw, c), _SPLIT[fmt][0])
-            return ws.get(name, tuple(shape_bhw) + (c,))
+                rg.register(name, key, word_of)
+                return ws.get(name, split_shape(fmt, *shape_bhw, c), _SPLIT[fmt][0]), name
+            return ws.get(name, tuple(shape_bhw) + (c,)), None
 
         def dconv(name, src0, h, w, cout, src1=None, pool0=False, pad1=(0, 0), want_pool=False, out_f32=False, head=None):
-            mid = act(name + ".mid", (B, h, w), L[name + ".0"].cout_real)
-            out = act(name + ".out", (B, h, w), cout, f32=out_f32)
-            pooled = act(name + ".pool", (B, h // 2, w // 2), cout) if (want_pool and s3) else None
-            L[name + ".0"].run(src0, B, h, w, mid, src1=src1, pool0=pool0, pad1=pad1)
-            L[name + ".3"].run(mid, B, h, w, out, dst_pool=pooled, head=head)
-            return out, pooled
+            """src0 / src1: (tensor, name) pairs"""
+            (t0, n0), (t1, _) = src0, (src1 if src1 is not None else (None, None))
+            mid, nmid = act(name + ".mid", (B, h, w), L[name + ".0"].cout_real)
+            out, nout = act(name + ".out", (B, h, w), cout, f32=out_f32)
+            pooled, npool = (act(name + ".pool", (B, h // 2, w // 2), cout, key=nout, word_of=nout)
+                             if (want_pool and s3) else (None, None))
+            l0, l3 = L[name + ".0"], L[name + ".3"]
+            do((nmid,) if nmid else (), lambda: l0.run(t0, B, h, w, mid, src1=t1, pool0=pool0, pad1=pad1, **rg.args(n0, nmid)))
+            do((nout,) if nout else (), lambda: l3.run(mid, B, h, w, out, dst_pool=pooled, head=head, **rg.args(nmid, nout)))
+            return (out, nout), (pooled, npool)
 
         # encoder: in bf16x6 mode every Down's MaxPool2d(2) is written by the producer's epilogue;
         # in fp32 mode it is applied while the consumer loads its halo (pool0)
-        f0, p0 = dconv("inc", xin, H, W, 64, want_pool=True)
+        f0, p0 = dconv("inc", (xin, None), H, W, 64, want_pool=True)
         feats, pooled = [f0], [p0]
         h, w = H, W
         for i in range(1, 5):
@@ -589,7 +778,7 @@ class UNetEngine:
             f, p = dconv(f"down{i}", src, h, w, cout, pool0=not s3, want_pool=i < 4)
             feats.append(f)
             pooled.append(p)
-        y = feats[4]
+        y, ny = feats[4]
         # OutConv (+ the STN input) rides in the epilogue of the last 3x3 conv when nothing else needs y
         logits = torch.empty((B, self.nc, H, W), dtype=torch.float32, device=x.device)
         if want_stn_in and self.nc + 3 > 8:
@@ -601,50 +790,63 @@ class UNetEngine:
             head = {"w": self.outc_w, "b": self.outc_b, "nc": self.nc, "logits": logits, "stn": stn_in,
                     "frame": xin if want_stn_in else None, "skip_dst": True}
         for i in range(1, 5):
-            skip = feats[4 - i]
+            skip, nskip = feats[4 - i]
             hs, ws_ = _hw(skip)
             hy, wy = _hw(y)
             cout = L[f"up{i}.conv.3"].cout_real
             ey, ex = hs - 2 * hy, ws_ - 2 * wy   # F.pad of Up: diff 1 pads one row / column AFTER the tensor
             if f"up{i}.fused" in L and ey in (0, 1) and ex in (0, 1):
                 part = ws.get(f"up{i}.part", (B, hs, ws_, L[f"up{i}.skip"].cout_real))     # fp32 partial
-                mid = act(f"up{i}.conv.mid", (B, hs, ws_), L[f"up{i}.fused"].cout_real)
+                mid, nmid = act(f"up{i}.conv.mid", (B, hs, ws_), L[f"up{i}.fused"].cout_real)
                 fu, sk = L[f"up{i}.fused"], L[f"up{i}.skip"]
-                if i in self.up_swap:
-                    # composed 2x2 conv first: it writes the 4 B fp32 partial instead of reading one and writing
-                    # 6 B of S3; the MFMA-bound skip-half 3x3 conv then absorbs the residual, the ReLU and the split
-                    fu.relu, sk.relu = False, True
-                    fu.run(y, B, hy + ey, wy + ex, part, up_dst=(hs, ws_) if (ey or ex) else None)
-                    sk.run(skip, B, hs, ws_, mid, residual=part)
-                else:
-                    fu.relu, sk.relu = True, False
-                    sk.run(skip, B, hs, ws_, part)
-                    fu.run(y, B, hy + ey, wy + ex, mid, residual=part, up_dst=(hs, ws_) if (ey or ex) else None)
-                y = act(f"up{i}.conv.out", (B, hs, ws_), cout, f32=(i == 4))
-                L[f"up{i}.conv.3"].run(mid, B, hs, ws_, y, head=head if i == 4 else None)
+                up_dst = (hs, ws_) if (ey or ex) else None
+
+                def level(y=y, ny=ny, skip=skip, nskip=nskip, part=part, mid=mid, nmid=nmid, fu=fu, sk=sk,
+                          up_dst=up_dst, hs=hs, ws_=ws_, hy=hy, wy=wy, ey=ey, ex=ex, swap=i in self.up_swap):
+                    if swap:
+                        # composed 2x2 conv first: it writes the 4 B fp32 partial instead of reading one and writing
+                        # 6 B of S3; the MFMA-bound skip-half 3x3 conv then absorbs the residual, the ReLU and the split
+                        fu.relu, sk.relu = False, True
+                        fu.run(y, B, hy + ey, wy + ex, part, up_dst=up_dst, **rg.args(ny, None))
+                        sk.run(skip, B, hs, ws_, mid, residual=part, **rg.args(nskip, nmid))
+                    else:
+                        fu.relu, sk.relu = True, False
+                        sk.run(skip, B, hs, ws_, part, **rg.args(nskip, None))
+                        fu.run(y, B, hy + ey, wy + ex, mid, residual=part, up_dst=up_dst, **rg.args(ny, nmid))
+                do((nmid,) if nmid else (), level)
+                ymid, l3 = mid, L[f"up{i}.conv.3"]
+                y, ny = act(f"up{i}.conv.out", (B, hs, ws_), cout, f32=(i == 4))
+                do((ny,) if ny else (), lambda ymid=ymid, nmid=nmid, y=y, ny=ny, l3=l3, hs=hs, ws_=ws_, i=i:
+                   l3.run(ymid, B, hs, ws_, y, head=head if i == 4 else None, **rg.args(nmid, ny)))
                 continue
             cup = _chan(y) if self.bilinear else L[f"up{i}.up"].cout_real
-            upb = act(f"up{i}.up", (B, 2 * hy, 2 * wy), cup)
+            # the up-sampled tensor is the second source of the conv over cat([skip, up]): it shares the skip's exponent
+            upb, nup = act(f"up{i}.up", (B, 2 * hy, 2 * wy), cup, key=nskip)
             if self.bilinear:  # nn.Upsample(2x, bilinear, align_corners=True) on an fp32 view of y
-                yf = y
-                if s3:
-                    yf = ws.get(f"up{i}.yf", (B, hy, wy, cup))
-                    _split_to_f32_into(y, yf)
+                yf = ws.get(f"up{i}.yf", (B, hy, wy, cup)) if s3 else y
                 uf = ws.get(f"up{i}.uf", (B, 2 * hy, 2 * wy, cup)) if s3 else upb
-                _lib.check(lib.sfh_upsample2x_bilinear_nhwc(_ptr(yf), _ptr(uf), B, hy, wy, cup, st), "upsample2x")
-                if s3:
-                    _f32_to_split_into(uf, upb, self.overflow)
+
+                def upsample(y=y, ny=ny, yf=yf, uf=uf, upb=upb, nup=nup, hy=hy, wy=wy, cup=cup):
+                    if s3:
+                        _split_to_f32_into(y, yf, rg.exp(ny))
+                    _lib.check(lib.sfh_upsample2x_bilinear_nhwc(_ptr(yf), _ptr(uf), B, hy, wy, cup, _stream()), "upsample2x")
+                    if s3:
+                        _f32_to_split_into(uf, upb, self.overflow, rg.exp(nup), rg.word_ptr(nup))
+                do((nup,) if nup else (), upsample)
             else:
-                L[f"up{i}.up"].run(y, B, hy, wy, upb)
+                lu = L[f"up{i}.up"]
+                do((nup,) if nup else (), lambda y=y, ny=ny, upb=upb, nup=nup, lu=lu, hy=hy, wy=wy:
+                   lu.run(y, B, hy, wy, upb, **rg.args(ny, nup)))
             dy, dx = hs - 2 * hy, ws_ - 2 * wy
-            y, _ = dconv(f"up{i}.conv", skip, hs, ws_, cout, src1=upb, pad1=(dy // 2, dx // 2), out_f32=(i == 4),
-                         head=head if i == 4 else None)
-        out = {"x_top": feats[4], "y4": y}
+            (y, ny), _ = dconv(f"up{i}.conv", (skip, nskip), hs, ws_, cout, src1=(upb, nup), pad1=(dy // 2, dx // 2),
+                               out_f32=(i == 4), head=head if i == 4 else None)
+        out = {"x_top": feats[4][0], "x_top_name": feats[4][1], "y4": y}
         amax = torch.empty((B, H, W), dtype=torch.uint8, device=x.device) if want_argmax else None
         if head is None:
-            _lib.check(lib.sfh_outconv_fwd(_ptr(y), 64, _ptr(self.outc_w), _ptr(self.outc_b), self.nc, B, H, W,
-                                           _ptr(logits), _ptr(amax), _ptr(stn_in), 8 if want_stn_in else 0,
-                                           _ptr(xin) if want_stn_in else None, 4, st), "outconv")
+            do((), lambda y=y: _lib.check(
+                lib.sfh_outconv_fwd(_ptr(y), 64, _ptr(self.outc_w), _ptr(self.outc_b), self.nc, B, H, W,
+                                    _ptr(logits), _ptr(amax), _ptr(stn_in), 8 if want_stn_in else 0,
+                                    _ptr(xin) if want_stn_in else None, 4, _stream()), "outconv"))
         else:
             out.pop("y4")   # not materialised: the fused head consumed it in registers
         out["logits"] = logits
@@ -654,10 +856,16 @@ class UNetEngine:
             out["stn_in"] = stn_in
         if want_uv and self.outuv is not None:
             uv = torch.empty((B, 2, H, W), dtype=torch.float32, device=x.device)
-            _lib.check(lib.sfh_outconv_fwd(_ptr(y), 64, _ptr(self.outuv[0]), _ptr(self.outuv[1]), 2, B, H, W,
-                                           _ptr(uv), None, None, 0, None, 0, st), "outconv(uv)")
+            do((), lambda y=y: _lib.check(
+                lib.sfh_outconv_fwd(_ptr(y), 64, _ptr(self.outuv[0]), _ptr(self.outuv[1]), 2, B, H, W,
+                                    _ptr(uv), None, None, 0, None, 0, _stream()), "outconv(uv)"))
             out["uv"] = uv
+        self._last_out = out
         return out
+
+    def x_top_exp(self, out):
+        """exponent of out["x_top"] when it is an H2 tensor (for nhwc_to_nchw)"""
+        return self.ranges.exp(out.get("x_top_name"))
 
 
 class StemConv:
@@ -675,6 +883,7 @@ class StemConv:
             raise ValueError(f"fmt={fmt!r}: expected 's3' or 'h2'")
         dev = w.device
         self.tag, self.cin, self.fmt, self.overflow = tag, cin, fmt, overflow
+        self.exp_src = _lib.H2_ACT_EXP     # h2: the input planes carry x * 2^exp_src (folded into `scale`)
         self.wpacked = torch.empty(lib.sfh_packed_stem_weight_bytes(), dtype=torch.uint8, device=dev)
         wexp, self.escale = 0, 1.0
         if fmt == "h2":
@@ -694,9 +903,18 @@ class StemConv:
         if self.escale != 1.0:
             self.scale.mul_(self.escale)
 
-    def run(self, x_nhwc8, B, H, W, dst):
+    def run(self, x_nhwc8, B, H, W, dst, exp_src=None, range_word=None):
+        """exp_src / range_word (h2 arithmetic): exponent of the split the kernel makes of its fp32 input, and the
+        device word that receives the largest |x * 2^exp_src| (H2Ranges)."""
         lib = _lib.load()
         d = ConvDesc()
+        if self.fmt == "h2" and exp_src is not None and int(exp_src) != self.exp_src:
+            f = 2.0 ** (self.exp_src - int(exp_src))
+            self.scale.mul_(f)
+            self.escale *= f
+            self.exp_src = int(exp_src)
+        d.h2_exp_src = self.exp_src
+        d.h2_range = range_word if (range_word and self.fmt == "h2") else None
         d.src0, d.c0, d.cs0, d.h0, d.w0 = x_nhwc8.data_ptr(), self.cin, 8, H, W
         d.batch, d.H, d.W, d.ksize, d.stride = B, H, W, 7, 2
         d.wpacked, d.scale, d.shift = self.wpacked.data_ptr(), self.scale.data_ptr(), self.shift.data_ptr()
@@ -722,16 +940,19 @@ class StemConv:
 class ResNetEngine:
     """ResNetSTN forward (models/resnet.py:235-254) on the HIP kernels (BasicBlock and Bottleneck depths)."""
 
-    def __init__(self, rn, in_channels, device, precision="bf16x6", overflow=None):
+    def __init__(self, rn, in_channels, device, precision="bf16x6", overflow=None, ranges=None):
         """precision "bf16x6" / "f16x3": the 3x3 convs (stride 1 and 2) and the 1x1 stride-2 downsample convs run
         on the split-operand kernel with S3 / H2 activations; the stem stays on the fp32 kernel (or, with at most
-        8 input channels, on the tap-packed split-bf16 stem kernel)."""
+        8 input channels, on the tap-packed split-bf16 stem kernel).  ranges / overflow: as UNetEngine."""
         if precision not in PRECISIONS:
             raise ValueError(f"precision={precision!r}: expected one of {sorted(PRECISIONS)}")
         self.fmt = fmt = PRECISIONS[precision]
         self.s3 = fmt is not None
         s3 = self.s3
         self.overflow = overflow if fmt == "h2" else None
+        self.ranges = (ranges if ranges is not None else H2Ranges(device)) if fmt == "h2" else _NoRanges()
+        self.steps = []
+        self._last_out = None
         self.device = device
         self.ws = _Workspace(device)
         self.cin = in_channels
@@ -782,68 +1003,91 @@ class ResNetEngine:
         with _stream_scope():
             return self._run(y_nhwc, B, H, W)
 
+    first_step = UNetEngine.first_step
+    rerun = UNetEngine.rerun
+
     def _run(self, y_nhwc, B, H, W):
         lib = _lib.load()
-        ws, L, st = self.ws, self.L, _stream()
+        ws, L, rg = self.ws, self.L, self.ranges
         if y_nhwc.shape[3] != self.cs_in:
             raise ValueError(f"STN input has {y_nhwc.shape[3]} stored channels, engine expects {self.cs_in}")
+        steps = self.steps = []
+
+        def do(outs, fn):   # as UNetEngine._run
+            steps.append((tuple(outs), fn))
+            fn()
+
+        s3, fmt = self.s3, self.fmt
         H2, W2 = (H + 1) // 2, (W + 1) // 2
         c1 = ws.get("stem", (B, H2, W2, 64))
         if self.stem7 is not None:
-            self.stem7.run(y_nhwc, B, H, W, c1)
+            # the stem kernel splits its fp32 input itself: "rn.stem.in" names that (never stored) split
+            rg.register("rn.stem.in")
+            do(("rn.stem.in",) if fmt == "h2" else (),
+               lambda: self.stem7.run(y_nhwc, B, H, W, c1, exp_src=rg.exp("rn.stem.in"), range_word=rg.word_ptr("rn.stem.in")))
         else:
             s2d = ws.get("s2d", (B, H2, W2, 4 * self.cs_in))
-            _lib.check(lib.sfh_space_to_depth2(_ptr(y_nhwc), _ptr(s2d), B, H, W, self.cs_in, st), "space_to_depth2")
+            do((), lambda: _lib.check(lib.sfh_space_to_depth2(_ptr(y_nhwc), _ptr(s2d), B, H, W, self.cs_in, _stream()),
+                                      "space_to_depth2"))
             if L["stem"].s3:
                 s2d3 = ws.get("s2d.s3", s3_shape(B, H2, W2, 4 * self.cs_in), torch.bfloat16)
-                _lib.check(lib.sfh_f32_to_s3(_ptr(s2d), _ptr(s2d3), B * H2, W2, 4 * self.cs_in, st), "f32_to_s3")
+                do((), lambda: _lib.check(lib.sfh_f32_to_s3(_ptr(s2d), _ptr(s2d3), B * H2, W2, 4 * self.cs_in, _stream()),
+                                          "f32_to_s3"))
                 s2d = s2d3
-            L["stem"].run(s2d, B, H2, W2, c1)
+            do((), lambda s2d=s2d: L["stem"].run(s2d, B, H2, W2, c1))
         h, w = (H2 - 1) // 2 + 1, (W2 - 1) // 2 + 1
         x = ws.get("pool", (B, h, w, 64))
-        _lib.check(lib.sfh_maxpool3x3s2_fwd(_ptr(c1), _ptr(x), B, H2, W2, 64, st), "maxpool3x3s2")
-        s3, fmt = self.s3, self.fmt
+        do((), lambda x=x: _lib.check(lib.sfh_maxpool3x3s2_fwd(_ptr(c1), _ptr(x), B, H2, W2, 64, _stream()), "maxpool3x3s2"))
 
         def act(name, hh, ww, c):
             if s3:
-                return ws.get(name, split_shape(fmt, B, hh, ww, c), _SPLIT[fmt][0])
-            return ws.get(name, (B, hh, ww, c))
+                rg.register("rn." + name)
+                return ws.get(name, split_shape(fmt, B, hh, ww, c), _SPLIT[fmt][0]), "rn." + name
+            return ws.get(name, (B, hh, ww, c)), None
 
+        nx = None
         if s3:  # the pooled stem output enters the split domain (small tensor: 1/16 of the frame area)
-            xs = act("pool.s3", h, w, 64)
-            _f32_to_split_into(x, xs, self.overflow)
-            x = xs
+            xs, nxs = act("pool.s3", h, w, 64)
+            do((nxs,), lambda x=x, xs=xs, nxs=nxs: _f32_to_split_into(x, xs, self.overflow, rg.exp(nxs), rg.word_ptr(nxs)))
+            x, nx = xs, nxs
         for name, width, cout, stride, has_down, bottleneck in self.blocks:
             ho, wo = (h - 1) // stride + 1, (w - 1) // stride + 1
+
+            def conv(layer, src, nsrc, hh, ww, dst, ndst, residual=None, nres=None):
+                do((ndst,) if ndst else (), lambda: L[layer].run(src, B, hh, ww, dst, residual=residual,
+                                                                 **rg.args(nsrc, ndst, nres)))
             if has_down:
-                idn = act(name + ".idn", ho, wo, cout)
-                L[name + ".down"].run(x, B, h, w, idn)
+                idn, nidn = act(name + ".idn", ho, wo, cout)
+                conv(name + ".down", x, nx, h, w, idn, nidn)
             else:
-                idn = x
-            out = act(name + ".out", ho, wo, cout)
+                idn, nidn = x, nx
+            out, nout = act(name + ".out", ho, wo, cout)
             if bottleneck:
-                t1 = act(name + ".t1", h, w, width)
-                L[name + ".conv1"].run(x, B, h, w, t1)
-                t2 = act(name + ".t2", ho, wo, width)
-                L[name + ".conv2"].run(t1, B, h, w, t2)
-                L[name + ".conv3"].run(t2, B, ho, wo, out, residual=idn)
+                t1, nt1 = act(name + ".t1", h, w, width)
+                conv(name + ".conv1", x, nx, h, w, t1, nt1)
+                t2, nt2 = act(name + ".t2", ho, wo, width)
+                conv(name + ".conv2", t1, nt1, h, w, t2, nt2)
+                conv(name + ".conv3", t2, nt2, ho, wo, out, nout, residual=idn, nres=nidn)
             else:
-                t = act(name + ".t", ho, wo, width)
-                L[name + ".conv1"].run(x, B, h, w, t)
-                L[name + ".conv2"].run(t, B, ho, wo, out, residual=idn)
-            x, h, w = out, ho, wo
+                t, nt = act(name + ".t", ho, wo, width)
+                conv(name + ".conv1", x, nx, h, w, t, nt)
+                conv(name + ".conv2", t, nt, ho, wo, out, nout, residual=idn, nres=nidn)
+            x, nx, h, w = out, nout, ho, wo
         if s3:
             xf = ws.get("final.f32", (B, h, w, _chan(x)))
-            _split_to_f32_into(x, xf)
+            do((), lambda x=x, nx=nx, xf=xf: _split_to_f32_into(x, xf, rg.exp(nx)))
             x = xf
         theta = torch.empty((B, 9), dtype=torch.float32, device=x.device)
         pooled = ws.get("pooled", (B, x.shape[3]))
-        _lib.check(lib.sfh_avgpool_linear_fwd(_ptr(x), _ptr(self.reg_w), _ptr(self.reg_b), B, h, w,
-                                              x.shape[3], 9, _ptr(pooled), _ptr(theta), st), "avgpool_linear")
-        return theta.view(B, 1, 3, 3)
+        do((), lambda x=x, h=h, w=w: _lib.check(
+            lib.sfh_avgpool_linear_fwd(_ptr(x), _ptr(self.reg_w), _ptr(self.reg_b), B, h, w, x.shape[3], 9,
+                                       _ptr(pooled), _ptr(theta), _stream()), "avgpool_linear"))
+        self._last_out = theta.view(B, 1, 3, 3)
+        return self._last_out
 
 
-def _split_to_f32_into(t, out):
+def _split_to_f32_into(t, out, exp=_lib.H2_ACT_EXP):
+    """exp: exponent of an H2 tensor (ignored for S3)"""
     lib = _lib.load()
     B = t.shape[0]
     H, W = _hw(t)
@@ -851,29 +1095,32 @@ def _split_to_f32_into(t, out):
     if tuple(out.shape) != (B, H, W, C) or out.dtype != torch.float32:
         raise ValueError(f"split_to_f32: destination {tuple(out.shape)} does not match {(B, H, W, C)}")
     if _fmt_of(t) == "h2":
-        _lib.check(lib.sfh_h2_to_f32(_ptr(t), _ptr(out), B * H, W, C, _stream()), "h2_to_f32")
+        _lib.check(lib.sfh_h2_to_f32(_ptr(t), _ptr(out), B * H, W, C, int(exp), _stream()), "h2_to_f32")
     else:
         _lib.check(lib.sfh_s3_to_f32(_ptr(t), _ptr(out), B * H, W, C, _stream()), "s3_to_f32")
     return out
 
 
-def _f32_to_split_into(t, out, overflow=None):
+def _f32_to_split_into(t, out, overflow=None, exp=_lib.H2_ACT_EXP, range_word=None):
+    """H2 destinations: exp = the tensor's exponent, overflow / range_word: optional device words (OR 1 on
+    saturation / atomic max of |v * 2^exp|, see H2Ranges)"""
     lib = _lib.load()
     B, H, W, C = t.shape
     if (out.shape[0],) + _hw(out) + (_chan(out),) != (B, H, W, C):
         raise ValueError(f"f32_to_split: destination {tuple(out.shape)} does not match {(B, H, W, C)}")
     if _fmt_of(out) == "h2":
-        _lib.check(lib.sfh_f32_to_h2(_ptr(t), _ptr(out), B * H, W, C, _ptr(overflow), _stream()), "f32_to_h2")
+        _lib.check(lib.sfh_f32_to_h2(_ptr(t), _ptr(out), B * H, W, C, int(exp), _ptr(overflow),
+                                     ctypes.c_void_p(range_word) if range_word else None, _stream()), "f32_to_h2")
     else:
         _lib.check(lib.sfh_f32_to_s3(_ptr(t), _ptr(out), B * H, W, C, _stream()), "f32_to_s3")
     return out
 
 
-def s3_to_f32(t):
-    """split tensor (S3: (B,H,C/32,3,4,W,8) bf16, exact sum of the planes; H2: (B,H,C/32,2,4,W,8) fp16) ->
-    (B,H,W,C) float32."""
+def s3_to_f32(t, exp=_lib.H2_ACT_EXP):
+    """split tensor (S3: (B,H,C/32,3,4,W,8) bf16, exact sum of the planes; H2: (B,H,C/32,2,4,W,8) fp16 carrying
+    v * 2^exp) -> (B,H,W,C) float32."""
     out = torch.empty((t.shape[0],) + _hw(t) + (_chan(t),), dtype=torch.float32, device=t.device)
-    return _split_to_f32_into(t, out)
+    return _split_to_f32_into(t, out, exp)
 
 
 def split_empty(fmt, b, h, w, c, device):
@@ -881,18 +1128,19 @@ def split_empty(fmt, b, h, w, c, device):
     return torch.empty(split_shape(fmt, b, h, w, c), dtype=_SPLIT[fmt][0], device=device)
 
 
-def f32_to_split(t, fmt, overflow=None):
-    """(B,H,W,C) float32 -> split tensor of format "s3" or "h2" """
+def f32_to_split(t, fmt, overflow=None, exp=_lib.H2_ACT_EXP):
+    """(B,H,W,C) float32 -> split tensor of format "s3" or "h2" (h2: carrying v * 2^exp) """
     t = _f32c(t, "nhwc tensor")
-    return _f32_to_split_into(t, split_empty(fmt, *t.shape, t.device), overflow)
+    return _f32_to_split_into(t, split_empty(fmt, *t.shape, t.device), overflow, exp)
 
 
-def f32_to_h2(t, overflow=None):
-    """(B,H,W,C) float32 -> (B,H,C/32,2,4,W,8) fp16 two-plane tensor (include/sfh_amd.h, SFH_FMT_H2)."""
+def f32_to_h2(t, overflow=None, exp=_lib.H2_ACT_EXP, range_word=None):
+    """(B,H,W,C) float32 -> (B,H,C/32,2,4,W,8) fp16 two-plane tensor of v * 2^exp (include/sfh_amd.h, SFH_FMT_H2);
+    range_word: an int32 tensor whose first word receives the largest bit pattern of |v * 2^exp|."""
     t = _f32c(t, "nhwc tensor")
     B, H, W, C = t.shape
     out = torch.empty(split_shape("h2", B, H, W, C), dtype=torch.float16, device=t.device)
-    return _f32_to_split_into(t, out, overflow)
+    return _f32_to_split_into(t, out, overflow, exp, range_word.data_ptr() if range_word is not None else None)
 
 
 def f32_to_s3(t):
@@ -940,9 +1188,9 @@ def resize_nchw(t, size_hw, mode, align_corners=False):
     return out
 
 
-def nhwc_to_nchw(t, channels=None):
+def nhwc_to_nchw(t, channels=None, exp=_lib.H2_ACT_EXP):
     if t.dtype in _SPLIT_DTYPES:
-        t = s3_to_f32(t)
+        t = s3_to_f32(t, exp)
     lib = _lib.load()
     B, H, W, cs = t.shape
     C = cs if channels is None else channels
@@ -976,9 +1224,18 @@ def homography_warp(theta, template, h, w, nearest, scale=None, want_f32=True, w
     out_f = torch.empty((B, h, w), dtype=torch.float32, device=theta.device) if want_f32 else None
     out_i = torch.empty((B, h, w), dtype=torch.int32, device=theta.device) if want_i32 else None
     bstride = 0 if shared_template else ht * wt
+    tm = PackedConv.timer
+    if tm is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     _lib.check(lib.sfh_homography_warp_fwd(_ptr(theta), _ptr(template), bstride, ht, wt, B, h, w,
                                            0 if nearest else 1, float(scale if scale is not None else 1.0),
                                            _ptr(out_f), _ptr(out_i), _stream()), "homography_warp")
+    if tm is not None:
+        e1.record()
+        # algorithmic BYTES: every output once, the template once (per frame if not shared), theta
+        nout = (1 if want_f32 else 0) + (1 if want_i32 else 0)
+        tm.records.append(("warp", float(B * h * w * 4 * nout + (1 if shared_template else B) * ht * wt * 4 + 36 * B), e0, e1))
     return out_f, out_i
 
 

@@ -125,17 +125,19 @@ class Reconstructor(nn.Module):
 
         # Arithmetic of the conv stack (fp32 accumulation in all modes, see csrc/conv_s3.hip):
         #   "f16x3" (default) = two-plane fp16 activations / weights (22 significand bits), three fp16 MFMAs per
-        #                       product; activations must stay below 16376 in magnitude - a batch that leaves that
-        #                       range is detected on the device and re-run in "bf16x6" (see _range_guarded);
+        #                       product; every activation tensor carries its own power-of-two exponent (2 at first:
+        #                       |v| < 16376); a tensor that leaves its range is detected on the device, its exponent
+        #                       is lowered for good and the pass is repeated from that layer (see _guarded);
         #   "bf16x6"          = three-plane bf16 operands (the exact fp32 value), six bf16 MFMAs per product;
         #   "fp32"            = fp32 MFMA throughout.
         # Plain attribute (or env SFH_PRECISION) so the constructor signature stays the reference's.
         self.precision = os.environ.get("SFH_PRECISION", "f16x3")
         self._engines = None       # (UNetEngine | None, ResNetEngine | None)
         self._engines_by_precision = {}
-        self._h2_overflow = None   # int32 device word raised by the kernels of the "f16x3" mode
+        self._h2_ranges = None     # engine.H2Ranges: exponents + device range words of the "f16x3" activations
         self._forced_precision = None
-        self.range_fallbacks = 0   # batches re-run in "bf16x6" because an activation left the fp16 range
+        self.range_rescales = 0    # passes repeated from a layer whose output left its fp16 range (exponent lowered)
+        self.range_fallbacks = 0   # batches re-run in "bf16x6" because an activation was not finite
         # False: predict() / forward() skip the 4-byte read-back (a device synchronisation) after every call; a
         # caller that pipelines several batches then asks range_overflowed() itself once it has synchronised
         self.range_guard = True
@@ -146,14 +148,26 @@ class Reconstructor(nn.Module):
     # ------------------------------------------------------------------ engine plumbing
     def _param_stamp(self):
         # walking the module tree costs ~1 ms per call (354 tensors behind ~200 modules), more than enqueueing the
-        # whole UNet: the tensor list is collected once.  load_state_dict(), .to() and optimizers change these
-        # tensors in place (their torch _version moves); a Parameter / buffer / sub-module that is REPLACED anywhere
-        # in the process registers with torch's module hooks, which advance _REGISTRATIONS: the list is rebuilt then.
+        # whole UNet: the tensor list is collected once.  load_state_dict() and optimizers change these tensors in
+        # place (their torch _version moves); .to() / .half() on the model OR ON A SUB-MODULE give every Parameter a
+        # new storage (its data_ptr moves) and replace the buffers; a Parameter / buffer / sub-module that is REPLACED
+        # anywhere in the process registers with torch's module hooks, which advance _REGISTRATIONS.  Either of the
+        # last two makes this walk the tree again - and only a list that really differs forces new engines
+        # (constructing an unrelated module elsewhere, e.g. a loss with a weight buffer, changes nothing here).
         lst = self.__dict__.get("_stamp_tensors")
-        if lst is None or self.__dict__.get("_stamp_regs") != _REGISTRATIONS[0]:
-            lst = self.__dict__["_stamp_tensors"] = list(self.parameters()) + list(self.buffers())
+        ptrs = 0
+        if lst is not None:
+            for t in lst:
+                ptrs += t.data_ptr()
+        if (lst is None or self.__dict__.get("_stamp_regs") != _REGISTRATIONS[0]
+                or ptrs != self.__dict__.get("_stamp_ptrs")):
+            new = list(self.parameters()) + list(self.buffers())
+            if lst is None or len(new) != len(lst) or any(a is not b for a, b in zip(new, lst)) \
+                    or ptrs != self.__dict__.get("_stamp_ptrs"):
+                self._weights_generation += 1      # a replaced tensor may carry any _version: force a new stamp
+            lst = self.__dict__["_stamp_tensors"] = new
             self.__dict__["_stamp_regs"] = _REGISTRATIONS[0]
-            self._weights_generation += 1          # a replaced tensor may carry any _version: force a new stamp
+            self.__dict__["_stamp_ptrs"] = sum(t.data_ptr() for t in lst)
         dev = None
         ver = 0
         for t in lst:
@@ -194,53 +208,100 @@ class Reconstructor(nn.Module):
                     f"Reconstructor parameters are on {dev}: move the model to the GPU with .to('cuda'); "
                     "the HIP path has no CPU fallback")
             with torch.cuda.device(dev):
-                if precision == "f16x3" and (self._h2_overflow is None or self._h2_overflow.device != dev):
-                    self._h2_overflow = torch.zeros(1, dtype=torch.int32, device=dev)
-                ovf = self._h2_overflow if precision == "f16x3" else None
-                un = E.UNetEngine(self, dev, precision, overflow=ovf) if self.use_unet else None
-                rn = (E.ResNetEngine(self.resnet_reg, self._stn_in_channels, dev, precision, overflow=ovf)
+                rg = None
+                if precision == "f16x3":
+                    if self._h2_ranges is None or self._h2_ranges.device != dev:
+                        self._h2_ranges = E.H2Ranges(dev)
+                    rg = self._h2_ranges
+                un = E.UNetEngine(self, dev, precision, ranges=rg) if self.use_unet else None
+                rn = (E.ResNetEngine(self.resnet_reg, self._stn_in_channels, dev, precision, ranges=rg)
                       if self.use_resnet else None)
             eng = self._engines_by_precision[precision] = (un, rn)
         self._engines = eng
         return eng
 
-    def _range_guarded(self, fn, x, off, *args):
-        """Run fn(x, off, *args); in "f16x3" mode read back the device word the kernels raise when an activation had
-        to be saturated to the fp16 range (|v| >= 16376) and, if it is set, run fn again with the three-plane bf16
-        operands, which have fp32's exponent range (in as many sub-batches as their 6 bytes per element need).
-        Still the HIP path - there is no CPU fallback."""
-        ret = fn(x, off, *args)
-        if (self._forced_precision or self.precision) != "f16x3" or self._h2_overflow is None or not self.range_guard:
+    @staticmethod
+    def _run_phases(phases):
+        run_unet, run_stn, tail = phases
+        r = run_unet()
+        return tail(r, run_stn(r))
+
+    def _guarded(self, make_phases, x, off):
+        """One forward pass = three phases, make_phases(x, off) -> (run_unet(resume=None) -> r,
+        run_stn(r, resume=None) -> theta, tail(r, theta) -> dict).  In "f16x3" mode the kernels leave the largest
+        magnitude of every activation tensor in a device word (engine.H2Ranges); ONE read-back per call tells whether
+        a tensor left the fp16 range of its exponent.  If so, that tensor's exponent is lowered for good (8x headroom
+        over what was seen) and the pass is repeated FROM THE LAUNCH THAT WRITES IT, with everything upstream kept
+        (`range_rescales`) - the model stays on the two-plane fp16 path.  Only a non-finite activation (a NaN / Inf
+        frame) sends the batch through the three-plane bf16 operands, which carry NaN / Inf to the outputs as the
+        reference does (`range_fallbacks`).  Still the HIP path - there is no CPU fallback."""
+        phases = make_phases(x, off)
+        run_unet, run_stn, tail = phases
+        r = run_unet()
+        theta = run_stn(r)
+        ret = tail(r, theta)
+        rg = self._h2_ranges
+        if (self._forced_precision or self.precision) != "f16x3" or rg is None or not self.range_guard:
             return ret
-        if int(self._h2_overflow.item()) == 0:     # one 4-byte read-back per call
-            return ret
-        self._h2_overflow.zero_()
-        self.range_fallbacks += 1
-        if self.range_fallbacks == 1:
-            import warnings
-            warnings.warn("sfh_amd: an activation left the fp16 range of the 'f16x3' mode; the batch was re-run "
-                          "with precision 'bf16x6' (set net.precision = 'bf16x6' to avoid the double work)")
-        self._forced_precision = "bf16x6"
-        try:
-            return self._chunked(fn, x, *args, base=off)
-        finally:
-            self._forced_precision = None
+        un, rn = self._engines
+        for _ in range(256):
+            bits = rg.read()                     # one read-back of ~100 words per call
+            bad, nonfinite = rg.saturated(bits)
+            if not bad:
+                return ret
+            rg.reset_words()
+            if nonfinite:
+                self.range_fallbacks += 1
+                if self.range_fallbacks == 1:
+                    import warnings
+                    warnings.warn("sfh_amd: a non-finite activation in the 'f16x3' mode; the batch was re-run with "
+                                  "precision 'bf16x6', which carries NaN / Inf to the outputs like the reference")
+                self._forced_precision = "bf16x6"
+                try:
+                    return self._chunked(lambda xi, o: self._run_phases(make_phases(xi, o)), x, base=off)
+                finally:
+                    self._forced_precision = None
+            keys = {rg.lower(n, bits[n]) for n in bad}
+            self.range_rescales += 1
+            k = un.first_step(keys) if un is not None else None
+            if k is not None:
+                r = run_unet(resume=k)
+                theta = run_stn(r)
+            else:
+                k = rn.first_step(keys) if rn is not None else None
+                if k is None:
+                    continue                     # a tensor of an earlier call shape: nothing of this pass depends on it
+                theta = run_stn(r, resume=k)
+            ret = tail(r, theta)
+        raise RuntimeError("sfh_amd: the fp16 range guard did not converge")
 
     def range_overflowed(self, reset=True):
-        """True if a kernel of the "f16x3" mode saturated an activation since the last reset (synchronises)."""
-        if self._h2_overflow is None:
+        """For callers that pipeline batches with `range_guard = False`: True if an activation tensor of the "f16x3"
+        mode was saturated since the last reset (synchronises).  With reset, the exponents of those tensors are
+        lowered so that the following batches fit; the caller re-submits the batches it had in flight."""
+        rg = self._h2_ranges
+        if rg is None:
             return False
-        hit = bool(int(self._h2_overflow.item()))
-        if hit and reset:
-            self._h2_overflow.zero_()
-        return hit
+        bits = rg.read()
+        bad, _ = rg.saturated(bits)
+        if bad and reset:
+            for n in bad:
+                if bits[n] < rg.NONFINITE:
+                    rg.lower(n, bits[n])
+            rg.reset_words()
+        return bool(bad)
+
+    def h2_headroom(self):
+        """{activation tensor: factor between its fp16 range and the largest magnitude seen} ("f16x3" mode)"""
+        return self._h2_ranges.headroom() if self._h2_ranges is not None else {}
 
     def __getstate__(self):
         """The model is pickled into spawned worker processes (predict.py:130,252): ship parameters and
         configuration only - packed weights and workspaces are rebuilt in the worker on first use."""
         st = self.__dict__.copy()
-        st["_engines"] = st["_engine_stamp"] = st["_tmpl_shared"] = st["_h2_overflow"] = None
+        st["_engines"] = st["_engine_stamp"] = st["_tmpl_shared"] = st["_h2_ranges"] = None
         st.pop("_stamp_tensors", None)
+        st.pop("_stamp_ptrs", None)
         st.pop("_bn_snapshot", None)       # training: copies of the BatchNorm statistics (training._BNSnapshot)
         st["_engines_by_precision"] = {}
         return st
@@ -282,21 +343,25 @@ class Reconstructor(nn.Module):
         """Project the court PoI into the frame with inverse(theta) (reference: :120-130)."""
         return E.poi_project(theta, court_poi, normalize)
 
-    def _run_unet(self, x, **kw):
+    def _run_unet(self, x, resume=None, **kw):
         """forward_unet core.  Input bilinear resize to unet_size and nearest resize of logits / uv to
         target_size as in models/reconstructor.py:134-156; with a resize active the fused STN input
-        (built from the UNet-sized frame) is not valid and is dropped."""
+        (built from the UNet-sized frame) is not valid and is dropped.  resume: repeat the engine's last run from
+        that launch on (range guard) instead of starting a new one."""
         un, _ = self._get_engines()
         w, h = self.unet_size
         with torch.cuda.device(x.device):
-            xin = x.contiguous()
-            if x.shape[3] != w or x.shape[2] != h:
-                xin = E.resize_nchw(xin, (h, w), "bilinear", align_corners=False)
-                kw["want_stn_in"] = False
             tw, th = self.target_size
-            if (tw, th) != (w, h):
-                kw["want_stn_in"] = False
-            r = un.run(xin, **kw)
+            if resume is not None:
+                r = dict(un.rerun(resume))
+            else:
+                xin = x.contiguous()
+                if x.shape[3] != w or x.shape[2] != h:
+                    xin = E.resize_nchw(xin, (h, w), "bilinear", align_corners=False)
+                    kw["want_stn_in"] = False
+                if (tw, th) != (w, h):
+                    kw["want_stn_in"] = False
+                r = dict(un.run(xin, **kw))      # a copy: the engine keeps its own dict for a later rerun()
             if (tw, th) != (w, h):
                 r["logits"] = E.resize_nchw(r["logits"], (th, tw), "nearest")
                 if "uv" in r:
@@ -307,18 +372,25 @@ class Reconstructor(nn.Module):
         """Reference: models/reconstructor.py:132-158.  Returns (logits, x_top, uv) in NCHW."""
         self._require_eval("forward_unet")
 
-        def run(x, off):
-            r = self._run_unet(x, want_uv=self.unet_uv)
-            o = {"logits": r["logits"], "x_top": E.nhwc_to_nchw(r["x_top"])}
-            if r.get("uv") is not None:
-                o["uv"] = r["uv"]
-            return o
-        o = self._chunked(lambda xi, off: self._range_guarded(run, xi, off), x)
+        def phases(x, off):
+            def tail(r, theta):
+                un, _ = self._get_engines()
+                o = {"logits": r["logits"], "x_top": E.nhwc_to_nchw(r["x_top"], exp=un.x_top_exp(r))}
+                if r.get("uv") is not None:
+                    o["uv"] = r["uv"]
+                return o
+            return (lambda resume=None: self._run_unet(x, resume=resume, want_uv=self.unet_uv),
+                    lambda r, resume=None: None, tail)
+        o = self._chunked(lambda xi, off: self._guarded(phases, xi, off), x)
         return o["logits"], o["x_top"], o.get("uv")
 
-    def _stn(self, x, r):
-        """theta = resnet_reg(cat(...)) for the configured input mode (reference: :174-185)."""
+    def _stn(self, x, r, resume=None):
+        """theta = resnet_reg(cat(...)) for the configured input mode (reference: :174-185).  resume: repeat the
+        ResNet engine's last run from that launch on (range guard)."""
         _, rn = self._get_engines()
+        if resume is not None:
+            with torch.cuda.device(x.device):
+                return rn.rerun(resume)
         B, _, H, W = x.shape
         if self.resnet_input == Input.IMG_AND_MASK and "stn_in" in r:
             y = r["stn_in"]
@@ -366,23 +438,31 @@ class Reconstructor(nn.Module):
         return self._chunked(self._forward_one, x)
 
     def _forward_one(self, x, off):
-        return self._range_guarded(self._forward_one_unguarded, x, off)
+        return self._guarded(self._forward_phases, x, off)
 
-    def _forward_one_unguarded(self, x, off):
-        ret = {}
-        r = None
-        if self.use_unet:
-            r = self._run_unet(x, want_stn_in=self.resnet_input == Input.IMG_AND_MASK, want_uv=self.unet_uv)
-            ret['logits'] = r["logits"]
-            if "uv" in r:
-                ret['uv'] = r["uv"]
-        if self.use_resnet:
-            theta = self._stn(x, r)
-            ret['theta'] = theta
-            ret['poi'] = self.transform_poi(theta, self.court_poi[off:])
-            if self.warper:
-                ret['warp_mask'] = self.warp(theta, self.court_img[off:])
-        return ret
+    def _forward_phases(self, x, off):
+        def run_unet(resume=None):
+            if not self.use_unet:
+                return None
+            return self._run_unet(x, resume=resume, want_stn_in=self.resnet_input == Input.IMG_AND_MASK,
+                                  want_uv=self.unet_uv)
+
+        def run_stn(r, resume=None):
+            return self._stn(x, r, resume=resume) if self.use_resnet else None
+
+        def tail(r, theta):
+            ret = {}
+            if r is not None:
+                ret['logits'] = r["logits"]
+                if "uv" in r:
+                    ret['uv'] = r["uv"]
+            if theta is not None:
+                ret['theta'] = theta
+                ret['poi'] = self.transform_poi(theta, self.court_poi[off:])
+                if self.warper:
+                    ret['warp_mask'] = self.warp(theta, self.court_img[off:])
+            return ret
+        return run_unet, run_stn, tail
 
     def predict(self, x, consistency=True, project_poi=False):
         """Reference: models/reconstructor.py:196-247."""
@@ -414,32 +494,41 @@ class Reconstructor(nn.Module):
         return ret
 
     def _predict_one(self, x, off, consistency, project_poi):
-        return self._range_guarded(self._predict_one_unguarded, x, off, consistency, project_poi)
+        return self._guarded(lambda xi, o: self._predict_phases(xi, o, consistency, project_poi), x, off)
 
-    def _predict_one_unguarded(self, x, off, consistency, project_poi):
-        ret = {}
-        r = None
-        if self.use_unet:
-            r = self._run_unet(x, want_stn_in=self.resnet_input == Input.IMG_AND_MASK)
-            ret['logits'] = r["logits"]
-        if self.use_resnet:
+    def _predict_phases(self, x, off, consistency, project_poi):
+        def run_unet(resume=None):
+            if not self.use_unet:
+                return None
+            return self._run_unet(x, resume=resume, want_stn_in=self.resnet_input == Input.IMG_AND_MASK)
+
+        def run_stn(r, resume=None):
+            if not self.use_resnet:
+                return None
             if self.resnet_input == Input.IMG_AND_MASK_AND_UV:
                 raise NotImplementedError  # the reference's predict() has no uv branch either (:216)
-            theta = self._stn(x, r)
-            ret['theta'] = theta
-            if self.warper:
-                bs = theta.shape[0]
-                h, w = self._warp_hw
-                tmpl = self.court_img[off:off + bs]
-                if tmpl.shape[0] < bs:
-                    raise ValueError(f"batch {bs} exceeds the court template batch {self.court_img.shape[0]}")
-                # warp * mask_classes -> int32, fused in the kernel (reference: :223,240)
-                _, wm = E.homography_warp(theta, tmpl.contiguous(), h, w, self.warp_with_nearest,
-                                          scale=float(self.mask_classes), want_f32=False, want_i32=True,
-                                          shared_template=self._template_is_shared(self.court_img, bs))
-                if consistency and self.use_unet:
-                    ret['consist_score'] = E.consistency_ce(ret['logits'], wm)
-                ret['warp_mask'] = wm
-            if project_poi:
-                ret['poi'] = self.transform_poi(theta, self.court_poi[off:])
-        return ret
+            return self._stn(x, r, resume=resume)
+
+        def tail(r, theta):
+            ret = {}
+            if r is not None:
+                ret['logits'] = r["logits"]
+            if theta is not None:
+                ret['theta'] = theta
+                if self.warper:
+                    bs = theta.shape[0]
+                    h, w = self._warp_hw
+                    tmpl = self.court_img[off:off + bs]
+                    if tmpl.shape[0] < bs:
+                        raise ValueError(f"batch {bs} exceeds the court template batch {self.court_img.shape[0]}")
+                    # warp * mask_classes -> int32, fused in the kernel (reference: :223,240)
+                    _, wm = E.homography_warp(theta, tmpl.contiguous(), h, w, self.warp_with_nearest,
+                                              scale=float(self.mask_classes), want_f32=False, want_i32=True,
+                                              shared_template=self._template_is_shared(self.court_img, bs))
+                    if consistency and self.use_unet:
+                        ret['consist_score'] = E.consistency_ce(ret['logits'], wm)
+                    ret['warp_mask'] = wm
+                if project_poi:
+                    ret['poi'] = self.transform_poi(theta, self.court_poi[off:])
+            return ret
+        return run_unet, run_stn, tail

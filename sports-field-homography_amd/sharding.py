@@ -53,6 +53,62 @@ def gather_results(theta, consist_score=None, group=None, n_max=None):
     return allrows[:, :9].reshape(-1, 1, 3, 3), allrows[:, 9].clone()
 
 
+class ResultGather:
+    """The exchange step of the sharded path, off the compute stream: every step's rows [theta(9), score] are
+    all-gathered on a SIDE HIP stream while the next batch's kernels already run on the caller's stream (40 B per
+    frame: the collective is pure latency, which this hides).  A ring of `depth` slots (rows + receive buffers);
+    a slot is reused only after an event says its previous gather has finished.  On CPU tensors (gloo tests) the
+    same calls run synchronously.
+
+        g = ResultGather(world, frames_per_rank, device)
+        slot = g.submit(out["theta"], out.get("consist_score"))     # returns at once
+        theta_all, score_all = g.result(slot)                        # orders the caller's stream behind the gather
+    """
+
+    def __init__(self, world, n, device, depth=2, group=None):
+        device = torch.device(device)
+        self.world, self.n, self.group = world, n, group
+        self.cuda = device.type == "cuda"
+        self.side = torch.cuda.Stream(device) if self.cuda else None
+        self.slots = [{"rows": torch.zeros((n, 10), dtype=torch.float32, device=device),
+                       "bufs": [torch.empty((n, 10), dtype=torch.float32, device=device) for _ in range(world)],
+                       "done": None} for _ in range(depth)]
+        self.k = 0
+
+    def submit(self, theta, consist_score=None):
+        slot = self.slots[self.k % len(self.slots)]
+        self.k += 1
+        n = theta.shape[0]
+        if n != self.n:
+            raise ValueError(f"ResultGather was sized for {self.n} frames per rank, got {n}")
+        if self.cuda and slot["done"] is not None:
+            torch.cuda.current_stream().wait_event(slot["done"])   # the gather that used this slot last has read its rows
+        slot["rows"][:, :9] = theta.reshape(n, 9)
+        if consist_score is not None:
+            slot["rows"][:, 9] = consist_score
+        if self.world == 1 or not dist.is_initialized():
+            slot["bufs"][0].copy_(slot["rows"])
+            return slot
+        if not self.cuda:
+            dist.all_gather(slot["bufs"], slot["rows"], group=self.group)
+            return slot
+        ready = torch.cuda.Event()
+        ready.record()
+        with torch.cuda.stream(self.side):
+            self.side.wait_event(ready)
+            dist.all_gather(slot["bufs"], slot["rows"], group=self.group)
+            slot["done"] = torch.cuda.Event()
+            slot["done"].record()
+        return slot
+
+    def result(self, slot):
+        """(theta_all (world*n,1,3,3), score_all (world*n,)) in rank order"""
+        if self.cuda and slot["done"] is not None:
+            torch.cuda.current_stream().wait_event(slot["done"])
+        rows = torch.cat(slot["bufs"], 0)
+        return rows[:, :9].reshape(-1, 1, 3, 3), rows[:, 9].clone()
+
+
 def predict_sharded(net, frames, consistency=True, group=None):
     """Run ``net.predict`` on this rank's shard of ``frames`` (a tensor holding the WHOLE batch
     or a callable rank_range -> shard tensor) and gather theta/consist_score from all ranks.

@@ -4,12 +4,14 @@ restatement oracle/warp_ref.py, see its header for the pin status):
 
 * C2: 640x360, batch 16, NCAA template: theta / poi / consistency / logits, arg-max mask with the number
   of differing pixels and the margin they sit at, exact warp for the GPU's own theta, rounded POI pixels.
-* C5: 1280x720, batch 16 through the real sub-batch path, 4-class pitch template, 33-point POI.
+* C5: 1280x720, batch 16 through the real sub-batch path, 4-class pitch template, 33-point POI: all 16 frames
+  against the golden vector.
 * C3: one training forward + backward at 640x360 (B=2 of the 16): losses and, for every parameter, the
   gradient against an fp64 run of the reference classes - bounded by a multiple of the error the
-  reference's own fp32 run has against fp64.
+  reference's own fp32 run has against fp64; and the forward pass + losses + BatchNorm running statistics at the
+  stated batch of 16 (batch-statistics BatchNorm depends on it) against the reference classes' fp32 run.
 
-Measured figures are appended to gpurun_out/parity_r02.jsonl when that directory exists (they are quoted
+Measured figures are appended to gpurun_out/parity_r03.jsonl when that directory exists (they are quoted
 in DESIGN.md).
 """
 import json
@@ -33,7 +35,7 @@ def _record(tag, **kw):
     out = os.path.join(os.path.dirname(HERE), "gpurun_out")
     print(tag, json.dumps({k: v for k, v in kw.items() if k != "table"}))
     if os.path.isdir(out):
-        with open(os.path.join(out, "parity_r02.jsonl"), "a") as f:
+        with open(os.path.join(out, "parity_r03.jsonl"), "a") as f:
             f.write(json.dumps(dict(case=tag, **kw)) + "\n")
 
 
@@ -126,15 +128,15 @@ def test_c2_640x360_batch16_golden(precision):
 def test_c5_1280x720_batch16_pitch_template_poi(precision):
     """predict.py's HD configuration (predict.py:151-155,186-192): 16 frames in one call - whatever sub-batching
     the 32-bit tensor addressing needs happens inside predict()."""
-    g = np.load(os.path.join(GOLD, "c5_1280x720_b2.npz"))
+    g = np.load(os.path.join(GOLD, "c5_1280x720_b16.npz"))
     net, _, court, _ = _net("pitch_v3_nc4_1280x720", (1280, 720), 16, precision)
     x = synth.frames_to_float(synth.synth_frames_u8(16, 720, 1280, seed=0))
     with torch.no_grad():
         out = net.predict(x.cuda(), consistency=True, project_poi=True)
     torch.cuda.synchronize()
     assert tuple(out["logits"].shape) == (16, 4, 720, 1280) and tuple(out["poi"].shape) == (16, 33, 2)
-    _check_predict(f"C5 1280x720 B=16 {precision}", out, g, court, (1280, 720), 2)
-    assert net.range_fallbacks == 0
+    _check_predict(f"C5 1280x720 B=16 {precision}", out, g, court, (1280, 720), 16)
+    assert net.range_fallbacks == 0 and net.range_rescales == 0
     # frames are independent (eval-mode BatchNorm): a frame gives the same bits wherever it sits in the batch
     with torch.no_grad():
         solo = net.predict(x[:2].cuda(), consistency=True, project_poi=True)
@@ -232,6 +234,55 @@ def test_public_methods_direct():
     with torch.no_grad():
         wb = net.warp(th.cuda(), net.court_img)
     assert float((wb.cpu() - warp_ref.homography_warp(th, court, 360, 640, "bilinear")).abs().max()) < 1e-6
+
+
+@pytest.mark.parametrize("precision", ["f16x3", "bf16x6", "fp32"])  # training precisions
+def test_c3_batch16_forward_losses_and_running_stats(precision, monkeypatch):
+    """BASELINE config 3 at its stated batch: 16 frames of 640x360 through TrainStep.loss_and_grads (forward with
+    batch statistics, the four losses, the whole backward) against the reference classes' own train()-mode forward
+    in fp32 (oracle/make_fixtures.py:make_c3_b16_golden): loss values, theta, sub-sampled logits / warp, and EVERY
+    BatchNorm layer's running_mean / running_var / num_batches_tracked after the step."""
+    from oracle.fixture_inputs import c3_batch
+    from sfh_amd import training
+    from sfh_amd.reconstructor import Reconstructor
+    monkeypatch.setenv("SFH_TRAIN_PRECISION", precision)
+    g = np.load(os.path.join(GOLD, "c3_fwd_640x360_b16.npz"))
+    B, H, W = 16, 360, 640
+    court = synth.load_court_template("ncaa_nc4_640x360", 4, B)
+    poi = synth.load_court_poi("pitch", B)
+    net = Reconstructor(court.cuda(), poi.cuda(), target_size=(W, H), unet_size=(W, H), warp_size=(W, H))
+    net.load_state_dict(synth.synth_state_dict(net.state_dict(), 0))
+    net.cuda().train()
+    ts = training.TrainStep(net, lr=1e-5, weight_decay=1e-8, seg_lambda=1.0, rec_lambda=1.0, reproj_lambda=1.0,
+                            consist_lambda=1.0)
+    x = synth.frames_to_float(synth.synth_frames_u8(B, H, W, seed=0)).cuda()
+    batch = {k: v.cuda() for k, v in c3_batch(B, H, W, poi.shape[1]).items()}
+    losses = ts.loss_and_grads(x, batch).cpu().numpy()      # [seg, rec, consist, reproj]
+    torch.cuda.synchronize()
+    got = dict(zip(("seg", "rec", "consist", "reproj"), losses.tolist()))
+    rec = {}
+    for k, tol in (("seg", 2e-5), ("rec", 2e-5), ("reproj", 2e-5), ("consist", 1e-3)):
+        want = float(g[f"loss.{k}"])
+        rec[k] = (got[k], want)
+        # trunc(warp * 4) targets of the consistency term flip with the last bit of the bilinear warp
+        assert abs(got[k] - want) < tol * max(1.0, abs(want)), (k, got[k], want)
+    assert ts.range_fallbacks == 0
+    bufs = dict(net.named_buffers())
+    worst = {"running_mean": 0.0, "running_var": 0.0}
+    names = [str(n) for n in g["buffers"]]
+    assert len(names) == 162 and all(n in bufs for n in names)
+    for n in names:
+        want, have = g[f"buf.{n}"], bufs[n].detach().cpu().numpy()
+        if n.endswith("num_batches_tracked"):
+            assert int(have) == int(want) == 101, n      # the synthetic checkpoint starts at 100
+            continue
+        kind = n.rsplit(".", 1)[1]
+        # relative to the size of the statistic's own tensor (means of some channels sit near zero)
+        err = float(np.abs(have - want).max() / max(np.abs(want).max(), 1e-6))
+        worst[kind] = max(worst[kind], err)
+        assert err < 2e-4, (n, err)
+    _record(f"C3 forward 640x360 B=16 {precision}", losses=rec, batchnorm_layers=len(names) // 3,
+            max_rel_err_running_mean=worst["running_mean"], max_rel_err_running_var=worst["running_var"])
 
 
 @pytest.mark.parametrize("precision", ["f16x3", "bf16x6", "fp32"])  # training precisions

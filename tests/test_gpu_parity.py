@@ -209,6 +209,24 @@ def test_h2_split_format(E):
         big[1, 2, 3, 4] = bad
         E.f32_to_h2(big, ovf)
         assert int(ovf.item()) == 1, bad
+    # the exponent belongs to the tensor: at 2^-3 the same format carries |v| up to 65504 * 8 with the same 22 bits,
+    # and the range word receives the largest |v * 2^e| (here 3.0e5 / 8), or the bit pattern of a NaN
+    rw = torch.zeros(1, dtype=torch.int32, device="cuda")
+    wide = x * 16.0
+    wide[0, 1, 2, 3] = -3.0e5
+    ovf.zero_()
+    sw = E.f32_to_h2(wide, ovf, exp=-3, range_word=rw)
+    back = E.s3_to_f32(sw, exp=-3)
+    assert int(ovf.item()) == 0 and ((back - wide).abs() / wide.abs()).max().item() <= 2.0 ** -21
+    assert np.array([rw.item()], np.int32).view(np.float32)[0] == np.float32(3.0e5 / 8)
+    E.f32_to_h2(wide * 0.5, ovf, exp=-3, range_word=rw)            # a smaller maximum leaves the word alone
+    assert np.array([rw.item()], np.int32).view(np.float32)[0] == np.float32(3.0e5 / 8)
+    E.f32_to_h2(wide, ovf, exp=2, range_word=rw)                   # 1.2e6 at exponent 2: saturated, the word says by how much
+    assert int(ovf.item()) == 1 and np.array([rw.item()], np.int32).view(np.float32)[0] == np.float32(1.2e6)
+    big = x.clone()
+    big[1, 2, 3, 4] = float("nan")
+    E.f32_to_h2(big, None, range_word=rw)
+    assert (int(rw.item()) & 0x7FFFFFFF) > 0x7F800000
 
 
 def test_down_pool_on_load_golden(E, golden_blocks):
@@ -315,18 +333,29 @@ def test_resnet_stn_golden(E, golden_blocks, name, key, seed, precision):
     g = golden_blocks
     rn, _ = _mods_to_cuda(modules.ResNetSTN(name, 7), seed)
     x = torch.from_numpy(g["resnet34_7.x"])
-    ovf = torch.zeros(1, dtype=torch.int32, device="cuda")
-    eng = E.ResNetEngine(rn, 7, torch.device("cuda"), precision, overflow=ovf)
+    rg = E.H2Ranges(torch.device("cuda")) if precision == "f16x3" else None
+    eng = E.ResNetEngine(rn, 7, torch.device("cuda"), precision, ranges=rg)
     y = E.nchw_to_nhwc(x.cuda(), 8)
     theta = eng.run(y, 2, 72, 128)
     torch.cuda.synchronize()
-    if precision == "f16x3" and int(ovf.item()):
+    rescales = 0
+    while rg is not None:
         # these randomly initialised ResNets (no trained BatchNorm) grow to activations of several thousand in
-        # layer3 / layer4 (resnet34: 7346).  A net that leaves the range of the H2 format (16376) must have raised
-        # the overflow word (checked here); Reconstructor re-runs such a batch in bf16x6
-        # (test_f16x3_range_guard_falls_back)
-        return
+        # layer3 / layer4 (resnet34: 7346; the Bottleneck depths go beyond the 16376 of the default exponent): the
+        # kernels leave the magnitudes in the range words, the saturated tensors get a smaller exponent and the
+        # engine resumes at the first of them - what Reconstructor._guarded does
+        bits = rg.read()
+        bad, nonfinite = rg.saturated(bits)
+        assert not nonfinite
+        if not bad:
+            break
+        rg.reset_words()
+        theta = eng.rerun(eng.first_step({rg.lower(n, bits[n]) for n in bad}))
+        rescales += 1
+        assert rescales < 40
     assert _maxerr(theta.cpu(), g[key]) < 1e-4
+    if rg is not None:
+        assert min(rg.headroom().values()) >= 1.0 and len(rg.peak) > 10
 
 
 # ---------------------------------------------------------------- warp / POI / CE
@@ -571,10 +600,26 @@ def test_predict_resnet50_variant(E):
     assert torch.equal(out["warp_mask"].cpu(), wm.to(torch.int32))
 
 
-def test_f16x3_range_guard_falls_back(E):
-    """A checkpoint whose activations leave the fp16 range of the H2 format (here: the first BatchNorm scaled by
-    2^16 and the next conv divided by it - the same function, since ReLU is positively homogeneous) must not give
-    saturated results: the kernels raise the overflow word and predict() re-runs the batch in bf16x6."""
+def _rescaled_checkpoint(sd, factor, pairs):
+    """The same function with larger intermediate activations: BatchNorm affine of layer a times `factor`, the conv
+    that reads it divided by `factor` (ReLU and max-pool are positively homogeneous)."""
+    sd2 = {k: v.clone() for k, v in sd.items()}
+    for bn, convs in pairs:
+        sd2[bn + ".weight"] *= factor
+        sd2[bn + ".bias"] *= factor
+        for c in convs:
+            if isinstance(c, tuple):    # (key, slice of input channels)
+                sd2[c[0]][:, c[1]] /= factor
+            else:
+                sd2[c] /= factor
+    return sd2
+
+
+def test_f16x3_range_guard_rescales_and_resumes(E):
+    """A checkpoint whose activations leave the fp16 range of the default H2 exponent (here: BatchNorms scaled by
+    2^16 / 2^8 and the convs that read them divided by it - the same function) must neither give saturated results
+    nor leave the two-plane path: the kernels record the magnitudes, the saturated tensors get a smaller exponent
+    and the pass resumes at the first of them; afterwards the model runs such batches with no extra work."""
     from sfh_amd.reconstructor import Reconstructor
     B, H, W = 2, 48, 64
     court = synth.load_court_template("ncaa_nc4_640x360", 4, B)[:, :, :H, :W].contiguous()
@@ -588,25 +633,84 @@ def test_f16x3_range_guard_falls_back(E):
     net.precision = "f16x3"
     with torch.no_grad():
         base = net.predict(x, consistency=False)
-    assert net.range_fallbacks == 0                      # the ordinary checkpoint stays inside the range
-    sd2 = {k: v.clone() for k, v in sd.items()}
-    sd2["inc.double_conv.1.weight"] *= 65536.0
-    sd2["inc.double_conv.1.bias"] *= 65536.0
-    sd2["inc.double_conv.3.weight"] /= 65536.0
+    assert net.range_fallbacks == 0 and net.range_rescales == 0     # the ordinary checkpoint stays inside the range
+    sd2 = _rescaled_checkpoint(sd, 65536.0, [("inc.double_conv.1", ["inc.double_conv.3.weight"])])
+    sd2 = _rescaled_checkpoint(sd2, 256.0, [
+        # inc.out feeds down1 (through the pool) and, as the skip, the first 64 input channels of up4's conv
+        ("inc.double_conv.4", ["down1.maxpool_conv.1.double_conv.0.weight", ("up4.conv.double_conv.0.weight", slice(0, 64))]),
+        ("down3.maxpool_conv.1.double_conv.1", ["down3.maxpool_conv.1.double_conv.3.weight"]),
+        ("up2.conv.double_conv.1", ["up2.conv.double_conv.3.weight"]),
+        ("resnet_reg.layer2.1.bn1", ["resnet_reg.layer2.1.conv2.weight"])])
     net.load_state_dict(sd2)
-    with torch.no_grad(), pytest.warns(UserWarning, match="fp16 range"):
+    with torch.no_grad(), warnings.catch_warnings():
+        warnings.simplefilter("error")
         got = net.predict(x, consistency=False)
-    assert net.range_fallbacks == 1
-    net.precision = "bf16x6"
-    with torch.no_grad():
-        want = net.predict(x, consistency=False)
-    assert torch.equal(got["logits"], want["logits"]) and torch.equal(got["theta"], want["theta"])
+    n1 = net.range_rescales
+    assert net.range_fallbacks == 0 and n1 >= 1
+    xc = x.cpu()
+    want = torch_ref.predict(xc, sd2, court, poi, warp_size=(W, H), unet_size=(W, H), target_size=(W, H), consistency=False)
+    assert _maxerr(got["theta"].cpu(), want["theta"]) < 1e-4
+    assert _maxerr(got["logits"].cpu(), want["logits"]) < 5e-4
     assert _maxerr(got["logits"].cpu(), base["logits"].cpu()) < 2e-3    # same function up to rounding
-    # forward() and forward_unet() take the same guard
-    net.precision = "f16x3"
+    ex = net._h2_ranges.exps
+    # the scaled tensors got smaller exponents (how much smaller depends on the headroom they had), nothing else moved
+    assert ex["inc.mid"] <= 2 - 6 and all(ex[k] < 2 for k in ("inc.out", "down3.mid", "up2.conv.mid", "rn.layer2.1.t"))
+    assert set(ex) == {"inc.mid", "inc.out", "down3.mid", "up2.conv.mid", "rn.layer2.1.t"}
+    assert min(net.h2_headroom().values()) >= 1.0
+    # sticky: the next batches - predict(), forward() and forward_unet() alike - repeat nothing and give the same bits
     with torch.no_grad():
+        again = net.predict(x, consistency=False)
         lg, _, _ = net.forward_unet(x)
-    assert net.range_fallbacks == 2 and torch.equal(lg, want["logits"])
+        fw = net(x)
+    assert net.range_rescales == n1 and net.range_fallbacks == 0
+    assert torch.equal(again["logits"], got["logits"]) and torch.equal(again["theta"], got["theta"])
+    assert torch.equal(lg, got["logits"]) and torch.equal(fw["theta"], got["theta"])
+    # new weights keep the exponents (same model): loading the checkpoint again costs no second calibration
+    net.load_state_dict(sd2)
+    with torch.no_grad():
+        third = net.predict(x, consistency=False)
+    assert net.range_rescales == n1 and torch.equal(third["theta"], got["theta"])
+    # a caller that pipelines batches switches the guard off and asks afterwards
+    net2 = Reconstructor(court.cuda(), poi.cuda(), target_size=(W, H), unet_size=(W, H), warp_size=(W, H), warp_with_nearest=True)
+    net2.load_state_dict(sd2)
+    net2.cuda().eval()
+    net2.range_guard = False
+    with torch.no_grad():
+        net2.predict(x, consistency=False)
+    assert net2.range_overflowed() is True and net2.range_rescales == 0
+
+
+def test_f16x3_stays_on_the_two_plane_path_with_2_to_8_scaled_logits_and_gammas(E):
+    """Larger frames, every encoder level's second BatchNorm and the logit head scaled by 2^8 (the head for real:
+    the STN then sees 256x the logits, a different function - compared with the CPU restatement of that checkpoint)."""
+    from sfh_amd.reconstructor import Reconstructor
+    B, H, W = 2, 90, 112
+    court = synth.load_court_template("ncaa_nc4_640x360", 4, B)[:, :, :H, :W].contiguous()
+    poi = synth.load_court_poi("pitch", B)
+    net = Reconstructor(court.cuda(), poi.cuda(), target_size=(W, H), unet_size=(W, H), warp_size=(W, H), warp_with_nearest=True)
+    sd = synth.synth_state_dict(net.state_dict(), 61)
+    pairs = [(f"down{i}.maxpool_conv.1.double_conv.1", [f"down{i}.maxpool_conv.1.double_conv.3.weight"]) for i in (1, 2, 3, 4)]
+    pairs += [(f"up{i}.conv.double_conv.1", [f"up{i}.conv.double_conv.3.weight"]) for i in (1, 2, 3, 4)]
+    pairs += [("resnet_reg.layer1.0.bn1", ["resnet_reg.layer1.0.conv2.weight"]), ("resnet_reg.layer4.2.bn1", ["resnet_reg.layer4.2.conv2.weight"])]
+    sd2 = _rescaled_checkpoint(sd, 256.0, pairs)
+    sd2["outc.conv.weight"] *= 256.0
+    sd2["outc.conv.bias"] *= 256.0
+    net.load_state_dict(sd2)
+    net.cuda().eval()
+    x = synth.smooth_frames(B, H, W, seed=61)
+    with torch.no_grad():
+        got = net.predict(x.cuda(), consistency=True, project_poi=True)
+        want = torch_ref.predict(x, sd2, court, poi, warp_size=(W, H), unet_size=(W, H), target_size=(W, H), project_poi=True)
+    assert net.range_fallbacks == 0 and net.range_rescales >= 1
+    assert _maxerr(got["theta"].cpu(), want["theta"]) < 1e-4
+    assert _maxerr(got["logits"].cpu(), want["logits"]) < 5e-4 * 256
+    assert _maxerr(got["poi"].cpu(), want["poi"]) < 1e-4
+    wm = (warp_ref.homography_warp(got["theta"].cpu(), court, H, W, "nearest") * 4).to(torch.int32)
+    assert torch.equal(got["warp_mask"].cpu(), wm)
+    n1 = net.range_rescales
+    with torch.no_grad():
+        net.predict(x.cuda(), consistency=True, project_poi=True)
+    assert net.range_rescales == n1 and net.range_fallbacks == 0
 
 
 @pytest.mark.parametrize("B,size", [(1, (50, 70)), (3, (33, 47)), (1, (16, 16)), (5, (64, 48))])

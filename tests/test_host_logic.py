@@ -1,5 +1,6 @@
 """Host-side logic of the Reconstructor mirror that needs no GPU: sub-batching around the 32-bit buffer
-descriptors, the fp16-range guard of the "f16x3" mode and its re-run in "bf16x6", weight-exponent choice."""
+descriptors, the fp16-range guard of the "f16x3" mode (per-tensor exponents, resume from the saturated layer, bf16x6
+only for non-finite values), weight-exponent choice."""
 import math
 import os
 import sys
@@ -15,18 +16,37 @@ from sfh_amd import synth  # noqa: E402
 from sfh_amd.reconstructor import Reconstructor  # noqa: E402
 
 
-class _Flag:
-    """stands in for the int32 device word the H2 kernels raise"""
+class _Ranges:
+    """stands in for engine.H2Ranges: successive read() results, what was lowered, how often the words were zeroed"""
+    NONFINITE = 0x7F800000
 
-    def __init__(self, hits):
-        self.hits = list(hits)     # value returned by successive item() calls
+    def __init__(self, reads):
+        self.reads = [dict(r) for r in reads]
+        self.lowered = []
         self.zeroed = 0
 
-    def item(self):
-        return self.hits.pop(0) if self.hits else 0
+    def read(self):
+        return self.reads.pop(0) if self.reads else {}
 
-    def zero_(self):
+    def saturated(self, bits):
+        bad = [n for n, b in bits.items() if b > 0x477FE000]
+        return bad, any(bits[n] >= self.NONFINITE for n in bad)
+
+    def lower(self, name, bits):
+        self.lowered.append(name)
+        return name
+
+    def reset_words(self):
         self.zeroed += 1
+
+
+class _Engine:
+    def __init__(self, steps):
+        self.steps = steps      # {key: index of the first launch that writes it}
+
+    def first_step(self, keys):
+        hit = [self.steps[k] for k in keys if k in self.steps]
+        return min(hit) if hit else None
 
 
 def _net(wh):
@@ -34,11 +54,29 @@ def _net(wh):
                         unet_size=wh, warp_size=wh).eval()
     calls = []
 
-    def fake(x, off, consistency, project_poi):
-        calls.append((x.shape[0], off, net._forced_precision or net.precision))
-        return {"theta": torch.full((x.shape[0], 1), float(off))}
-    net._predict_one_unguarded = fake
+    def fake_phases(x, off, consistency, project_poi):
+        prec = net._forced_precision or net.precision
+
+        def run_unet(resume=None):
+            calls.append(("unet", x.shape[0], off, prec, resume))
+            return {"logits": None}
+
+        def run_stn(r, resume=None):
+            calls.append(("stn", x.shape[0], off, prec, resume))
+            return "theta"
+
+        def tail(r, theta):
+            calls.append(("tail", x.shape[0], off, prec, None))
+            return {"theta": torch.full((x.shape[0], 1), float(off))}
+        return run_unet, run_stn, tail
+    net._predict_phases = fake_phases
+    net._engines = (_Engine({"inc.out": 1, "down2.mid": 5}), _Engine({"rn.layer3.0.out": 7}))
     return net, calls
+
+
+def _passes(calls):
+    """(frames, offset, precision) of every full pass = every un-resumed unet phase"""
+    return [(b, o, p) for what, b, o, p, resume in calls if what == "unet" and resume is None]
 
 
 def test_sub_batches_follow_the_bytes_per_element_of_the_precision():
@@ -49,7 +87,7 @@ def test_sub_batches_follow_the_bytes_per_element_of_the_precision():
         net.range_guard = False
         calls.clear()
         out = net.predict(x)
-        assert [(b, o) for b, o, _ in calls] == want, prec
+        assert [(b, o) for b, o, _ in _passes(calls)] == want, prec
         assert out["theta"].shape[0] == 16
     # 640x360: 64 frames of 6 B/element need two launches (48 fit), of 4 B/element one (72 fit)
     x = torch.empty((64, 3, 360, 640))
@@ -57,44 +95,105 @@ def test_sub_batches_follow_the_bytes_per_element_of_the_precision():
     net.range_guard = False
     net.precision = "bf16x6"
     net.predict(x)
-    assert [(b, o) for b, o, _ in calls] == [(32, 0), (32, 32)]
+    assert [(b, o) for b, o, _ in _passes(calls)] == [(32, 0), (32, 32)]
     calls.clear()
     net.precision = "f16x3"
     net.predict(x)
-    assert [(b, o) for b, o, _ in calls] == [(64, 0)]
+    assert [(b, o) for b, o, _ in _passes(calls)] == [(64, 0)]
 
 
-def test_range_guard_reruns_in_bf16x6_and_rechunks():
+BIG, NAN = 0x47800000, 0x7FC00000     # bit patterns: 65536.f (beyond 65504), a NaN
+
+
+def test_range_guard_lowers_the_exponent_and_resumes_from_the_layer():
+    """A tensor beyond its fp16 range: its exponent goes down and the pass resumes at the launch that writes it -
+    the UNet from that step (then the whole STN and the tail), or only the ResNet from its step; the model stays on
+    the two-plane path (no bf16x6 re-run)."""
     x = torch.empty((16, 3, 720, 1280))
     net, calls = _net((1280, 720))
     net.precision = "f16x3"
-    net._h2_overflow = _Flag([1])
-    with pytest.warns(UserWarning, match="fp16 range"):
+    net._h2_ranges = rg = _Ranges([{"down2.mid": BIG, "inc.out": 5}, {"rn.layer3.0.out": BIG}, {}])
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
         out = net.predict(x)
-    # one f16x3 launch of 16 frames, flagged; then 8 + 8 frames with the three-plane operands, offsets kept
-    assert calls == [(16, 0, "f16x3"), (8, 0, "bf16x6"), (8, 8, "bf16x6")]
+    assert [c[0] + ("" if c[4] is None else f"@{c[4]}") for c in calls] == [
+        "unet", "stn", "tail",            # the pass
+        "unet@5", "stn", "tail",          # down2.mid saturated: UNet from launch 5, everything behind it again
+        "stn@7", "tail"]                  # then a ResNet tensor: only the ResNet from launch 7 and the tail
+    assert rg.lowered == ["down2.mid", "rn.layer3.0.out"] and rg.zeroed == 2
+    assert net.range_rescales == 2 and net.range_fallbacks == 0 and out["theta"].shape[0] == 16
+    # a clean pass reads the words once and repeats nothing
+    net._h2_ranges = _Ranges([{"inc.out": 5}])
+    calls.clear()
+    net.predict(x)
+    assert [c[0] for c in calls] == ["unet", "stn", "tail"] and net.range_rescales == 2
+
+
+def test_range_guard_reruns_a_non_finite_batch_in_bf16x6_and_rechunks():
+    x = torch.empty((16, 3, 720, 1280))
+    net, calls = _net((1280, 720))
+    net.precision = "f16x3"
+    net._h2_ranges = _Ranges([{"inc.mid": NAN}])
+    with pytest.warns(UserWarning, match="non-finite"):
+        out = net.predict(x)
+    # one f16x3 pass of 16 frames, flagged; then 8 + 8 frames with the three-plane operands, offsets kept
+    assert _passes(calls) == [(16, 0, "f16x3"), (8, 0, "bf16x6"), (8, 8, "bf16x6")]
     assert out["theta"][:, 0].tolist() == [0.0] * 8 + [8.0] * 8
-    assert net.range_fallbacks == 1 and net._h2_overflow.zeroed == 1 and net._forced_precision is None
+    assert net.range_fallbacks == 1 and net._h2_ranges.zeroed == 1 and net._forced_precision is None
+    assert net._h2_ranges.lowered == []
     # second hit: counted, no second warning
-    net._h2_overflow = _Flag([0, 1])
+    net._h2_ranges = _Ranges([{}, {"inc.mid": NAN}])
     calls.clear()
     with warnings.catch_warnings():
         warnings.simplefilter("error")
         net.predict(x)              # clean
         net.predict(x)              # flagged
-    assert net.range_fallbacks == 2 and [c[2] for c in calls] == ["f16x3", "f16x3", "bf16x6", "bf16x6"]
-    # guard switched off: the caller asks
+    assert net.range_fallbacks == 2 and [p for _, _, p in _passes(calls)] == ["f16x3", "f16x3", "bf16x6", "bf16x6"]
+    # guard switched off: the caller asks, and the exponents are lowered for the batches that follow
     net.range_guard = False
-    net._h2_overflow = _Flag([1])
+    net._h2_ranges = _Ranges([{"inc.out": BIG}, {}])
     calls.clear()
     net.predict(x)
-    assert [c[2] for c in calls] == ["f16x3"] and net.range_overflowed() is True and net.range_overflowed() is False
-    # other precisions never read the word
+    assert [p for _, _, p in _passes(calls)] == ["f16x3"]
+    assert net.range_overflowed() is True and net._h2_ranges.lowered == ["inc.out"] and net.range_overflowed() is False
+    # other precisions never read the words
     net.range_guard = True
     net.precision = "bf16x6"
-    net._h2_overflow = _Flag([1])
+    net._h2_ranges = _Ranges([{"inc.out": BIG}])
     net.predict(x)
-    assert net._h2_overflow.hits == [1]
+    assert len(net._h2_ranges.reads) == 1
+
+
+def test_h2_ranges_bookkeeping():
+    """engine.H2Ranges on the host: shared exponent keys, shared words, the exponent a saturated tensor gets."""
+    import numpy as np
+    from sfh_amd import engine as E
+    rg = E.H2Ranges(torch.device("cpu"), capacity=8)
+    rg.register("inc.out")
+    rg.register("inc.pool", key="inc.out", word_of="inc.out")
+    rg.register("up4.up", key="inc.out")
+    rg.register("down1.mid")
+    assert rg.exp("inc.out") == rg.exp("nope") == 2 and rg.key("up4.up") == "inc.out"
+    assert rg.word_ptr("inc.pool") == rg.word_ptr("inc.out") != rg.word_ptr("up4.up")
+    with pytest.raises(ValueError):
+        rg.register("up4.up", key="down1.mid")
+    a = rg.args("inc.out", "down1.mid", None)
+    assert a["exp_src"] == a["exp_dst"] == a["exp_res"] == 2 and a["range_word"] == rg.word_ptr("down1.mid")
+    # the kernels saw |u| = 3e5 at exponent 2, i.e. |v| = 75000 in up4.up: new exponent puts it into [2^12, 2^13)
+    w = rg.words.numpy().view("uint32")
+    w[rg.slot["up4.up"][1]] = np.float32(3.0e5).view("uint32")
+    w[rg.slot["down1.mid"][1]] = np.float32(100.0).view("uint32")
+    bits = rg.read()
+    bad, nonfinite = rg.saturated(bits)
+    assert bad == ["up4.up"] and not nonfinite
+    assert rg.lower("up4.up", bits["up4.up"]) == "inc.out"
+    e = rg.exp("inc.out")
+    assert e == rg.exp("inc.pool") == rg.exp("up4.up") == -4 and 2.0 ** 12 <= 75000.0 * 2.0 ** e < 2.0 ** 13
+    assert rg.exp("down1.mid") == 2 and abs(rg.peak["down1.mid"] - 25.0) < 1e-6
+    assert abs(rg.headroom()["down1.mid"] - 65504.0 / 4 / 25.0) < 1e-3
+    rg.reset_words()
+    w[rg.slot["down1.mid"][1]] = 0x7F800000
+    assert rg.saturated(rg.read()) == (["down1.mid"], True)
 
 
 def test_weight_exponent_puts_the_largest_weight_below_2_to_14():

@@ -133,3 +133,45 @@ def test_bench_self_launch_builds_one_child_per_gpu(monkeypatch):
     assert cmd[-6:] == ["--gpus", "4", "--steps", "3", "--warmup", "1"] and cmd[-7].endswith("bench.py")
     assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
     assert "torch.cuda" not in "".join(m for m in sys.modules if m.startswith("bench_under_test"))
+
+
+def _gather_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        g = sharding.ResultGather(world, 3, "cpu", depth=2)
+        got = []
+        slots = []
+        for step in range(5):     # more steps than slots: the ring wraps
+            theta = (torch.arange(27.0).reshape(3, 1, 3, 3) + 100 * rank + 1000 * step)
+            slots.append(g.submit(theta, torch.full((3,), float(10 * rank + step))))
+            th, sc = g.result(slots[-1])
+            got.append((th[:, 0, 0, 0].tolist(), sc.tolist()))
+        q.put((rank, got))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_result_gather_ring_gloo_world2():
+    """The side-stream gather of bench.py's sharded step (synchronous on CPU tensors): every rank sees every rank's
+    rows of the step it asked for, in rank order, also after the slot ring has wrapped."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000) + 77
+    procs = [ctx.Process(target=_gather_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+    assert res[0] == res[1]
+    for step, (th00, sc) in enumerate(res[0]):
+        assert th00 == [1000.0 * step + 9 * i for i in range(3)] + [1000.0 * step + 100 + 9 * i for i in range(3)]
+        assert sc == [float(step)] * 3 + [10.0 + step] * 3
+
+
+def test_result_gather_single_process():
+    g = sharding.ResultGather(1, 2, "cpu")
+    th, sc = g.result(g.submit(torch.ones(2, 1, 3, 3), torch.tensor([3.0, 4.0])))
+    assert th.shape == (2, 1, 3, 3) and sc.tolist() == [3.0, 4.0]
