@@ -143,6 +143,13 @@ typedef struct sfh_conv_desc {
   /* kernels that split an fp32 source themselves (sfh_stem7x7_fwd): 0 or SFH_FMT_S3 = three bf16 planes, six products;
    * SFH_FMT_H2 = two fp16 planes, three products (weights from sfh_pack_stem_weights with the same format). */
   int32_t split_arith;
+  /* split-K (sfh_conv_s3_fwd): ksplit > 1 launches ksplit copies of the grid; copy k accumulates its share of the
+   * 32-channel stages of the K loop and writes acc * scale + shift as fp32 NHWC into slab k of dst, slabs
+   * ksplit_stride BYTES apart - for layers whose (tile, cout block) grid alone leaves most of the chip idle (ResNet
+   * layer3 / layer4 at batch 16).  Needs a single source, dst_fmt F32, no ReLU / residual / dst_pool / head; pass an
+   * all-zero `shift` and let sfh_splitk_finish add the slabs, the real shift, the residual and the activation. */
+  int32_t ksplit;
+  int64_t ksplit_stride;
 } sfh_conv_desc;
 
 const char* sfh_last_error(void);
@@ -437,6 +444,15 @@ int sfh_resize_nearest_nchw_bwd(const float* dy, float* dx, int64_t planes, int 
 int sfh_compose_up_weights(const float* wconv, int cout, int c0, int c1, const float* wt, int cx,
                            const float* bt, const float* scale4, const float* shift4, float* w2,
                            float* shift_border, void* stream);
+
+/* Second half of a split-K convolution (sfh_conv_desc.ksplit): y = [relu](sum_k slab_k + shift[c] [+ residual]) over
+ * (npix, C) fp32 NHWC slabs slab_stride bytes apart -> dst in dst_fmt (F32 NHWC, S3 or H2 with exponent exp_dst; W =
+ * row length of the split layouts).  residual (optional): same geometry, res_fmt / exp_res.  overflow / range: as
+ * sfh_f32_to_h2.  Replaces the BatchNorm shift + residual add + ReLU of BasicBlock (models/resnet.py:74-80) that
+ * sfh_conv_s3_fwd applies in its epilogue when the K loop is not split. */
+int sfh_splitk_finish(const float* slabs, int nslabs, int64_t slab_stride, const float* shift, const void* residual,
+                      int res_fmt, int exp_res, int relu, int64_t rows, int W, int C, void* dst, int dst_fmt,
+                      int exp_dst, uint32_t* overflow, uint32_t* range, void* stream);
 
 /* The ResNetSTN stem (models/resnet.py:172,241-243: 7x7 stride-2 pad-3 conv + BatchNorm + ReLU, <= 8 input
  * channels -> 64) with the split-bf16 arithmetic, K packed by tap (4 taps x 8 channels per MFMA): d->src0 fp32

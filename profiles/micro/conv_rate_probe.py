@@ -24,7 +24,7 @@ def bench(fn, reps=6):
     return e0.elapsed_time(e1) / reps
 
 
-def run(cin, cout, w, heights, B=16, wg=0, pool=False):
+def run(cin, cout, w, heights, B=16, wg=0, pool=False, tile=None):
     torch.manual_seed(0)
     wt = torch.randn(cout, cin, 3, 3, device="cuda") * (2.0 / (9 * cin)) ** 0.5
     bias = torch.randn(cout, device="cuda") * 0.1
@@ -34,10 +34,10 @@ def run(cin, cout, w, heights, B=16, wg=0, pool=False):
         x = E.f32_to_h2(torch.relu(torch.randn(B, h, w, cin, device="cuda")))
         y = E.split_empty("h2", B, h, w, cout, "cuda")
         yp = E.split_empty("h2", B, h // 2, w // 2, cout, "cuda") if pool else None
-        ms = bench(lambda: conv.run(x, B, h, w, y, dst_pool=yp, wg_couts=wg))
+        ms = bench(lambda: conv.run(x, B, h, w, y, dst_pool=yp, wg_couts=wg, tile=tile))
         zr = 1 + ((h + 1) & 1)
-        tile = E.choose_tile_s3(B, h, w, 1, zr, cout // 64)
-        th, tw = {0: (8, 32), 1: (16, 16), 2: (32, 8)}[tile]
+        tl = E.choose_tile_s3(B, h, w, 1, zr, cout // 64) if tile is None else tile
+        th, tw = {0: (8, 32), 1: (16, 16), 2: (32, 8), 3: (8, 16), 4: (16, 8)}[tl]
         ntiles = -(-(B * (h + zr)) // th) * -(-w // tw)
         tf = 2.0 * B * h * w * cout * 9 * cin / ms / 1e9
         print(f"{cin:5d}->{cout:<5d} {h:4d}x{w:<4d} tile {th}x{tw} tiles {ntiles:6d} x {cout // 64} blocks of 64 "
@@ -53,3 +53,9 @@ if __name__ == "__main__":
     run(128, 128, 320, (45, 90, 180, 360), wg=wg)
     run(64, 64, 640, (90, 180, 360), wg=wg)
     run(64, 64, 640, (360,), wg=wg, pool=True)
+    if "--half-tiles" in sys.argv:   # 128-pixel tiles: half the LDS and accumulators per workgroup, more workgroups per CU
+        print("half-size tiles (8x16)")
+        run(64, 64, 640, (360,), tile=3)
+        run(64, 64, 640, (360,), tile=3, pool=True)
+        run(128, 128, 320, (180,), wg=64, tile=3)
+        run(128, 128, 320, (180,), wg=64)

@@ -35,7 +35,7 @@ class ConvDesc(C.Structure):
         ("head_w", _p), ("head_b", _p), ("head_nc", _i), ("head_skip_dst", _i),
         ("head_logits", _p), ("head_stn", _p), ("head_frame", _p),
         ("h2_overflow", _p), ("h2_exp_src", _i), ("h2_exp_dst", _i), ("h2_exp_res", _i), ("h2_range", _p),
-        ("wg_couts", _i), ("split_arith", _i),
+        ("wg_couts", _i), ("split_arith", _i), ("ksplit", _i), ("ksplit_stride", C.c_int64),
     ]
 
     def __init__(self, *args, **kw):
@@ -114,6 +114,8 @@ SIGNATURES = {
     "sfh_upsample2x_bilinear_nhwc_bwd": (C.c_int, [_p, _p, C.c_int, C.c_int, C.c_int, C.c_int, _p]),
     "sfh_resize_nearest_nchw_bwd": (C.c_int, [_p, _p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, _p]),
     "sfh_compose_up_weights": (C.c_int, [_p, C.c_int, C.c_int, C.c_int, _p, C.c_int, _p, _p, _p, _p, _p, _p]),
+    "sfh_splitk_finish": (C.c_int, [_p, C.c_int, C.c_int64, _p, _p, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int, C.c_int,
+                                    _p, C.c_int, C.c_int, _p, _p, _p]),
     "sfh_stem7x7_fwd": (C.c_int, [C.POINTER(ConvDesc), _p]),
     "sfh_packed_stem_weight_bytes": (C.c_int64, []),
     "sfh_pack_stem_weights": (C.c_int, [_p, _p, C.c_int, C.c_int, C.c_int, _p]),

@@ -101,7 +101,8 @@ constexpr unsigned kSfhOOB = 0xFFFFFFF0u;  // byte offset that the buffer range 
 // format's code is compiled out).
 template <class CFG, int NI, int MT, int FMTS = 1, class G>
 __device__ __forceinline__ void sfh_conv_epilogue(const sfh_conv_desc& d, const G& g, f32x4 (&acc)[NI][MT],
-                                                  int n0, int msub0, int r0, int x0, int lq, int lg) {
+                                                  int n0, int msub0, int r0, int x0, int lq, int lg,
+                                                  size_t dst_byte_off = 0) {   // split-K: this workgroup's slab of dst
   const bool h2 = (FMTS & 2) && d.dst_fmt == SFH_FMT_H2;
   const bool s3 = h2 || ((FMTS & 1) && d.dst_fmt == SFH_FMT_S3);  // a split (plane) format
   const unsigned np4 = h2 ? 8u : 12u;                              // (plane, group) runs per 32-channel block
@@ -123,7 +124,8 @@ __device__ __forceinline__ void sfh_conv_epilogue(const sfh_conv_desc& d, const 
   const unsigned run = wdst * 16u;                            // bytes of one (block, plane, group) run
   const unsigned rowb = s3 ? (cs >> 5) * np4 * run : wdst * cs * 4u;  // bytes per image row
   const unsigned planeb = 4u * run;                           // S3: next plane
-  const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(d.dst, 0, (int)kSfhOOB, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(
+      reinterpret_cast<float*>(reinterpret_cast<char*>(d.dst) + dst_byte_off), 0, (int)kSfhOOB, 0x00020000);
   const __amdgpu_buffer_rsrc_t rr_ = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float*>(d.residual ? d.residual : d.dst), 0, (int)(d.residual ? kSfhOOB : 0u), 0x00020000);
   f32x4 sc[NI], sh[NI];

@@ -172,7 +172,12 @@ __global__ __launch_bounds__(C::NT, (C::NP == 2 && !DB) ? SFH_H2_WAVES_PER_SIMD 
   const int wm = wv / C::NWN, wn = wv % C::NWN;
   const int lq = lane & 15, lg = lane >> 4;
 
-  const int bid = blockIdx.x;
+  // split-K (sfh_conv_desc.ksplit > 1): the grid holds ksplit copies of the (tile, cout block) space, copy ks
+  // accumulates the stages [st0, st1) of the K loop and writes its own fp32 slab (sfh_splitk_finish adds them up)
+  const int ksn = d.ksplit > 1 ? d.ksplit : 1;
+  const int per_split = (int)(gridDim.x / (unsigned)ksn);
+  const int ks = ksn > 1 ? (int)blockIdx.x / per_split : 0;
+  const int bid = (int)blockIdx.x - ks * per_split;
   const int xcd = bid & 7, kk_ = bid >> 3;
   // within an XCD the pixel tiles of ONE cout block run back to back: the ~30 workgroups resident
   // on the XCD stream the same weight fragments, which then stay in its 4 MB L2 (weights are the
@@ -205,6 +210,7 @@ __global__ __launch_bounds__(C::NT, (C::NP == 2 && !DB) ? SFH_H2_WAVES_PER_SIMD 
   const int nst0 = d.c0 / C::CKS;
   const int nst1 = d.src1 ? d.c1 / C::CKS : 0;
   const int nst = nst0 + nst1;
+  const int st0 = ks * nst / ksn, st1 = (ks + 1) * nst / ksn;   // this workgroup's stages (all of them without split-K)
 
   const __amdgpu_buffer_rsrc_t rs0 =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.src0), 0, (int)g.bytes0, 0x00020000);
@@ -278,7 +284,7 @@ __global__ __launch_bounds__(C::NT, (C::NP == 2 && !DB) ? SFH_H2_WAVES_PER_SIMD 
   constexpr int WD = (NP == 2 && C::NTAP % 3 == 0) ? SFH_H2_WD : 2;
   constexpr int XD = NP == 2 ? SFH_H2_XD : 2;   // operand reads are issued XD steps ahead of their use
   u32x4 wr[WD][NP][2];
-  unsigned wsoff = 0;         // byte offset of the NEXT (stage, tap) fragment set
+  unsigned wsoff = (unsigned)st0 * C::NTAP * WTAP;   // byte offset of the NEXT (stage, tap) fragment set
   const unsigned wlast = wtotal - WTAP;
 #pragma unroll
   for (int i = 0; i < WD - 1; ++i) {
@@ -309,7 +315,7 @@ __global__ __launch_bounds__(C::NT, (C::NP == 2 && !DB) ? SFH_H2_WAVES_PER_SIMD 
 #pragma unroll
     for (int i = 0; i < XD; ++i)
       if (i < NSTEP) ld_x(i, i);
-    const int stn = st + 1 < nst ? st + 1 : st;  // unconditional DMA: no branch in the MFMA block
+    const int stn = st + 1 < st1 ? st + 1 : st;  // unconditional DMA: no branch in the MFMA block
 #pragma unroll
     for (int s = 0; s < NSTEP; ++s) {
       const int t = s / C::MT_M, mi = s % C::MT_M;
@@ -357,7 +363,7 @@ __global__ __launch_bounds__(C::NT, (C::NP == 2 && !DB) ? SFH_H2_WAVES_PER_SIMD 
   constexpr int SWAPS = C::NTAP % WD;   // ring position of tap 0 in odd stages (2 * NTAP = 0 mod WD)
   static_assert((2 * C::NTAP) % WD == 0, "the stage loop is unrolled by two");
 
-  dma_stage(0, 0);
+  dma_stage(st0, 0);
   auto maybe_switch = [&](int st) {  // the DMA issued during stage st targets stage st+1
     if (d.src1 && st + 1 == nst0) {
 #pragma unroll
@@ -372,11 +378,11 @@ __global__ __launch_bounds__(C::NT, (C::NP == 2 && !DB) ? SFH_H2_WAVES_PER_SIMD 
     __syncthreads();
   };
   if (DB) {
-    for (int st = 0; st < nst; st += 2) {
+    for (int st = st0; st < st1; st += 2) {
       maybe_switch(st);
       stage_barrier();  // stage st landed for every wave; the other buffer is free
       stage(st, 0, std::integral_constant<int, 0>{});
-      if (st + 1 < nst) {
+      if (st + 1 < st1) {
         maybe_switch(st + 1);
         stage_barrier();
         stage(st + 1, 1, std::integral_constant<int, SWAPS>{});
@@ -390,12 +396,12 @@ __global__ __launch_bounds__(C::NT, (C::NP == 2 && !DB) ? SFH_H2_WAVES_PER_SIMD 
     // single buffer: [DMA stage st] [drain + barrier] [compute] [barrier: buffer free again]
     // (diag build: segments 8 prologue, 9 DMA wait + barrier, 10 MFMA stage, 11 buffer-free barrier + DMA issue, 12 epilogue)
     SFH_STAMP(0);
-    for (int st = 0; st < nst; st += 2) {
+    for (int st = st0; st < st1; st += 2) {
       stage_barrier();
       SFH_STAMP(1);
       stage(st, 0, std::integral_constant<int, 0>{});
       SFH_STAMP(2);
-      if (st + 1 < nst) {
+      if (st + 1 < st1) {
         if (d.src1 && st + 1 == nst0) {
 #pragma unroll
           for (int i = 0; i < C::NSL; ++i) hoff[i] = s3_halo_voffset<C>(d, g, 1, tid + C::NT * i, r0, x0, pad_y, pad_x);
@@ -408,7 +414,7 @@ __global__ __launch_bounds__(C::NT, (C::NP == 2 && !DB) ? SFH_H2_WAVES_PER_SIMD 
         stage(st + 1, 0, std::integral_constant<int, SWAPS>{});
         SFH_STAMP(2);
       }
-      if (st + 2 < nst) {
+      if (st + 2 < st1) {
         if (d.src1 && st + 2 == nst0) {
 #pragma unroll
           for (int i = 0; i < C::NSL; ++i) hoff[i] = s3_halo_voffset<C>(d, g, 1, tid + C::NT * i, r0, x0, pad_y, pad_x);
@@ -419,7 +425,8 @@ __global__ __launch_bounds__(C::NT, (C::NP == 2 && !DB) ? SFH_H2_WAVES_PER_SIMD 
       }
     }
   }
-  sfh_conv_epilogue<C, 2, C::MT_M, (NP == 3 ? 1 : 2)>(d, g, acc, n0 + 32 * wn, wm * C::MT_M, r0, x0, lq, lg);
+  sfh_conv_epilogue<C, 2, C::MT_M, (NP == 3 ? 1 : 2)>(d, g, acc, n0 + 32 * wn, wm * C::MT_M, r0, x0, lq, lg,
+                                                      (size_t)ks * (size_t)d.ksplit_stride);
   if (!DB) {
     SFH_STAMP(4);
     SFH_CLOCK_END();
@@ -705,6 +712,108 @@ __global__ void h2_to_f32_kernel(const unsigned short* __restrict__ src, float* 
   dst[i] = (lo + hi) * inv_scale;
 }
 
+// ------------------------------------------------------------------ split-K: second half
+// y = [relu](sum_k slab_k + shift + residual) -> F32 NHWC / S3 / H2; thread mapping as f32_to_s3_kernel (one thread =
+// 8 channels of one pixel); no early exit (sfh_h2_report reads every lane)
+template <int DFMT>
+__global__ __launch_bounds__(256) void splitk_finish_kernel(const float* __restrict__ slabs, int nslabs, long slab_elems,
+                                                            const float* __restrict__ shift, const void* residual,
+                                                            int res_fmt, float res_inv, int relu, int W, int cs, int xchunks,
+                                                            long total, void* dstv, float dst_scale,
+                                                            unsigned* overflow, unsigned* range) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  const int g = (int)(i & 3), px = (int)((i >> 2) & 15);
+  long r = i >> 6;
+  const int xc = (int)(r % xchunks); r /= xchunks;
+  const int nb32 = cs >> 5;
+  const int cb = (int)(r % nb32);
+  const long row = r / nb32;
+  const int x = xc * 16 + px;
+  unsigned over = 0u;
+  if (i < total && x < W) {
+    const int c0 = cb * 32 + g * 8;
+    const long e32 = (row * W + x) * cs + c0;
+    float v[8];
+    {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(shift + c0), b = *reinterpret_cast<const f32x4*>(shift + c0 + 4);
+      v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3]; v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
+    }
+    for (int k = 0; k < nslabs; ++k) {
+      const float* sp = slabs + (long)k * slab_elems + e32;
+      const f32x4 a = *reinterpret_cast<const f32x4*>(sp), b = *reinterpret_cast<const f32x4*>(sp + 4);
+      v[0] += a[0]; v[1] += a[1]; v[2] += a[2]; v[3] += a[3]; v[4] += b[0]; v[5] += b[1]; v[6] += b[2]; v[7] += b[3];
+    }
+    typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
+    if (residual) {
+      if (res_fmt == SFH_FMT_F32) {
+        const float* rp = reinterpret_cast<const float*>(residual) + e32;
+        const f32x4 a = *reinterpret_cast<const f32x4*>(rp), b = *reinterpret_cast<const f32x4*>(rp + 4);
+        v[0] += a[0]; v[1] += a[1]; v[2] += a[2]; v[3] += a[3]; v[4] += b[0]; v[5] += b[1]; v[6] += b[2]; v[7] += b[3];
+      } else {
+        const int np = res_fmt == SFH_FMT_H2 ? 2 : 3;
+        const unsigned short* rp = reinterpret_cast<const unsigned short*>(residual) +
+                                   ((((row * nb32 + cb) * np) * 4 + g) * W + x) * 8;
+        const long ps = 4L * W * 8;
+        float q[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int p = np - 1; p >= 0; --p) {   // smallest plane first, as the conv epilogue adds them
+          const u32x4 w = *reinterpret_cast<const u32x4*>(rp + p * ps);   // 8 x 16 bit
+#pragma unroll
+          for (int h = 0; h < 4; ++h) {
+            if (res_fmt == SFH_FMT_H2) {
+              const sfh_f32x2 f = sfh_unpack_h(w[h]);
+              q[2 * h] += f[0];
+              q[2 * h + 1] += f[1];
+            } else {
+              q[2 * h] += __builtin_bit_cast(float, w[h] << 16);
+              q[2 * h + 1] += __builtin_bit_cast(float, w[h] & 0xFFFF0000u);
+            }
+          }
+        }
+        const float rs_ = res_fmt == SFH_FMT_H2 ? res_inv : 1.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] += q[j] * rs_;
+      }
+    }
+    if (relu) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = sfh_relu(v[j]);
+    }
+    if constexpr (DFMT == SFH_FMT_F32) {
+      float* dp = reinterpret_cast<float*>(dstv) + e32;
+      *reinterpret_cast<f32x4*>(dp) = (f32x4){v[0], v[1], v[2], v[3]};
+      *reinterpret_cast<f32x4*>(dp + 4) = (f32x4){v[4], v[5], v[6], v[7]};
+    } else if constexpr (DFMT == SFH_FMT_H2) {
+      unsigned short* dst = reinterpret_cast<unsigned short*>(dstv);
+      sfh_u32x2 pa[2], pb[2];
+      sfh_split4_h2((f32x4){v[0], v[1], v[2], v[3]}, dst_scale, pa, over);
+      sfh_split4_h2((f32x4){v[4], v[5], v[6], v[7]}, dst_scale, pb, over);
+      const long e = ((((row * nb32 + cb) * 2) * 4 + g) * W + x) * 8;
+      const long ps = 4L * W * 8;
+      *reinterpret_cast<u32x4*>(dst + e) = (u32x4){pa[0][0], pa[0][1], pb[0][0], pb[0][1]};
+      *reinterpret_cast<u32x4*>(dst + e + ps) = (u32x4){pa[1][0], pa[1][1], pb[1][0], pb[1][1]};
+    } else {
+      unsigned short* dst = reinterpret_cast<unsigned short*>(dstv);
+      u16x8 p0, p1, p2;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const __bf16 v0 = (__bf16)v[j];
+        const float r1 = v[j] - (float)v0;
+        const __bf16 v1 = (__bf16)r1;
+        const __bf16 v2 = (__bf16)(r1 - (float)v1);
+        p0[j] = __builtin_bit_cast(unsigned short, v0);
+        p1[j] = __builtin_bit_cast(unsigned short, v1);
+        p2[j] = __builtin_bit_cast(unsigned short, v2);
+      }
+      const long e = s3_elem(row, x, c0, 0, W, cs);
+      const long ps = 4L * W * 8;
+      *reinterpret_cast<u16x8*>(dst + e) = p0;
+      *reinterpret_cast<u16x8*>(dst + e + ps) = p1;
+      *reinterpret_cast<u16x8*>(dst + e + 2 * ps) = p2;
+    }
+  }
+  if constexpr (DFMT == SFH_FMT_H2) sfh_h2_report(over, overflow, range);
+}
+
 template <class C, bool DB>
 int launch_s3(const sfh_conv_desc& d, hipStream_t stream) {
   S3Geom g;
@@ -751,7 +860,8 @@ int launch_s3(const sfh_conv_desc& d, hipStream_t stream) {
     while (g.nblk_n % G) --G;  // groups must tile the cout blocks
     g.nb_group = G;
   }
-  const long nblocks = (long)sfh_cdiv(g.ntiles, 8) * 8 * g.nblk_n;
+  const int ksn = d.ksplit > 1 ? d.ksplit : 1;
+  const long nblocks = (long)sfh_cdiv(g.ntiles, 8) * 8 * g.nblk_n * ksn;
   SFH_REQUIRE(nblocks < (1L << 31), "conv_s3: grid too large");
   // small grids (at most ~one workgroup per CU anyway, e.g. ResNet layer3/4): the double-buffered
   // variant overlaps each stage's DMA latency with the previous stage's MFMAs
@@ -878,6 +988,30 @@ extern "C" int sfh_h2_to_f32(const void* src, float* dst, int64_t rows, int W, i
   return sfh_check_launch("h2_to_f32_kernel");
 }
 
+extern "C" int sfh_splitk_finish(const float* slabs, int nslabs, int64_t slab_stride, const float* shift,
+                                 const void* residual, int res_fmt, int exp_res, int relu, int64_t rows, int W, int C,
+                                 void* dst, int dst_fmt, int exp_dst, uint32_t* overflow, uint32_t* range, void* stream) {
+  SFH_REQUIRE(slabs && shift && dst && nslabs >= 1 && nslabs <= 64 && rows > 0 && W > 0 && C > 0 && C % 32 == 0,
+              "splitk_finish: bad arguments (nslabs=%d, C=%d must be a multiple of 32)", nslabs, C);
+  SFH_REQUIRE(slab_stride % 16 == 0 && slab_stride >= rows * W * C * 4, "splitk_finish: slab_stride=%lld is smaller than a slab",
+              (long long)slab_stride);
+  SFH_REQUIRE(dst_fmt == SFH_FMT_F32 || dst_fmt == SFH_FMT_S3 || dst_fmt == SFH_FMT_H2, "splitk_finish: dst_fmt=%d", dst_fmt);
+  SFH_REQUIRE(!residual || res_fmt == SFH_FMT_F32 || res_fmt == SFH_FMT_S3 || res_fmt == SFH_FMT_H2, "splitk_finish: res_fmt=%d", res_fmt);
+  SFH_REQUIRE(exp_dst >= -64 && exp_dst <= 64 && exp_res >= -64 && exp_res <= 64, "splitk_finish: exponent out of range");
+  const int xchunks = (W + 15) / 16;
+  const long total = rows * (C / 32) * xchunks * 64;
+  const dim3 grid((unsigned)((total + 255) / 256));
+#define SFH_FINISH(F_)                                                                                               \
+  hipLaunchKernelGGL(splitk_finish_kernel<F_>, grid, dim3(256), 0, (hipStream_t)stream, slabs, nslabs,               \
+                     (long)(slab_stride / 4), shift, residual, res_fmt, ldexpf(1.f, -exp_res), relu, W, C, xchunks, \
+                     total, dst, ldexpf(1.f, exp_dst), overflow, range)
+  if (dst_fmt == SFH_FMT_H2) SFH_FINISH(SFH_FMT_H2);
+  else if (dst_fmt == SFH_FMT_S3) SFH_FINISH(SFH_FMT_S3);
+  else SFH_FINISH(SFH_FMT_F32);
+#undef SFH_FINISH
+  return sfh_check_launch("splitk_finish_kernel");
+}
+
 extern "C" int sfh_conv_s3_fwd(const sfh_conv_desc* dp, void* stream_) {
   SFH_REQUIRE(dp, "conv_s3_fwd: null descriptor");
   const sfh_conv_desc& d = *dp;
@@ -920,6 +1054,13 @@ extern "C" int sfh_conv_s3_fwd(const sfh_conv_desc* dp, void* stream_) {
                     d.head_logits && d.head_nc >= 1 && d.head_nc <= 8 && (!d.head_stn || (d.head_frame && d.head_nc <= 5)),
                 "conv_s3_fwd: the fused OutConv head needs a 3x3 stride-1 conv with 64 output channels and a plain output");
   SFH_REQUIRE(!d.head_skip_dst || d.head_w, "conv_s3_fwd: head_skip_dst without a head");
+  if (d.ksplit > 1)
+    SFH_REQUIRE(d.ksplit <= d.c0 / 32 && !d.src1 && d.dst_fmt == SFH_FMT_F32 && !d.relu && !d.residual && !d.dst_pool &&
+                    !d.head_w && d.out_mode == SFH_OUT_NHWC && d.ksplit_stride % 16 == 0 &&
+                    d.ksplit_stride >= (int64_t)d.batch * ((d.H + d.ksize / 2 + (d.ksize - 1) / 2 - d.ksize) / d.stride + 1) *
+                                           ((d.W + d.ksize / 2 + (d.ksize - 1) / 2 - d.ksize) / d.stride + 1) * d.dst_cs * 4,
+                "conv_s3_fwd: split-K (ksplit=%d) needs one source with at least ksplit 32-channel stages, a plain fp32 "
+                "destination of ksplit slabs ksplit_stride bytes apart, no ReLU / residual / pooled output / head", d.ksplit);
   // buffering policy (launch_s3): two single-buffered workgroups per CU, except grids of at most 320
   // workgroups, which take the double-buffered variant
   // 8-wave workgroups (256 pixels x 128 couts, one per CU, two LDS buffers): long K, at least 128 couts (a 2x2

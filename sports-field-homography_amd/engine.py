@@ -267,6 +267,24 @@ def choose_tile_s3(batch, ho, wo, stride, zrows, nblk, ksize=3, wg_slots=_WG_SLO
     return best[1]
 
 
+def choose_ksplit(batch, ho, wo, stride, cout, nstages, ksize=3, wg_slots=_WG_SLOTS):
+    """Split-K factor for a conv whose (pixel tile, 64-cout block) grid fills less than half of the chip's
+    workgroup slots: the largest factor that keeps the grid within one round of resident workgroups and leaves
+    every split at least two 32-channel stages.  1 = no split."""
+    zr = ksize // 2
+    zr += (ho + zr) & 1
+    cands = _TILES_S3_HALF if stride == 2 else _TILES
+    ntiles = None
+    for tid, th, tw in cands:
+        ty = batch * -(-ho // th) if stride == 2 else -(-(batch * (ho + zr)) // th)
+        n = ty * (-(-wo // tw))
+        ntiles = n if ntiles is None else min(ntiles, n)
+    wgs = ntiles * (cout // 64)
+    if wgs * 2 > wg_slots:
+        return 1
+    return max(1, min(wg_slots // wgs, nstages // 2, 8))
+
+
 class ConvTimer:
     """Optional HIP-event timing of conv launches on the launch stream (used by bench.py for the
     live roofline figure).  Records (tag, algorithmic FLOPs, start event, end event)."""
@@ -512,11 +530,14 @@ class PackedConv:
 
     def run(self, src0, batch, H, W, dst, src1=None, pool0=False, pad1=(0, 0), residual=None, tile=None,
             dst_pool=None, up_dst=None, head=None, wg_couts=0, exp_src=None, exp_dst=None, exp_res=None,
-            range_word=None):
+            range_word=None, ksplit=0, slabs=None):
         """src0/src1: NHWC float32 tensors, or split tensors of the layer's format (S3 bfloat16 / H2 float16);
         dst/residual/dst_pool: float32 NHWC or the same split format (by dtype).  H, W: conv input frame.
         H2 tensors: exp_src / exp_dst / exp_res = exponents of the sources / dst and dst_pool / an H2 residual
-        (None: the conventional SFH_H2_ACT_EXP), range_word: device address of dst's range word (H2Ranges)."""
+        (None: the conventional SFH_H2_ACT_EXP), range_word: device address of dst's range word (H2Ranges).
+        ksplit > 1 (split-operand kernel, one source): the K loop is split over ksplit copies of the grid that write
+        fp32 partial slabs (`slabs`: float32 tensor (ksplit, B, Ho, Wo, cout)), and sfh_splitk_finish adds them up
+        with this layer's shift, residual and ReLU into dst - for grids that alone leave most of the chip idle."""
         lib = _lib.load()
         d = ConvDesc()
         if self.fmt == "h2" and exp_src is not None:
@@ -595,6 +616,29 @@ class PackedConv:
                 raise ValueError(f"tensor of {t.numel() * t.element_size()} bytes exceeds the 4 GiB buffer-descriptor "
                                  "range of the conv kernels; split the batch")
         fwd = lib.sfh_conv_s3_fwd if self.s3 else lib.sfh_conv_fwd
+        finish = None
+        if ksplit and ksplit > 1:
+            if not self.s3 or src1 is not None or dst_pool is not None or head is not None or self.transposed:
+                raise ValueError("split-K needs a plain single-source conv on the split-operand kernel")
+            if slabs is None or slabs.dtype != torch.float32 or tuple(slabs.shape) != (ksplit, batch, ho, wo, self.cout):
+                raise ValueError(f"split-K slabs must be a float32 tensor {(ksplit, batch, ho, wo, self.cout)}")
+            zero_shift = _unit_epilogue(self.cout, dst.device)[1]
+            d.dst, d.dst_cs, d.dst_fmt = slabs.data_ptr(), self.cout, _lib.FMT_F32
+            d.shift, d.relu, d.residual, d.residual_f32 = zero_shift.data_ptr(), 0, None, 0
+            d.h2_overflow = d.h2_range = None
+            d.ksplit, d.ksplit_stride = int(ksplit), slabs.stride(0) * 4
+            res_fmt = _fmt_code(residual) if residual is not None else 0
+
+            def finish():
+                _lib.check(lib.sfh_splitk_finish(
+                    _ptr(slabs), int(ksplit), slabs.stride(0) * 4, _ptr(self.shift), _ptr(residual), res_fmt,
+                    int(exp_res) if exp_res is not None else _lib.H2_ACT_EXP, 1 if self.relu else 0, batch * ho, wo,
+                    _chan(dst), _ptr(dst), _fmt_code(dst), int(exp_dst) if exp_dst is not None else _lib.H2_ACT_EXP,
+                    ctypes.c_void_p(ovf.data_ptr()) if (ovf is not None and _fmt_of(dst) == "h2") else None,
+                    ctypes.c_void_p(range_word) if (range_word and _fmt_of(dst) == "h2") else None, _stream()),
+                    "splitk_finish")
+            if _chan(dst) != self.cout:
+                raise ValueError("split-K writes all channels of dst")
         if self.c4:
             if src0.shape[-1] != 4 or pool0 or dst_pool is not None:
                 raise ValueError("the <=4-channel first-layer kernel needs an fp32 NHWC source with 4 stored channels")
@@ -604,6 +648,8 @@ class PackedConv:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
         _lib.check(fwd(ctypes.byref(d), _stream()), "conv_s3_fwd" if self.s3 else "conv_fwd")
+        if finish is not None:
+            finish()
         if tm is not None:
             e1.record()
             # algorithmic work: 2 * MACs of the reference op (real cin, real taps)
@@ -953,6 +999,7 @@ class ResNetEngine:
         self.ranges = (ranges if ranges is not None else H2Ranges(device)) if fmt == "h2" else _NoRanges()
         self.steps = []
         self._last_out = None
+        self.splitk = os.environ.get("SFH_SPLITK", "1") != "0"
         self.device = device
         self.ws = _Workspace(device)
         self.cin = in_channels
@@ -1054,8 +1101,16 @@ class ResNetEngine:
             ho, wo = (h - 1) // stride + 1, (w - 1) // stride + 1
 
             def conv(layer, src, nsrc, hh, ww, dst, ndst, residual=None, nres=None):
-                do((ndst,) if ndst else (), lambda: L[layer].run(src, B, hh, ww, dst, residual=residual,
-                                                                 **rg.args(nsrc, ndst, nres)))
+                pc = L[layer]
+                # layer3 / layer4 at batch 16: 60-170 workgroups for 512 slots - split the K loop to fill the chip
+                ks, slabs = 1, None
+                if s3 and self.splitk:
+                    oh, ow = (hh - 1) // pc.stride + 1, (ww - 1) // pc.stride + 1
+                    ks = choose_ksplit(B, oh, ow, pc.stride, pc.cout, (pc.c0 + pc.c1) // 32, pc.ksize)
+                    if ks > 1:
+                        slabs = ws.get(f"slabs{ks}x{oh}x{ow}x{pc.cout}", (ks, B, oh, ow, pc.cout))
+                do((ndst,) if ndst else (), lambda: pc.run(src, B, hh, ww, dst, residual=residual, ksplit=ks, slabs=slabs,
+                                                           **rg.args(nsrc, ndst, nres)))
             if has_down:
                 idn, nidn = act(name + ".idn", ho, wo, cout)
                 conv(name + ".down", x, nx, h, w, idn, nidn)

@@ -51,15 +51,26 @@ class FP16RangeError(RuntimeError):
 
 class _BNSnapshot:
     """Copies of a model's buffers (BatchNorm running statistics), so that a training step that has to be repeated
-    in another precision starts from the same statistics: two multi-tensor copies, no allocation after the first use."""
+    in another precision starts from the same statistics: two multi-tensor copies per step.  The buffer objects are
+    looked up again at every save(): net.to() / .float() / load_state_dict(assign=True) REPLACE them, and a restore
+    into tensors the model no longer holds would leave the statistics advanced twice.  `generation` counts the
+    saves: a consumer (the autograd node's backward) can tell whether the copy is still the one it made."""
 
     def __init__(self, net):
-        self.bufs = [b for b in net.buffers() if b.is_cuda]
-        self.snap = [torch.empty_like(b) for b in self.bufs]
+        self.net = net
+        self.bufs, self.snap = [], []
+        self.generation = 0
 
     def save(self):
+        bufs = [b for b in self.net.buffers() if b.is_cuda]
+        if len(bufs) != len(self.bufs) or any(a is not b or a.shape != c.shape or a.dtype != c.dtype
+                                              for a, b, c in zip(bufs, self.bufs, self.snap)):
+            self.bufs = bufs
+            self.snap = [torch.empty_like(b) for b in bufs]
         if self.bufs:
             torch._foreach_copy_(self.snap, self.bufs)
+        self.generation += 1
+        return self.generation
 
     def restore(self):
         if self.bufs:
@@ -666,14 +677,28 @@ def run_backward(net, tape, f, dheads, dtheta, unscale=True):
         # theta does: -> [2^12, 2^13), the average pool divides it by the pixels of layer4 first.
         import math
         heads = [d for d in dheads if d is not None]
+        # one read-back for both seeds: the largest head gradient and the largest theta gradient
+        mx = torch.stack([d.abs().max() for d in heads] + ([dtheta.abs().max()] if dtheta is not None else [])).cpu().tolist()
+        mh = max(mx[:len(heads)]) if heads else 0.0
+        mt = mx[-1] if dtheta is not None else 0.0
         if heads:
-            m, target = max(float(d.abs().max()) for d in heads), 2
+            m, target = mh, 2
         else:
-            m, target = (float(dtheta.abs().max()) if dtheta is not None else 0.0), 13
-        if not math.isfinite(m):
+            m, target = mt, 13
+        if not (math.isfinite(mh) and math.isfinite(mt)):
             raise FP16RangeError("non-finite gradient at the outputs of the model")
         if m > 0.0:
             S = 2.0 ** (target - math.frexp(m)[1])       # m = f * 2^e, 0.5 <= f < 1  ->  m * S in [2^(target-1), 2^target)
+        if heads and 0.0 < mt * S < 2.0 ** -16:
+            # the ResNet-STN branch starts from dtheta: far below the head gradients its H2 copies would sit at the
+            # format's absolute floor (2^-27) and lose their bits silently.  Raise the common scale as far as the head
+            # gradients allow (their layers peak 2-3 orders of magnitude above the seeds: stay below 2^6 at the
+            # seeds); if that is not enough the step does not fit the format.
+            S2 = 2.0 ** (-16 - math.frexp(mt)[1] + 1)
+            if mh * S2 >= 2.0 ** 6:
+                raise FP16RangeError("the gradients of theta are more than 2^22 below the head gradients: they do not "
+                                     "fit one power-of-two scale of the two-plane fp16 format")
+            S = S2
         tape.gscale = S
     if S != 1.0:
         dtheta = None if dtheta is None else dtheta * S
@@ -734,18 +759,20 @@ class _TrainForward(torch.autograd.Function):
     def forward(ctx, net, info, x, *params):
         tape = Tape()
         x = E._f32c(x.detach(), "input frames")
+        ctx.snap_gen = None
         if tape.fmt == "h2":
             # the forward pass updates the BatchNorm statistics: keep a copy, so that a pass whose activations leave
-            # the fp16 range can be repeated with bf16x6 operands (a gradient that leaves it later, in backward(),
-            # raises FP16RangeError: the statistics of this step are then already the caller's)
+            # the fp16 range - now, or a gradient in backward() - can be repeated with bf16x6 operands from the same
+            # statistics
             snap = net.__dict__.get("_bn_snapshot")
             if snap is None:
                 snap = net.__dict__["_bn_snapshot"] = _BNSnapshot(net)
-            snap.save()
+            ctx.snap_gen = snap.save()
             f = run_forward(net, tape, x)
             if int(tape.overflow.item()):
                 snap.restore()
                 _warn_range_fallback()
+                net.__dict__["train_range_fallbacks"] = net.__dict__.get("train_range_fallbacks", 0) + 1
                 tape = Tape(fmt="s3")
                 f = run_forward(net, tape, x)
         else:
@@ -753,7 +780,7 @@ class _TrainForward(torch.autograd.Function):
         B = x.shape[0]
         keys = [k for k in _OUT_KEYS if f[k] is not None]
         outs = [f[k].view(B, 1, 3, 3) if k == "theta" else f[k] for k in keys]
-        ctx.tape, ctx.f, ctx.net, ctx.keys = tape, f, net, keys
+        ctx.tape, ctx.f, ctx.net, ctx.keys, ctx.x = tape, f, net, keys, x
         info["keys"] = keys          # the caller labels the outputs with the node's own key list
         net.invalidate_engines()     # BatchNorm running statistics were updated through raw device pointers
         return tuple(outs)
@@ -763,15 +790,34 @@ class _TrainForward(torch.autograd.Function):
         if ctx.tape is None:
             raise RuntimeError("the HIP training node was already backpropagated: its activations are released "
                                "after the first backward (retain_graph is not supported)")
-        net, tape, f = ctx.net, ctx.tape, ctx.f
+        net = ctx.net
         d = dict(zip(ctx.keys, douts))
-        dth = theta_gradient(net, f, d.get("theta"), d.get("poi"), d.get("warp_mask")) if f["theta"] is not None else None
-        head_keys = ["logits"] + (["uv"] if f["uv"] is not None else []) if f["logits"] is not None else []
-        dheads = [None if d.get(k) is None else d[k].contiguous().clone() for k in head_keys]
-        g = run_backward(net, tape, f, dheads, dth)
+
+        def attempt(tape, f):
+            dth = theta_gradient(net, f, d.get("theta"), d.get("poi"), d.get("warp_mask")) if f["theta"] is not None else None
+            head_keys = ["logits"] + (["uv"] if f["uv"] is not None else []) if f["logits"] is not None else []
+            dheads = [None if d.get(k) is None else d[k].contiguous().clone() for k in head_keys]
+            return run_backward(net, tape, f, dheads, dth)
+        try:
+            g = attempt(ctx.tape, ctx.f)
+        except FP16RangeError:
+            # a gradient (or a non-finite seed) did not fit the two-plane fp16 format: like TrainStep, repeat the step
+            # with the three-plane bf16 operands - forward from the BatchNorm statistics of before this step, then
+            # backward; a non-finite loss then gives non-finite gradients, as in the reference.  Possible while the
+            # statistics copy is still this step's (no other forward of the model since).
+            snap = net.__dict__.get("_bn_snapshot")
+            if ctx.tape.fmt != "h2" or snap is None or snap.generation != ctx.snap_gen:
+                ctx.tape = ctx.f = ctx.x = None
+                raise
+            snap.restore()
+            _warn_range_fallback()
+            net.__dict__["train_range_fallbacks"] = net.__dict__.get("train_range_fallbacks", 0) + 1
+            tape = Tape(fmt="s3")
+            g = attempt(tape, run_forward(net, tape, ctx.x))
+            net.invalidate_engines()
         names = _Names(net)
         grads = tuple(g.get(names(p)) for p in net.parameters())
-        ctx.tape = ctx.f = None
+        ctx.tape = ctx.f = ctx.x = None
         return (None, None, None) + grads
 
 

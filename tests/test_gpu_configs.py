@@ -137,11 +137,13 @@ def test_c5_1280x720_batch16_pitch_template_poi(precision):
     assert tuple(out["logits"].shape) == (16, 4, 720, 1280) and tuple(out["poi"].shape) == (16, 33, 2)
     _check_predict(f"C5 1280x720 B=16 {precision}", out, g, court, (1280, 720), 16)
     assert net.range_fallbacks == 0 and net.range_rescales == 0
-    # frames are independent (eval-mode BatchNorm): a frame gives the same bits wherever it sits in the batch
+    # frames are independent (eval-mode BatchNorm): a frame gives the same bits wherever it sits in the batch (a batch
+    # of another SIZE may split the K loop of the small ResNet layers differently, engine.choose_ksplit)
+    perm = torch.tensor([5, 0, 11, 3, 15, 1, 8, 2, 13, 4, 9, 6, 14, 7, 10, 12])
     with torch.no_grad():
-        solo = net.predict(x[:2].cuda(), consistency=True, project_poi=True)
-    assert torch.equal(solo["theta"], out["theta"][:2]) and torch.equal(solo["warp_mask"], out["warp_mask"][:2])
-    assert torch.equal(solo["logits"], out["logits"][:2])
+        mixed = net.predict(x[perm].cuda(), consistency=True, project_poi=True)
+    assert torch.equal(mixed["theta"], out["theta"][perm.cuda()]) and torch.equal(mixed["warp_mask"], out["warp_mask"][perm.cuda()])
+    assert torch.equal(mixed["logits"], out["logits"][perm.cuda()])
 
 
 def test_warp_arithmetic_selftest():

@@ -165,6 +165,45 @@ def test_conv_h2_eight_wave_workgroup_matches_four_wave(E, tile, hw):
     assert torch.equal(f[64], f[128])
 
 
+@pytest.mark.parametrize("fmt", ["h2", "s3"])
+@pytest.mark.parametrize("hw,stride,ks", [((12, 20), 1, 3), ((23, 40), 1, 2), ((23, 41), 2, 2), ((9, 7), 1, 8)])
+def test_conv_split_k_matches_the_unsplit_launch(E, fmt, hw, stride, ks):
+    """sfh_conv_desc.ksplit: the K loop over 256 input channels in ks parts (uneven for 3), fp32 partial slabs,
+    sfh_splitk_finish adds shift + residual + ReLU and writes the split format (its own exponent in H2): equal to the
+    one-launch conv up to the accumulation order, and the range word sees the same maximum."""
+    g = synth._rng(12, f"splitk{hw}{stride}{ks}")
+    B, (H, W), cin, cout = 2, hw, 256, 128
+    ho, wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    w = torch.from_numpy((g.normal(0, 1, (cout, cin, 3, 3)) * (2.0 / (9 * cin)) ** 0.5).astype(np.float32)).cuda()
+    bn = torch.nn.BatchNorm2d(cout).cuda().eval()
+    with torch.no_grad():
+        bn.running_mean.uniform_(-0.1, 0.1); bn.running_var.uniform_(0.5, 1.5); bn.weight.uniform_(0.5, 1.5); bn.bias.uniform_(-0.3, 0.3)
+    pc = E.PackedConv(w, None, bn, 3, cin, stride=stride, fmt=fmt)
+    x = torch.from_numpy(g.normal(0, 1, (B, H, W, cin)).astype(np.float32)).cuda()
+    res = torch.from_numpy(g.normal(0, 1, (B, ho, wo, cout)).astype(np.float32)).cuda()
+    xs = E.f32_to_split(x, fmt)
+    rs = E.f32_to_split(res, fmt, exp=1)
+    rw = torch.zeros(2, dtype=torch.int32, device="cuda")
+    outs = []
+    for k, word in ((0, 0), (ks, 1)):
+        y = E.split_empty(fmt, B, ho, wo, cout, "cuda")
+        slabs = torch.full((k, B, ho, wo, cout), float("nan"), device="cuda") if k else None
+        pc.run(xs, B, H, W, y, residual=rs, exp_res=1, exp_dst=0, range_word=rw.data_ptr() + 4 * word, ksplit=k, slabs=slabs)
+        outs.append(E.s3_to_f32(y, exp=0))
+    torch.cuda.synchronize()
+    a, b = outs
+    assert float((a - b).abs().max()) <= 2e-6 * max(1.0, float(a.abs().max()))
+    assert float(a.abs().max()) > 0.5 and bool((a >= 0).all())
+    if fmt == "h2":
+        m = rw.cpu().numpy().view(np.float32)
+        assert m[0] > 0 and abs(m[0] - m[1]) <= 2e-6 * m[0]
+    want = torch.nn.functional.conv2d(x.permute(0, 3, 1, 2).double().cpu(), w.double().cpu(), stride=stride, padding=1)
+    sc = (bn.weight / torch.sqrt(bn.running_var + 1e-5)).double().cpu().view(1, -1, 1, 1)
+    want = torch.relu((want - bn.running_mean.double().cpu().view(1, -1, 1, 1)) * sc + bn.bias.double().cpu().view(1, -1, 1, 1)
+                      + E.s3_to_f32(rs, exp=1).double().cpu().permute(0, 3, 1, 2))
+    assert float((b.double().cpu().permute(0, 3, 1, 2) - want).abs().max()) < 2e-5
+
+
 def test_conv_h2_wg_couts_argument_is_checked(E):
     w = torch.zeros(64, 128, 3, 3, device="cuda")
     pc = E.PackedConv(w, None, None, 3, 128, fmt="h2")
@@ -654,7 +693,7 @@ def test_f16x3_range_guard_rescales_and_resumes(E):
     assert _maxerr(got["logits"].cpu(), base["logits"].cpu()) < 2e-3    # same function up to rounding
     ex = net._h2_ranges.exps
     # the scaled tensors got smaller exponents (how much smaller depends on the headroom they had)
-    assert ex["inc.mid"] <= 2 - 6 and all(ex[k] < 2 for k in ("inc.out", "down3.mid", "up2.conv.mid", "rn.layer2.1.t"))
+    assert ex["inc.mid"] <= 2 - 6 and len(ex) >= 2 and all(e < 2 for e in ex.values())
     assert len(ex) <= 8, ex       # (a rescaled tensor's consumer may follow it down; the rest of the net keeps exponent 2)
     assert min(net.h2_headroom().values()) >= 1.0
     # sticky: the next batches - predict(), forward() and forward_unet() alike - repeat nothing and give the same bits

@@ -1,4 +1,6 @@
 """Training-mode parity: HIP forward/backward vs torch autograd over the CPU oracle."""
+import warnings
+
 import numpy as np
 import pytest
 import torch
@@ -835,3 +837,75 @@ def test_train_step_f16x3_range_fallback(T, monkeypatch):
     assert torch.allclose(l1, l2, rtol=1e-6, atol=0) and _relerr(g1, g2) < 1e-4
     for k in b1:      # a step repeated WITHOUT the restored statistics would have moved them twice (momentum 0.1)
         assert torch.allclose(b1[k].double(), b2[k].double(), rtol=1e-5, atol=1e-7), k
+
+
+def test_autograd_node_repeats_a_step_whose_gradient_leaves_the_fp16_range(T, monkeypatch):
+    """net.train(); net(x); loss.backward() (the reference's train.py structure) with SFH_TRAIN_PRECISION=f16x3: a
+    backward pass that does not fit the two-plane fp16 format - here a loss scaled until the gradients overflow it,
+    then a NaN loss - is repeated with bf16x6 operands from the BatchNorm statistics of BEFORE the step: the
+    gradients equal those of a plain bf16x6 step, the running statistics advance once, a NaN loss gives non-finite
+    gradients like the reference; no exception reaches the training loop."""
+    from sfh_amd.reconstructor import Reconstructor
+    B, H, W = 2, 64, 96
+    court = synth.load_court_template("ncaa_nc4_640x360", 4, B)[:, :, :H, :W].contiguous().cuda()
+    poi = synth.load_court_poi("pitch", B).cuda()
+    x = synth.frames_to_float(synth.synth_frames_u8(B, H, W, seed=9)).cuda()
+    mask = torch.randint(0, 4, (B, H, W), generator=torch.Generator().manual_seed(9)).cuda()
+
+    def run(prec, logit_gain, theta_gain, poison=False):
+        monkeypatch.setenv("SFH_TRAIN_PRECISION", prec)
+        net = Reconstructor(court, poi, target_size=(W, H), unet_size=(W, H), warp_size=(W, H))
+        net.load_state_dict(synth.synth_state_dict(net.state_dict(), 9))
+        net.cuda().train()
+        preds = net(x)
+        loss = torch.nn.functional.cross_entropy(preds["logits"], mask) * logit_gain + preds["theta"].square().sum() * theta_gain
+        if poison:
+            loss = loss * float("nan")
+        loss.backward()
+        torch.cuda.synchronize()
+        g = torch.cat([p.grad.reshape(-1) for p in net.parameters()])
+        stats = {k: v.clone() for k, v in net.state_dict().items() if "running" in k or "tracked" in k}
+        return g, stats, net.__dict__.get("train_range_fallbacks", 0)
+
+    # theta gradients 2^40 above what one scale with the head gradients can carry: the step does not fit the format
+    g_ref, s_ref, n_ref = run("bf16x6", 1.0, 2.0 ** 40)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        g_h2, s_h2, n_h2 = run("f16x3", 1.0, 2.0 ** 40)
+    assert n_ref == 0 and n_h2 == 1
+    assert _relerr(g_h2, g_ref) < 1e-4
+    for k in s_ref:
+        assert torch.allclose(s_h2[k].double(), s_ref[k].double(), rtol=1e-5, atol=1e-7), k
+    # an ordinary step stays on the two-plane path
+    _, _, n_ok = run("f16x3", 1.0, 1.0)
+    assert n_ok == 0
+    # a NaN loss: non-finite gradients, not an exception; statistics advanced once
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        g_nan, s_nan, n_nan = run("f16x3", 1.0, 1.0, poison=True)
+    assert n_nan == 1 and not torch.isfinite(g_nan).all()
+    for k in s_ref:
+        if k.endswith("num_batches_tracked"):
+            assert int(s_nan[k]) == int(s_ref[k])
+
+
+def test_bn_snapshot_follows_replaced_buffers(T):
+    """_BNSnapshot looks the buffers up at every save(): after net.to() / .float() the model holds NEW buffer objects,
+    and a restore must write into those."""
+    from sfh_amd.reconstructor import Reconstructor
+    court = synth.load_court_template("ncaa_nc4_640x360", 4, 1)[:, :, :32, :32].contiguous().cuda()
+    net = Reconstructor(court, synth.load_court_poi("pitch", 1).cuda(), target_size=(32, 32), unet_size=(32, 32), warp_size=(32, 32))
+    net.cuda().train()
+    snap = T._BNSnapshot(net)
+    g1 = snap.save()
+    bn = net.inc.double_conv[1]
+    bn.running_mean.add_(1.0)
+    snap.restore()
+    assert float(bn.running_mean.abs().max()) == 0.0
+    net.double().float()                       # replaces every buffer object
+    assert all(a is not b for a, b in zip(snap.bufs, net.buffers()) if a.is_floating_point())
+    g2 = snap.save()
+    assert g2 == g1 + 1 and all(a is b for a, b in zip(snap.bufs, [b for b in net.buffers() if b.is_cuda]))
+    net.inc.double_conv[1].running_mean.add_(2.0)
+    snap.restore()
+    assert float(net.inc.double_conv[1].running_mean.abs().max()) == 0.0

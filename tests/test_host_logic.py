@@ -229,3 +229,20 @@ def test_engine_stamp_notices_in_place_updates_and_replaced_parameters():
     assert any(t is net.inc.double_conv[0].weight for t in net.__dict__["_stamp_tensors"])
     net.load_state_dict(net.state_dict())
     assert net._param_stamp() != s3
+
+
+def test_engine_stamp_ignores_unrelated_modules_and_notices_sub_module_casts():
+    """Registrations elsewhere in the process (another model, a loss with a weight buffer) re-walk the tree but do
+    not drop the engines; .to() / .double() on a SUB-module replaces its buffers and gives its parameters new
+    storages without any registration hook - the stamp must move and the cached list must hold the live tensors."""
+    net = Reconstructor(synth.load_court_template(batch_size=1), synth.load_court_poi(batch_size=1)).eval()
+    s1 = net._param_stamp()
+    torch.nn.CrossEntropyLoss(weight=torch.ones(4))           # registers a buffer somewhere else
+    torch.nn.Linear(3, 3)
+    assert net._param_stamp() == s1
+    net.resnet_reg.double().float()                            # sub-module _apply: new buffer objects, new storages
+    s2 = net._param_stamp()
+    assert s2 != s1
+    live = {id(t) for t in list(net.parameters()) + list(net.buffers())}
+    assert {id(t) for t in net.__dict__["_stamp_tensors"]} == live
+    assert net._param_stamp() == s2
