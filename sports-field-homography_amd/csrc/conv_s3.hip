@@ -131,6 +131,70 @@ __device__ __forceinline__ unsigned s3_halo_voffset(const sfh_conv_desc& d, cons
   return ((rowi * nblk * (4u * C::NP) + (unsigned)pl) * ws_ + xs_) * 16u;
 }
 
+// All NSL halo slots of a thread at once (slot = tid + NT * i), same results as s3_halo_voffset: straight-line code -
+// one validity predicate per slot instead of an early return per test (36 divergent branches in the prologue of a 3x3
+// instance), and (plane/group, halo row, halo column) of slot i + 1 follow from slot i by constant increments instead
+// of two divisions.  The prologue runs beside the co-resident workgroup's MFMAs at half the vector issue rate and was
+// 14 % of a wave's life in the 64-channel layers (profiles/r03_diag_h2.txt).
+template <class C>
+__device__ __forceinline__ void s3_halo_offsets(const sfh_conv_desc& d, const S3Geom& g, int which, int tid, int r0,
+                                                int x0, int pad_y, int pad_x, unsigned (&hoff)[C::NSL]) {
+  constexpr int QP = C::NT / C::HPIXP, RP = C::NT % C::HPIXP;     // slot + NT: pl += QP, p += RP (carry below)
+  constexpr int QH = RP / C::HW, RH = RP % C::HW;                 // p + RP:     hy += QH, hx += RH
+  constexpr int QX = C::HPIXP / C::HW, RX = C::HPIXP % C::HW;     // p - HPIXP:  hy -= QX, hx -= RX
+  int pl = tid / C::HPIXP, p = tid - pl * C::HPIXP;
+  int hy = p / C::HW, hx = p - hy * C::HW;
+  const int hsrc = which == 0 ? d.h0 : d.h1, wsrc = which == 0 ? d.w0 : d.w1;
+  const int oy = which == 0 ? 0 : d.pad_top1, ox = which == 0 ? 0 : d.pad_left1;
+  const unsigned nblk = (unsigned)(which == 0 ? d.cs0 : d.cs1) >> 5;
+  const unsigned rowmul = nblk * (4u * C::NP);
+  const int xbase = x0 * C::STRIDE - pad_x - ox;
+  int ybase, bimg = 0;
+  if (C::FLATROWS) {
+    ybase = r0 - pad_y;
+  } else {
+    bimg = r0 >> 16;
+    ybase = (r0 & 0xFFFF) * C::STRIDE - pad_y;
+  }
+#pragma unroll
+  for (int i = 0; i < C::NSL; ++i) {
+    bool ok = pl < 4 * C::NP && p < C::HPIX;
+    int b, y;
+    if (C::FLATROWS) {
+      const int r = ybase + hy;
+      b = (int)__umulhi((unsigned)r, g.rows_magic);
+      y = r - b * g.rows_per_img;
+      ok = ok && r >= 0 && b < d.batch && y < d.H;
+    } else {
+      b = bimg;
+      y = ybase + hy;
+      ok = ok && y >= 0 && y < d.H;
+    }
+    const int xs = xbase + hx;            // column inside the source (source 1: relative to its placement)
+    const int x = xs + ox;                // column inside the conv frame
+    ok = ok && x >= 0 && x < d.W;
+    const int ys = y - oy;
+    // source 0 of the fused Up conv (KS == 2) may be one row / column short of the frame; source 1 sits inside it
+    if (which != 0 || C::KS == 2) ok = ok && ys >= 0 && ys < hsrc && xs >= 0 && xs < wsrc;
+    const unsigned rowi = (unsigned)(b * hsrc + ys);
+    const unsigned off = ((rowi * rowmul + (unsigned)pl) * (unsigned)wsrc + (unsigned)xs) * 16u;
+    hoff[i] = ok ? off : kOOB;
+    // next slot of this thread
+    pl += QP;
+    p += RP;
+    hy += QH;
+    hx += RH;
+    if (hx >= C::HW) { hx -= C::HW; hy += 1; }
+    if (p >= C::HPIXP) {
+      p -= C::HPIXP;
+      pl += 1;
+      hy -= QX;
+      hx -= RX;
+      if (hx < 0) { hx += C::HW; hy -= 1; }
+    }
+  }
+}
+
 }  // namespace
 
 namespace {
@@ -235,8 +299,7 @@ __global__ __launch_bounds__(C::NT, (C::NP == 2 && !DB) ? SFH_H2_WAVES_PER_SIMD 
     pad_x = 1 - (qd & 1);
   }
   unsigned hoff[C::NSL];
-#pragma unroll
-  for (int i = 0; i < C::NSL; ++i) hoff[i] = s3_halo_voffset<C>(d, g, 0, tid + C::NT * i, r0, x0, pad_y, pad_x);
+  s3_halo_offsets<C>(d, g, 0, tid, r0, x0, pad_y, pad_x, hoff);
 
   // LDS-DMA piece i (64 slots of this wave) of stage st into buffer b
   auto dma_piece = [&](int st, int b, int i) {
@@ -366,8 +429,7 @@ __global__ __launch_bounds__(C::NT, (C::NP == 2 && !DB) ? SFH_H2_WAVES_PER_SIMD 
   dma_stage(st0, 0);
   auto maybe_switch = [&](int st) {  // the DMA issued during stage st targets stage st+1
     if (d.src1 && st + 1 == nst0) {
-#pragma unroll
-      for (int i = 0; i < C::NSL; ++i) hoff[i] = s3_halo_voffset<C>(d, g, 1, tid + C::NT * i, r0, x0, pad_y, pad_x);
+      s3_halo_offsets<C>(d, g, 1, tid, r0, x0, pad_y, pad_x, hoff);
     }
   };
   // hipcc's own wait before the barrier covers only part of the outstanding LDS-DMA (observed:
@@ -403,8 +465,7 @@ __global__ __launch_bounds__(C::NT, (C::NP == 2 && !DB) ? SFH_H2_WAVES_PER_SIMD 
       SFH_STAMP(2);
       if (st + 1 < st1) {
         if (d.src1 && st + 1 == nst0) {
-#pragma unroll
-          for (int i = 0; i < C::NSL; ++i) hoff[i] = s3_halo_voffset<C>(d, g, 1, tid + C::NT * i, r0, x0, pad_y, pad_x);
+          s3_halo_offsets<C>(d, g, 1, tid, r0, x0, pad_y, pad_x, hoff);
         }
         __syncthreads();
         dma_stage(st + 1, 0);
@@ -416,8 +477,7 @@ __global__ __launch_bounds__(C::NT, (C::NP == 2 && !DB) ? SFH_H2_WAVES_PER_SIMD 
       }
       if (st + 2 < st1) {
         if (d.src1 && st + 2 == nst0) {
-#pragma unroll
-          for (int i = 0; i < C::NSL; ++i) hoff[i] = s3_halo_voffset<C>(d, g, 1, tid + C::NT * i, r0, x0, pad_y, pad_x);
+          s3_halo_offsets<C>(d, g, 1, tid, r0, x0, pad_y, pad_x, hoff);
         }
         __syncthreads();
         dma_stage(st + 2, 0);

@@ -268,9 +268,12 @@ def choose_tile_s3(batch, ho, wo, stride, zrows, nblk, ksize=3, wg_slots=_WG_SLO
 
 
 def choose_ksplit(batch, ho, wo, stride, cout, nstages, ksize=3, wg_slots=_WG_SLOTS):
-    """Split-K factor for a conv whose (pixel tile, 64-cout block) grid fills less than half of the chip's
-    workgroup slots: the largest factor that keeps the grid within one round of resident workgroups and leaves
-    every split at least two 32-channel stages.  1 = no split."""
+    """Split-K factor for a conv whose (pixel tile, 64-cout block) grid fills at most a QUARTER of the chip's
+    workgroup slots (small batches: one frame of 640x360 has 4-60 workgroups per ResNet layer): the largest factor
+    that keeps the grid within one round of resident workgroups and leaves every split at least two 32-channel
+    stages.  1 = no split.  Measured at batch 16 (profiles/r03_resnet_table_*.txt): layer3 (240 workgroups) 53 us
+    unsplit against 49 + 10.5 us (conv x2 + finish), layer4 (192) 82 against 74 + 8 - grids of that size are bound
+    by the weight stream every pixel tile pulls from L2, not by idle CUs, so they are left alone."""
     zr = ksize // 2
     zr += (ho + zr) & 1
     cands = _TILES_S3_HALF if stride == 2 else _TILES
@@ -280,9 +283,9 @@ def choose_ksplit(batch, ho, wo, stride, cout, nstages, ksize=3, wg_slots=_WG_SL
         n = ty * (-(-wo // tw))
         ntiles = n if ntiles is None else min(ntiles, n)
     wgs = ntiles * (cout // 64)
-    if wgs * 2 > wg_slots:
+    if wgs * 4 > wg_slots:
         return 1
-    return max(1, min(wg_slots // wgs, nstages // 2, 8))
+    return max(1, min(wg_slots // (2 * wgs), nstages // 2, 8))
 
 
 class ConvTimer:
