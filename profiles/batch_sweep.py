@@ -1,0 +1,34 @@
+"""predict() at 640x360 over batch sizes (latency of one batch, frames/s), default f16x3 arithmetic; with
+SFH_SPLITK=0 the small-batch split-K of the ResNet layers is off.  GPU box only.
+usage: python profiles/batch_sweep.py [B ...]"""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+from sfh_amd import synth  # noqa: E402
+from sfh_amd.reconstructor import Reconstructor  # noqa: E402
+
+sizes = [int(a) for a in sys.argv[1:]] or [1, 2, 4, 8, 16, 32, 64]
+W, H = 640, 360
+dev = torch.device("cuda", 0)
+court = synth.load_court_template("ncaa_nc4_640x360", 4, max(sizes)).to(dev)
+poi = synth.load_court_poi("pitch", max(sizes)).to(dev)
+net = Reconstructor(court, poi, target_size=(W, H), unet_size=(W, H), warp_size=(W, H), warp_with_nearest=True)
+net.load_state_dict(synth.synth_state_dict(net.state_dict(), 0))
+net.to(dev).eval()
+for B in sizes:
+    x = synth.frames_to_float(synth.synth_frames_u8(B, H, W, seed=0)).to(dev)
+    with torch.no_grad():
+        for _ in range(3):
+            net.predict(x, consistency=False)
+        torch.cuda.synchronize()
+        n = max(5, 160 // B)
+        t0 = time.perf_counter()
+        for _ in range(n):
+            net.predict(x, consistency=False)
+        torch.cuda.synchronize()
+        el = (time.perf_counter() - t0) / n
+    print(f"B={B} {B / el:.2f} frames/s {el * 1e3:.3f} ms per batch  (split-K {'off' if os.environ.get('SFH_SPLITK') == '0' else 'on'})", flush=True)
