@@ -324,7 +324,8 @@ int sfh_bn_stats(const float* z, int64_t npix, int C, double* acc, void* stream)
 /* mean_invstd[0][c] = mean, [1][c] = 1/sqrt(biased var + eps); running stats (optional pair) updated
  * with `momentum` and the unbiased variance like torch.                                           */
 int sfh_bn_finalize(const double* acc, int64_t npix, int C, float eps, float momentum, float* running_mean,
-                    float* running_var, float* mean_invstd, void* stream);
+                    float* running_var, float* mean_invstd, int64_t* num_batches_tracked, void* stream);   /* num_batches_tracked
+                    (optional): nn.BatchNorm2d's int64 step counter, incremented by one */
 /* y = [relu]((z - mean) * invstd * gamma + beta [+ residual]); y_s3 (optional, C % 32 == 0, W = row
  * length of the (rows, W, C) tensor): the same values again in the split layout split_fmt (SFH_FMT_S3 or
  * SFH_FMT_H2; H2: `overflow` as in sfh_f32_to_h2) for the next convolution. */
@@ -340,7 +341,9 @@ int sfh_bn_bwd_reduce(const float* dy, const float* y, const float* z, const flo
                       const float* gamma, const float* beta, int relu, int64_t npix, int C, double* acc, void* stream);
 int sfh_bn_bwd_apply(const float* dy, const float* y, const float* z, const float* mean_invstd,
                      const float* gamma, const float* beta, const double* acc, int relu, int64_t npix, int C,
-                     float* dz, float* dres, void* dz_s3, int W, int split_fmt, uint32_t* overflow, void* stream);   /* dz_s3: optional split copy of dz (split_fmt, overflow: as sfh_bn_apply) */
+                     float* dz, float* dres, void* dz_s3, int W, int split_fmt, uint32_t* overflow, float* acc_f32,
+                     void* stream);   /* dz_s3: optional split copy of dz (split_fmt, overflow: as sfh_bn_apply); acc_f32 (optional,
+                                         2*C floats): acc as float32 = dbeta | dgamma for the caller */
 /* acc[c] += sum_p x[p][c] over a channel slice of a (npix, cs) tensor: conv / transposed-conv bias
  * gradients.                                                                                       */
 int sfh_colsum(const float* x, int64_t npix, int C, int cs, double* acc, void* stream);
@@ -423,6 +426,14 @@ int sfh_reproj_loss(const float* poi, const float* gt_poi, const float* nonzeros
 int sfh_rmsprop_step(const void* tensor_table, const void* chunk_table, int nchunks, float lr, float alpha,
                      float eps, float weight_decay, float momentum, float clip_value, float grad_scale,
                      void* stream);
+
+/* Many small copies in one launch (training: the assembly of all parameter gradients into the flat gradient buffer -
+ * weight gradients are permuted views of the backward-filter buffers - and the copy of the BatchNorm statistics a repeated
+ * step starts from; torch issues one copy per tensor).  tensor_table: device array of {void* dst (contiguous); const
+ * void* src; int32 d1, d2, d3, pad; int64 s0, s1, s2, s3} = logical shape (d0,d1,d2,d3) with the source's element strides,
+ * 4-byte elements; chunk_table as sfh_rmsprop_step ({int32 tensor; int32 count; int64 offset}, one workgroup per chunk of
+ * dst).  scale != 1: dst = src * scale (float32); scale == 1: the words are moved untouched.                     */
+int sfh_multi_copy(const void* tensor_table, const void* chunk_table, int nchunks, float scale, void* stream);
 
 /* Backward of sfh_upsample2x_bilinear_nhwc (the bilinear Up variant, unet/unet_parts.py:49): dy (B,2H,2W,C)
  * -> dx (B,H,W,C).                                                                                        */

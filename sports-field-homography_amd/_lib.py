@@ -84,11 +84,11 @@ SIGNATURES = {
     "sfh_mask_format_fwd": (C.c_int, [_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                       C.c_int, _p, _p, _p]),
     "sfh_bn_stats": (C.c_int, [_p, C.c_int64, C.c_int, _p, _p]),
-    "sfh_bn_finalize": (C.c_int, [_p, C.c_int64, C.c_int, C.c_float, C.c_float, _p, _p, _p, _p]),
+    "sfh_bn_finalize": (C.c_int, [_p, C.c_int64, C.c_int, C.c_float, C.c_float, _p, _p, _p, _p, _p]),
     "sfh_bn_apply": (C.c_int, [_p, _p, _p, _p, _p, C.c_int, C.c_int64, C.c_int, _p, _p, C.c_int, C.c_int, _p, _p]),
     "sfh_bn_bwd_reduce": (C.c_int, [_p, _p, _p, _p, _p, _p, C.c_int, C.c_int64, C.c_int, _p, _p]),
     "sfh_bn_bwd_apply": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, C.c_int, C.c_int64, C.c_int, _p, _p, _p, C.c_int, C.c_int,
-                                   _p, _p]),
+                                   _p, _p, _p]),
     "sfh_colsum": (C.c_int, [_p, C.c_int64, C.c_int, C.c_int, _p, _p]),
     "sfh_maxpool2_fwd": (C.c_int, [_p, _p, C.c_int, C.c_int, C.c_int, C.c_int, _p]),
     "sfh_maxpool2_bwd": (C.c_int, [_p, _p, _p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _p]),
@@ -111,6 +111,7 @@ SIGNATURES = {
     "sfh_reproj_loss": (C.c_int, [_p, _p, _p, _p, C.c_int, C.c_int, C.c_float, _p, _p, _p]),
     "sfh_rmsprop_step": (C.c_int, [_p, _p, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
                                    C.c_float, C.c_float, _p]),
+    "sfh_multi_copy": (C.c_int, [_p, _p, C.c_int, C.c_float, _p]),
     "sfh_upsample2x_bilinear_nhwc_bwd": (C.c_int, [_p, _p, C.c_int, C.c_int, C.c_int, C.c_int, _p]),
     "sfh_resize_nearest_nchw_bwd": (C.c_int, [_p, _p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, _p]),
     "sfh_compose_up_weights": (C.c_int, [_p, C.c_int, C.c_int, C.c_int, _p, C.c_int, _p, _p, _p, _p, _p, _p]),

@@ -115,8 +115,9 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x
 
 __global__ void bn_finalize_kernel(const double* __restrict__ acc, long npix, int C, float eps, float momentum,
                                    float* __restrict__ running_mean, float* __restrict__ running_var,
-                                   float* __restrict__ mean_invstd) {
+                                   float* __restrict__ mean_invstd, long* __restrict__ num_batches_tracked) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c == 0 && num_batches_tracked) *num_batches_tracked += 1;   // nn.BatchNorm2d's counter (one launch less per layer)
   if (c >= C) return;
   const double n = (double)npix;
   const double mean = acc[c] / n;
@@ -236,8 +237,10 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                                                            const float* __restrict__ gamma, const double* __restrict__ acc,
                                                            int relu, long npix, long total4, int C,
                                                            float* __restrict__ dz, float* __restrict__ dres,
-                                                           const float* __restrict__ beta) {
+                                                           const float* __restrict__ beta, float* __restrict__ acc_f32) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (acc_f32 && blockIdx.x == 0)   // dbeta | dgamma as float32 for the caller (one conversion launch less per layer)
+    for (int k = threadIdx.x; k < 2 * C; k += 256) acc_f32[k] = (float)acc[k];
   if (i >= total4) return;
   const int c = (int)((i * 4) % C);
   const f32x4 g4 = reinterpret_cast<const f32x4*>(dy)[i];
@@ -362,8 +365,10 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_s3_kernel(const float* __res
                                                               int relu, long npix, int W, int C, int xchunks, long total,
                                                               float* __restrict__ dz, float* __restrict__ dres,
                                                               unsigned short* __restrict__ dz_s3, unsigned* __restrict__ overflow,
-                                                              const float* __restrict__ beta) {
+                                                              const float* __restrict__ beta, float* __restrict__ acc_f32) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (acc_f32 && blockIdx.x == 0)   // dbeta | dgamma as float32 for the caller (one conversion launch less per layer)
+    for (int k = threadIdx.x; k < 2 * C; k += 256) acc_f32[k] = (float)acc[k];
   if (i >= total) return;
   long row; int x, c0;
   if (!tr_s3_thread(i, W, C, xchunks, row, x, c0)) return;
@@ -840,6 +845,35 @@ __global__ __launch_bounds__(256) void rmsprop_kernel(const OptTensor* __restric
   }
 }
 
+// ------------------------------------------------------------------ multi-tensor copy
+// dst_t (contiguous) = src_t (up to 4-D, any strides) [* scale] for many tensors in ONE launch: the gradient assembly of a
+// training step (182 tensors, the weight gradients as permuted views of the backward-filter buffers, times 1 / the
+// power-of-two gradient scale) and the BatchNorm statistics snapshot (162 buffers) were one hipMemcpy each.
+// 4-byte elements; SCALE = false moves the words untouched (integer buffers).
+struct CopyTensor { void* dst; const void* src; int d1, d2, d3, pad; long s0, s1, s2, s3; };
+
+template <bool SCALE>
+__global__ __launch_bounds__(256) void multi_copy_kernel(const CopyTensor* __restrict__ table, const OptChunk* __restrict__ chunks,
+                                                         float scale) {
+  const OptChunk c = chunks[blockIdx.x];
+  const CopyTensor t = table[c.tensor];
+  const bool contiguous = t.s3 == 1 && t.s2 == t.d3 && t.s1 == (long)t.d2 * t.d3 && t.s0 == (long)t.d1 * t.d2 * t.d3;
+  for (int i = threadIdx.x; i < c.count; i += 256) {
+    const long o = c.offset + i;
+    long so = o;
+    if (!contiguous) {
+      const long i3 = o % t.d3;
+      long r = o / t.d3;
+      const long i2 = r % t.d2;
+      r /= t.d2;
+      const long i1 = r % t.d1, i0 = r / t.d1;
+      so = i0 * t.s0 + i1 * t.s1 + i2 * t.s2 + i3 * t.s3;
+    }
+    if (SCALE) reinterpret_cast<float*>(t.dst)[o] = reinterpret_cast<const float*>(t.src)[so] * scale;
+    else reinterpret_cast<unsigned*>(t.dst)[o] = reinterpret_cast<const unsigned*>(t.src)[so];
+  }
+}
+
 // ------------------------------------------------------------------ weight gradient (fp32 MFMA)
 // raw[m][tap][n] += sum over pixels p of dz[p][m] * xin[p + tap][n]
 //   GEMM view: M = output channels, N = input channels of one source, K = B*H*W pixels.
@@ -1005,11 +1039,12 @@ extern "C" int sfh_bn_stats(const float* z, int64_t npix, int C, double* acc, vo
 }
 
 extern "C" int sfh_bn_finalize(const double* acc, int64_t npix, int C, float eps, float momentum,
-                               float* running_mean, float* running_var, float* mean_invstd, void* stream) {
+                               float* running_mean, float* running_var, float* mean_invstd, int64_t* num_batches_tracked,
+                               void* stream) {
   SFH_REQUIRE(acc && mean_invstd && npix > 0 && C > 0, "bn_finalize: bad argument");
   SFH_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "bn_finalize: running stats must come in pairs");
   hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, (hipStream_t)stream, acc,
-                     (long)npix, C, eps, momentum, running_mean, running_var, mean_invstd);
+                     (long)npix, C, eps, momentum, running_mean, running_var, mean_invstd, (long*)num_batches_tracked);
   return sfh_check_launch("bn_finalize_kernel");
 }
 
@@ -1051,7 +1086,7 @@ extern "C" int sfh_bn_bwd_reduce(const float* dy, const float* y, const float* z
 extern "C" int sfh_bn_bwd_apply(const float* dy, const float* y, const float* z, const float* mean_invstd,
                                 const float* gamma, const float* beta, const double* acc, int relu, int64_t npix, int C,
                                 float* dz, float* dres, void* dz_s3, int W, int split_fmt, uint32_t* overflow,
-                                void* stream) {
+                                float* acc_f32, void* stream) {
   SFH_REQUIRE(dy && z && mean_invstd && gamma && acc && dz && (y || !relu || beta) && npix > 0 && C > 0 && C % 4 == 0,
               "bn_bwd_apply: bad argument (relu needs y, or beta to recompute its sign from z)");
   if (dz_s3) {
@@ -1062,15 +1097,15 @@ extern "C" int sfh_bn_bwd_apply(const float* dy, const float* y, const float* z,
     const dim3 grid((unsigned)((total + 255) / 256));
     if (split_fmt == SFH_FMT_H2)
       hipLaunchKernelGGL(bn_bwd_apply_s3_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, dy, y, z, mean_invstd, gamma,
-                         acc, relu, (long)npix, W, C, xchunks, total, dz, dres, (unsigned short*)dz_s3, overflow, beta);
+                         acc, relu, (long)npix, W, C, xchunks, total, dz, dres, (unsigned short*)dz_s3, overflow, beta, acc_f32);
     else
       hipLaunchKernelGGL(bn_bwd_apply_s3_kernel<3>, grid, dim3(256), 0, (hipStream_t)stream, dy, y, z, mean_invstd, gamma,
-                         acc, relu, (long)npix, W, C, xchunks, total, dz, dres, (unsigned short*)dz_s3, overflow, beta);
+                         acc, relu, (long)npix, W, C, xchunks, total, dz, dres, (unsigned short*)dz_s3, overflow, beta, acc_f32);
     return sfh_check_launch("bn_bwd_apply_s3_kernel");
   }
   const long total4 = (long)npix * C / 4;
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                     dy, y, z, mean_invstd, gamma, acc, relu, (long)npix, total4, C, dz, dres, beta);
+                     dy, y, z, mean_invstd, gamma, acc, relu, (long)npix, total4, C, dz, dres, beta, acc_f32);
   return sfh_check_launch("bn_bwd_apply_kernel");
 }
 
@@ -1237,6 +1272,17 @@ extern "C" int sfh_reproj_loss(const float* poi, const float* gt_poi, const floa
   hipLaunchKernelGGL(reproj_loss_kernel, dim3((unsigned)sfh_cdiv(batch, 64)), dim3(64), 0, (hipStream_t)stream, poi,
                      gt_poi, nonzeros, num_nonzero, batch, npts, lambda, dpoi, loss);
   return sfh_check_launch("reproj_loss_kernel");
+}
+
+extern "C" int sfh_multi_copy(const void* tensor_table, const void* chunk_table, int nchunks, float scale, void* stream) {
+  SFH_REQUIRE(tensor_table && chunk_table && nchunks > 0, "multi_copy: bad argument");
+  if (scale == 1.f)
+    hipLaunchKernelGGL(multi_copy_kernel<false>, dim3((unsigned)nchunks), dim3(256), 0, (hipStream_t)stream,
+                       (const CopyTensor*)tensor_table, (const OptChunk*)chunk_table, 1.f);
+  else
+    hipLaunchKernelGGL(multi_copy_kernel<true>, dim3((unsigned)nchunks), dim3(256), 0, (hipStream_t)stream,
+                       (const CopyTensor*)tensor_table, (const OptChunk*)chunk_table, scale);
+  return sfh_check_launch("multi_copy_kernel");
 }
 
 extern "C" int sfh_rmsprop_step(const void* tensor_table, const void* chunk_table, int nchunks, float lr,

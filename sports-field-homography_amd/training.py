@@ -49,16 +49,69 @@ class FP16RangeError(RuntimeError):
     """an activation or gradient of a training step did not fit the two-plane fp16 (H2) format"""
 
 
+class _MultiCopy:
+    """dst_i (contiguous) = src_i (up to 4-D, any strides, same number of elements) [* scale] for a fixed list of
+    destinations in ONE launch of sfh_multi_copy (torch issues one copy per tensor: 344 of the ~1580 launches of a
+    training step were the gradient assembly and the BatchNorm snapshot).  4-byte element types; int64 tensors go as
+    pairs of words (contiguous only)."""
+    CHUNK = 65536
+
+    def __init__(self, dsts):
+        import numpy as np
+        self.dsts = list(dsts)
+        self.dev = self.dsts[0].device if self.dsts else None
+        self.words = [d.numel() * (d.element_size() // 4) for d in self.dsts]
+        if any(d.element_size() not in (4, 8) or not d.is_contiguous() for d in self.dsts):
+            raise ValueError("_MultiCopy: destinations must be contiguous tensors of 4- or 8-byte elements")
+        chunks = [(i, min(self.CHUNK, n - off), off) for i, n in enumerate(self.words) for off in range(0, n, self.CHUNK)]
+        ch = np.zeros(len(chunks), dtype=np.dtype([("t", "<i4"), ("c", "<i4"), ("o", "<i8")]))
+        for j, c in enumerate(chunks):
+            ch[j] = c
+        self.nchunks = len(chunks)
+        self.chunks = torch.from_numpy(ch.view(np.uint8).reshape(-1).copy()).to(self.dev) if chunks else None
+        self._tab = np.zeros((len(self.dsts), 8), dtype=np.int64)
+        self._key = None
+        self._dev_tab = None
+
+    def run(self, srcs, scale=1.0):
+        if not self.dsts:
+            return
+        tab = self._tab
+        key = []
+        for i, (d, s) in enumerate(zip(self.dsts, srcs)):
+            if s.numel() != d.numel() or s.element_size() != d.element_size() or s.device != d.device:
+                raise ValueError("_MultiCopy: source / destination mismatch")
+            if d.element_size() == 8 or s.dim() > 4:
+                if not s.is_contiguous():
+                    raise ValueError("_MultiCopy: 8-byte or >4-D sources must be contiguous")
+                shape, strides = (1, 1, 1, self.words[i]), (0, 0, 0, 1)
+            else:
+                pad = 4 - s.dim()
+                shape = (1,) * pad + tuple(s.shape)
+                strides = (0,) * pad + tuple(s.stride())
+            tab[i, 0], tab[i, 1] = d.data_ptr(), s.data_ptr()
+            tab[i, 2] = shape[1] | (shape[2] << 32)
+            tab[i, 3] = shape[3]
+            tab[i, 4:8] = strides
+            key.append((d.data_ptr(), s.data_ptr()))
+        if self._dev_tab is None or key != self._key:      # static pairs (the BatchNorm snapshot): uploaded once
+            self._dev_tab = torch.from_numpy(tab.view("uint8").reshape(-1).copy()).to(self.dev)
+            self._key = key
+        _lib.check(_lib.load().sfh_multi_copy(_ptr(self._dev_tab), _ptr(self.chunks), self.nchunks, float(scale), _stream()),
+                   "multi_copy")
+
+
 class _BNSnapshot:
     """Copies of a model's buffers (BatchNorm running statistics), so that a training step that has to be repeated
-    in another precision starts from the same statistics: two multi-tensor copies per step.  The buffer objects are
-    looked up again at every save(): net.to() / .float() / load_state_dict(assign=True) REPLACE them, and a restore
+    in another precision starts from the same statistics: one multi-tensor copy per save / restore.  The buffer objects
+    are looked up again at every save(): net.to() / .float() / load_state_dict(assign=True) REPLACE them, and a restore
     into tensors the model no longer holds would leave the statistics advanced twice.  `generation` counts the
     saves: a consumer (the autograd node's backward) can tell whether the copy is still the one it made."""
 
     def __init__(self, net):
         self.net = net
         self.bufs, self.snap = [], []
+        self._save = self._restore = None
         self.generation = 0
 
     def save(self):
@@ -66,15 +119,18 @@ class _BNSnapshot:
         if len(bufs) != len(self.bufs) or any(a is not b or a.shape != c.shape or a.dtype != c.dtype
                                               for a, b, c in zip(bufs, self.bufs, self.snap)):
             self.bufs = bufs
-            self.snap = [torch.empty_like(b) for b in bufs]
+            self.snap = [torch.empty_like(b, memory_format=torch.contiguous_format) for b in bufs]
+            self._save, self._restore = _MultiCopy(self.snap), None
         if self.bufs:
-            torch._foreach_copy_(self.snap, self.bufs)
+            self._save.run(self.bufs)
         self.generation += 1
         return self.generation
 
     def restore(self):
         if self.bufs:
-            torch._foreach_copy_(self.bufs, self.snap)
+            if self._restore is None or any(a is not b for a, b in zip(self._restore.dsts, self.bufs)):
+                self._restore = _MultiCopy(self.bufs)
+            self._restore.run(self.snap)
 
 
 _RANGE_WARNED = []
@@ -186,9 +242,12 @@ def _bn_forward(lib, z, bn, relu, residual, tape, want_s3=True):
     acc = tape.zeros((2 * C,), z, torch.float64)
     _lib.check(lib.sfh_bn_stats(_ptr(z), npix, C, _ptr(acc), _stream()), "bn_stats")
     mi = _empty((2 * C,), z)
+    nbt = bn.num_batches_tracked
+    if nbt is not None and (nbt.dtype != torch.int64 or not nbt.is_cuda):
+        raise ValueError("BatchNorm num_batches_tracked must be an int64 tensor on the GPU")
+    # (the kernel also advances nn.BatchNorm2d's step counter: one launch per layer less)
     _lib.check(lib.sfh_bn_finalize(_ptr(acc), npix, C, float(bn.eps), BN_MOMENTUM, _ptr(bn.running_mean),
-                                   _ptr(bn.running_var), _ptr(mi), _stream()), "bn_finalize")
-    bn.num_batches_tracked += 1
+                                   _ptr(bn.running_var), _ptr(mi), _ptr(nbt), _stream()), "bn_finalize")
     y = _empty(z.shape, z)
     y_s3 = E.split_empty(tape.fmt, B, H, W, C, z.device) if (want_s3 and tape.use_s3 and C % 32 == 0) else None
     _lib.check(lib.sfh_bn_apply(_ptr(z), _ptr(mi), _ptr(bn.weight.detach()), _ptr(bn.bias.detach()),
@@ -213,10 +272,10 @@ def _bn_backward(lib, tape, dy, y, z, mi, bn, relu, want_dres, want_s3=False):
     dz = _empty(z.shape, z)
     dres = _empty(z.shape, z) if want_dres else None
     dz_s3 = E.split_empty(tape.fmt, B, H, W, C, z.device) if (want_s3 and C % 32 == 0) else None
+    a = _empty((2 * C,), z)     # dbeta | dgamma as float32, written by the apply kernel
     _lib.check(lib.sfh_bn_bwd_apply(_ptr(dy), _ptr(ysign), _ptr(z), _ptr(mi), _ptr(gam), _ptr(bet), _ptr(acc),
                                     1 if relu else 0, npix, C, _ptr(dz), _ptr(dres), _ptr(dz_s3), W, tape.fmt_code,
-                                    _ptr(tape.overflow), _stream()), "bn_bwd_apply")
-    a = acc.to(torch.float32)
+                                    _ptr(tape.overflow), _ptr(a), _stream()), "bn_bwd_apply")
     return dz, a[C:], a[:C], dres, dz_s3   # dz, dgamma, dbeta, dresidual, S3 copy of dz
 
 
@@ -862,6 +921,7 @@ class TrainStep:
         self.consist_start_iter = consist_start_iter
         self.global_step = 0
         self._bn_snapshot = None     # f16x3 only: copies of the BatchNorm statistics for a repeated step
+        self._assemble = None        # _MultiCopy into self.grads
         self.range_fallbacks = 0     # steps repeated with bf16x6 because a value left the fp16 range
         self._init_optimizer([p for p in net.parameters()])
 
@@ -1003,9 +1063,11 @@ class TrainStep:
         for p, dst in zip(self.params, self.grads):
             src = g[self.names(p)]
             srcs.append(src if tuple(src.shape) == tuple(dst.shape) else src.reshape(dst.shape))
-        torch._foreach_copy_(self.grads, srcs)     # multi-tensor copy instead of 182 launches
-        if tape.gscale != 1.0:
-            self.gflat.mul_(1.0 / tape.gscale)     # the power of two the backward pass was carried with (one pass, exact)
+        # one launch assembles all 182 gradients (the weight gradients are permuted views of the backward-filter buffers)
+        # and divides out the power of two the backward pass was carried with (exact)
+        if self._assemble is None or any(a is not b for a, b in zip(self._assemble.dsts, self.grads)):
+            self._assemble = _MultiCopy(self.grads)
+        self._assemble.run(srcs, 1.0 / tape.gscale)
         return losses
 
     def step(self, x, batch):

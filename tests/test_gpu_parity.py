@@ -742,7 +742,8 @@ def test_f16x3_stays_on_the_two_plane_path_with_scaled_logits_and_gammas(E, fact
         got = net.predict(x.cuda(), consistency=True, project_poi=True)
         want = torch_ref.predict(x, sd2, court, poi, warp_size=(W, H), unet_size=(W, H), target_size=(W, H), project_poi=True)
     assert net.range_fallbacks == 0 and (net.range_rescales >= 1 or factor < 1000)
-    assert _maxerr(got["theta"].cpu(), want["theta"]) < 1e-4
+    # (with the logits scaled by 2^12 the STN's theta itself grows to a few hundred: the bound is relative to it)
+    assert _maxerr(got["theta"].cpu(), want["theta"]) < 1e-4 * max(1.0, float(want["theta"].abs().max()) / 8.0)
     assert _maxerr(got["logits"].cpu(), want["logits"]) < 5e-4 * factor
     assert _maxerr(got["poi"].cpu(), want["poi"]) < 1e-4
     wm = (warp_ref.homography_warp(got["theta"].cpu(), court, H, W, "nearest") * 4).to(torch.int32)
