@@ -28,6 +28,12 @@ from .engine import PackedConv, _ptr, _stream
 
 BN_MOMENTUM = 0.1  # nn.BatchNorm2d default, unchanged by the reference
 
+# Test hook: set to a dict and the next training pass leaves references to the ResNet blocks' activations
+# ("layer4.1": {"in", "t", "out"} NHWC tensors) and the theta gradient it starts its backward pass from ("dtheta").
+# tests/test_gpu_configs.py uses it to re-derive the gradients of the last ResNet stage in fp64 under the ReLU decisions
+# this pass took.  None (the default): nothing is kept.
+CAPTURE = None
+
 
 def _train_fmt():
     """split format of the training convs: "h2" (f16x3, default), "s3" (bf16x6) or None (fp32 MFMA)"""
@@ -595,9 +601,10 @@ class ResNetTrainer:
                                residual=residual)
 
         for li in range(1, 5):
-            for blk in getattr(rn, f"layer{li}"):
+            for bi, blk in enumerate(getattr(rn, f"layer{li}")):
                 s = blk.stride
                 ho, wo = (h - 1) // s + 1, (w - 1) // s + 1
+                x_in = x
                 idn = cba(blk.downsample[0], blk.downsample[1], x, h, w, relu=False) if blk.downsample is not None else x
                 if hasattr(blk, "conv3"):
                     t = cba(blk.conv1, blk.bn1, x, h, w)
@@ -606,6 +613,8 @@ class ResNetTrainer:
                 else:
                     t = cba(blk.conv1, blk.bn1, x, h, w)
                     x = cba(blk.conv2, blk.bn2, t, ho, wo, residual=idn)
+                if CAPTURE is not None:
+                    CAPTURE[f"layer{li}.{bi}"] = {"in": x_in, "t": t, "out": x}
                 h, w = ho, wo
         feat = x
         C = feat.shape[3]
@@ -759,6 +768,8 @@ def run_backward(net, tape, f, dheads, dtheta, unscale=True):
                                      "fit one power-of-two scale of the two-plane fp16 format")
             S = S2
         tape.gscale = S
+    if CAPTURE is not None and dtheta is not None:
+        CAPTURE["dtheta"] = dtheta.clone()
     if S != 1.0:
         dtheta = None if dtheta is None else dtheta * S
         dheads = [None if d is None else d.mul_(S) for d in dheads]
