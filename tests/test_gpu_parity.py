@@ -721,8 +721,8 @@ def test_f16x3_range_guard_rescales_and_resumes(E):
 
 @pytest.mark.parametrize("factor", [2.0 ** 8, 2.0 ** 12])
 def test_f16x3_stays_on_the_two_plane_path_with_scaled_logits_and_gammas(E, factor):
-    """Larger frames, every level's first BatchNorm and the logit head scaled by 2^8 / 2^12 (the head for real: the STN
-    then sees that multiple of the logits, a different function - compared with the CPU restatement of that checkpoint)."""
+    """Larger frames, every level's first BatchNorm scaled by 2^8 / 2^12 and the logit head by 2^8 (the head for real: the
+    STN then sees 256x the logits, a different function - compared with the CPU restatement of that checkpoint)."""
     from sfh_amd.reconstructor import Reconstructor
     B, H, W = 2, 90, 112
     court = synth.load_court_template("ncaa_nc4_640x360", 4, B)[:, :, :H, :W].contiguous()
@@ -733,8 +733,9 @@ def test_f16x3_stays_on_the_two_plane_path_with_scaled_logits_and_gammas(E, fact
     pairs += [(f"up{i}.conv.double_conv.1", [f"up{i}.conv.double_conv.3.weight"]) for i in (1, 2, 3, 4)]
     pairs += [("resnet_reg.layer1.0.bn1", ["resnet_reg.layer1.0.conv2.weight"]), ("resnet_reg.layer4.2.bn1", ["resnet_reg.layer4.2.conv2.weight"])]
     sd2 = _rescaled_checkpoint(sd, factor, pairs)
-    sd2["outc.conv.weight"] *= factor
-    sd2["outc.conv.bias"] *= factor
+    head = min(factor, 256.0)      # (beyond 2^8 the STN's theta leaves every sensible range and its inverse for the POI is ill-conditioned)
+    sd2["outc.conv.weight"] *= head
+    sd2["outc.conv.bias"] *= head
     net.load_state_dict(sd2)
     net.cuda().eval()
     x = synth.smooth_frames(B, H, W, seed=61)
@@ -742,9 +743,8 @@ def test_f16x3_stays_on_the_two_plane_path_with_scaled_logits_and_gammas(E, fact
         got = net.predict(x.cuda(), consistency=True, project_poi=True)
         want = torch_ref.predict(x, sd2, court, poi, warp_size=(W, H), unet_size=(W, H), target_size=(W, H), project_poi=True)
     assert net.range_fallbacks == 0 and (net.range_rescales >= 1 or factor < 1000)
-    # (with the logits scaled by 2^12 the STN's theta itself grows to a few hundred: the bound is relative to it)
-    assert _maxerr(got["theta"].cpu(), want["theta"]) < 1e-4 * max(1.0, float(want["theta"].abs().max()) / 8.0)
-    assert _maxerr(got["logits"].cpu(), want["logits"]) < 5e-4 * factor
+    assert _maxerr(got["theta"].cpu(), want["theta"]) < 1e-4
+    assert _maxerr(got["logits"].cpu(), want["logits"]) < 5e-4 * head
     assert _maxerr(got["poi"].cpu(), want["poi"]) < 1e-4
     wm = (warp_ref.homography_warp(got["theta"].cpu(), court, H, W, "nearest") * 4).to(torch.int32)
     assert torch.equal(got["warp_mask"].cpu(), wm)
