@@ -150,6 +150,11 @@ typedef struct sfh_conv_desc {
    * all-zero `shift` and let sfh_splitk_finish add the slabs, the real shift, the residual and the activation. */
   int32_t ksplit;
   int64_t ksplit_stride;
+  /* sfh_conv_s3_fwd, 3x3 stride 1, plain output (optional): fp32 NHWC tensor (B, H, W, cout) the accumulators START from,
+   * in accumulator units - i.e. a residual r enters as r / scale[c], which the caller arranges in the producer of that
+   * tensor (the fused Up block: the composed 2x2 conv writes its partial divided by the skip-half conv's scale).  Loaded
+   * in the prologue instead of sixteen dependent reads in the epilogue. */
+  const float* acc_init;
 } sfh_conv_desc;
 
 const char* sfh_last_error(void);

@@ -35,7 +35,7 @@ class ConvDesc(C.Structure):
         ("head_w", _p), ("head_b", _p), ("head_nc", _i), ("head_skip_dst", _i),
         ("head_logits", _p), ("head_stn", _p), ("head_frame", _p),
         ("h2_overflow", _p), ("h2_exp_src", _i), ("h2_exp_dst", _i), ("h2_exp_res", _i), ("h2_range", _p),
-        ("wg_couts", _i), ("split_arith", _i), ("ksplit", _i), ("ksplit_stride", C.c_int64),
+        ("wg_couts", _i), ("split_arith", _i), ("ksplit", _i), ("ksplit_stride", C.c_int64), ("acc_init", _p),
     ]
 
     def __init__(self, *args, **kw):

@@ -338,6 +338,32 @@ __global__ __launch_bounds__(C::NT, (C::NP == 2 && !DB) ? SFH_H2_WAVES_PER_SIMD 
   for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
     for (int mi = 0; mi < C::MT_M; ++mi) acc[ni][mi] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  // sfh_conv_desc.acc_init: the accumulators start from an fp32 NHWC tensor in ACCUMULATOR units (the partial of the
+  // other half of a fused Up block, written by its producer divided by this layer's scale) instead of zero.  The sixteen
+  // loads are requested here and land under the first stage's DMA wait; added as a residual in the epilogue they were
+  // sixteen load -> wait -> use round trips at the END of the workgroup (49 % of a wave's life at u4.skip).
+  if constexpr (C::KS == 3 && C::STRIDE == 1) {
+    if (d.acc_init) {
+      const __amdgpu_buffer_rsrc_t ri =
+          __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.acc_init), 0, (int)kOOB, 0x00020000);
+      const unsigned cs_i = (unsigned)d.cout;                        // channel stride of acc_init = all couts of the layer
+      const unsigned c_lane_i = (unsigned)(n0 + 32 * wn + 4 * lg);
+#pragma unroll
+      for (int mi = 0; mi < C::MT_M; ++mi) {
+        const int sgi = wm * C::MT_M + mi;
+        const int sy = sgi / C::SUBX, sx = sgi - sy * C::SUBX;
+        const int oy = sy * C::SH + lq / C::SW, ox = sx * C::SW + lq % C::SW;
+        const int x = x0 + ox, r = r0 + oy;
+        const int b = (int)__umulhi((unsigned)r, g.rows_magic);
+        const int y = r - b * g.rows_per_img;
+        const bool ok = x < g.Wo && r < g.rows_total && y < g.Ho;
+        const unsigned off = ok ? (((unsigned)(b * g.Ho + y) * (unsigned)g.Wo + (unsigned)x) * cs_i + c_lane_i) * 4u : kOOB;
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+          acc[ni][mi] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ri, (int)off, ni * 64, 0));
+      }
+    }
+  }
 
   // weight fragments: a ring of WD register sets, tap t of a stage lives in set (R0 + t) % WD and the set that
   // tap t - 1 leaves is refilled with tap t + WD - 1.  Two sets (one tap ahead) are the default for both formats.
@@ -1114,6 +1140,9 @@ extern "C" int sfh_conv_s3_fwd(const sfh_conv_desc* dp, void* stream_) {
                     d.head_logits && d.head_nc >= 1 && d.head_nc <= 8 && (!d.head_stn || (d.head_frame && d.head_nc <= 5)),
                 "conv_s3_fwd: the fused OutConv head needs a 3x3 stride-1 conv with 64 output channels and a plain output");
   SFH_REQUIRE(!d.head_skip_dst || d.head_w, "conv_s3_fwd: head_skip_dst without a head");
+  SFH_REQUIRE(!d.acc_init || (d.ksize == 3 && d.stride == 1 && d.out_mode == SFH_OUT_NHWC && !(d.ksplit > 1) &&
+                              (unsigned long long)d.batch * d.H * d.W * d.cout * 4ULL < 0xFFFFFFF0ULL),
+              "conv_s3_fwd: acc_init needs a 3x3 stride-1 conv with a plain output and an initial tensor below 4 GiB");
   if (d.ksplit > 1)
     SFH_REQUIRE(d.ksplit <= d.c0 / 32 && !d.src1 && d.dst_fmt == SFH_FMT_F32 && !d.relu && !d.residual && !d.dst_pool &&
                     !d.head_w && d.out_mode == SFH_OUT_NHWC && d.ksplit_stride % 16 == 0 &&

@@ -533,14 +533,16 @@ class PackedConv:
 
     def run(self, src0, batch, H, W, dst, src1=None, pool0=False, pad1=(0, 0), residual=None, tile=None,
             dst_pool=None, up_dst=None, head=None, wg_couts=0, exp_src=None, exp_dst=None, exp_res=None,
-            range_word=None, ksplit=0, slabs=None):
+            range_word=None, ksplit=0, slabs=None, acc_init=None, scale=None, shift_border=None):
         """src0/src1: NHWC float32 tensors, or split tensors of the layer's format (S3 bfloat16 / H2 float16);
         dst/residual/dst_pool: float32 NHWC or the same split format (by dtype).  H, W: conv input frame.
         H2 tensors: exp_src / exp_dst / exp_res = exponents of the sources / dst and dst_pool / an H2 residual
         (None: the conventional SFH_H2_ACT_EXP), range_word: device address of dst's range word (H2Ranges).
         ksplit > 1 (split-operand kernel, one source): the K loop is split over ksplit copies of the grid that write
         fp32 partial slabs (`slabs`: float32 tensor (ksplit, B, Ho, Wo, cout)), and sfh_splitk_finish adds them up
-        with this layer's shift, residual and ReLU into dst - for grids that alone leave most of the chip idle."""
+        with this layer's shift, residual and ReLU into dst - for grids that alone leave most of the chip idle.
+        acc_init (3x3 stride 1): float32 NHWC (B, H, W, cout) tensor the accumulators start from, in accumulator units
+        (sfh_conv_desc.acc_init); scale / shift_border: tensors used instead of the layer's own for this launch."""
         lib = _lib.load()
         d = ConvDesc()
         if self.fmt == "h2" and exp_src is not None:
@@ -591,8 +593,13 @@ class PackedConv:
             d.tile = choose_tile_s3(batch, ho, wo, self.stride, zr, self.cout // 64, self.ksize)
         else:
             d.tile = choose_tile(batch, ho, wo, self.stride, zr)
-        d.wpacked, d.scale, d.shift = self.wpacked.data_ptr(), self.scale.data_ptr(), self.shift.data_ptr()
+        d.wpacked, d.shift = self.wpacked.data_ptr(), self.shift.data_ptr()
+        d.scale = (scale if scale is not None else self.scale).data_ptr()
         d.cout, d.relu = self.cout, 1 if self.relu else 0
+        if acc_init is not None:
+            if acc_init.dtype != torch.float32 or tuple(acc_init.shape) != (batch, H, W, self.cout) or not acc_init.is_contiguous():
+                raise ValueError(f"acc_init must be a contiguous float32 tensor {(batch, H, W, self.cout)}")
+            d.acc_init = acc_init.data_ptr()
         if head is not None:   # OutConv fused behind this conv (sfh_conv_desc.head_*)
             d.head_w, d.head_b, d.head_nc = head["w"].data_ptr(), head["b"].data_ptr(), head["nc"]
             d.head_logits = head["logits"].data_ptr()
@@ -604,7 +611,7 @@ class PackedConv:
         d.residual = residual.data_ptr() if residual is not None else None
         d.residual_f32 = 1 if (residual is not None and residual.dtype == torch.float32
                                and dst.dtype in _SPLIT_DTYPES) else 0
-        sb = getattr(self, "shift_border", None)
+        sb = shift_border if shift_border is not None else getattr(self, "shift_border", None)
         d.shift_border = sb.data_ptr() if sb is not None else None
         d.dst, d.dst_cs = dst.data_ptr(), _chan(dst)
         d.out_mode = _lib.OUT_UPSCATTER2 if self.transposed else _lib.OUT_NHWC
@@ -695,10 +702,12 @@ class UNetEngine:
         exponents and the device words the kernels raise to the largest magnitude they produced; `overflow`:
         optional int32 device word OR-ed with 1 on any saturation); "fp32" - fp32 activations and fp32 MFMA."""
         self.bilinear = bool(net.unet_bilinear)
-        # fused Up levels where the composed 2x2 conv runs first (see run()): the two full-resolution-most
-        # levels, where that conv is memory-heavy (measured per level: none 629, {4} 634, {3,4} 638, all 635
-        # frames/s)
-        self.up_swap = {3, 4}
+        # fused Up levels where the composed 2x2 conv runs first (see run()) and the skip-half 3x3 conv finishes.  Round 2
+        # (the partial added as a residual at the end of the 3x3 conv): none 629, {4} 634, {3,4} 638, all four 635 frames/s;
+        # round 3 (the 3x3 conv STARTS from the partial, sfh_conv_desc.acc_init), one device, ms per batch: {3,4} without
+        # seeding 14.58 / 14.70, {3,4} seeded 14.58 / 14.66, {2,3,4} 14.60 / 14.57, all four 14.43 / 14.56
+        self.up_swap = {int(c) for c in os.environ.get("SFH_UP_SWAP", "1234") if c.isdigit()}
+        self.up_seed = {}          # level -> the skip-half conv starts from the partial (sfh_conv_desc.acc_init)
         if precision not in PRECISIONS:
             raise ValueError(f"precision={precision!r}: expected one of {sorted(PRECISIONS)}")
         self.device = device
@@ -735,6 +744,9 @@ class UNetEngine:
                 # the partial enters the fused conv's epilogue as a residual, i.e. after the BatchNorm scale:
                 # the skip-half carries that scale itself (shift stays 0), times its own operand scaling
                 L[f"up{i}.skip"].scale.copy_(L[f"up{i}.fused"].scale_bn[:cv1.out_channels] * L[f"up{i}.skip"].escale)
+                # accumulator seeding (run()) divides by this scale: only where no channel's BatchNorm scale vanishes
+                smin = float(L[f"up{i}.skip"].scale.abs().min())
+                self.up_seed[i] = (os.environ.get("SFH_UP_SEED", "1") != "0") and 1e-30 < smin < float("inf")
             if not self.bilinear:  # bilinear variant (A3b): parameter-free 2x upsampling kernel instead
                 L[f"up{i}.up"] = PackedConv(up.up.weight, up.up.bias, None, 1, cin, relu=False, transposed=True,
                                             tag="convT2x2", fmt=fmt)
@@ -851,8 +863,25 @@ class UNetEngine:
                 up_dst = (hs, ws_) if (ey or ex) else None
 
                 def level(y=y, ny=ny, skip=skip, nskip=nskip, part=part, mid=mid, nmid=nmid, fu=fu, sk=sk,
-                          up_dst=up_dst, hs=hs, ws_=ws_, hy=hy, wy=wy, ey=ey, ex=ex, swap=i in self.up_swap):
-                    if swap:
+                          up_dst=up_dst, hs=hs, ws_=ws_, hy=hy, wy=wy, ey=ey, ex=ex, swap=i in self.up_swap,
+                          seed=self.up_seed.get(i, False)):
+                    if swap and seed:
+                        # as below, but the partial is written in the skip-half conv's ACCUMULATOR units (divided by its
+                        # scale) and that conv STARTS from it (sfh_conv_desc.acc_init): sixteen loads in its prologue
+                        # instead of sixteen dependent reads at its end
+                        fu.relu, sk.relu = False, True
+                        a_fu, a_sk = rg.args(ny, None), rg.args(nskip, nmid)
+                        if fu.fmt == "h2":      # bring both scales up to date with the exponents before dividing them
+                            fu._fold_exp_src(a_fu["exp_src"])
+                            sk._fold_exp_src(a_sk["exp_src"])
+                        key = (fu.exp_src, sk.exp_src)
+                        if getattr(fu, "_seed_key", None) != key:
+                            div = sk.scale.repeat(4)
+                            fu._seed_scale, fu._seed_border, fu._seed_key = fu.scale / div, fu.shift_border / div, key
+                        fu.run(y, B, hy + ey, wy + ex, part, up_dst=up_dst, scale=fu._seed_scale,
+                               shift_border=fu._seed_border, **a_fu)
+                        sk.run(skip, B, hs, ws_, mid, acc_init=part, **a_sk)
+                    elif swap:
                         # composed 2x2 conv first: it writes the 4 B fp32 partial instead of reading one and writing
                         # 6 B of S3; the MFMA-bound skip-half 3x3 conv then absorbs the residual, the ReLU and the split
                         fu.relu, sk.relu = False, True
