@@ -91,6 +91,17 @@ __device__ __forceinline__ void sfh_h2_report(unsigned over, unsigned* overflow,
   }
 }
 
+
+// lane ^ 1 and lane ^ 8 exchanges of the pooling maxima as DPP moves (v_mov_b32_dpp quad_perm:[1,0,3,2] / row_ror:8): __shfl_xor
+// compiles to ds_bpermute_b32, i.e. 32-64 trips per lane through the LDS queue that the co-resident waves' operand reads
+// share (the pooled output was 14.6 % of a wave's life in the 64-channel layers, more than the four times larger pass 1)
+__device__ __forceinline__ float sfh_dpp_xor1(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float sfh_dpp_xor8(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xF, 0xF, true));
+}
+
 constexpr unsigned kSfhOOB = 0xFFFFFFF0u;  // byte offset that the buffer range check rejects
 
 // CFG supplies SUBX, SH, SW, FLATROWS; G supplies Ho, Wo, rows_total, rows_per_img, rows_magic.
@@ -307,14 +318,14 @@ __device__ __forceinline__ void sfh_conv_epilogue(const sfh_conv_desc& d, const 
         f32x4 m = acc[ni][mi];
         if (CFG::SH == 2) {
 #pragma unroll
-          for (int j = 0; j < 4; ++j) m[j] = sfh_max_nan(m[j], __shfl_xor(m[j], 8));
+          for (int j = 0; j < 4; ++j) m[j] = sfh_max_nan(m[j], sfh_dpp_xor8(m[j]));
         } else {
           const f32x4 o = acc[ni][mi + VSTEP < MT ? mi + VSTEP : mi];
 #pragma unroll
           for (int j = 0; j < 4; ++j) m[j] = sfh_max_nan(m[j], o[j]);
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) m[j] = sfh_max_nan(m[j], __shfl_xor(m[j], 1));
+        for (int j = 0; j < 4; ++j) m[j] = sfh_max_nan(m[j], sfh_dpp_xor1(m[j]));
         const unsigned nioff = pni_off(ni);
         if (h2) {
           if constexpr ((FMTS & 2) != 0) {
