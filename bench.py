@@ -156,6 +156,31 @@ def train_bench(args):
         "config": {"workload": "BASELINE config 3: Reconstructor training step, CE + SmoothL1 + RRMSE + consistency CE"}})
 
 
+def _timed_predicts(net, x, n, warm, pipeline, **kw):
+    """n timed predict() calls on one resident batch (pipeline: predict_async with two batches in flight) -> seconds"""
+    import torch
+
+    def run(m):
+        if not pipeline:
+            for _ in range(m):
+                net.predict(x, **kw)
+            return
+        prev = None
+        for _ in range(m):
+            h = net.predict_async(x, **kw)
+            if prev is not None:
+                prev.result()
+            prev = h
+        prev.result()
+    with torch.no_grad():
+        run(warm)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        run(n)
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0
+
+
 def extra_configs(args):
     """BASELINE configs 3 and 5 on this GPU, a few steps each (driver-observed numbers for every
     single-GPU config in one default run): C5 = predict() with consistency + POI on 16 frames of
@@ -178,16 +203,8 @@ def extra_configs(args):
     x = synth.frames_to_float(synth.synth_frames_u8(B, H, W, seed=0)).to(dev)
     for prec in ("bf16x6", "fp32"):
         net.precision = prec
-        with torch.no_grad():
-            for _ in range(2):
-                net.predict(x, consistency=False)
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            n = 4
-            for _ in range(n):
-                net.predict(x, consistency=False)
-            torch.cuda.synchronize()
-            el = time.perf_counter() - t0
+        n = 4
+        el = _timed_predicts(net, x, n, 2, not args.no_pipeline, consistency=False)
         res[f"C2_640x360_batch16_{prec}"] = {
             "value": round(B * n / el, 2), "unit": "frames/s", "ms_per_step": round(el / n * 1e3, 2), "steps": n, "warmup": 2,
             "precision": prec, "workload": "the headline workload (predict(), 640x360, batch 16, theta + warp_mask) in this arithmetic mode"}
@@ -202,16 +219,8 @@ def extra_configs(args):
     net.load_state_dict(synth.synth_state_dict(net.state_dict(), 0))
     net.to(dev).eval()
     x = synth.frames_to_float(synth.synth_frames_u8(B, H, W, seed=0)).to(dev)
-    with torch.no_grad():
-        for _ in range(2):
-            net.predict(x, consistency=True, project_poi=True)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        n = 4
-        for _ in range(n):
-            net.predict(x, consistency=True, project_poi=True)
-        torch.cuda.synchronize()
-        el = time.perf_counter() - t0
+    n = 4
+    el = _timed_predicts(net, x, n, 2, not args.no_pipeline, consistency=True, project_poi=True)
     res["C5_1280x720_batch16_pitch_template_poi"] = {
         "value": round(B * n / el, 2), "unit": "frames/s", "ms_per_step": round(el / n * 1e3, 2), "steps": n, "warmup": 2,
         "workload": "predict(consistency=True, project_poi=True), 1280x720, batch 16, pitch_mask_v3_nc4_hd template, 33-point POI"}
@@ -250,6 +259,9 @@ def main():
     ap.add_argument("--share-gpu", action="store_true",
                     help="rehearsal on a one-GPU box: every rank uses cuda:0 (needs --dist-backend gloo; the value "
                          "then measures nothing)")
+    ap.add_argument("--no-pipeline", action="store_true",
+                    help="call predict() per step instead of predict_async() (two batches in flight: the ResNet-STN + warp of "
+                         "batch k on a side stream under the UNet of batch k + 1)")
     ap.add_argument("--no-extra-configs", action="store_true",
                     help="skip the short C3 (training step) and C5 (1280x720) measurements appended at N=1")
     args = ap.parse_args()
@@ -302,15 +314,32 @@ def main():
     # while the next batch's kernels run (sharding.ResultGather; the final device synchronize covers it)
     gather = sharding.ResultGather(world, B, dev, depth=2) if world > 1 else None
 
-    def step(k):
-        out = net.predict(frames[k % nbatches], consistency=args.consistency, project_poi=args.consistency)
+    pending = []    # predict_async handles: at most two batches in flight
+
+    def finish(h):
+        out = h.result()
         if gather is not None:
             gather.submit(out["theta"], out.get("consist_score"))
         return out
 
+    def step(k, last=False):
+        """one batch through the hot path.  Pipelined (default): submit batch k, then take the result of batch k - 1, so
+        that the small launches behind the UNet (ResNet-STN, warp, CE) run under the next batch's UNet; `last` drains."""
+        x = frames[k % nbatches]
+        if args.no_pipeline:
+            out = net.predict(x, consistency=args.consistency, project_poi=args.consistency)
+            if gather is not None:
+                gather.submit(out["theta"], out.get("consist_score"))
+            return out
+        pending.append(net.predict_async(x, consistency=args.consistency, project_poi=args.consistency))
+        out = None
+        while len(pending) > (0 if last else 1):
+            out = finish(pending.pop(0))
+        return out
+
     with torch.no_grad():
         for k in range(args.warmup):
-            step(k)
+            step(k, last=(k == args.warmup - 1))
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -318,13 +347,28 @@ def main():
         engine.PackedConv.timer = timer
         t0 = time.perf_counter()
         for k in range(args.steps):
-            out = step(k)
+            out = step(k, last=(k == args.steps - 1))      # the K-th call drains the pipeline: exactly K batches are timed
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         elapsed = time.perf_counter() - t0
         engine.PackedConv.timer = None
 
+    # the same K steps once more WITHOUT the pipeline: per-kernel durations of launches that run alone on the chip (under
+    # the pipeline the ResNet-STN launches of batch k share the CUs with the UNet launches of batch k + 1, so every launch
+    # of the timed region above takes longer than it would alone although the batch takes less)
+    alone = None
+    if not args.no_pipeline:
+        with torch.no_grad():
+            tm2 = engine.ConvTimer()
+            engine.PackedConv.timer = tm2
+            t1 = time.perf_counter()
+            for k in range(args.steps):
+                net.predict(frames[k % nbatches], consistency=args.consistency, project_poi=args.consistency)
+            torch.cuda.synchronize()
+            el2 = time.perf_counter() - t1
+            engine.PackedConv.timer = None
+        alone = (tm2.summary(), el2)
     el = torch.tensor([elapsed], device=dev, dtype=torch.float64)
     if world > 1:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
@@ -354,10 +398,19 @@ def main():
                 "avg_launch_ms": round(ms / max(n, 1), 4),
                 "algorithmic_gflop_per_launch": round(fl / max(n, 1) / 1e9, 2),
                 "share_of_step_time": round(ms * 1e-3 / elapsed, 4)}
+    if alone is not None:
+        n2, fl2, ms2 = alone[0].get("doubleconv3x3", (0, 0.0, 1.0))
+        a2 = fl2 / (ms2 * 1e-3) / 1e12 if n2 else 0.0
+        roofline["note"] = ("timed region = predict_async(): launches of two batches share the chip, so a launch's duration here "
+                            "includes what it gives to the other batch's launches; `unpipelined` = the same kernel timed over "
+                            "the same number of predict() steps right after, alone on the chip")
+        roofline["unpipelined"] = {"achieved": round(a2, 2), "frac": round(a2 / peak, 4), "avg_launch_ms": round(ms2 / max(n2, 1), 4),
+                                   "ms_per_step": round(alone[1] / args.steps * 1e3, 3),
+                                   "frames_per_s": round(B * args.steps / alone[1], 2)}
     # every timed kernel group against the roofline that bounds it: conv groups against the matrix peak of the mode
     # (algorithmic FLOPs), the homography warp against HBM (algorithmic bytes, SURVEY 8d: B*h*w*4 + Ht*Wt*4 + 36*B)
     other = {}
-    for t, v in summ.items():
+    for t, v in (alone[0] if alone is not None else summ).items():      # (pipelined run: from the unpipelined pass, see above)
         if t == "warp":
             tbs = v[1] / (v[2] * 1e-3) / 1e12
             other[t] = {"launches": v[0], "bound": "hbm", "us_per_launch": round(v[2] * 1e3 / v[0], 2),
@@ -425,6 +478,8 @@ def main():
                                    f"batch {B}/GPU, req_outputs=theta,warp_mask"
                                    + (",consistency,poi" if args.consistency else ""),
                        "frames_per_gpu_per_step": B, "global_batch": B * world,
+                       "pipeline": ("none: predict() per step" if args.no_pipeline else
+                                    "predict_async(): two batches in flight, ResNet-STN + warp of batch k on a side stream under the UNet of batch k + 1"),
                        "precision": prec, "range_fallbacks": int(getattr(net, "range_fallbacks", 0)),
                        "range_rescales": int(getattr(net, "range_rescales", 0)),
                        "parallelism": (f"frame-sharded x{world}, all_gather(theta) over "
@@ -436,6 +491,8 @@ def main():
                            "note": "UNet + ResNet34-STN algorithmic FLOPs of a batch / ms_per_step, against the matrix peak of the mode"},
             "cpu_baseline": cpu_baseline,
             "kernel_groups": other,
+            "kernel_groups_measured_in": ("the unpipelined pass after the timed region (launches alone on the chip)"
+                                          if alone is not None else "the timed region"),
             "other_configs": other_configs,
         }
         print(json.dumps(line), flush=True)

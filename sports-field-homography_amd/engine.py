@@ -763,12 +763,12 @@ class UNetEngine:
             self.outuv = (_f32c(net.outuv.conv.weight.detach(), "outuv.weight"),
                           _f32c(net.outuv.conv.bias.detach(), "outuv.bias"))
 
-    def run(self, x, want_stn_in=False, want_argmax=False, want_uv=False):
+    def run(self, x, want_stn_in=False, want_argmax=False, want_uv=False, stn_slot=0):
         """x: (B,3,H,W) float32 NCHW on the GPU.  Returns dict with logits (NCHW, fresh),
         and optionally stn_in (NHWC8 workspace), argmax (B,H,W uint8), uv, plus the NHWC
         workspace tensors x_top / y4 for callers that need them (x_top_exp: exponent of x_top if it is H2)."""
         with _stream_scope():
-            return self._run(x, want_stn_in, want_argmax, want_uv)
+            return self._run(x, want_stn_in, want_argmax, want_uv, stn_slot)
 
     def first_step(self, keys):
         """index of the first launch of the last run() that writes an H2 tensor whose exponent key is in `keys`"""
@@ -786,7 +786,9 @@ class UNetEngine:
                 fn()
         return self._last_out
 
-    def _run(self, x, want_stn_in, want_argmax, want_uv):
+    def _run(self, x, want_stn_in, want_argmax, want_uv, stn_slot=0):
+        """stn_slot: which of the STN-input buffers this pass writes (Reconstructor.predict_async alternates two, so that
+        the ResNet of batch k can still read its input while the UNet of batch k + 1 writes the other)"""
         lib = _lib.load()
         x = _f32c(x, "input frames")
         B, C, H, W = x.shape
@@ -844,7 +846,7 @@ class UNetEngine:
         logits = torch.empty((B, self.nc, H, W), dtype=torch.float32, device=x.device)
         if want_stn_in and self.nc + 3 > 8:
             raise NotImplementedError("mask_classes > 5 with resnet_input='img+mask' needs a wider STN input buffer")
-        stn_in = ws.get("stn_in", (B, H, W, 8), zero=True) if want_stn_in else None
+        stn_in = ws.get("stn_in" if not stn_slot else f"stn_in{stn_slot}", (B, H, W, 8), zero=True) if want_stn_in else None
         head = None
         if (s3 and not want_argmax and not (want_uv and self.outuv is not None)
                 and L["up4.conv.3"].cout_real == 64 and os.environ.get("SFH_FUSE_HEAD", "1") != "0"):

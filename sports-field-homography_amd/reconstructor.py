@@ -51,6 +51,41 @@ torch.nn.modules.module.register_module_buffer_registration_hook(_count_registra
 torch.nn.modules.module.register_module_module_registration_hook(_count_registration)
 
 
+class _Done:
+    """handle of a batch that was computed synchronously"""
+
+    def __init__(self, out):
+        self._out = out
+
+    def result(self):
+        return self._out
+
+
+class _Pending:
+    """handle of a batch in flight (Reconstructor.predict_async)"""
+
+    def __init__(self, net, x, consistency, project_poi, out, done):
+        self.net, self.x, self.args, self.out, self.done = net, x, (consistency, project_poi), out, done
+        self.stale = False
+        self._final = None
+
+    def result(self):
+        """predict()'s dict; the caller's current stream is ordered behind the batch"""
+        if self._final is not None:
+            return self._final
+        net = self.net
+        if not self.stale and net._pipe_check(self):
+            cur = torch.cuda.current_stream(self.x.device)
+            cur.wait_event(self.done)
+            for t in self.out.values():
+                t.record_stream(cur)
+            self._final = self.out
+        else:      # its range check (or an earlier batch's) found a saturated tensor: recompute with the fixed exponents
+            self._final = net.predict(self.x, consistency=self.args[0], project_poi=self.args[1])
+        self.out = self.x = None
+        return self._final
+
+
 class Reconstructor(nn.Module):
     """UNet segmentation + ResNet-STN homography regression + court-template warp."""
 
@@ -300,6 +335,7 @@ class Reconstructor(nn.Module):
         configuration only - packed weights and workspaces are rebuilt in the worker on first use."""
         st = self.__dict__.copy()
         st["_engines"] = st["_engine_stamp"] = st["_tmpl_shared"] = st["_h2_ranges"] = None
+        st.pop("_pipe", None)
         st.pop("_stamp_tensors", None)
         st.pop("_stamp_ptrs", None)
         st.pop("_bn_snapshot", None)       # training: copies of the BatchNorm statistics (training._BNSnapshot)
@@ -469,7 +505,83 @@ class Reconstructor(nn.Module):
         self._require_eval("predict")
         if x.shape[0] == 0:
             return self._empty_outputs(x, predict=True, consistency=consistency, project_poi=project_poi)
+        p = self.__dict__.get("_pipe")
+        if p is not None:       # batches of predict_async() may still be reading the buffers this call is about to write
+            for ev in p["stem_read"]:
+                if ev is not None:
+                    torch.cuda.current_stream(p["device"]).wait_event(ev)
         return self._chunked(self._predict_one, x, consistency, project_poi)
+
+    def predict_async(self, x, consistency=True, project_poi=False):
+        """predict() for callers that feed batch after batch (predict.py's loop): returns a handle at once; `handle.result()`
+        gives predict()'s dict.  The UNet of this batch is enqueued on the caller's stream, everything behind it - ResNet-STN,
+        warp, consistency CE, POI: 36 small launches that leave most CUs idle - on a SIDE stream behind an event, so that it
+        runs UNDER THE UNET OF THE NEXT BATCH the caller submits (two STN-input buffers alternate; outputs are fresh
+        tensors).  Same kernels, same bits as predict().  Keep at most two batches in flight: submit k + 1, then take
+        result(k).  The fp16 range check of a batch happens in its result() (one read-back on a third stream, behind that
+        batch only); if a tensor was saturated the pipeline is drained, the exponent lowered and the batches in flight are
+        recomputed with predict()."""
+        self._require_eval("predict_async")
+        simple = (self.use_unet and self.use_resnet and x.shape[0] > 0 and x.shape[0] <= self._max_frames(x)
+                  and not self._needs_resize(x) and self.resnet_input == Input.IMG_AND_MASK)
+        if not simple:      # configurations the pipeline does not cover run synchronously
+            return _Done(self.predict(x, consistency=consistency, project_poi=project_poi))
+        p = self.__dict__.get("_pipe")
+        dev = x.device
+        if p is None or p["device"] != dev:
+            with torch.cuda.device(dev):
+                p = self.__dict__["_pipe"] = {"device": dev, "side": torch.cuda.Stream(dev), "copy": torch.cuda.Stream(dev),
+                                              "slot": 0, "stem_read": [None, None], "inflight": []}
+        cur = torch.cuda.current_stream(dev)
+        slot = p["slot"]
+        p["slot"] ^= 1
+        if p["stem_read"][slot] is not None:          # the batch that used this STN-input buffer last has consumed it
+            cur.wait_event(p["stem_read"][slot])
+        off = 0
+        run_unet, run_stn, tail = self._predict_phases(x, off, consistency, project_poi, stn_slot=slot)
+        r = run_unet()
+        unet_done = torch.cuda.Event()
+        unet_done.record(cur)
+        side = p["side"]
+        side.wait_event(unet_done)
+        with torch.cuda.stream(side):
+            r["logits"].record_stream(side)
+            theta = run_stn(r)
+            stem_read = torch.cuda.Event()
+            stem_read.record(side)                    # (recorded behind the whole ResNet: coarser than needed, never early)
+            ret = tail(r, theta)
+            done = torch.cuda.Event()
+            done.record(side)
+        p["stem_read"][slot] = stem_read
+        h = _Pending(self, x, consistency, project_poi, ret, done)
+        p["inflight"].append(h)
+        return h
+
+    def _pipe_check(self, h):
+        """range check of one pipelined batch (called by its result()): True = the outputs stand"""
+        rg = self._h2_ranges
+        p = self.__dict__["_pipe"]
+        if h in p["inflight"]:
+            p["inflight"].remove(h)
+        if (self._forced_precision or self.precision) != "f16x3" or rg is None or not self.range_guard:
+            return True
+        with torch.cuda.stream(p["copy"]):
+            p["copy"].wait_event(h.done)
+            bits = rg.read()            # synchronises the copy stream only: the next batch's UNet keeps running
+        bad, nonfinite = rg.saturated(bits)
+        if not bad:
+            return True
+        # drain, fix the exponents, and let every batch in flight (this one included) be recomputed synchronously
+        torch.cuda.synchronize(p["device"])
+        rg.reset_words()
+        if not nonfinite:
+            for n in bad:
+                rg.lower(n, bits[n])
+            self.range_rescales += 1
+        for o in p["inflight"]:
+            o.stale = True
+        p["inflight"].clear()
+        return False
 
     def _empty_outputs(self, x, predict, consistency=False, project_poi=False):
         """A batch of zero frames: the reference's torch ops return empty tensors of the usual trailing shapes."""
@@ -496,11 +608,11 @@ class Reconstructor(nn.Module):
     def _predict_one(self, x, off, consistency, project_poi):
         return self._guarded(lambda xi, o: self._predict_phases(xi, o, consistency, project_poi), x, off)
 
-    def _predict_phases(self, x, off, consistency, project_poi):
+    def _predict_phases(self, x, off, consistency, project_poi, stn_slot=0):
         def run_unet(resume=None):
             if not self.use_unet:
                 return None
-            return self._run_unet(x, resume=resume, want_stn_in=self.resnet_input == Input.IMG_AND_MASK)
+            return self._run_unet(x, resume=resume, want_stn_in=self.resnet_input == Input.IMG_AND_MASK, stn_slot=stn_slot)
 
         def run_stn(r, resume=None):
             if not self.use_resnet:

@@ -754,6 +754,58 @@ def test_f16x3_stays_on_the_two_plane_path_with_scaled_logits_and_gammas(E, fact
     assert net.range_rescales == n1 and net.range_fallbacks == 0
 
 
+def test_predict_async_pipeline_gives_predict_s_bits(E):
+    """predict_async(): the ResNet-STN / warp / CE / POI of batch k run on a side stream under the UNet of batch k + 1.
+    Five different batches through the pipeline (two in flight) give exactly predict()'s outputs; a batch that
+    saturates a tensor is noticed in its result(), the pipeline drains, the exponent goes down and the batches in flight
+    are recomputed - still equal to predict(); a synchronous predict() between pipelined batches is safe."""
+    from sfh_amd.reconstructor import Reconstructor
+    B, H, W = 2, 48, 64
+    court = synth.load_court_template("ncaa_nc4_640x360", 4, B)[:, :, :H, :W].contiguous()
+    poi = synth.load_court_poi("pitch", B)
+    sd = None
+    nets = []
+    for _ in range(2):
+        net = Reconstructor(court.cuda(), poi.cuda(), target_size=(W, H), unet_size=(W, H), warp_size=(W, H), warp_with_nearest=True)
+        sd = sd or synth.synth_state_dict(net.state_dict(), 71)
+        net.load_state_dict(sd)
+        nets.append(net.cuda().eval())
+    ref, pipe = nets
+    xs = [synth.smooth_frames(B, H, W, seed=100 + k).cuda() for k in range(5)]
+    with torch.no_grad():
+        want = [ref.predict(x, consistency=True, project_poi=True) for x in xs]
+        got, prev = [], None
+        for k, x in enumerate(xs):
+            h = pipe.predict_async(x, consistency=True, project_poi=True)
+            if prev is not None:
+                got.append(prev.result())
+            if k == 2:      # a synchronous call in the middle of the stream of batches
+                mid = pipe.predict(xs[0], consistency=True, project_poi=True)
+                assert torch.equal(mid["theta"], want[0]["theta"])
+            prev = h
+        got.append(prev.result())
+    torch.cuda.synchronize()
+    for g, w in zip(got, want):
+        assert sorted(g) == sorted(w)
+        for key in w:
+            assert torch.equal(g[key], w[key]), key
+    assert pipe.range_rescales == 0
+    # a checkpoint that saturates inc.mid at the default exponent: noticed in result(), recomputed, same answer as predict()
+    sd2 = _rescaled_checkpoint(sd, 65536.0, [("inc.double_conv.1", ["inc.double_conv.3.weight"])])
+    for n in nets:
+        n.load_state_dict(sd2)
+    with torch.no_grad():
+        want = [ref.predict(x, consistency=True, project_poi=True) for x in xs[:3]]
+        hs = [pipe.predict_async(xs[0], consistency=True, project_poi=True), pipe.predict_async(xs[1], consistency=True, project_poi=True)]
+        got = [hs[0].result()]
+        hs.append(pipe.predict_async(xs[2], consistency=True, project_poi=True))
+        got += [hs[1].result(), hs[2].result()]
+    assert pipe.range_rescales >= 1 and pipe.range_fallbacks == 0
+    for g, w in zip(got, want):
+        for key in w:
+            assert torch.equal(g[key], w[key]), key
+
+
 @pytest.mark.parametrize("B,size", [(1, (50, 70)), (3, (33, 47)), (1, (16, 16)), (5, (64, 48))])
 def test_ragged_batches_and_sizes_vs_oracle(E, B, size):
     """Batch sizes 1 / 3 / 5, odd and minimal frame sizes (16x16 is the smallest frame four 2x2 poolings allow),
