@@ -9,11 +9,16 @@ TAG=${1:-r01}
 ROOTD=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOTD/gpurun_out
 mkdir -p $OUT
-rm -rf $OUT/${TAG}_trace $OUT/${TAG}_fetch $OUT/${TAG}_write $OUT/${TAG}_mfma
+rm -rf $OUT/${TAG}_trace $OUT/${TAG}_trace_np $OUT/${TAG}_fetch $OUT/${TAG}_write $OUT/${TAG}_mfma
 cd /tmp && export TMPDIR=/tmp
 ARGS="--steps 3 --warmup 1 --no-cpu-baseline --no-extra-configs"
+# the default command (two batches in flight): kernel stats that bench.py's roofline.avg_launch_ms must agree with
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_trace -- python3 $ROOTD/bench.py $ARGS > $OUT/${TAG}_trace.log 2>&1
 echo "trace done"
+# one predict() per step: launches alone on the chip, in order (per-layer table; the counter passes below serialise anyway)
+ARGS="$ARGS --no-pipeline"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_trace_np -- python3 $ROOTD/bench.py $ARGS > $OUT/${TAG}_trace_np.log 2>&1
+echo "trace (no pipeline) done"
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/${TAG}_fetch -- python3 $ROOTD/bench.py $ARGS > $OUT/${TAG}_fetch.log 2>&1
 echo "fetch done"
 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/${TAG}_write -- python3 $ROOTD/bench.py $ARGS > $OUT/${TAG}_write.log 2>&1
