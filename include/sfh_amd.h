@@ -333,7 +333,8 @@ int sfh_bn_finalize(const double* acc, int64_t npix, int C, float eps, float mom
                     (optional): nn.BatchNorm2d's int64 step counter, incremented by one */
 /* y = [relu]((z - mean) * invstd * gamma + beta [+ residual]); y_s3 (optional, C % 32 == 0, W = row
  * length of the (rows, W, C) tensor): the same values again in the split layout split_fmt (SFH_FMT_S3 or
- * SFH_FMT_H2; H2: `overflow` as in sfh_f32_to_h2) for the next convolution. */
+ * SFH_FMT_H2; H2: `overflow` as in sfh_f32_to_h2) for the next convolution.  With y_s3, y may be NULL (only the
+ * split copy is written: a layer whose consumers all read the split copy moves a third less). */
 int sfh_bn_apply(const float* z, const float* mean_invstd, const float* gamma, const float* beta,
                  const float* residual, int relu, int64_t npix, int C, float* y, void* y_s3, int W,
                  int split_fmt, uint32_t* overflow, void* stream);
@@ -347,7 +348,7 @@ int sfh_bn_bwd_reduce(const float* dy, const float* y, const float* z, const flo
 int sfh_bn_bwd_apply(const float* dy, const float* y, const float* z, const float* mean_invstd,
                      const float* gamma, const float* beta, const double* acc, int relu, int64_t npix, int C,
                      float* dz, float* dres, void* dz_s3, int W, int split_fmt, uint32_t* overflow, float* acc_f32,
-                     void* stream);   /* dz_s3: optional split copy of dz (split_fmt, overflow: as sfh_bn_apply); acc_f32 (optional,
+                     void* stream);   /* dz_s3: optional split copy of dz (split_fmt, overflow: as sfh_bn_apply; with it dz may be NULL); acc_f32 (optional,
                                          2*C floats): acc as float32 = dbeta | dgamma for the caller */
 /* acc[c] += sum_p x[p][c] over a channel slice of a (npix, cs) tensor: conv / transposed-conv bias
  * gradients.                                                                                       */

@@ -246,34 +246,75 @@ __device__ __forceinline__ void up_tap(int p, int k, int& a, int& d) {
 
 // w2[(q*cout + co)][cx][a][b] = sum over the conv taps that land in window slot (a,b) and over the
 // intermediate channels cu of wconv[co][c0+cu][ky][kx] * wt[cx][cu][dy][dx]
-__global__ void compose_up_weights_kernel(const float* __restrict__ wc, int cout, int c0, int c1,
-                                          const float* __restrict__ wt, int cx, float* __restrict__ w2, long total) {
-  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= total) return;
-  const int b = idx & 1, a = (idx >> 1) & 1;
-  long r = idx >> 2;
-  const int x = (int)(r % cx); r /= cx;
-  const int co = (int)(r % cout);
-  const int q = (int)(r / cout);
-  const int py = q >> 1, px = q & 1;
-  const int cin = c0 + c1;
-  float acc = 0.f;
+// One workgroup = 16 output channels x 16 low-resolution channels of one output parity q; the two weight slabs
+// of 32 intermediate channels are staged through LDS with coalesced loads (the tensors' own layouts have the
+// channel at stride 9 / 4 floats).  Every thread keeps the nine per-tap sums in cu order and adds them into the
+// four window slots in (ky, kx) order.
+constexpr int kUpCu = 32;
+
+template <int PY, int PX>
+__device__ __forceinline__ void compose_up_tile(const float (*swc)[kUpCu * 9 + 1], const float (*swt)[kUpCu * 4 + 4],
+                                                int col, int xl, int n, float (&s)[9]) {
+  for (int cu = 0; cu < n; ++cu) {
+    const float4 t4 = *reinterpret_cast<const float4*>(&swt[xl][cu * 4]);
+    const float t[4] = {t4.x, t4.y, t4.z, t4.w};
+    const float* w = &swc[col][cu * 9];
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const int dy = (PY + ky - 1) & 1, dx = (PX + kx - 1) & 1;
+        s[ky * 3 + kx] += w[ky * 3 + kx] * t[dy * 2 + dx];
+      }
+  }
+}
+
+__global__ __launch_bounds__(256) void compose_up_weights_kernel(const float* __restrict__ wc, int cout, int c0, int c1,
+                                                                 const float* __restrict__ wt, int cx,
+                                                                 float* __restrict__ w2) {
+  __shared__ float swc[16][kUpCu * 9 + 1];
+  __shared__ __attribute__((aligned(16))) float swt[16][kUpCu * 4 + 4];
+  const int tid = threadIdx.x, xl = tid & 15, col = tid >> 4;
+  const int x0 = blockIdx.x * 16, co0 = blockIdx.y * 16, q = blockIdx.z;
+  const int py = q >> 1, px = q & 1, cin = c0 + c1;
+  float s[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int cu0 = 0; cu0 < c1; cu0 += kUpCu) {
+    const int n = min(kUpCu, c1 - cu0);
+    __syncthreads();
+    for (int i = tid; i < 16 * n * 9; i += 256) {
+      const int r = i / (n * 9), k = i - r * (n * 9);
+      swc[r][k] = wc[((long)(co0 + r) * cin + c0 + cu0) * 9 + k];
+    }
+    for (int i = tid; i < 16 * n * 4; i += 256) {
+      const int r = i / (n * 4), k = i - r * (n * 4);
+      swt[r][k] = wt[((long)(x0 + r) * c1 + cu0) * 4 + k];
+    }
+    __syncthreads();
+    switch (q) {
+      case 0: compose_up_tile<0, 0>(swc, swt, col, xl, n, s); break;
+      case 1: compose_up_tile<0, 1>(swc, swt, col, xl, n, s); break;
+      case 2: compose_up_tile<1, 0>(swc, swt, col, xl, n, s); break;
+      default: compose_up_tile<1, 1>(swc, swt, col, xl, n, s); break;
+    }
+  }
+  float acc[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
+#pragma unroll
   for (int ky = 0; ky < 3; ++ky) {
     int ay, dy;
     up_tap(py, ky, ay, dy);
-    if (ay != a) continue;
+#pragma unroll
     for (int kx = 0; kx < 3; ++kx) {
       int ax, dx;
       up_tap(px, kx, ax, dx);
-      if (ax != b) continue;
-      const float* wcp = wc + (((long)co * cin + c0) * 3 + ky) * 3 + kx;   // + cu*9
-      const float* wtp = wt + ((long)x * c1 * 2 + dy) * 2 + dx;             // + cu*4
-      float s = 0.f;
-      for (int cu = 0; cu < c1; ++cu) s += wcp[(long)cu * 9] * wtp[(long)cu * 4];
-      acc += s;
+      const float v = s[ky * 3 + kx];
+      if (ay == 0 && ax == 0) acc[0][0] += v;
+      else if (ay == 0) acc[0][1] += v;
+      else if (ax == 0) acc[1][0] += v;
+      else acc[1][1] += v;
     }
   }
-  w2[idx] = acc;
+  float4* out = reinterpret_cast<float4*>(w2 + (((long)q * cout + co0 + col) * cx + x0 + xl) * 4);
+  *out = make_float4(acc[0][0], acc[0][1], acc[1][0], acc[1][1]);
 }
 
 // shift_border[cls][cv] = shift[cv] + scale[cv] * (sum over the conv taps that fall inside the up-sampled tensor
@@ -774,9 +815,9 @@ extern "C" int sfh_compose_up_weights(const float* wconv, int cout, int c0, int 
                                       float* shift_border, void* stream) {
   SFH_REQUIRE(wconv && wt && bt && scale4 && shift4 && w2 && shift_border && cout > 0 && c0 >= 0 && c1 > 0 && cx > 0,
               "compose_up_weights: bad argument");
-  const long total = 4L * cout * cx * 4;
-  hipLaunchKernelGGL(compose_up_weights_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                     wconv, cout, c0, c1, wt, cx, w2, total);
+  SFH_REQUIRE(cout % 16 == 0 && cx % 16 == 0, "compose_up_weights: cout and cx must be multiples of 16");
+  hipLaunchKernelGGL(compose_up_weights_kernel, dim3((unsigned)(cx / 16), (unsigned)(cout / 16), 4), dim3(256), 0,
+                     (hipStream_t)stream, wconv, cout, c0, c1, wt, cx, w2);
   int rc = sfh_check_launch("compose_up_weights_kernel");
   if (rc) return rc;
   hipLaunchKernelGGL(compose_up_bias_kernel, dim3((unsigned)((64 * cout + 255) / 256)), dim3(256), 0, (hipStream_t)stream,

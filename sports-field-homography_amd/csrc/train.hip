@@ -290,18 +290,6 @@ __device__ __forceinline__ void tr_split8(const float (&v)[8], unsigned short* _
   *reinterpret_cast<tr_u16x8*>(dst + e + 2 * ps) = p2;
 }
 
-// decode thread index -> (row, x, first channel); returns false outside the tensor
-__device__ __forceinline__ bool tr_s3_thread(long i, int W, int C, int xchunks, long& row, int& x, int& c0) {
-  const int g = (int)(i & 3), px = (int)((i >> 2) & 15);
-  long r = i >> 6;
-  const int xc = (int)(r % xchunks); r /= xchunks;
-  const int cb = (int)(r % (C >> 5));
-  row = r / (C >> 5);
-  x = xc * 16 + px;
-  c0 = cb * 32 + g * 8;
-  return x < W;
-}
-
 __device__ __forceinline__ long tr_s3_elem(long row, int x, int c, int W, int C, int np = 3) {
   return ((((row * (C >> 5) + (c >> 5)) * np) * 4 + ((c & 31) >> 3)) * W + x) * 8;
 }
@@ -317,26 +305,47 @@ __device__ __forceinline__ void tr_split8_h2(const float (&v)[8], unsigned short
   *reinterpret_cast<tr_u32x4*>(dst + e + ps) = (tr_u32x4){pa[1][0], pa[1][1], pb[1][0], pb[1][1]};
 }
 
+// Thread mapping of the two kernels below: a workgroup = 64 consecutive pixels (of the flattened (rows, W) tensor) x one
+// 32-channel block, wave g of it = channel group g (8 channels): the per-channel terms are wave-uniform (scalar loads, no
+// vector-memory traffic beside the tensors themselves) and a wave's split-layout store is one 1 KB run per plane.  The
+// fp32 copy (y / dz) is optional: a layer whose only consumers read the split copy skips a third of its traffic.
+__device__ __forceinline__ bool tr_block_thread(long npix, int W, int C, long& p, long& row, int& x, int& c0) {
+  const int nb = C >> 5;
+  const int cb = (int)(blockIdx.x % (unsigned)nb);
+  const long chunk = (long)(blockIdx.x / (unsigned)nb);
+  const int g = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  c0 = cb * 32 + g * 8;
+  p = chunk * 64 + (threadIdx.x & 63);
+  const unsigned r32 = (unsigned)p / (unsigned)W;   // the launchers require npix < 2^31
+  row = (long)r32;
+  x = (int)((unsigned)p - r32 * (unsigned)W);
+  return p < npix;
+}
+
 template <int NP>   // planes of the split copy: 3 = S3 (bf16), 2 = H2 (fp16)
 __global__ __launch_bounds__(256) void bn_apply_s3_kernel(const float* __restrict__ z, const float* __restrict__ mi,
                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                          const float* __restrict__ residual, int relu, int W, int C,
-                                                          int xchunks, long total, float* __restrict__ y,
+                                                          const float* __restrict__ residual, int relu, long npix, int W,
+                                                          int C, float* __restrict__ y,
                                                           unsigned short* __restrict__ y_s3, unsigned* __restrict__ overflow) {
-  const long i = (long)blockIdx.x * 256 + threadIdx.x;
-  if (i >= total) return;
-  long row; int x, c0;
-  if (!tr_s3_thread(i, W, C, xchunks, row, x, c0)) return;
-  const long o = (row * W + x) * C + c0;
+  long p, row; int x, c0;
+  const bool live = tr_block_thread(npix, W, C, p, row, x, c0);
+  float mean[8], invstd[8], gam[8], bet[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    mean[j] = mi[c0 + j];
+    invstd[j] = mi[C + c0 + j];
+    gam[j] = gamma[c0 + j];
+    bet[j] = beta[c0 + j];
+  }
+  if (!live) return;
+  const long o = p * C + c0;
   float v[8];
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
     const f32x4 zz = *reinterpret_cast<const f32x4*>(z + o + 4 * h);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int c = c0 + 4 * h + j;
-      v[4 * h + j] = (zz[j] - mi[c]) * mi[C + c] * gamma[c] + beta[c];
-    }
+    for (int j = 0; j < 4; ++j) v[4 * h + j] = (zz[j] - mean[4 * h + j]) * invstd[4 * h + j] * gam[4 * h + j] + bet[4 * h + j];
     if (residual) {
       const f32x4 r = *reinterpret_cast<const f32x4*>(residual + o + 4 * h);
 #pragma unroll
@@ -347,8 +356,10 @@ __global__ __launch_bounds__(256) void bn_apply_s3_kernel(const float* __restric
 #pragma unroll
     for (int j = 0; j < 8; ++j) v[j] = sfh_relu(v[j]);
   }
-  *reinterpret_cast<f32x4*>(y + o) = (f32x4){v[0], v[1], v[2], v[3]};
-  *reinterpret_cast<f32x4*>(y + o + 4) = (f32x4){v[4], v[5], v[6], v[7]};
+  if (y) {
+    *reinterpret_cast<f32x4*>(y + o) = (f32x4){v[0], v[1], v[2], v[3]};
+    *reinterpret_cast<f32x4*>(y + o + 4) = (f32x4){v[4], v[5], v[6], v[7]};
+  }
   if constexpr (NP == 3) {
     tr_split8(v, y_s3, tr_s3_elem(row, x, c0, W, C), 4L * W * 8);
   } else {
@@ -362,18 +373,28 @@ template <int NP>
 __global__ __launch_bounds__(256) void bn_bwd_apply_s3_kernel(const float* __restrict__ dy, const float* __restrict__ y,
                                                               const float* __restrict__ z, const float* __restrict__ mi,
                                                               const float* __restrict__ gamma, const double* __restrict__ acc,
-                                                              int relu, long npix, int W, int C, int xchunks, long total,
+                                                              int relu, long npix, int W, int C,
                                                               float* __restrict__ dz, float* __restrict__ dres,
                                                               unsigned short* __restrict__ dz_s3, unsigned* __restrict__ overflow,
                                                               const float* __restrict__ beta, float* __restrict__ acc_f32) {
-  const long i = (long)blockIdx.x * 256 + threadIdx.x;
   if (acc_f32 && blockIdx.x == 0)   // dbeta | dgamma as float32 for the caller (one conversion launch less per layer)
     for (int k = threadIdx.x; k < 2 * C; k += 256) acc_f32[k] = (float)acc[k];
-  if (i >= total) return;
-  long row; int x, c0;
-  if (!tr_s3_thread(i, W, C, xchunks, row, x, c0)) return;
-  const long o = (row * W + x) * C + c0;
+  long p, row; int x, c0;
+  const bool live = tr_block_thread(npix, W, C, p, row, x, c0);
   const float inv_n = 1.0f / (float)npix;
+  const bool sign_from_z = relu && !y;
+  float mean[8], invstd[8], gam[8], bet[8], mg[8], mgx[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    mean[j] = mi[c0 + j];
+    invstd[j] = mi[C + c0 + j];
+    gam[j] = gamma[c0 + j];
+    bet[j] = sign_from_z ? beta[c0 + j] : 0.f;
+    mg[j] = (float)acc[c0 + j] * inv_n;
+    mgx[j] = (float)acc[C + c0 + j] * inv_n;
+  }
+  if (!live) return;
+  const long o = p * C + c0;
   float v[8], gg[8];
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
@@ -381,26 +402,23 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_s3_kernel(const float* __res
     const f32x4 zz = *reinterpret_cast<const f32x4*>(z + o + 4 * h);
     f32x4 yy = {1.f, 1.f, 1.f, 1.f};
     if (relu && y) yy = *reinterpret_cast<const f32x4*>(y + o + 4 * h);
-    if (relu && !y) {   // sign recomputed from z (see bn_bwd_reduce_kernel)
+    if (sign_from_z) {   // sign recomputed from z (see bn_bwd_reduce_kernel)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int c = c0 + 4 * h + j;
-        yy[j] = (zz[j] - mi[c]) * mi[C + c] * gamma[c] + beta[c];
-      }
+      for (int j = 0; j < 4; ++j) yy[j] = (zz[j] - mean[4 * h + j]) * invstd[4 * h + j] * gam[4 * h + j] + bet[4 * h + j];
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const int c = c0 + 4 * h + j;
+      const int k = 4 * h + j;
       const float g = yy[j] > 0.f ? g4[j] : 0.f;
-      const float invstd = mi[C + c];
-      const float xh = (zz[j] - mi[c]) * invstd;
-      const float mg = (float)acc[c] * inv_n, mgx = (float)acc[C + c] * inv_n;
-      v[4 * h + j] = gamma[c] * invstd * (g - mg - xh * mgx);
-      gg[4 * h + j] = g;
+      const float xh = (zz[j] - mean[k]) * invstd[k];
+      v[k] = gam[k] * invstd[k] * (g - mg[k] - xh * mgx[k]);
+      gg[k] = g;
     }
   }
-  *reinterpret_cast<f32x4*>(dz + o) = (f32x4){v[0], v[1], v[2], v[3]};
-  *reinterpret_cast<f32x4*>(dz + o + 4) = (f32x4){v[4], v[5], v[6], v[7]};
+  if (dz) {
+    *reinterpret_cast<f32x4*>(dz + o) = (f32x4){v[0], v[1], v[2], v[3]};
+    *reinterpret_cast<f32x4*>(dz + o + 4) = (f32x4){v[4], v[5], v[6], v[7]};
+  }
   if (dres) {
     *reinterpret_cast<f32x4*>(dres + o) = (f32x4){gg[0], gg[1], gg[2], gg[3]};
     *reinterpret_cast<f32x4*>(dres + o + 4) = (f32x4){gg[4], gg[5], gg[6], gg[7]};
@@ -1051,19 +1069,19 @@ extern "C" int sfh_bn_finalize(const double* acc, int64_t npix, int C, float eps
 extern "C" int sfh_bn_apply(const float* z, const float* mean_invstd, const float* gamma, const float* beta,
                             const float* residual, int relu, int64_t npix, int C, float* y, void* y_s3, int W,
                             int split_fmt, uint32_t* overflow, void* stream) {
-  SFH_REQUIRE(z && mean_invstd && gamma && beta && y && npix > 0 && C > 0 && C % 4 == 0, "bn_apply: bad argument");
+  SFH_REQUIRE(z && mean_invstd && gamma && beta && (y || y_s3) && npix > 0 && C > 0 && C % 4 == 0, "bn_apply: bad argument");
   if (y_s3) {
     SFH_REQUIRE(C % 32 == 0 && W > 0 && npix % W == 0, "bn_apply: the split copy needs C %% 32 == 0 and npix = rows * W");
     SFH_REQUIRE(split_fmt == SFH_FMT_S3 || split_fmt == SFH_FMT_H2, "bn_apply: split_fmt=%d (S3 or H2)", split_fmt);
-    const int xchunks = (W + 15) / 16;
-    const long total = (npix / W) * (C / 32) * xchunks * 64;
-    const dim3 grid((unsigned)((total + 255) / 256));
+    const long nblk = ((long)npix + 63) / 64 * (C / 32);
+    SFH_REQUIRE(nblk < (1L << 31) && npix < (1L << 31) - 64, "bn_apply: tensor too large for one launch");
+    const dim3 grid((unsigned)nblk);
     if (split_fmt == SFH_FMT_H2)
       hipLaunchKernelGGL(bn_apply_s3_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, z, mean_invstd, gamma, beta,
-                         residual, relu, W, C, xchunks, total, y, (unsigned short*)y_s3, overflow);
+                         residual, relu, (long)npix, W, C, y, (unsigned short*)y_s3, overflow);
     else
       hipLaunchKernelGGL(bn_apply_s3_kernel<3>, grid, dim3(256), 0, (hipStream_t)stream, z, mean_invstd, gamma, beta,
-                         residual, relu, W, C, xchunks, total, y, (unsigned short*)y_s3, overflow);
+                         residual, relu, (long)npix, W, C, y, (unsigned short*)y_s3, overflow);
     return sfh_check_launch("bn_apply_s3_kernel");
   }
   const long total4 = (long)npix * C / 4;
@@ -1087,20 +1105,21 @@ extern "C" int sfh_bn_bwd_apply(const float* dy, const float* y, const float* z,
                                 const float* gamma, const float* beta, const double* acc, int relu, int64_t npix, int C,
                                 float* dz, float* dres, void* dz_s3, int W, int split_fmt, uint32_t* overflow,
                                 float* acc_f32, void* stream) {
-  SFH_REQUIRE(dy && z && mean_invstd && gamma && acc && dz && (y || !relu || beta) && npix > 0 && C > 0 && C % 4 == 0,
+  SFH_REQUIRE(dy && z && mean_invstd && gamma && acc && (dz || dz_s3) && (y || !relu || beta) && npix > 0 && C > 0 &&
+                  C % 4 == 0,
               "bn_bwd_apply: bad argument (relu needs y, or beta to recompute its sign from z)");
   if (dz_s3) {
     SFH_REQUIRE(C % 32 == 0 && W > 0 && npix % W == 0, "bn_bwd_apply: the split copy needs C %% 32 == 0 and npix = rows * W");
     SFH_REQUIRE(split_fmt == SFH_FMT_S3 || split_fmt == SFH_FMT_H2, "bn_bwd_apply: split_fmt=%d (S3 or H2)", split_fmt);
-    const int xchunks = (W + 15) / 16;
-    const long total = (npix / W) * (C / 32) * xchunks * 64;
-    const dim3 grid((unsigned)((total + 255) / 256));
+    const long nblk = ((long)npix + 63) / 64 * (C / 32);
+    SFH_REQUIRE(nblk < (1L << 31) && npix < (1L << 31) - 64, "bn_bwd_apply: tensor too large for one launch");
+    const dim3 grid((unsigned)nblk);
     if (split_fmt == SFH_FMT_H2)
       hipLaunchKernelGGL(bn_bwd_apply_s3_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, dy, y, z, mean_invstd, gamma,
-                         acc, relu, (long)npix, W, C, xchunks, total, dz, dres, (unsigned short*)dz_s3, overflow, beta, acc_f32);
+                         acc, relu, (long)npix, W, C, dz, dres, (unsigned short*)dz_s3, overflow, beta, acc_f32);
     else
       hipLaunchKernelGGL(bn_bwd_apply_s3_kernel<3>, grid, dim3(256), 0, (hipStream_t)stream, dy, y, z, mean_invstd, gamma,
-                         acc, relu, (long)npix, W, C, xchunks, total, dz, dres, (unsigned short*)dz_s3, overflow, beta, acc_f32);
+                         acc, relu, (long)npix, W, C, dz, dres, (unsigned short*)dz_s3, overflow, beta, acc_f32);
     return sfh_check_launch("bn_bwd_apply_s3_kernel");
   }
   const long total4 = (long)npix * C / 4;

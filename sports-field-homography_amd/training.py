@@ -162,6 +162,7 @@ class Tape:
         self.use_s3 = self.fmt is not None
         self.fmt_code = {"s3": _lib.FMT_S3, "h2": _lib.FMT_H2}.get(self.fmt, _lib.FMT_F32)
         self._s3 = {}
+        self.no_f32 = set()   # ids of activation handles without fp32 storage (conv_bn_act(f32_out=False))
         # f16x3 (H2 copies of activations and gradients): fp16's exponent range has to hold them.
         #   overflow - device word the kernels raise when a value does not fit (checked at the end of the backward pass);
         #   gscale   - power of two all gradients are carried with (the losses are means over B*H*W pixels, their
@@ -240,9 +241,11 @@ class Tape:
 
 
 # --------------------------------------------------------------------------------------- layers
-def _bn_forward(lib, z, bn, relu, residual, tape, want_s3=True):
-    """Batch-statistics BatchNorm (+residual) (+ReLU); updates the running stats in place.  In split-bf16 mode
-    (and want_s3) the S3 copy the next convolution needs is written by the same kernel."""
+def _bn_forward(lib, z, bn, relu, residual, tape, want_s3=True, want_f32=True):
+    """Batch-statistics BatchNorm (+residual) (+ReLU); updates the running stats in place.  In split-operand mode
+    (and want_s3) the split copy the next convolution needs is written by the same kernel.  want_f32=False (with a
+    split copy): nobody reads the fp32 values - the returned tensor is a handle (shape + identity for the tape,
+    no storage behind it) and the kernel writes a third less."""
     B, H, W, C = z.shape
     npix = B * H * W
     acc = tape.zeros((2 * C,), z, torch.float64)
@@ -254,18 +257,23 @@ def _bn_forward(lib, z, bn, relu, residual, tape, want_s3=True):
     # (the kernel also advances nn.BatchNorm2d's step counter: one launch per layer less)
     _lib.check(lib.sfh_bn_finalize(_ptr(acc), npix, C, float(bn.eps), BN_MOMENTUM, _ptr(bn.running_mean),
                                    _ptr(bn.running_var), _ptr(mi), _ptr(nbt), _stream()), "bn_finalize")
-    y = _empty(z.shape, z)
     y_s3 = E.split_empty(tape.fmt, B, H, W, C, z.device) if (want_s3 and tape.use_s3 and C % 32 == 0) else None
+    handle_only = y_s3 is not None and not want_f32
+    y = z.new_empty((1,)).expand(z.shape) if handle_only else _empty(z.shape, z)
     _lib.check(lib.sfh_bn_apply(_ptr(z), _ptr(mi), _ptr(bn.weight.detach()), _ptr(bn.bias.detach()),
-                                _ptr(residual), 1 if relu else 0, npix, C, _ptr(y), _ptr(y_s3), W, tape.fmt_code,
-                                _ptr(tape.overflow), _stream()), "bn_apply")
+                                _ptr(residual), 1 if relu else 0, npix, C, None if handle_only else _ptr(y), _ptr(y_s3),
+                                W, tape.fmt_code, _ptr(tape.overflow), _stream()), "bn_apply")
+    if handle_only:
+        tape.no_f32.add(id(y))
     if y_s3 is not None:
         tape._s3[id(y)] = (y, y_s3)
     return y, mi
 
 
-def _bn_backward(lib, tape, dy, y, z, mi, bn, relu, want_dres, want_s3=False):
-    """want_dres: the layer added a residual before its ReLU (its gradient is returned as dres)."""
+def _bn_backward(lib, tape, dy, y, z, mi, bn, relu, want_dres, want_s3=False, want_f32=True):
+    """want_dres: the layer added a residual before its ReLU (its gradient is returned as dres).
+    want_f32=False (with want_s3): only the split copy of dz is written (its consumers are the split-operand
+    backward-data and backward-filter kernels); the returned dz is None."""
     B, H, W, C = z.shape
     npix = B * H * W
     acc = tape.zeros((2 * C,), z, torch.float64)
@@ -275,9 +283,9 @@ def _bn_backward(lib, tape, dy, y, z, mi, bn, relu, want_dres, want_s3=False):
     gam, bet = bn.weight.detach(), bn.bias.detach()
     _lib.check(lib.sfh_bn_bwd_reduce(_ptr(dy), _ptr(ysign), _ptr(z), _ptr(mi), _ptr(gam), _ptr(bet), 1 if relu else 0,
                                      npix, C, _ptr(acc), _stream()), "bn_bwd_reduce")
-    dz = _empty(z.shape, z)
     dres = _empty(z.shape, z) if want_dres else None
     dz_s3 = E.split_empty(tape.fmt, B, H, W, C, z.device) if (want_s3 and C % 32 == 0) else None
+    dz = _empty(z.shape, z) if (want_f32 or dz_s3 is None) else None
     a = _empty((2 * C,), z)     # dbeta | dgamma as float32, written by the apply kernel
     _lib.check(lib.sfh_bn_bwd_apply(_ptr(dy), _ptr(ysign), _ptr(z), _ptr(mi), _ptr(gam), _ptr(bet), _ptr(acc),
                                     1 if relu else 0, npix, C, _ptr(dz), _ptr(dres), _ptr(dz_s3), W, tape.fmt_code,
@@ -332,8 +340,11 @@ class _Names:
         return self.by_id[id(p)]
 
 
-def conv_bn_act(tape, names, conv, bn, srcs, B, H, W, relu=True, residual=None, need_dx=True, s3_out=True):
+def conv_bn_act(tape, names, conv, bn, srcs, B, H, W, relu=True, residual=None, need_dx=True, s3_out=True,
+                f32_out=True):
     """z = conv(cat(srcs)) + bias; y = [relu](bn_train(z) [+ residual]).
+    f32_out=False: the only consumer of y is a split-operand conv (forward and backward-filter read the split
+    copy): y comes back as a handle without fp32 storage (see _bn_forward).
 
     srcs: [(tensor NHWC, channels used, pad_top, pad_left)], one or two (skip first, like torch.cat
     in unet/unet_parts.py:67).  Stride-1 3x3 / 1x1 convs, and stride-2 ones via zero-stuffing in the
@@ -353,7 +364,10 @@ def conv_bn_act(tape, names, conv, bn, srcs, B, H, W, relu=True, residual=None, 
     z = _empty((B, ho, wo, cout), t0)
     pc.run(tape.s3(t0) if s3 else t0, B, H, W, z, src1=(tape.s3(t1) if s3 else t1) if t1 is not None else None,
            pad1=(srcs[1][2], srcs[1][3]) if t1 is not None else (0, 0))
-    y, mi = _bn_forward(lib, z, bn, relu, residual, tape, want_s3=s3_out)   # s3_out: a conv consumes y
+    if any(id(t) in tape.no_f32 for t in (t0, t1) if t is not None) and not s3:
+        raise RuntimeError("conv_bn_act: a source has no fp32 storage (f32_out=False) but this conv reads fp32")
+    y, mi = _bn_forward(lib, z, bn, relu, residual, tape, want_s3=s3_out,   # s3_out: a conv consumes y
+                        want_f32=f32_out or residual is not None)
 
     def backward():
         dy = tape.pop_grad(y)
@@ -363,14 +377,18 @@ def conv_bn_act(tape, names, conv, bn, srcs, B, H, W, relu=True, residual=None, 
         if t1 is not None:
             wsrc.append((t1, c1, c0, srcs[1][2], srcs[1][3]))
         wg_s3 = s3 and wgrad_s3_ok(ks, stride, cout, wsrc)
+        if not wg_s3 and any(id(t) in tape.no_f32 for (t, *_r) in wsrc):
+            raise RuntimeError("conv_bn_act: a source has no fp32 storage (f32_out=False) but its backward-filter reads fp32")
+        # fp32 dz is read by the fp32 backward-filter kernel and by the zero-stuffing of stride-2 layers only
         dz, dgamma, dbeta, dres, dz_s3 = _bn_backward(lib, tape, dy, y, z, mi, bn, relu, residual is not None,
-                                                      want_s3=s3 and stride == 1 and (need_dx or wg_s3))
+                                                      want_s3=s3 and stride == 1 and (need_dx or wg_s3),
+                                                      want_f32=not (s3 and stride == 1 and wg_s3))
         g = tape.param_grads
         g[names(bn.weight)], g[names(bn.bias)] = dgamma, dbeta
         if conv.bias is not None:
             # a bias in front of a batch-statistics BatchNorm has exactly zero gradient (the batch mean
             # absorbs it); autograd's value is rounding noise around 0
-            g[names(conv.bias)] = tape.zeros((cout,), dz)
+            g[names(conv.bias)] = tape.zeros((cout,), z)
         if residual is not None:
             tape.add_grad(residual, dres)
         if stride == 2:  # zero-stuff dz to the input resolution: stride-1 backward from here on
@@ -388,15 +406,15 @@ def conv_bn_act(tape, names, conv, bn, srcs, B, H, W, relu=True, residual=None, 
             return
         bd = PackedConv.backward_data(w, ks, fmt=tape.fmt if s3 else None, wexp=tape.wexp_of(conv.weight))
         bd.order = tape.order
-        dx = _empty((B, H, W, bd.cout), dz)
+        dx = _empty((B, H, W, bd.cout), z)
         bd.run((dz_s3 if dz_s3 is not None else E.f32_to_split(dz, tape.fmt, tape.overflow)) if s3 else dz, B, H, W, dx)
         if t1 is None:
             tape.add_grad(t0, dx)
             return
-        d0 = _empty(t0.shape, dz)
+        d0 = _empty(t0.shape, z)
         _lib.check(lib.sfh_slice_add(_ptr(dx), H, W, bd.cout, 0, 0, 0, _ptr(d0), B, H, W, c0, 0, _stream()), "slice_add")
         tape.add_grad(t0, d0)
-        d1 = _empty(t1.shape, dz)
+        d1 = _empty(t1.shape, z)
         _lib.check(lib.sfh_slice_add(_ptr(dx), H, W, bd.cout, c0, srcs[1][2], srcs[1][3], _ptr(d1), B, t1.shape[1],
                                      t1.shape[2], c1, 0, _stream()), "slice_add")
         tape.add_grad(t1, d1)
@@ -517,7 +535,9 @@ class UNetTrainer:
 
         def dconv(block, srcs, h, w, need_dx=True, s3_out=True):
             (cv1, bn1), (cv2, bn2) = block.convs()
-            y1 = conv_bn_act(tape, names, cv1, bn1, srcs, B, h, w, need_dx=need_dx)
+            # y1 feeds cv2 only: forward, backward-data and backward-filter of cv2 read its split copy
+            mid_f32 = not (tape.use_s3 and cv1.out_channels % 32 == 0 and cv2.out_channels % 64 == 0 and CAPTURE is None)
+            y1 = conv_bn_act(tape, names, cv1, bn1, srcs, B, h, w, need_dx=need_dx, f32_out=mid_f32)
             return conv_bn_act(tape, names, cv2, bn2, [(y1, y1.shape[3], 0, 0)], B, h, w, s3_out=s3_out)
 
         x1 = dconv(net.inc, [(x, 3, 0, 0)], H, W, need_dx=False)
