@@ -16,8 +16,8 @@
 // Workgroup (4 waves) = 64 couts x 32 cins x 9 taps, looped over a contiguous range of 64-pixel tiles
 // (split-K over workgroups, fp32 atomics at the end).  Per tile the dz pixels and the input halo go
 // global -> LDS by LDS-DMA in the S3 chunk order ([plane][8-channel group][pixel][16 B]; group stride = 4 mod
-// 16 chunks, which makes the transposed reads of a 32-lane half conflict-free); two LDS buffers (the DMA of tile
-// t + 1 lands under the MFMAs of tile t) and two workgroups per CU.  Wave w: cin half w&1
+// 16 chunks, which makes the transposed reads of a 32-lane half conflict-free); one LDS buffer, two
+// workgroups per CU, so that the DMA of one hides under the MFMAs of the other.  Wave w: cin half w&1
 // (16 cins), cout half w>>1 (32 couts): 18 accumulator tiles, per 32-pixel k-step 66 transposed reads
 // against 108 MFMAs.
 #include <hip/amd_detail/amd_hip_unsafe_atomics.h>
@@ -54,7 +54,7 @@ __device__ __forceinline__ bf16x8 frag(s16x4 lo, s16x4 hi) {
 // NP = planes per operand: 3 = S3 tensors (bf16, six products), 2 = H2 tensors (fp16 planes of v * 2^SFH_H2_ACT_EXP,
 // three products; the accumulators are multiplied by 2^-(2 * SFH_H2_ACT_EXP) before they are added to raw)
 template <int TR, int TW, int NP>
-__global__ __launch_bounds__(256, 2) void wgrad_s3_kernel(const WgS3Args a) {
+__global__ __launch_bounds__(256, NP == 2 ? 3 : 2) void wgrad_s3_kernel(const WgS3Args a) {
   static_assert(TR * TW == 64 && (TW == 8 || TW == 16 || TW == 32), "64-pixel tiles, two 32-pixel k-steps");
   constexpr int R4 = 4 * NP;                                         // (plane, group) runs per 32-channel block
   constexpr int HWD = TW + 2, HR = TR + 2, HP = HR * HWD;           // input halo of a tile
@@ -63,7 +63,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_s3_kernel(const WgS3Args a) {
   constexpr int XCH = R4 * PX;
   constexpr int NXI = (HP + 63) / 64;                               // DMA instructions per (plane, group) of the halo
   constexpr int RS = 32 / TW;                                       // tile rows per k-step
-  extern __shared__ __attribute__((aligned(16))) u32x4 lds[];       // 2 buffers x [halo image 4 NP * PX][dz image 8 NP * PD] chunks
+  extern __shared__ __attribute__((aligned(16))) u32x4 lds[];       // [halo image 12 * PX][dz image 24 * PD] chunks
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -101,59 +101,48 @@ __global__ __launch_bounds__(256, 2) void wgrad_s3_kernel(const WgS3Args a) {
 
   const int t_begin = split * a.tps;
   const int t_end = (t_begin + a.tps < a.ntiles) ? t_begin + a.tps : a.ntiles;
-  constexpr unsigned BUFB = (unsigned)(XCH + 8 * NP * PD) * 16u;   // bytes of one LDS buffer (halo image + dz image)
-  // LDS-DMA of tile t into buffer bf: 4 * NP (plane, group) runs of the input halo, 8 * NP of dz; wave w takes NP and 2 * NP
-  auto dma_tile = [&](int t, int bf) {
+  for (int t = t_begin; t < t_end; ++t) {
     const int tx = t % a.ntx, r1 = t / a.ntx;
     const int ty = r1 % a.nty, b = r1 / a.nty;
     const int y0 = ty * TR, x0 = tx * TW;
-    u32x4* const base = lds + bf * (XCH + 8 * NP * PD);
-    unsigned voff[NXI];
-    bool act[NXI];
-#pragma unroll
-    for (int i = 0; i < NXI; ++i) {
-      const int hp = i * 64 + lane;
-      const int r = hp / HWD, c = hp - r * HWD;
-      const int yy = y0 - 1 + r - a.pad_top, xx = x0 - 1 + c - a.pad_left;
-      const bool ok = (unsigned)yy < (unsigned)a.xh && (unsigned)xx < (unsigned)a.xw;
-      voff[i] = ok ? (unsigned)((yy * CBX * R4 * a.xw + xx) * 16) : kOOB;
-      act[i] = hp < HP;
-    }
-    const unsigned xsb = (unsigned)((b * a.xh * CBX + nb32) * R4) * (unsigned)a.xw * 16u;
-#pragma unroll
-    for (int j = 0; j < NP; ++j) {
-      const int pg = wv * NP + j;                      // plane * 4 + group
-      const unsigned soff = xsb + (unsigned)pg * (unsigned)a.xw * 16u;
+    // ---- LDS-DMA: 12 (plane, group) runs of the input halo, 24 of dz; wave w takes 3 and 6 of them
+    {
+      unsigned voff[NXI];
+      bool act[NXI];
 #pragma unroll
       for (int i = 0; i < NXI; ++i) {
-        if (act[i])
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr_t)(base + pg * PX + i * 64), 16, (int)voff[i], (int)soff, 0, 0);
+        const int hp = i * 64 + lane;
+        const int r = hp / HWD, c = hp - r * HWD;
+        const int yy = y0 - 1 + r - a.pad_top, xx = x0 - 1 + c - a.pad_left;
+        const bool ok = (unsigned)yy < (unsigned)a.xh && (unsigned)xx < (unsigned)a.xw;
+        voff[i] = ok ? (unsigned)((yy * CBX * R4 * a.xw + xx) * 16) : kOOB;
+        act[i] = hp < HP;
+      }
+      const unsigned xsb = (unsigned)((b * a.xh * CBX + nb32) * R4) * (unsigned)a.xw * 16u;
+#pragma unroll
+      for (int j = 0; j < NP; ++j) {
+        const int pg = wv * NP + j;                      // plane * 4 + group
+        const unsigned soff = xsb + (unsigned)pg * (unsigned)a.xw * 16u;
+#pragma unroll
+        for (int i = 0; i < NXI; ++i) {
+          if (act[i])
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr_t)(lds + pg * PX + i * 64), 16, (int)voff[i], (int)soff, 0, 0);
+        }
+      }
+      const int py = lane / TW, px = lane - py * TW;
+      const int y = y0 + py, x = x0 + px;
+      const unsigned dvoff = (y < a.H && x < a.W) ? (unsigned)((y * MB * R4 * a.W + x) * 16) : kOOB;
+      const unsigned dsb = (unsigned)((b * a.H * MB + mb64 * 2) * R4) * (unsigned)a.W * 16u;
+#pragma unroll
+      for (int j = 0; j < 2 * NP; ++j) {
+        const int pg8 = wv * (2 * NP) + j;               // plane * 8 + group of the 64 couts
+        const int p = pg8 >> 3, g8 = pg8 & 7;
+        const unsigned soff = dsb + (unsigned)(((g8 >> 2) * R4 + p * 4 + (g8 & 3))) * (unsigned)a.W * 16u;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rdz, (lds_ptr_t)(lds + XCH + pg8 * PD), 16, (int)dvoff, (int)soff, 0, 0);
       }
     }
-    const int py = lane / TW, px = lane - py * TW;
-    const int y = y0 + py, x = x0 + px;
-    const unsigned dvoff = (y < a.H && x < a.W) ? (unsigned)((y * MB * R4 * a.W + x) * 16) : kOOB;
-    const unsigned dsb = (unsigned)((b * a.H * MB + mb64 * 2) * R4) * (unsigned)a.W * 16u;
-#pragma unroll
-    for (int j = 0; j < 2 * NP; ++j) {
-      const int pg8 = wv * (2 * NP) + j;               // plane * 8 + group of the 64 couts
-      const int p = pg8 >> 3, g8 = pg8 & 7;
-      const unsigned soff = dsb + (unsigned)(((g8 >> 2) * R4 + p * 4 + (g8 & 3))) * (unsigned)a.W * 16u;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rdz, (lds_ptr_t)(base + XCH + pg8 * PD), 16, (int)dvoff, (int)soff, 0, 0);
-    }
-  };
-  // Two LDS buffers: the DMA of tile t + 1 is requested right behind the barrier that publishes tile t and lands
-  // under tile t's MFMAs (one barrier per tile; with a single buffer every tile's DMA latency was exposed to its own
-  // workgroup and only the co-resident one covered it: matrix pipe 54 % busy).
-  // (three-plane operands: two buffers of 53 KB would leave one workgroup per CU - single buffer, two barriers per tile)
-  constexpr int NBUF = NP == 2 ? 2 : 1;
-  if (t_begin < t_end) dma_tile(t_begin, 0);
-  for (int t = t_begin; t < t_end; ++t) {
-    const int bf = NBUF == 2 ? ((t - t_begin) & 1) : 0;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();   // tile t has landed for every wave, and every wave is past its reads of the other buffer
-    if (NBUF == 2 && t + 1 < t_end) dma_tile(t + 1, bf ^ 1);
-    const unsigned dzc = dzb + (unsigned)bf * BUFB, xc = xb + (unsigned)bf * BUFB;
+    __syncthreads();
     // ---- two k-steps of 32 pixels
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
@@ -162,7 +151,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_s3_kernel(const WgS3Args a) {
       for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
-          const unsigned ad = dzc + (unsigned)(((p * 8 + 2 * mb) * PD + 32 * s) * 16);
+          const unsigned ad = dzb + (unsigned)(((p * 8 + 2 * mb) * PD + 32 * s) * 16);
           af[mb][p] = frag(tr(ad), tr(ad + 64));
         }
 #pragma unroll
@@ -171,7 +160,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_s3_kernel(const WgS3Args a) {
         bf16x8 bfr[NP];
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
-          const unsigned ad = xc + (unsigned)(((p * 4) * PX + (s * RS + ky) * HWD + kx) * 16);
+          const unsigned ad = xb + (unsigned)(((p * 4) * PX + (s * RS + ky) * HWD + kx) * 16);
           bfr[p] = frag(tr(ad), tr(ad + 64));
         }
         // the kept partial products, smallest first (as in the forward kernel)
@@ -189,10 +178,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_s3_kernel(const WgS3Args a) {
           }
       }
     }
-    if (NBUF == 1) {
-      __syncthreads();   // every wave is done with the buffer before the next tile's DMA lands in it
-      if (t + 1 < t_end) dma_tile(t + 1, 0);
-    }
+    __syncthreads();   // every wave is done with the buffer before the next tile's DMA lands in it
   }
 
   // ---- split-K: add this workgroup's partial sums
@@ -212,7 +198,7 @@ template <int TR, int TW, int NP>
 int launch(WgS3Args a, hipStream_t stream) {
   constexpr int HP = (TR + 2) * (TW + 2);
   constexpr int PX = ((HP - 4 + 15) / 16) * 16 + 4;
-  constexpr int LDS_BYTES = (NP == 2 ? 2 : 1) * (4 * NP * PX + 8 * NP * 68) * 16;   // two buffers for two-plane operands
+  constexpr int LDS_BYTES = (4 * NP * PX + 8 * NP * 68) * 16;
   a.ntx = sfh_cdiv(a.W, TW);
   a.nty = sfh_cdiv(a.H, TR);
   a.ntiles = a.ntx * a.nty * a.batch;
@@ -221,6 +207,11 @@ int launch(WgS3Args a, hipStream_t stream) {
   // fewer than 8 (or 12: 8 + 4) splits leave XCDs idle (22x40 layers: 3 splits ran on 3 of the 8 XCDs, 103
   // instead of 250 TFLOP/s-equivalent)
   int nsplit = ((1536 / mn + 7) / 8) * 8;
+  // Every split ends with 64 x 32 x 9 fp32 atomics per workgroup: a split of a few tiles spends longer in that tail than
+  // in its MFMAs (ResNet layer1, 90x160: 768 splits of 5 tiles = 28 M atomics for 17 GFLOP, 138 us).  At least 16 tiles
+  // per split, as long as one round of workgroups (512) is still launched.
+  const int by_tiles = ((a.ntiles / 16 + 7) / 8) * 8, one_round = ((512 / mn + 7) / 8) * 8;
+  if (nsplit > by_tiles) nsplit = by_tiles > one_round ? by_tiles : (one_round < nsplit ? one_round : nsplit);
   if (nsplit < 8) nsplit = 8;
   if (nsplit > a.ntiles) nsplit = a.ntiles;
   a.tps = sfh_cdiv(a.ntiles, nsplit);
