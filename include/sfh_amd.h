@@ -155,6 +155,13 @@ typedef struct sfh_conv_desc {
    * tensor (the fused Up block: the composed 2x2 conv writes its partial divided by the skip-half conv's scale).  Loaded
    * in the prologue instead of sixteen dependent reads in the epilogue. */
   const float* acc_init;
+  /* sfh_conv_s3_fwd, H2 sources, 3x3 stride 1, plain fp32 destination without ReLU / residual (the raw z = conv + bias of
+   * a training-mode layer; optional): batch-statistics BatchNorm sums from the epilogue.  stats_partial = float64 table
+   * [stats_rows][2][cout], zero before the launch; every wave ADDS (fp64 sums, fp64 atomics) the sums of z and of z * z
+   * over its in-frame pixels into row (wave's tile slot) % stats_rows.  sfh_bn_stats_partials then adds the rows up
+   * - the separate statistics pass over z (sfh_bn_stats) is not needed.  stats_rows: a power of two, 64 .. 65536. */
+  double* stats_partial;
+  int32_t stats_rows;
 } sfh_conv_desc;
 
 const char* sfh_last_error(void);
@@ -326,6 +333,9 @@ int sfh_avgpool_linear_fwd(const float* x, const float* w, const float* bias, in
 /* nn.BatchNorm2d(training=True) (unet/unet_parts.py:16,19; models/resnet.py:174 etc.):
  * acc[0][c] += sum_p z[p][c], acc[1][c] += sum_p z[p][c]^2   (acc: 2*C doubles)                  */
 int sfh_bn_stats(const float* z, int64_t npix, int C, double* acc, void* stream);
+/* the same sums from the table a convolution's epilogue left (sfh_conv_desc.stats_partial: [rows][2][C] float64):
+ * acc[0][c] += sum_r partial[r][0][c], acc[1][c] += sum_r partial[r][1][c].                                */
+int sfh_bn_stats_partials(const double* partial, int rows, int C, double* acc, void* stream);
 /* mean_invstd[0][c] = mean, [1][c] = 1/sqrt(biased var + eps); running stats (optional pair) updated
  * with `momentum` and the unbiased variance like torch.                                           */
 int sfh_bn_finalize(const double* acc, int64_t npix, int C, float eps, float momentum, float* running_mean,

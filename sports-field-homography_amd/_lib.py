@@ -36,6 +36,7 @@ class ConvDesc(C.Structure):
         ("head_logits", _p), ("head_stn", _p), ("head_frame", _p),
         ("h2_overflow", _p), ("h2_exp_src", _i), ("h2_exp_dst", _i), ("h2_exp_res", _i), ("h2_range", _p),
         ("wg_couts", _i), ("split_arith", _i), ("ksplit", _i), ("ksplit_stride", C.c_int64), ("acc_init", _p),
+        ("stats_partial", _p), ("stats_rows", _i),
     ]
 
     def __init__(self, *args, **kw):
@@ -84,6 +85,7 @@ SIGNATURES = {
     "sfh_mask_format_fwd": (C.c_int, [_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                       C.c_int, _p, _p, _p]),
     "sfh_bn_stats": (C.c_int, [_p, C.c_int64, C.c_int, _p, _p]),
+    "sfh_bn_stats_partials": (C.c_int, [_p, C.c_int, C.c_int, _p, _p]),
     "sfh_bn_finalize": (C.c_int, [_p, C.c_int64, C.c_int, C.c_float, C.c_float, _p, _p, _p, _p, _p]),
     "sfh_bn_apply": (C.c_int, [_p, _p, _p, _p, _p, C.c_int, C.c_int64, C.c_int, _p, _p, C.c_int, C.c_int, _p, _p]),
     "sfh_bn_bwd_reduce": (C.c_int, [_p, _p, _p, _p, _p, _p, C.c_int, C.c_int64, C.c_int, _p, _p]),

@@ -6,6 +6,8 @@
 // Accumulator layout (both kernels): acc[ni][mi] holds, for pixel (lane & 15) of pixel group
 // msub0+mi, the 4 consecutive couts n0 + ni*16 + 4*(lane >> 4) + {0..3}.
 #pragma once
+#include <hip/amd_detail/amd_hip_unsafe_atomics.h>
+
 #include "common.h"
 
 typedef unsigned int sfh_u32x2 __attribute__((ext_vector_type(2)));
@@ -102,6 +104,32 @@ __device__ __forceinline__ float sfh_dpp_xor8(float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xF, 0xF, true));
 }
 
+// sum over the 16 lanes of a DPP row (lane & 15 = the pixel of a pixel group), result in every lane of the row (fp64)
+__device__ __forceinline__ double sfh_dpp_f64(double v, int ctrl) {   // the same DPP move on both halves
+  const long long u = __builtin_bit_cast(long long, v);
+  int lo = (int)u, hi = (int)(u >> 32);
+  switch (ctrl) {   // the control word is an immediate of the instruction
+    case 0xB1: lo = __builtin_amdgcn_update_dpp(0, lo, 0xB1, 0xF, 0xF, true); hi = __builtin_amdgcn_update_dpp(0, hi, 0xB1, 0xF, 0xF, true); break;
+    case 0x4E: lo = __builtin_amdgcn_update_dpp(0, lo, 0x4E, 0xF, 0xF, true); hi = __builtin_amdgcn_update_dpp(0, hi, 0x4E, 0xF, 0xF, true); break;
+    case 0x124: lo = __builtin_amdgcn_update_dpp(0, lo, 0x124, 0xF, 0xF, true); hi = __builtin_amdgcn_update_dpp(0, hi, 0x124, 0xF, 0xF, true); break;
+    default: lo = __builtin_amdgcn_update_dpp(0, lo, 0x128, 0xF, 0xF, true); hi = __builtin_amdgcn_update_dpp(0, hi, 0x128, 0xF, 0xF, true); break;
+  }
+  return __builtin_bit_cast(double, ((long long)hi << 32) | (long long)(unsigned)lo);
+}
+__device__ __forceinline__ double sfh_row16_sum(double v) {
+  v += sfh_dpp_f64(v, 0xB1);
+  v += sfh_dpp_f64(v, 0x4E);
+  v += sfh_dpp_f64(v, 0x124);
+  v += sfh_dpp_f64(v, 0x128);
+  return v;
+}
+
+// a kernel configuration opts into the BatchNorm-statistics epilogue with `static constexpr bool STATS = true`
+template <class CFG, class = void>
+struct sfh_cfg_stats { static constexpr bool value = false; };
+template <class CFG>
+struct sfh_cfg_stats<CFG, decltype((void)CFG::STATS)> { static constexpr bool value = CFG::STATS; };
+
 constexpr unsigned kSfhOOB = 0xFFFFFFF0u;  // byte offset that the buffer range check rejects
 
 // CFG supplies SUBX, SH, SW, FLATROWS; G supplies Ho, Wo, rows_total, rows_per_img, rows_magic.
@@ -113,7 +141,8 @@ constexpr unsigned kSfhOOB = 0xFFFFFFF0u;  // byte offset that the buffer range 
 template <class CFG, int NI, int MT, int FMTS = 1, class G>
 __device__ __forceinline__ void sfh_conv_epilogue(const sfh_conv_desc& d, const G& g, f32x4 (&acc)[NI][MT],
                                                   int n0, int msub0, int r0, int x0, int lq, int lg,
-                                                  size_t dst_byte_off = 0) {   // split-K: this workgroup's slab of dst
+                                                  size_t dst_byte_off = 0,     // split-K: this workgroup's slab of dst
+                                                  unsigned stats_slot = 0u) {  // STATS configurations: the wave's row of stats_partial
   const bool h2 = (FMTS & 2) && d.dst_fmt == SFH_FMT_H2;
   const bool s3 = h2 || ((FMTS & 1) && d.dst_fmt == SFH_FMT_S3);  // a split (plane) format
   const unsigned np4 = h2 ? 8u : 12u;                              // (plane, group) runs per 32-channel block
@@ -205,6 +234,7 @@ __device__ __forceinline__ void sfh_conv_epilogue(const sfh_conv_desc& d, const 
                 (xo == 0u ? 0u : (xo == uw - 1u ? 2u : (xo >= uw ? 3u : 1u)));
     }
   }
+  constexpr bool STATS = sfh_cfg_stats<CFG>::value;
   // ---- pass 1: finish the values in place and store them
 #pragma unroll
   for (int mi = 0; mi < MT; ++mi) {
@@ -346,6 +376,33 @@ __device__ __forceinline__ void sfh_conv_epilogue(const sfh_conv_desc& d, const 
           __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(sfh_u32x4, m), rp, (int)pv, (int)nioff, 0);
         }
       }
+    }
+  }
+  // BatchNorm statistics of a training-mode layer (sfh_conv_desc.stats_partial; configurations with STATS only): the sums of
+  // z and z * z over the in-frame pixels, one channel at a time from the finished values still in `acc`, in fp64 like the
+  // separate pass (sfh_bn_stats) - two accumulators live at a time, so the instance keeps its register count
+  if constexpr (STATS) {
+    if (d.stats_partial) {
+      double* const row = d.stats_partial + (size_t)(stats_slot & (unsigned)(d.stats_rows - 1)) * (size_t)(2 * d.cout);
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          double a = 0.0, b = 0.0;
+#pragma unroll
+          for (int mi = 0; mi < MT; ++mi) {
+            const double z = voff[mi] != kSfhOOB ? (double)acc[ni][mi][j] : 0.0;
+            a += z;
+            b += z * z;
+          }
+          a = sfh_row16_sum(a);
+          b = sfh_row16_sum(b);
+          if (lq == 0) {
+            const int c = n0 + ni * 16 + 4 * lg + j;
+            unsafeAtomicAdd(row + c, a);
+            unsafeAtomicAdd(row + d.cout + c, b);
+          }
+        }
     }
   }
   // H2 destination: leave the largest |u| for the host - beyond the fp16 range the value was saturated: the engine

@@ -53,9 +53,12 @@ constexpr unsigned kOOB = 0xFFFFFFF0u;
 // NWM_ = waves along the pixel axis: 2 = each wave owns half of the tile's pixel groups; 1 = every wave covers all 256
 //        pixels for its own 32 couts (with NWN_ = 4: 4 waves, 256 pixels x 128 couts - no two waves of a workgroup
 //        request the same weight fragments, and the halo feeds twice the MFMAs)
-template <int KS_, int STRIDE_, int SH_, int SW_, int TH_, int TW_, int NP_ = 3, int NWN_ = 2, int NWM_ = 2>
+// STATS_ = the epilogue also leaves BatchNorm batch statistics (sfh_conv_desc.stats_partial): training-mode layers; a separate
+//        instantiation, so that the inference instances keep their register counts
+template <int KS_, int STRIDE_, int SH_, int SW_, int TH_, int TW_, int NP_ = 3, int NWN_ = 2, int NWM_ = 2, bool STATS_ = false>
 struct S3Cfg {
   static constexpr int KS = KS_, STRIDE = STRIDE_, NP = NP_, NWN = NWN_, NWM = NWM_;
+  static constexpr bool STATS = STATS_;
   static constexpr int NT = 64 * NWM * NWN;   // threads
   static constexpr int NCO = 32 * NWN;        // couts per workgroup
   static constexpr int SH = SH_, SW = SW_, TH = TH_, TW = TW_;
@@ -512,7 +515,8 @@ __global__ __launch_bounds__(C::NT, (C::NP == 2 && !DB) ? SFH_H2_WAVES_PER_SIMD 
     }
   }
   sfh_conv_epilogue<C, 2, C::MT_M, (NP == 3 ? 1 : 2)>(d, g, acc, n0 + 32 * wn, wm * C::MT_M, r0, x0, lq, lg,
-                                                      (size_t)ks * (size_t)d.ksplit_stride);
+                                                      (size_t)ks * (size_t)d.ksplit_stride,
+                                                      (unsigned)(tile * C::NWM + wm));
   if (!DB) {
     SFH_STAMP(4);
     SFH_CLOCK_END();
@@ -1159,16 +1163,28 @@ extern "C" int sfh_conv_s3_fwd(const sfh_conv_desc* dp, void* stream_) {
                      (d.ksize != 2 || (d.cout / 4) % 128 == 0) && d.src_fmt == SFH_FMT_H2;
   SFH_REQUIRE(d.wg_couts == 0 || d.wg_couts == 64 || (d.wg_couts == 128 && w8_ok),
               "conv_s3_fwd: wg_couts=%d is not available for this launch (see sfh_conv_desc.wg_couts)", d.wg_couts);
+  if (d.stats_partial) {
+    SFH_REQUIRE(d.src_fmt == SFH_FMT_H2 && d.dst_fmt == SFH_FMT_F32 && d.ksize == 3 && d.stride == 1 && !d.relu && !d.residual &&
+                    !d.dst_pool && !d.head_w && !(d.ksplit > 1) && d.out_mode == SFH_OUT_NHWC && d.stats_rows >= 64 &&
+                    d.stats_rows <= 65536 && (d.stats_rows & (d.stats_rows - 1)) == 0,
+                "conv_s3_fwd: stats_partial needs H2 sources, a 3x3 stride-1 conv with a plain fp32 destination (no ReLU / "
+                "residual / pooled output / head / split-K) and stats_rows a power of two in 64 .. 65536");
+  }
 #define SFH_S3CASE_W8(KS, ST, TILE, SH, SW, TH, TW)                                                          \
   if (w8_ok && d.ksize == KS && d.stride == ST && d.tile == TILE) {                                           \
     using CFG = S3Cfg<KS, ST, SH, SW, TH, TW, 2, 4, SFH_W128_NWM>;                                            \
+    using CFGS = S3Cfg<KS, ST, SH, SW, TH, TW, 2, 4, SFH_W128_NWM, true>;                                     \
     const int Ho_ = d.H, Wo_ = d.W;                                                                           \
     int zr_ = CFG::PAD;                                                                                       \
     if ((Ho_ + zr_) & 1) ++zr_;                                                                               \
     if (zr_ == 0) zr_ = (Ho_ & 1) ? 1 : 0;                                                                    \
     const long tiles_ = (long)sfh_cdiv(Wo_, TW) * sfh_cdiv(d.batch * (Ho_ + zr_), TH);                        \
-    if (d.wg_couts == 128 || (d.wg_couts == 0 && tiles_ * (d.cout / 128) >= SFH_W8_MIN_BLOCKS))              \
+    if (d.wg_couts == 128 || (d.wg_couts == 0 && tiles_ * (d.cout / 128) >= SFH_W8_MIN_BLOCKS)) {            \
+      if constexpr (KS == 3) {                                                                                \
+        if (d.stats_partial) return launch_s3<CFGS, (SFH_W128_NWM == 2)>(d, stream);                          \
+      }                                                                                                       \
       return launch_s3<CFG, (SFH_W128_NWM == 2)>(d, stream);                                                  \
+    }                                                                                                         \
   }
   SFH_S3CASE_W8(3, 1, SFH_TILE_8x32, 1, 16, 8, 32)
   SFH_S3CASE_W8(3, 1, SFH_TILE_16x16, 1, 16, 16, 16)
@@ -1183,6 +1199,10 @@ extern "C" int sfh_conv_s3_fwd(const sfh_conv_desc* dp, void* stream_) {
   if (d.ksize == KS && d.stride == ST && d.tile == TILE) {             \
     if (d.src_fmt == SFH_FMT_H2) {                                     \
       using CFG = S3Cfg<KS, ST, SH, SW, TH, TW, 2>;                    \
+      if constexpr (KS == 3 && ST == 1) {                              \
+        using CFGS = S3Cfg<KS, ST, SH, SW, TH, TW, 2, 2, 2, true>;     \
+        if (d.stats_partial) return launch_s3<CFGS, false>(d, stream); \
+      }                                                                \
       return launch_s3<CFG, false>(d, stream);                         \
     }                                                                  \
     using CFG = S3Cfg<KS, ST, SH, SW, TH, TW, 3>;                      \

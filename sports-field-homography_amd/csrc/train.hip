@@ -82,6 +82,21 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__
   }
 }
 
+// acc[k] += sum_r partial[r][k], k < 2 * C: the per-wave fp64 sums a convolution's epilogue left (sfh_conv_desc.stats_partial).
+// Block = 64 columns x 4 row lanes; blockIdx.y strides over the rows.
+__global__ __launch_bounds__(256) void bn_stats_partials_kernel(const double* __restrict__ partial, int rows, int ncol,
+                                                                double* __restrict__ acc) {
+  __shared__ double sh[256];
+  const int col = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
+  double s = 0.0;
+  if (col < ncol)
+    for (int r = blockIdx.y * 4 + rl; r < rows; r += gridDim.y * 4) s += partial[(long)r * ncol + col];
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  if (threadIdx.x < 64 && col < ncol)
+    unsafeAtomicAdd(&acc[col], sh[threadIdx.x] + sh[threadIdx.x + 64] + sh[threadIdx.x + 128] + sh[threadIdx.x + 192]);
+}
+
 // acc[c] += sum x[:, c] over a channel slice (cs >= C)
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, long npix, int C, int cs,
                                                      double* __restrict__ acc) {
@@ -1054,6 +1069,14 @@ extern "C" int sfh_bn_stats(const float* z, int64_t npix, int C, double* acc, vo
   const unsigned nb = red_grid((long)npix);
   hipLaunchKernelGGL(bn_stats_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, z, (long)npix, C, acc);
   return sfh_check_launch("bn_stats_kernel");
+}
+
+extern "C" int sfh_bn_stats_partials(const double* partial, int rows, int C, double* acc, void* stream) {
+  SFH_REQUIRE(partial && acc && rows > 0 && C > 0, "bn_stats_partials: bad argument");
+  const int ncol = 2 * C;
+  const dim3 grid((unsigned)((ncol + 63) / 64), (unsigned)(rows >= 128 ? 32 : (rows + 3) / 4));
+  hipLaunchKernelGGL(bn_stats_partials_kernel, grid, dim3(256), 0, (hipStream_t)stream, partial, rows, ncol, acc);
+  return sfh_check_launch("bn_stats_partials_kernel");
 }
 
 extern "C" int sfh_bn_finalize(const double* acc, int64_t npix, int C, float eps, float momentum,

@@ -414,6 +414,12 @@ class PackedConv:
         if self.escale != 1.0:
             self.scale.mul_(self.escale)     # a power of two: exact
 
+    @property
+    def stats_ok(self):
+        """this layer's launch can leave BatchNorm batch statistics from its epilogue (run(stats=...))"""
+        return (self.fmt == "h2" and self.ksize == 3 and self.stride == 1 and not self.relu and not self.transposed
+                and not self.stem_cin and not self.c4)
+
     def _pack_split(self, w, ksize, c0, c1, mode, aux, wexp=None):
         """Pack w for the split-operand kernel in this layer's format.  H2: planes of w * 2^wexp with
         max |w| * 2^wexp in [2^13, 2^14) (wexp given by a caller that has the maximum already, else one
@@ -533,7 +539,7 @@ class PackedConv:
 
     def run(self, src0, batch, H, W, dst, src1=None, pool0=False, pad1=(0, 0), residual=None, tile=None,
             dst_pool=None, up_dst=None, head=None, wg_couts=0, exp_src=None, exp_dst=None, exp_res=None,
-            range_word=None, ksplit=0, slabs=None, acc_init=None, scale=None, shift_border=None):
+            range_word=None, ksplit=0, slabs=None, acc_init=None, scale=None, shift_border=None, stats=None):
         """src0/src1: NHWC float32 tensors, or split tensors of the layer's format (S3 bfloat16 / H2 float16);
         dst/residual/dst_pool: float32 NHWC or the same split format (by dtype).  H, W: conv input frame.
         H2 tensors: exp_src / exp_dst / exp_res = exponents of the sources / dst and dst_pool / an H2 residual
@@ -542,7 +548,10 @@ class PackedConv:
         fp32 partial slabs (`slabs`: float32 tensor (ksplit, B, Ho, Wo, cout)), and sfh_splitk_finish adds them up
         with this layer's shift, residual and ReLU into dst - for grids that alone leave most of the chip idle.
         acc_init (3x3 stride 1): float32 NHWC (B, H, W, cout) tensor the accumulators start from, in accumulator units
-        (sfh_conv_desc.acc_init); scale / shift_border: tensors used instead of the layer's own for this launch."""
+        (sfh_conv_desc.acc_init); scale / shift_border: tensors used instead of the layer's own for this launch.
+        stats (training, H2 3x3 stride-1 layers with a plain fp32 dst): zero-filled float64 table (rows, 2, cout), rows a
+        power of two - the epilogue adds the per-wave sums of z and z^2 for batch-statistics BatchNorm into it
+        (sfh_conv_desc.stats_partial; PackedConv.stats_ok says whether a layer qualifies)."""
         lib = _lib.load()
         d = ConvDesc()
         if self.fmt == "h2" and exp_src is not None:
@@ -600,6 +609,11 @@ class PackedConv:
             if acc_init.dtype != torch.float32 or tuple(acc_init.shape) != (batch, H, W, self.cout) or not acc_init.is_contiguous():
                 raise ValueError(f"acc_init must be a contiguous float32 tensor {(batch, H, W, self.cout)}")
             d.acc_init = acc_init.data_ptr()
+        if stats is not None:
+            if (stats.dtype != torch.float64 or not stats.is_contiguous() or stats.dim() != 3
+                    or tuple(stats.shape[1:]) != (2, self.cout)):
+                raise ValueError(f"stats must be a contiguous float64 tensor (rows, 2, {self.cout})")
+            d.stats_partial, d.stats_rows = stats.data_ptr(), int(stats.shape[0])
         if head is not None:   # OutConv fused behind this conv (sfh_conv_desc.head_*)
             d.head_w, d.head_b, d.head_nc = head["w"].data_ptr(), head["b"].data_ptr(), head["nc"]
             d.head_logits = head["logits"].data_ptr()

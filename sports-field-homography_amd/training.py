@@ -241,7 +241,11 @@ class Tape:
 
 
 # --------------------------------------------------------------------------------------- layers
-def _bn_forward(lib, z, bn, relu, residual, tape, want_s3=True, want_f32=True):
+STATS_IN_EPILOGUE = os.environ.get("SFH_TRAIN_STATS_EPILOGUE", "1") != "0"
+STATS_ROWS = 2048   # most rows of the table a conv epilogue adds its per-wave BatchNorm sums into (sfh_conv_desc.stats_partial)
+
+
+def _bn_forward(lib, z, bn, relu, residual, tape, want_s3=True, want_f32=True, stats=None):
     """Batch-statistics BatchNorm (+residual) (+ReLU); updates the running stats in place.  In split-operand mode
     (and want_s3) the split copy the next convolution needs is written by the same kernel.  want_f32=False (with a
     split copy): nobody reads the fp32 values - the returned tensor is a handle (shape + identity for the tape,
@@ -249,7 +253,10 @@ def _bn_forward(lib, z, bn, relu, residual, tape, want_s3=True, want_f32=True):
     B, H, W, C = z.shape
     npix = B * H * W
     acc = tape.zeros((2 * C,), z, torch.float64)
-    _lib.check(lib.sfh_bn_stats(_ptr(z), npix, C, _ptr(acc), _stream()), "bn_stats")
+    if stats is not None:   # the conv that wrote z left the per-wave sums: no pass over z
+        _lib.check(lib.sfh_bn_stats_partials(_ptr(stats), stats.shape[0], C, _ptr(acc), _stream()), "bn_stats_partials")
+    else:
+        _lib.check(lib.sfh_bn_stats(_ptr(z), npix, C, _ptr(acc), _stream()), "bn_stats")
     mi = _empty((2 * C,), z)
     nbt = bn.num_batches_tracked
     if nbt is not None and (nbt.dtype != torch.int64 or not nbt.is_cuda):
@@ -362,12 +369,19 @@ def conv_bn_act(tape, names, conv, bn, srcs, B, H, W, relu=True, residual=None, 
     pc.overflow = tape.overflow
     ho, wo = (H - 1) // stride + 1, (W - 1) // stride + 1
     z = _empty((B, ho, wo, cout), t0)
+    # BatchNorm's batch sums ride in the conv epilogue where the kernel offers it (H2, 3x3, stride 1)
+    stats = None
+    if s3 and pc.stats_ok and STATS_IN_EPILOGUE:
+        rows = 64
+        while rows < STATS_ROWS and rows * 1024 < B * ho * wo:   # about a quarter as many rows as pixel tiles
+            rows *= 2
+        stats = tape.zeros((rows, 2, cout), t0, torch.float64)
     pc.run(tape.s3(t0) if s3 else t0, B, H, W, z, src1=(tape.s3(t1) if s3 else t1) if t1 is not None else None,
-           pad1=(srcs[1][2], srcs[1][3]) if t1 is not None else (0, 0))
+           pad1=(srcs[1][2], srcs[1][3]) if t1 is not None else (0, 0), stats=stats)
     if any(id(t) in tape.no_f32 for t in (t0, t1) if t is not None) and not s3:
         raise RuntimeError("conv_bn_act: a source has no fp32 storage (f32_out=False) but this conv reads fp32")
     y, mi = _bn_forward(lib, z, bn, relu, residual, tape, want_s3=s3_out,   # s3_out: a conv consumes y
-                        want_f32=f32_out or residual is not None)
+                        want_f32=f32_out or residual is not None, stats=stats)
 
     def backward():
         dy = tape.pop_grad(y)
