@@ -38,7 +38,7 @@ def test_conv_desc_layout_matches_header():
     fields = []
     for decl in body.split(";"):
         decl = decl.strip()
-        m = re.match(r"(const float\*|float\*|uint32_t\*|int32_t|int64_t)\s+(.*)", decl, flags=re.S)
+        m = re.match(r"(const float\*|float\*|double\*|uint32_t\*|int32_t|int64_t)\s+(.*)", decl, flags=re.S)
         if m:
             fields += [f.strip() for f in m.group(2).split(",")]
     assert fields == [f[0] for f in _lib.ConvDesc._fields_]
