@@ -46,6 +46,11 @@ namespace {
 
 constexpr unsigned kOOB = 0xFFFFFFF0u;
 
+// experiment knob (profiles/ab_bench.sh): wave priority inside the MFMA stages (s_setprio), 0 = leave it alone
+#ifndef SFH_STAGE_PRIO
+#define SFH_STAGE_PRIO 0
+#endif
+
 // NP_ = planes per operand: 3 = S3 tensors, bf16, six products per fp32 product ("bf16x6");
 //                           2 = H2 tensors, fp16, three products ("f16x3", include/sfh_amd.h)
 // NWN_ = waves along the cout axis: 2 = the 4-wave workgroup (256 pixels x 64 couts), 4 = the 8-wave workgroup
@@ -456,6 +461,7 @@ __global__ __launch_bounds__(C::NT, (C::NP == 2 && !DB) ? SFH_H2_WAVES_PER_SIMD 
   static_assert((2 * C::NTAP) % WD == 0, "the stage loop is unrolled by two");
 
   dma_stage(st0, 0);
+  if (SFH_STAGE_PRIO) __builtin_amdgcn_s_setprio(SFH_STAGE_PRIO);
   auto maybe_switch = [&](int st) {  // the DMA issued during stage st targets stage st+1
     if (d.src1 && st + 1 == nst0) {
       s3_halo_offsets<C>(d, g, 1, tid, r0, x0, pad_y, pad_x, hoff);
@@ -514,6 +520,7 @@ __global__ __launch_bounds__(C::NT, (C::NP == 2 && !DB) ? SFH_H2_WAVES_PER_SIMD 
       }
     }
   }
+  if (SFH_STAGE_PRIO) __builtin_amdgcn_s_setprio(0);
   sfh_conv_epilogue<C, 2, C::MT_M, (NP == 3 ? 1 : 2)>(d, g, acc, n0 + 32 * wn, wm * C::MT_M, r0, x0, lq, lg,
                                                       (size_t)ks * (size_t)d.ksplit_stride,
                                                       (unsigned)(tile * C::NWM + wm));
