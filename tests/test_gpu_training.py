@@ -909,3 +909,78 @@ def test_bn_snapshot_follows_replaced_buffers(T):
     net.inc.double_conv[1].running_mean.add_(2.0)
     snap.restore()
     assert float(net.inc.double_conv[1].running_mean.abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("shape,c0,c1,cout", [((2, 13, 37), 64, 0, 64), ((1, 22, 40), 128, 64, 128), ((3, 9, 20), 256, 0, 256),
+                                              ((16, 45, 80), 128, 0, 128)])
+def test_conv_epilogue_leaves_the_batchnorm_sums(T, shape, c0, c1, cout, monkeypatch):
+    """sfh_conv_desc.stats_partial (training-only instances of the split-operand conv kernel): the per-channel sums of z
+    and z^2 the epilogue leaves, added up by sfh_bn_stats_partials, equal what the separate pass (sfh_bn_stats) finds in the
+    z the same launch wrote - partial tiles, frames that end inside a tile, two sources, 64- and 128-cout workgroups,
+    a grid large enough for the single-buffered instance."""
+    from sfh_amd import _lib, engine as E
+    from sfh_amd.engine import PackedConv, _ptr, _stream
+    monkeypatch.setenv("SFH_TRAIN_PRECISION", "f16x3")
+    lib = _lib.load()
+    B, H, W = shape
+    g = torch.Generator().manual_seed(11 + H)
+    w = (torch.randn(cout, c0 + c1, 3, 3, generator=g) * 0.05).cuda()
+    b = torch.randn(cout, generator=g).cuda()
+    x0 = torch.randn(B, H, W, c0, generator=g).cuda() + 0.5
+    x1 = torch.randn(B, H - 3, W - 2, c1, generator=g).cuda() if c1 else None
+    pc = PackedConv(w, b, None, 3, c0, c1, relu=False, tag="train_fwd", fmt="h2", shared_unit_scale=True)
+    assert pc.stats_ok
+    z = torch.empty(B, H, W, cout, device="cuda")
+    stats = torch.zeros(256, 2, cout, dtype=torch.float64, device="cuda")
+    pc.run(E.f32_to_split(x0, "h2"), B, H, W, z, src1=E.f32_to_split(x1, "h2") if c1 else None, pad1=(1, 1), stats=stats)
+    acc = torch.zeros(2 * cout, dtype=torch.float64, device="cuda")
+    _lib.check(lib.sfh_bn_stats_partials(_ptr(stats), 256, cout, _ptr(acc), _stream()), "bn_stats_partials")
+    ref = torch.zeros(2 * cout, dtype=torch.float64, device="cuda")
+    _lib.check(lib.sfh_bn_stats(_ptr(z), B * H * W, cout, _ptr(ref), _stream()), "bn_stats")
+    torch.cuda.synchronize()
+    zz = z.double().reshape(-1, cout)
+    exact = torch.cat([zz.sum(0), (zz * zz).sum(0)])
+    assert float(((acc - exact).abs() / (exact.abs() + 1e-9)).max()) < 1e-12
+    assert float(((ref - exact).abs() / (exact.abs() + 1e-9)).max()) < 1e-12
+    # a launch without the table takes the ordinary instance and writes the same z
+    z2 = torch.empty_like(z)
+    pc.run(E.f32_to_split(x0, "h2"), B, H, W, z2, src1=E.f32_to_split(x1, "h2") if c1 else None, pad1=(1, 1))
+    assert torch.equal(z, z2)
+
+
+@pytest.mark.parametrize("prec", ["bf16x6", "f16x3"])
+def test_batchnorm_split_copy_without_the_fp32_copy(T, prec, monkeypatch):
+    """bn_apply / bn_bwd_apply with y == NULL / dz == NULL (layers whose consumers read the split copy only): the split
+    copy holds the same bits as with the fp32 copy, odd row length and a pixel count that is no multiple of 64."""
+    from sfh_amd import _lib, engine as E
+    from sfh_amd.engine import _ptr, _stream
+    monkeypatch.setenv("SFH_TRAIN_PRECISION", prec)
+    lib = _lib.load()
+    tape = T.Tape()
+    B, H, W, C = 3, 7, 37, 96
+    g = torch.Generator().manual_seed(4)
+    z = torch.randn(B, H, W, C, generator=g).cuda()
+    dy = torch.randn(B, H, W, C, generator=g).cuda()
+    mi = torch.cat([torch.randn(C, generator=g) * 0.1, torch.rand(C, generator=g) + 0.5]).cuda()
+    gam, bet = (torch.rand(C, generator=g) + 0.5).cuda(), (torch.randn(C, generator=g) * 0.1).cuda()
+    acc = torch.randn(2 * C, generator=g).double().cuda()
+    npix = B * H * W
+    outs = []
+    for with_f32 in (True, False):
+        y = torch.empty_like(z) if with_f32 else None
+        ys = E.split_empty(tape.fmt, B, H, W, C, "cuda")
+        _lib.check(lib.sfh_bn_apply(_ptr(z), _ptr(mi), _ptr(gam), _ptr(bet), None, 1, npix, C, _ptr(y), _ptr(ys), W,
+                                    tape.fmt_code, None, _stream()), "bn_apply")
+        dz = torch.empty_like(z) if with_f32 else None
+        dzs = E.split_empty(tape.fmt, B, H, W, C, "cuda")
+        a32 = torch.empty(2 * C, device="cuda")
+        _lib.check(lib.sfh_bn_bwd_apply(_ptr(dy), None, _ptr(z), _ptr(mi), _ptr(gam), _ptr(bet), _ptr(acc), 1, npix, C,
+                                        _ptr(dz), None, _ptr(dzs), W, tape.fmt_code, None, _ptr(a32), _stream()), "bn_bwd_apply")
+        outs.append((y, ys, dz, dzs, a32))
+    torch.cuda.synchronize()
+    (y, ys, dz, dzs, a32), (_, ys2, _, dzs2, a32b) = outs
+    assert torch.equal(ys.view(torch.int16), ys2.view(torch.int16)) and torch.equal(dzs.view(torch.int16), dzs2.view(torch.int16))
+    assert torch.equal(a32, a32b) and torch.equal(a32, acc.float())
+    want = torch.relu((z - mi[:C]) * mi[C:] * gam + bet)
+    assert torch.equal(y, want) or float((y - want).abs().max()) < 1e-6
+    assert float((E.s3_to_f32(ys) - y).abs().max()) < 2e-6 * float(y.abs().max())
