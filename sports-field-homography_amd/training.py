@@ -461,7 +461,9 @@ def maxpool2(tape, x):
 
 
 def conv_transpose2x2(tape, names, up, x):
-    """nn.ConvTranspose2d(cin, cin/2, 2, stride=2) (unet/unet_parts.py:52)."""
+    """nn.ConvTranspose2d(cin, cin/2, 2, stride=2) (unet/unet_parts.py:52).  In split-operand mode the result is written
+    in the split format only: its consumer is the Up block's conv, whose forward and backward-filter read the split copy
+    (the returned tensor is a handle without fp32 storage, see _bn_forward)."""
     lib = tape.lib
     B, h, w, cin = x.shape
     wt = up.weight.detach()
@@ -469,8 +471,17 @@ def conv_transpose2x2(tape, names, up, x):
     s3 = tape.use_s3 and cin % 32 == 0
     pc = PackedConv(wt, up.bias, None, 1, cin, relu=False, transposed=True, tag="train_fwd",
                     fmt=tape.fmt if s3 else None, wexp=tape.wexp_of(up.weight), shared_unit_scale=True)
-    u = _empty((B, 2 * h, 2 * w, cout), x)
-    pc.run(tape.s3(x) if s3 else x, B, h, w, u)
+    pc.overflow = tape.overflow
+    split_only = s3 and cout % 32 == 0 and CAPTURE is None
+    if split_only:
+        u = x.new_empty((1,)).expand(B, 2 * h, 2 * w, cout)
+        u_s3 = E.split_empty(tape.fmt, B, 2 * h, 2 * w, cout, x.device)
+        pc.run(tape.s3(x), B, h, w, u_s3)
+        tape._s3[id(u)] = (u, u_s3)
+        tape.no_f32.add(id(u))
+    else:
+        u = _empty((B, 2 * h, 2 * w, cout), x)
+        pc.run(tape.s3(x) if s3 else x, B, h, w, u)
 
     def backward():
         du = tape.pop_grad(u)
