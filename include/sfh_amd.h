@@ -386,12 +386,12 @@ int sfh_conv_wgrad(const float* dz, int dz_cs, int M, const float* x, int x_cs, 
                    int pad_top, int pad_left, int batch, int H, int W, int ksize, float* raw, int raw_n,
                    int n_off, void* stream);
 
-/* The same weight gradient for 3x3 stride-1 convs on the bf16 matrix cores, fp32-equivalent ("bf16x6", six
- * bf16 MFMA products per fp32 product, as sfh_conv_s3_fwd): dz and the layer input are S3 (split-bf16)
+/* The same weight gradient for 3x3 (pad 1) and 1x1 stride-1 convs on the 16-bit matrix cores, fp32-equivalent ("bf16x6",
+ * six bf16 MFMA products per fp32 product, as sfh_conv_s3_fwd): dz and the layer input are S3 (split-bf16)
  * tensors - dz (B,H,M/32,3,4,W,8) with M a multiple of 64; x (B,xh,x_channels/32,3,4,xw,8) of which the
- * first N channels (multiple of 32) are used.  raw (M, 9, raw_n) fp32, caller-zeroed, atomics.          */
+ * first N channels (multiple of 32) are used.  raw (M, ksize^2, raw_n) fp32, caller-zeroed, atomics.    */
 int sfh_conv_wgrad_s3(const void* dz_s3, int M, const void* x_s3, int x_channels, int xh, int xw, int N,
-                      int pad_top, int pad_left, int batch, int H, int W, float* raw, int raw_n, int n_off,
+                      int pad_top, int pad_left, int batch, int H, int W, int ksize, float* raw, int raw_n, int n_off,
                       int fmt, void* stream);   /* fmt: SFH_FMT_S3, or SFH_FMT_H2 (both tensors two-plane fp16, three
                                                    fp16 MFMA products per product) */
 

@@ -1,6 +1,6 @@
-// wgrad_s3.hip - backward-filter (weight gradient) of stride-1 3x3 convolutions on the bf16 matrix cores.
+// wgrad_s3.hip - backward-filter (weight gradient) of stride-1 3x3 and 1x1 convolutions on the 16-bit matrix cores.
 //
-//   raw[m][tap][n_off + n] += sum_{b,y,x} dz[b][y][x][m] * xin[b][y + ky - 1][x + kx - 1][n]
+//   raw[m][tap][n_off + n] += sum_{b,y,x} dz[b][y][x][m] * xin[b][y + ky - 1][x + kx - 1][n]        (1x1: one tap, no shift)
 //
 // Same "bf16x6" arithmetic as the forward kernel (conv_s3.hip): both operands are exact three-plane bf16
 // splits of fp32 values (S3 tensors), every product is accumulated from its six partial products >= 2^-16
@@ -53,11 +53,16 @@ __device__ __forceinline__ bf16x8 frag(s16x4 lo, s16x4 hi) {
 
 // NP = planes per operand: 3 = S3 tensors (bf16, six products), 2 = H2 tensors (fp16 planes of v * 2^SFH_H2_ACT_EXP,
 // three products; the accumulators are multiplied by 2^-(2 * SFH_H2_ACT_EXP) before they are added to raw)
-template <int TR, int TW, int NP>
+// KS = 3: nine taps; KS = 1: one tap (ConvTranspose2d as a 1x1 conv over space_to_depth2(dY), Bottleneck 1x1s) - the same
+// tile loop with 12 instead of 108 MFMAs per wave and tile, i.e. bound by the LDS-DMA of the two operands, which is still
+// several times the rate of the fp32 kernel these layers ran on
+template <int TR, int TW, int NP, int KS = 3>
 __global__ __launch_bounds__(256, NP == 2 ? 3 : 2) void wgrad_s3_kernel(const WgS3Args a) {
   static_assert(TR * TW == 64 && (TW == 8 || TW == 16 || TW == 32), "64-pixel tiles, two 32-pixel k-steps");
+  static_assert(KS == 3 || KS == 1, "3x3 or 1x1");
+  constexpr int NTAP = KS * KS, PADK = KS / 2;
   constexpr int R4 = 4 * NP;                                         // (plane, group) runs per 32-channel block
-  constexpr int HWD = TW + 2, HR = TR + 2, HP = HR * HWD;           // input halo of a tile
+  constexpr int HWD = TW + KS - 1, HR = TR + KS - 1, HP = HR * HWD; // input halo of a tile
   constexpr int PX = ((HP - 4 + 15) / 16) * 16 + 4;                 // chunks per (plane, group) of the halo image
   constexpr int PD = 68;                                            // ... of the dz image (64 pixels)
   constexpr int XCH = R4 * PX;
@@ -87,11 +92,11 @@ __global__ __launch_bounds__(256, NP == 2 ? 3 : 2) void wgrad_s3_kernel(const Wg
   const unsigned dzb = (unsigned)(((4 * mh + (pp >> 1)) * PD + kk0) * 16 + (pp & 1) * 8 + XCH * 16);
   const unsigned xb = (unsigned)(((2 * nb16 + (pp >> 1)) * PX + (kk0 / TW) * HWD + (kk0 % TW)) * 16 + (pp & 1) * 8);
 
-  f32x4 acc[2][9];
+  f32x4 acc[2][NTAP];
 #pragma unroll
   for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
-    for (int t = 0; t < 9; ++t) acc[mb][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < NTAP; ++t) acc[mb][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   typedef __attribute__((address_space(3))) char* lds_char_ptr;
   const lds_char_ptr ldsc = (lds_char_ptr)(lds_ptr_t)lds;
@@ -113,7 +118,7 @@ __global__ __launch_bounds__(256, NP == 2 ? 3 : 2) void wgrad_s3_kernel(const Wg
       for (int i = 0; i < NXI; ++i) {
         const int hp = i * 64 + lane;
         const int r = hp / HWD, c = hp - r * HWD;
-        const int yy = y0 - 1 + r - a.pad_top, xx = x0 - 1 + c - a.pad_left;
+        const int yy = y0 - PADK + r - a.pad_top, xx = x0 - PADK + c - a.pad_left;
         const bool ok = (unsigned)yy < (unsigned)a.xh && (unsigned)xx < (unsigned)a.xw;
         voff[i] = ok ? (unsigned)((yy * CBX * R4 * a.xw + xx) * 16) : kOOB;
         act[i] = hp < HP;
@@ -155,8 +160,8 @@ __global__ __launch_bounds__(256, NP == 2 ? 3 : 2) void wgrad_s3_kernel(const Wg
           af[mb][p] = frag(tr(ad), tr(ad + 64));
         }
 #pragma unroll
-      for (int t9 = 0; t9 < 9; ++t9) {
-        const int ky = t9 / 3, kx = t9 % 3;
+      for (int t9 = 0; t9 < NTAP; ++t9) {
+        const int ky = t9 / KS, kx = t9 % KS;
         bf16x8 bfr[NP];
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
@@ -187,16 +192,16 @@ __global__ __launch_bounds__(256, NP == 2 ? 3 : 2) void wgrad_s3_kernel(const Wg
 #pragma unroll
   for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
-    for (int t9 = 0; t9 < 9; ++t9)
+    for (int t9 = 0; t9 < NTAP; ++t9)
 #pragma unroll
       for (int r = 0; r < 4; ++r)
-        unsafeAtomicAdd(a.raw + ((long)(m0 + 16 * mb + r) * 9 + t9) * a.raw_n + n,
+        unsafeAtomicAdd(a.raw + ((long)(m0 + 16 * mb + r) * NTAP + t9) * a.raw_n + n,
                         NP == 2 ? acc[mb][t9][r] * (1.f / (float)(1 << (2 * SFH_H2_ACT_EXP))) : acc[mb][t9][r]);
 }
 
-template <int TR, int TW, int NP>
+template <int TR, int TW, int NP, int KS = 3>
 int launch(WgS3Args a, hipStream_t stream) {
-  constexpr int HP = (TR + 2) * (TW + 2);
+  constexpr int HP = (TR + KS - 1) * (TW + KS - 1);
   constexpr int PX = ((HP - 4 + 15) / 16) * 16 + 4;
   constexpr int LDS_BYTES = (4 * NP * PX + 8 * NP * 68) * 16;
   a.ntx = sfh_cdiv(a.W, TW);
@@ -223,17 +228,18 @@ int launch(WgS3Args a, hipStream_t stream) {
   }
   const long nblocks = (long)sfh_cdiv(a.nsplit, 8) * 8 * mn;
   SFH_REQUIRE(nblocks < (1L << 31), "conv_wgrad_s3: grid too large");
-  sfh_allow_big_lds(reinterpret_cast<const void*>(&wgrad_s3_kernel<TR, TW, NP>));
-  hipLaunchKernelGGL((wgrad_s3_kernel<TR, TW, NP>), dim3((unsigned)nblocks), dim3(256), LDS_BYTES, stream, a);
+  sfh_allow_big_lds(reinterpret_cast<const void*>(&wgrad_s3_kernel<TR, TW, NP, KS>));
+  hipLaunchKernelGGL((wgrad_s3_kernel<TR, TW, NP, KS>), dim3((unsigned)nblocks), dim3(256), LDS_BYTES, stream, a);
   return sfh_check_launch("wgrad_s3_kernel");
 }
 
 }  // namespace
 
 extern "C" int sfh_conv_wgrad_s3(const void* dz_s3, int M, const void* x_s3, int x_channels, int xh, int xw, int N,
-                                 int pad_top, int pad_left, int batch, int H, int W, float* raw, int raw_n, int n_off,
-                                 int fmt, void* stream) {
+                                 int pad_top, int pad_left, int batch, int H, int W, int ksize, float* raw, int raw_n,
+                                 int n_off, int fmt, void* stream) {
   SFH_REQUIRE(fmt == SFH_FMT_S3 || fmt == SFH_FMT_H2, "conv_wgrad_s3: fmt=%d (S3 or H2)", fmt);
+  SFH_REQUIRE(ksize == 3 || ksize == 1, "conv_wgrad_s3: ksize=%d (3 or 1)", ksize);
   const unsigned long long bpe = fmt == SFH_FMT_H2 ? 4ULL : 6ULL;
   SFH_REQUIRE(dz_s3 && x_s3 && raw, "conv_wgrad_s3: null pointer");
   SFH_REQUIRE(batch > 0 && H > 0 && W > 0 && xh > 0 && xw > 0, "conv_wgrad_s3: bad geometry");
@@ -258,12 +264,17 @@ extern "C" int sfh_conv_wgrad_s3(const void* dz_s3, int M, const void* x_s3, int
   const long c0 = (long)sfh_cdiv(H, 2) * sfh_cdiv(W, 32), c1 = (long)sfh_cdiv(H, 4) * sfh_cdiv(W, 16),
              c2 = (long)sfh_cdiv(H, 8) * sfh_cdiv(W, 8);
   hipStream_t st = (hipStream_t)stream;
+#define SFH_WG_PICK(NP_, KS_)                                        \
+  do {                                                               \
+    if (c0 <= c1 && c0 <= c2) return launch<2, 32, NP_, KS_>(a, st); \
+    if (c1 <= c2) return launch<4, 16, NP_, KS_>(a, st);             \
+    return launch<8, 8, NP_, KS_>(a, st);                            \
+  } while (0)
   if (fmt == SFH_FMT_H2) {
-    if (c0 <= c1 && c0 <= c2) return launch<2, 32, 2>(a, st);
-    if (c1 <= c2) return launch<4, 16, 2>(a, st);
-    return launch<8, 8, 2>(a, st);
+    if (ksize == 1) SFH_WG_PICK(2, 1);
+    SFH_WG_PICK(2, 3);
   }
-  if (c0 <= c1 && c0 <= c2) return launch<2, 32, 3>(a, st);
-  if (c1 <= c2) return launch<4, 16, 3>(a, st);
-  return launch<8, 8, 3>(a, st);
+  if (ksize == 1) SFH_WG_PICK(3, 1);
+  SFH_WG_PICK(3, 3);
+#undef SFH_WG_PICK
 }

@@ -310,19 +310,21 @@ def _colsum(lib, t, C=None, cs=None):
 
 
 def wgrad_s3_ok(ksize, stride, M, srcs):
-    """the split-bf16 backward-filter kernel (csrc/wgrad_s3.hip) covers 3x3 stride-1 convs with cout % 64 == 0
-    whose sources are whole S3 tensors (every source's channel count a multiple of 32, all of them used)"""
-    return ksize == 3 and stride == 1 and M % 64 == 0 and all(n % 32 == 0 and n == t.shape[3] for (t, n, *_r) in srcs)
+    """the split-operand backward-filter kernel (csrc/wgrad_s3.hip) covers 3x3 and 1x1 stride-1 convs with cout % 64 == 0
+    whose sources are whole split tensors (every source's channel count a multiple of 32, all of them used)"""
+    return (ksize in (1, 3) and stride == 1 and M % 64 == 0
+            and all(n % 32 == 0 and n == t.shape[3] for (t, n, *_r) in srcs))
 
 
-def _wgrad_s3(lib, tape, dz_s3, M, srcs, B, H, W, cin_store):
-    """raw (M, 9, cin_store) on the bf16 matrix cores; srcs as in _wgrad (fp32 NHWC tensors whose S3 copies the
-    tape holds since the forward pass)."""
-    raw = tape.zeros((M, 9, cin_store), dz_s3)
+def _wgrad_s3(lib, tape, dz_s3, M, srcs, B, H, W, cin_store, ksize=3):
+    """raw (M, ksize^2, cin_store) on the 16-bit matrix cores; srcs as in _wgrad (fp32 NHWC tensors whose split copies
+    the tape holds since the forward pass)."""
+    raw = tape.zeros((M, ksize * ksize, cin_store), dz_s3)
     for (t, n, n_off, pt, pl) in srcs:
         xs = tape.s3(t)
         _lib.check(lib.sfh_conv_wgrad_s3(_ptr(dz_s3), M, _ptr(xs), t.shape[3], t.shape[1], t.shape[2], n, pt, pl,
-                                         B, H, W, _ptr(raw), cin_store, n_off, tape.fmt_code, _stream()), "conv_wgrad_s3")
+                                         B, H, W, ksize, _ptr(raw), cin_store, n_off, tape.fmt_code, _stream()),
+                   "conv_wgrad_s3")
     return raw
 
 
@@ -411,7 +413,7 @@ def conv_bn_act(tape, names, conv, bn, srcs, B, H, W, relu=True, residual=None, 
             dz = u
         cin_store = t0.shape[3] if t1 is None else c0 + c1
         if wg_s3:
-            raw = _wgrad_s3(lib, tape, dz_s3, cout, wsrc, B, H, W, cin_store)
+            raw = _wgrad_s3(lib, tape, dz_s3, cout, wsrc, B, H, W, cin_store, ks)
         else:
             raw = _wgrad(lib, dz, wsrc, B, H, W, ks, cin_store, tape)
         # a strided view: the copy into the gradient buffer (TrainStep) or autograd's accumulation does the permute
@@ -489,11 +491,16 @@ def conv_transpose2x2(tape, names, up, x):
         g[names(up.bias)] = _colsum(lib, du)
         s = _empty((B, h, w, 4 * cout), x)  # s[(py*2+px)*cout + co] = du[2y+py][2x+px][co]
         _lib.check(lib.sfh_space_to_depth2(_ptr(du), _ptr(s), B, 2 * h, 2 * w, cout, _stream()), "space_to_depth2")
-        raw = _wgrad(lib, s, [(x, cin, 0, 0, 0)], B, h, w, 1, cin, tape)      # (4*cout, 1, cin)
+        s_split = E.f32_to_split(s, tape.fmt, tape.overflow) if s3 else None
+        wsrc = [(x, cin, 0, 0, 0)]
+        if s3 and wgrad_s3_ok(1, 1, 4 * cout, wsrc):   # one split copy of s feeds backward-filter and backward-data
+            raw = _wgrad_s3(lib, tape, s_split, 4 * cout, wsrc, B, h, w, cin, 1)
+        else:
+            raw = _wgrad(lib, s, wsrc, B, h, w, 1, cin, tape)      # (4*cout, 1, cin)
         g[names(up.weight)] = raw.view(2, 2, cout, cin).permute(3, 2, 0, 1)
         bd = PackedConv.backward_data(wt, 1, transposed=True, fmt=tape.fmt if s3 else None, wexp=tape.wexp_of(up.weight))
         dx = _empty((B, h, w, bd.cout), x)
-        bd.run(E.f32_to_split(s, tape.fmt, tape.overflow) if s3 else s, B, h, w, dx)
+        bd.run(s_split if s3 else s, B, h, w, dx)
         tape.add_grad(x, dx)
 
     tape.push(backward)

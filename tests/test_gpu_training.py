@@ -69,8 +69,9 @@ def test_wgrad_kernel_vs_autograd(T):
 
 
 @pytest.mark.parametrize("prec", ["bf16x6", "f16x3"])
+@pytest.mark.parametrize("ks", [3, 1])
 @pytest.mark.parametrize("shape", [(2, 11, 37), (1, 6, 70), (3, 9, 20), (2, 12, 8), (1, 40, 10)])
-def test_wgrad_s3_kernel_vs_fp64(T, shape, prec, monkeypatch):
+def test_wgrad_s3_kernel_vs_fp64(T, shape, prec, ks, monkeypatch):
     """backward-filter on the bf16 matrix cores (split-bf16 operands, transposing LDS reads): two-source
     (concat + pad), all three tile shapes, partial tiles, against an fp64 reference and the fp32-MFMA kernel."""
     from sfh_amd import _lib, engine as E
@@ -83,18 +84,18 @@ def test_wgrad_s3_kernel_vs_fp64(T, shape, prec, monkeypatch):
     x1 = torch.randn(B, 32, h1, w1, generator=g)
     dz = torch.randn(B, 128, H, W, generator=g)
     xin = torch.cat([x0, torch.nn.functional.pad(x1, [pl, W - w1 - pl, pt, H - h1 - pt])], 1).double().requires_grad_(True)
-    w = torch.zeros(128, 96, 3, 3, dtype=torch.float64, requires_grad=True)
-    torch.nn.functional.conv2d(xin, w, padding=1).backward(dz.double())
+    w = torch.zeros(128, 96, ks, ks, dtype=torch.float64, requires_grad=True)
+    torch.nn.functional.conv2d(xin, w, padding=ks // 2).backward(dz.double())
     nh = lambda t: t.permute(0, 2, 3, 1).contiguous().cuda()
     tape = T.Tape()
     t0, t1, dzc = nh(x0), nh(x1), nh(dz)
     srcs = [(t0, 64, 0, 0, 0), (t1, 32, 64, pt, pl)]
-    assert T.wgrad_s3_ok(3, 1, 128, srcs)
-    raw = T._wgrad_s3(lib, tape, E.f32_to_split(dzc, tape.fmt), 128, srcs, B, H, W, 96)
-    ref32 = T._wgrad(lib, dzc, srcs, B, H, W, 3, 96)
+    assert T.wgrad_s3_ok(ks, 1, 128, srcs)
+    raw = T._wgrad_s3(lib, tape, E.f32_to_split(dzc, tape.fmt), 128, srcs, B, H, W, 96, ks)
+    ref32 = T._wgrad(lib, dzc, srcs, B, H, W, ks, 96)
     torch.cuda.synchronize()
-    got = raw.view(128, 3, 3, 96).permute(0, 3, 1, 2)
-    old = ref32.view(128, 3, 3, 96).permute(0, 3, 1, 2)
+    got = raw.view(128, ks, ks, 96).permute(0, 3, 1, 2)
+    old = ref32.view(128, ks, ks, 96).permute(0, 3, 1, 2)
     e_new, e_old = _relerr(got, w.grad), _relerr(old, w.grad)
     assert e_new < 2e-5, (e_new, e_old)
     assert e_new < 4 * e_old + 1e-6, (e_new, e_old)       # fp32-grade accuracy
