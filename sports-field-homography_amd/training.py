@@ -420,10 +420,23 @@ def conv_bn_act(tape, names, conv, bn, srcs, B, H, W, relu=True, residual=None, 
         g[names(conv.weight)] = raw.view(cout, ks, ks, cin_store)[..., :c0 + c1].permute(0, 3, 1, 2)
         if not need_dx:
             return
+        dz_in = ((dz_s3 if dz_s3 is not None else E.f32_to_split(dz, tape.fmt, tape.overflow)) if s3 else dz)
+        if (t1 is not None and c0 % 64 == 0 and c1 % 64 == 0 and (srcs[1][2], srcs[1][3]) == (0, 0)
+                and tuple(t1.shape[1:3]) == (H, W) and c0 == t0.shape[3]):
+            # two sources of the same size: one backward-data conv per source writes that source's gradient directly
+            # (no gradient of the concatenated tensor, no slicing passes)
+            for (t, lo, hi) in ((t0, 0, c0), (t1, c0, c0 + c1)):
+                bdh = PackedConv.backward_data(w[:, lo:hi].contiguous(), ks, fmt=tape.fmt if s3 else None,
+                                               wexp=tape.wexp_of(conv.weight))
+                bdh.order = tape.order
+                dh = _empty((B, H, W, hi - lo), z)
+                bdh.run(dz_in, B, H, W, dh)
+                tape.add_grad(t, dh)
+            return
         bd = PackedConv.backward_data(w, ks, fmt=tape.fmt if s3 else None, wexp=tape.wexp_of(conv.weight))
         bd.order = tape.order
         dx = _empty((B, H, W, bd.cout), z)
-        bd.run((dz_s3 if dz_s3 is not None else E.f32_to_split(dz, tape.fmt, tape.overflow)) if s3 else dz, B, H, W, dx)
+        bd.run(dz_in, B, H, W, dx)
         if t1 is None:
             tape.add_grad(t0, dx)
             return
