@@ -162,6 +162,15 @@ typedef struct sfh_conv_desc {
    * - the separate statistics pass over z (sfh_bn_stats) is not needed.  stats_rows: a power of two, 64 .. 65536. */
   double* stats_partial;
   int32_t stats_rows;
+  /* backward mode of the same table (optional, with stats_partial): this launch is the backward-data conv whose fp32 output
+   * dy is the ONLY gradient of a BatchNorm (+ReLU) layer; bwd_z = that layer's pre-BatchNorm tensor (fp32 NHWC, the shape of
+   * dst, dst_cs == cout), bwd_mi = its mean | invstd (2 * cout floats), bwd_gamma / bwd_beta = its affine parameters (both
+   * NULL: the layer has no ReLU).  The table then receives sum g and sum g * xhat with g = dy * (y > 0),
+   * y = (z - mean) * invstd * gamma + beta exactly as sfh_bn_apply computes it: sfh_bn_bwd_reduce is not needed. */
+  const float* bwd_z;
+  const float* bwd_mi;
+  const float* bwd_gamma;
+  const float* bwd_beta;
 } sfh_conv_desc;
 
 const char* sfh_last_error(void);

@@ -37,6 +37,7 @@ class ConvDesc(C.Structure):
         ("h2_overflow", _p), ("h2_exp_src", _i), ("h2_exp_dst", _i), ("h2_exp_res", _i), ("h2_range", _p),
         ("wg_couts", _i), ("split_arith", _i), ("ksplit", _i), ("ksplit_stride", C.c_int64), ("acc_init", _p),
         ("stats_partial", _p), ("stats_rows", _i),
+        ("bwd_z", _p), ("bwd_mi", _p), ("bwd_gamma", _p), ("bwd_beta", _p),
     ]
 
     def __init__(self, *args, **kw):

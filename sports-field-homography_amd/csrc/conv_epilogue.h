@@ -378,31 +378,73 @@ __device__ __forceinline__ void sfh_conv_epilogue(const sfh_conv_desc& d, const 
       }
     }
   }
-  // BatchNorm statistics of a training-mode layer (sfh_conv_desc.stats_partial; configurations with STATS only): the sums of
-  // z and z * z over the in-frame pixels, one channel at a time from the finished values still in `acc`, in fp64 like the
-  // separate pass (sfh_bn_stats) - two accumulators live at a time, so the instance keeps its register count
+  // BatchNorm sums of a training-mode layer (sfh_conv_desc.stats_partial; configurations with STATS only).  Forward mode: the
+  // sums of z and z * z over the in-frame pixels, one channel at a time from the finished values still in `acc`, in fp64 like
+  // the separate pass (sfh_bn_stats) - two accumulators live at a time, so the instance keeps its register count
   if constexpr (STATS) {
     if (d.stats_partial) {
       double* const row = d.stats_partial + (size_t)(stats_slot & (unsigned)(d.stats_rows - 1)) * (size_t)(2 * d.cout);
+      if (d.bwd_z) {
+        // backward mode (this launch is the backward-data conv whose output dy is the ONLY gradient of a BatchNorm + ReLU
+        // layer): with z the pre-BatchNorm tensor of that layer (same fp32 NHWC shape as dst), g = dy * (y > 0),
+        // y = (z - mean) * invstd * gamma + beta as bn_apply computes it; the sums of g and of g * xhat (= dbeta, dgamma)
+        // - the separate reduction pass over dy and z (sfh_bn_bwd_reduce) is not needed
+        const __amdgpu_buffer_rsrc_t rz =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.bwd_z), 0, (int)kSfhOOB, 0x00020000);
 #pragma unroll
-      for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          double a = 0.0, b = 0.0;
+        for (int ni = 0; ni < NI; ++ni) {
+          const int c0 = n0 + ni * 16 + 4 * lg;
+          const f32x4 mean = *reinterpret_cast<const f32x4*>(d.bwd_mi + c0);
+          const f32x4 inv = *reinterpret_cast<const f32x4*>(d.bwd_mi + d.cout + c0);
+          f32x4 gam = {1.f, 1.f, 1.f, 1.f}, bet = {1.f, 1.f, 1.f, 1.f};   // without a ReLU: y > 0 for every element
+          if (d.bwd_beta) {
+            gam = *reinterpret_cast<const f32x4*>(d.bwd_gamma + c0);
+            bet = *reinterpret_cast<const f32x4*>(d.bwd_beta + c0);
+          }
+          double a[4] = {0.0, 0.0, 0.0, 0.0}, b[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
           for (int mi = 0; mi < MT; ++mi) {
-            const double z = voff[mi] != kSfhOOB ? (double)acc[ni][mi][j] : 0.0;
-            a += z;
-            b += z * z;
+            const f32x4 zq = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rz, (int)voff[mi], (int)ni_off(ni), 0));
+            const bool in_frame = voff[mi] != kSfhOOB;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const float xh = (zq[j] - mean[j]) * inv[j];
+              const float y = d.bwd_beta ? xh * gam[j] + bet[j] : 1.f;
+              const float gj = (in_frame && y > 0.f) ? acc[ni][mi][j] : 0.f;
+              a[j] += (double)gj;
+              b[j] += (double)gj * (double)xh;
+            }
           }
-          a = sfh_row16_sum(a);
-          b = sfh_row16_sum(b);
-          if (lq == 0) {
-            const int c = n0 + ni * 16 + 4 * lg + j;
-            unsafeAtomicAdd(row + c, a);
-            unsafeAtomicAdd(row + d.cout + c, b);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const double sa = sfh_row16_sum(a[j]), sb = sfh_row16_sum(b[j]);
+            if (lq == 0) {
+              unsafeAtomicAdd(row + c0 + j, sa);
+              unsafeAtomicAdd(row + d.cout + c0 + j, sb);
+            }
           }
         }
+      } else {
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            double a = 0.0, b = 0.0;
+#pragma unroll
+            for (int mi = 0; mi < MT; ++mi) {
+              const double z = voff[mi] != kSfhOOB ? (double)acc[ni][mi][j] : 0.0;
+              a += z;
+              b += z * z;
+            }
+            a = sfh_row16_sum(a);
+            b = sfh_row16_sum(b);
+            if (lq == 0) {
+              const int c = n0 + ni * 16 + 4 * lg + j;
+              unsafeAtomicAdd(row + c, a);
+              unsafeAtomicAdd(row + d.cout + c, b);
+            }
+          }
+      }
     }
   }
   // H2 destination: leave the largest |u| for the host - beyond the fp16 range the value was saturated: the engine

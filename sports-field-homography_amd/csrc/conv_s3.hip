@@ -1176,6 +1176,11 @@ extern "C" int sfh_conv_s3_fwd(const sfh_conv_desc* dp, void* stream_) {
                     d.stats_rows <= 65536 && (d.stats_rows & (d.stats_rows - 1)) == 0,
                 "conv_s3_fwd: stats_partial needs H2 sources, a 3x3 stride-1 conv with a plain fp32 destination (no ReLU / "
                 "residual / pooled output / head / split-K) and stats_rows a power of two in 64 .. 65536");
+    SFH_REQUIRE(!d.bwd_z || (d.bwd_mi && d.dst_cs == d.cout && (!d.bwd_gamma == !d.bwd_beta) &&
+                             (unsigned long long)d.batch * d.H * d.W * d.cout * 4ULL < 0xFFFFFFF0ULL),
+                "conv_s3_fwd: bwd_z needs bwd_mi, bwd_gamma and bwd_beta together, dst_cs == cout and tensors below 4 GiB");
+  } else {
+    SFH_REQUIRE(!d.bwd_z, "conv_s3_fwd: bwd_z without stats_partial");
   }
 #define SFH_S3CASE_W8(KS, ST, TILE, SH, SW, TH, TW)                                                          \
   if (w8_ok && d.ksize == KS && d.stride == ST && d.tile == TILE) {                                           \

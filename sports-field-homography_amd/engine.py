@@ -539,7 +539,7 @@ class PackedConv:
 
     def run(self, src0, batch, H, W, dst, src1=None, pool0=False, pad1=(0, 0), residual=None, tile=None,
             dst_pool=None, up_dst=None, head=None, wg_couts=0, exp_src=None, exp_dst=None, exp_res=None,
-            range_word=None, ksplit=0, slabs=None, acc_init=None, scale=None, shift_border=None, stats=None):
+            range_word=None, ksplit=0, slabs=None, acc_init=None, scale=None, shift_border=None, stats=None, bwd=None):
         """src0/src1: NHWC float32 tensors, or split tensors of the layer's format (S3 bfloat16 / H2 float16);
         dst/residual/dst_pool: float32 NHWC or the same split format (by dtype).  H, W: conv input frame.
         H2 tensors: exp_src / exp_dst / exp_res = exponents of the sources / dst and dst_pool / an H2 residual
@@ -551,7 +551,9 @@ class PackedConv:
         (sfh_conv_desc.acc_init); scale / shift_border: tensors used instead of the layer's own for this launch.
         stats (training, H2 3x3 stride-1 layers with a plain fp32 dst): zero-filled float64 table (rows, 2, cout), rows a
         power of two - the epilogue adds the per-wave sums of z and z^2 for batch-statistics BatchNorm into it
-        (sfh_conv_desc.stats_partial; PackedConv.stats_ok says whether a layer qualifies)."""
+        (sfh_conv_desc.stats_partial; PackedConv.stats_ok says whether a layer qualifies).  bwd (with stats, this launch
+        being a backward-data conv): (z, mean_invstd, gamma, beta) of the BatchNorm + ReLU layer whose only gradient dst
+        is - the table then receives sum g and sum g * xhat (sfh_conv_desc.bwd_z)."""
         lib = _lib.load()
         d = ConvDesc()
         if self.fmt == "h2" and exp_src is not None:
@@ -614,6 +616,15 @@ class PackedConv:
                     or tuple(stats.shape[1:]) != (2, self.cout)):
                 raise ValueError(f"stats must be a contiguous float64 tensor (rows, 2, {self.cout})")
             d.stats_partial, d.stats_rows = stats.data_ptr(), int(stats.shape[0])
+            if bwd is not None:
+                z, mi, gamma, beta = bwd
+                if (z.dtype != torch.float32 or not z.is_contiguous() or tuple(z.shape) != tuple(dst.shape)
+                        or dst.dtype != torch.float32 or mi.numel() != 2 * self.cout):
+                    raise ValueError("bwd: z must be a contiguous float32 tensor of dst's shape, mean_invstd 2 * cout floats")
+                d.bwd_z, d.bwd_mi = z.data_ptr(), mi.data_ptr()
+                d.bwd_gamma, d.bwd_beta = gamma.data_ptr(), beta.data_ptr()
+        elif bwd is not None:
+            raise ValueError("bwd needs the stats table")
         if head is not None:   # OutConv fused behind this conv (sfh_conv_desc.head_*)
             d.head_w, d.head_b, d.head_nc = head["w"].data_ptr(), head["b"].data_ptr(), head["nc"]
             d.head_logits = head["logits"].data_ptr()

@@ -163,6 +163,9 @@ class Tape:
         self.fmt_code = {"s3": _lib.FMT_S3, "h2": _lib.FMT_H2}.get(self.fmt, _lib.FMT_F32)
         self._s3 = {}
         self.no_f32 = set()   # ids of activation handles without fp32 storage (conv_bn_act(f32_out=False))
+        # BatchNorm + ReLU layers whose output has ONE consumer (the next conv): id(y) -> {z, mi, bn}; that conv's
+        # backward-data launch leaves the layer's backward sums in entry["table"] (sfh_conv_desc.bwd_z)
+        self.single_consumer = {}
         # f16x3 (H2 copies of activations and gradients): fp16's exponent range has to hold them.
         #   overflow - device word the kernels raise when a value does not fit (checked at the end of the backward pass);
         #   gscale   - power of two all gradients are carried with (the losses are means over B*H*W pixels, their
@@ -225,6 +228,9 @@ class Tape:
         if cur is None:
             self.grads[id(t)] = g
             return
+        ent = self.single_consumer.get(id(t))
+        if ent is not None:
+            ent.pop("table", None)   # a second gradient arrives: the sums of the first are not the layer's
         B, H, W, C = g.shape
         _lib.check(self.lib.sfh_slice_add(_ptr(g), H, W, C, 0, 0, 0, _ptr(cur), B, H, W, C, 1, _stream()), "slice_add")
 
@@ -242,6 +248,7 @@ class Tape:
 
 # --------------------------------------------------------------------------------------- layers
 STATS_IN_EPILOGUE = os.environ.get("SFH_TRAIN_STATS_EPILOGUE", "1") != "0"
+BWD_SUMS_IN_EPILOGUE = os.environ.get("SFH_TRAIN_BWD_SUMS_EPILOGUE", "1") != "0"
 STATS_ROWS = 2048   # most rows of the table a conv epilogue adds its per-wave BatchNorm sums into (sfh_conv_desc.stats_partial)
 
 
@@ -277,7 +284,7 @@ def _bn_forward(lib, z, bn, relu, residual, tape, want_s3=True, want_f32=True, s
     return y, mi
 
 
-def _bn_backward(lib, tape, dy, y, z, mi, bn, relu, want_dres, want_s3=False, want_f32=True):
+def _bn_backward(lib, tape, dy, y, z, mi, bn, relu, want_dres, want_s3=False, want_f32=True, sums_table=None):
     """want_dres: the layer added a residual before its ReLU (its gradient is returned as dres).
     want_f32=False (with want_s3): only the split copy of dz is written (its consumers are the split-operand
     backward-data and backward-filter kernels); the returned dz is None."""
@@ -288,8 +295,12 @@ def _bn_backward(lib, tape, dy, y, z, mi, bn, relu, want_dres, want_s3=False, wa
     # bn_apply) instead of reading y - 8 instead of 12 bytes per element in the reduction, 16 instead of 20 in the apply
     ysign = y if (relu and want_dres) else None
     gam, bet = bn.weight.detach(), bn.bias.detach()
-    _lib.check(lib.sfh_bn_bwd_reduce(_ptr(dy), _ptr(ysign), _ptr(z), _ptr(mi), _ptr(gam), _ptr(bet), 1 if relu else 0,
-                                     npix, C, _ptr(acc), _stream()), "bn_bwd_reduce")
+    if sums_table is not None:   # the backward-data launch that produced dy left the sums (conv_bn_act)
+        _lib.check(lib.sfh_bn_stats_partials(_ptr(sums_table), sums_table.shape[0], C, _ptr(acc), _stream()),
+                   "bn_stats_partials")
+    else:
+        _lib.check(lib.sfh_bn_bwd_reduce(_ptr(dy), _ptr(ysign), _ptr(z), _ptr(mi), _ptr(gam), _ptr(bet), 1 if relu else 0,
+                                         npix, C, _ptr(acc), _stream()), "bn_bwd_reduce")
     dres = _empty(z.shape, z) if want_dres else None
     dz_s3 = E.split_empty(tape.fmt, B, H, W, C, z.device) if (want_s3 and C % 32 == 0) else None
     dz = _empty(z.shape, z) if (want_f32 or dz_s3 is None) else None
@@ -384,6 +395,8 @@ def conv_bn_act(tape, names, conv, bn, srcs, B, H, W, relu=True, residual=None, 
         raise RuntimeError("conv_bn_act: a source has no fp32 storage (f32_out=False) but this conv reads fp32")
     y, mi = _bn_forward(lib, z, bn, relu, residual, tape, want_s3=s3_out,   # s3_out: a conv consumes y
                         want_f32=f32_out or residual is not None, stats=stats)
+    if not f32_out and residual is None and relu and BWD_SUMS_IN_EPILOGUE:
+        tape.single_consumer[id(y)] = {"z": z, "mi": mi, "bn": bn}
 
     def backward():
         dy = tape.pop_grad(y)
@@ -396,9 +409,11 @@ def conv_bn_act(tape, names, conv, bn, srcs, B, H, W, relu=True, residual=None, 
         if not wg_s3 and any(id(t) in tape.no_f32 for (t, *_r) in wsrc):
             raise RuntimeError("conv_bn_act: a source has no fp32 storage (f32_out=False) but its backward-filter reads fp32")
         # fp32 dz is read by the fp32 backward-filter kernel and by the zero-stuffing of stride-2 layers only
+        ent = tape.single_consumer.pop(id(y), None)
         dz, dgamma, dbeta, dres, dz_s3 = _bn_backward(lib, tape, dy, y, z, mi, bn, relu, residual is not None,
                                                       want_s3=s3 and stride == 1 and (need_dx or wg_s3),
-                                                      want_f32=not (s3 and stride == 1 and wg_s3))
+                                                      want_f32=not (s3 and stride == 1 and wg_s3),
+                                                      sums_table=ent.get("table") if ent is not None else None)
         g = tape.param_grads
         g[names(bn.weight)], g[names(bn.bias)] = dgamma, dbeta
         if conv.bias is not None:
@@ -436,7 +451,19 @@ def conv_bn_act(tape, names, conv, bn, srcs, B, H, W, relu=True, residual=None, 
         bd = PackedConv.backward_data(w, ks, fmt=tape.fmt if s3 else None, wexp=tape.wexp_of(conv.weight))
         bd.order = tape.order
         dx = _empty((B, H, W, bd.cout), z)
-        bd.run(dz_in, B, H, W, dx)
+        src_ent = tape.single_consumer.get(id(t0)) if t1 is None else None
+        if (src_ent is not None and s3 and bd.stats_ok and bd.cout == t0.shape[3] and tape.peek_grad(t0) is None):
+            # t0 is a BatchNorm + ReLU output that only this conv consumed: its backward sums ride in this launch
+            rows = 64
+            while rows < STATS_ROWS and rows * 1024 < B * H * W:
+                rows *= 2
+            table = tape.zeros((rows, 2, bd.cout), z, torch.float64)
+            sb = src_ent["bn"]
+            bd.run(dz_in, B, H, W, dx, stats=table,
+                   bwd=(src_ent["z"], src_ent["mi"], sb.weight.detach(), sb.bias.detach()))
+            src_ent["table"] = table
+        else:
+            bd.run(dz_in, B, H, W, dx)
         if t1 is None:
             tape.add_grad(t0, dx)
             return
@@ -661,9 +688,9 @@ class ResNetTrainer:
 
         tape.push(stem_backward)
 
-        def cba(conv, bn, src, hh, ww, relu=True, residual=None):
+        def cba(conv, bn, src, hh, ww, relu=True, residual=None, f32_out=True):
             return conv_bn_act(tape, names, conv, bn, [(src, src.shape[3], 0, 0)], B, hh, ww, relu=relu,
-                               residual=residual)
+                               residual=residual, f32_out=f32_out)
 
         for li in range(1, 5):
             for bi, blk in enumerate(getattr(rn, f"layer{li}")):
@@ -676,7 +703,10 @@ class ResNetTrainer:
                     t = cba(blk.conv2, blk.bn2, t, h, w)
                     x = cba(blk.conv3, blk.bn3, t, ho, wo, residual=idn)
                 else:
-                    t = cba(blk.conv1, blk.bn1, x, h, w)
+                    # t feeds conv2 only (3x3 stride 1): forward, backward-data and backward-filter read its split copy
+                    mid_f32 = not (tape.use_s3 and blk.conv1.out_channels % 64 == 0 and blk.conv2.out_channels % 64 == 0
+                                   and CAPTURE is None)
+                    t = cba(blk.conv1, blk.bn1, x, h, w, f32_out=mid_f32)
                     x = cba(blk.conv2, blk.bn2, t, ho, wo, residual=idn)
                 if CAPTURE is not None:
                     CAPTURE[f"layer{li}.{bi}"] = {"in": x_in, "t": t, "out": x}
