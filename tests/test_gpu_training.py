@@ -985,3 +985,37 @@ def test_batchnorm_split_copy_without_the_fp32_copy(T, prec, monkeypatch):
     want = torch.relu((z - mi[:C]) * mi[C:] * gam + bet)
     assert torch.equal(y, want) or float((y - want).abs().max()) < 1e-6
     assert float((E.s3_to_f32(ys) - y).abs().max()) < 2e-6 * float(y.abs().max())
+
+
+@pytest.mark.parametrize("shape,cin,cout", [((2, 13, 37), 64, 64), ((1, 22, 40), 128, 256), ((16, 45, 80), 128, 128)])
+def test_backward_data_epilogue_leaves_the_batchnorm_backward_sums(T, shape, cin, cout, monkeypatch):
+    """sfh_conv_desc.bwd_z: the backward-data launch of a conv whose input is a BatchNorm + ReLU output with no other
+    consumer leaves sum g and sum g * xhat of that layer (g = dy * (y > 0), y recomputed from z as bn_apply does) -
+    equal to what sfh_bn_bwd_reduce finds in the dy the same launch wrote."""
+    from sfh_amd import _lib, engine as E
+    from sfh_amd.engine import PackedConv, _ptr, _stream
+    monkeypatch.setenv("SFH_TRAIN_PRECISION", "f16x3")
+    lib = _lib.load()
+    B, H, W = shape
+    g = torch.Generator().manual_seed(23 + H)
+    w = (torch.randn(cout, cin, 3, 3, generator=g) * 0.05).cuda()          # the consumer conv: cin -> cout
+    dz2 = torch.randn(B, H, W, cout, generator=g).cuda()                    # its dz
+    z1 = torch.randn(B, H, W, cin, generator=g).cuda()                      # pre-BatchNorm tensor of the producer layer
+    mi = torch.cat([torch.randn(cin, generator=g) * 0.2, torch.rand(cin, generator=g) + 0.5]).cuda()
+    gam, bet = (torch.rand(cin, generator=g) + 0.5).cuda(), (torch.randn(cin, generator=g) * 0.3).cuda()
+    bd = PackedConv.backward_data(w, 3, fmt="h2")
+    assert bd.stats_ok and bd.cout == cin
+    dy = torch.empty(B, H, W, cin, device="cuda")
+    table = torch.zeros(128, 2, cin, dtype=torch.float64, device="cuda")
+    bd.run(E.f32_to_split(dz2, "h2"), B, H, W, dy, stats=table, bwd=(z1, mi, gam, bet))
+    acc = torch.zeros(2 * cin, dtype=torch.float64, device="cuda")
+    _lib.check(lib.sfh_bn_stats_partials(_ptr(table), 128, cin, _ptr(acc), _stream()), "bn_stats_partials")
+    ref = torch.zeros(2 * cin, dtype=torch.float64, device="cuda")
+    _lib.check(lib.sfh_bn_bwd_reduce(_ptr(dy), None, _ptr(z1), _ptr(mi), _ptr(gam), _ptr(bet), 1, B * H * W, cin, _ptr(ref),
+                                     _stream()), "bn_bwd_reduce")
+    torch.cuda.synchronize()
+    scale = torch.cat([dy.abs().double().reshape(-1, cin).sum(0)] * 2) + 1e-9
+    assert float(((acc - ref).abs() / scale).max()) < 1e-12
+    dy2 = torch.empty_like(dy)
+    bd.run(E.f32_to_split(dz2, "h2"), B, H, W, dy2)
+    assert torch.equal(dy, dy2)
