@@ -701,37 +701,52 @@ __global__ __launch_bounds__(256) void stem_bwd_data_kernel(const float* __restr
     wl[i] = c < nc ? w[((long)co * cin + c_off + c) * 49 + t] : 0.f;
   }
   __syncthreads();
-  const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+  // a thread owns the pixels x and x + 64 of a row: same column parity, i.e. the same taps (ky, kx) and the same weights -
+  // every 16-byte LDS read of a weight quad feeds two pixels (the kernel was bound by those reads: one per four FMAs)
+  const int x = blockIdx.x * 128 + (threadIdx.x & 63);
   const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
   const int b = blockIdx.z;
   if (x >= W || y >= H) return;
-  float acc[4 * NC4];
+  const bool two = x + 64 < W;
+  float acc[2][4 * NC4];
 #pragma unroll
-  for (int c = 0; c < 4 * NC4; ++c) acc[c] = 0.f;
+  for (int p = 0; p < 2; ++p)
+#pragma unroll
+    for (int c = 0; c < 4 * NC4; ++c) acc[p][c] = 0.f;
   for (int ky = (y + 3) & 1; ky < 7; ky += 2) {
     const int Y = (y + 3 - ky) >> 1;
     if (Y < 0 || Y >= Ho) continue;
     for (int kx = (x + 3) & 1; kx < 7; kx += 2) {
-      const int X = (x + 3 - kx) >> 1;
-      if (X < 0 || X >= Wo) continue;
-      const float* dp = dz + (((long)b * Ho + Y) * Wo + X) * 64;
+      const int X0 = (x + 3 - kx) >> 1, X1 = X0 + 32;
+      const bool ok0 = X0 >= 0 && X0 < Wo, ok1 = two && X1 >= 0 && X1 < Wo;
+      if (!ok0 && !ok1) continue;
+      const float* dp0 = dz + (((long)b * Ho + Y) * Wo + (ok0 ? X0 : 0)) * 64;
+      const float* dp1 = dz + (((long)b * Ho + Y) * Wo + (ok1 ? X1 : 0)) * 64;
       const float* wp = wl + (ky * 7 + kx) * 64 * 4 * NC4;
 #pragma unroll 4
       for (int co4 = 0; co4 < 16; ++co4) {
-        const f32x4 d = *reinterpret_cast<const f32x4*>(dp + 4 * co4);
+        f32x4 d0 = *reinterpret_cast<const f32x4*>(dp0 + 4 * co4), d1 = *reinterpret_cast<const f32x4*>(dp1 + 4 * co4);
+        if (!ok0) d0 = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (!ok1) d1 = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
 #pragma unroll
           for (int q = 0; q < NC4; ++q) {
             const f32x4 ww = *reinterpret_cast<const f32x4*>(wp + ((4 * co4 + j) * NC4 + q) * 4);
 #pragma unroll
-            for (int c = 0; c < 4; ++c) acc[4 * q + c] += d[j] * ww[c];
+            for (int c = 0; c < 4; ++c) {
+              acc[0][4 * q + c] += d0[j] * ww[c];
+              acc[1][4 * q + c] += d1[j] * ww[c];
+            }
           }
         }
       }
     }
   }
-  for (int c = 0; c < nc; ++c) dlogits[(((long)b * nc + c) * H + y) * W + x] += acc[c];
+  for (int c = 0; c < nc; ++c) {
+    dlogits[(((long)b * nc + c) * H + y) * W + x] += acc[0][c];
+    if (two) dlogits[(((long)b * nc + c) * H + y) * W + x + 64] += acc[1][c];
+  }
 }
 
 // ------------------------------------------------------------------ losses of the training step
@@ -1269,7 +1284,7 @@ extern "C" int sfh_stem_bwd_data(const float* dz, const float* w, int cin, int c
   SFH_REQUIRE(dz && w && dlogits_nchw && batch > 0 && batch <= 65535 && H > 0 && W > 0, "stem_bwd_data: bad argument");
   SFH_REQUIRE(nc >= 1 && nc <= 8 && c_off >= 0 && c_off + nc <= cin, "stem_bwd_data: c_off=%d nc=%d cin=%d", c_off, nc, cin);
   const int Ho = (H + 6 - 7) / 2 + 1, Wo = (W + 6 - 7) / 2 + 1;
-  const dim3 grid((unsigned)sfh_cdiv(W, 64), (unsigned)sfh_cdiv(H, 4), (unsigned)batch);
+  const dim3 grid((unsigned)sfh_cdiv(W, 128), (unsigned)sfh_cdiv(H, 4), (unsigned)batch);
   if (nc <= 4) {
     hipLaunchKernelGGL(stem_bwd_data_kernel<1>, grid, dim3(256), 49 * 64 * 4 * sizeof(float), (hipStream_t)stream, dz, w,
                        cin, c_off, nc, H, W, Ho, Wo, dlogits_nchw);
