@@ -48,11 +48,29 @@ def run(cin, cout, w, heights, B=16, wg=0, pool=False, tile=None):
 if __name__ == "__main__":
     wg = int(sys.argv[sys.argv.index("--wg") + 1]) if "--wg" in sys.argv else 0
     # the shapes of the model (d3.3 / u1.3, d2.3, d1.3, inc.3) and taller / shorter frames of the same width
-    run(512, 512, 80, (11, 22, 45, 90, 180, 360), wg=wg)
-    run(256, 256, 160, (22, 45, 90, 180, 360), wg=wg)
-    run(128, 128, 320, (45, 90, 180, 360), wg=wg)
-    run(64, 64, 640, (90, 180, 360), wg=wg)
-    run(64, 64, 640, (360,), wg=wg, pool=True)
+    if "--w8-half" not in sys.argv:
+        run(512, 512, 80, (11, 22, 45, 90, 180, 360), wg=wg)
+        run(256, 256, 160, (22, 45, 90, 180, 360), wg=wg)
+        run(128, 128, 320, (45, 90, 180, 360), wg=wg)
+        run(64, 64, 640, (90, 180, 360), wg=wg)
+        run(64, 64, 640, (360,), wg=wg, pool=True)
+    if "--w8-half" in sys.argv:   # variant build with -DSFH_EXPERIMENT_W8_HALF_DB: 128-pixel x 128-cout workgroups, double-buffered
+        print("128 x 128 workgroups, two LDS buffers (tile 8x16)")
+        run(512, 512, 80, (45, 360), wg=128, tile=3)
+        run(256, 256, 160, (90, 360), wg=128, tile=3)
+        run(128, 128, 320, (180, 360), wg=128, tile=3)
+        print("128 x 64 workgroups, two LDS buffers (tile 8x16)")
+        run(64, 64, 640, (360,), wg=64, tile=3)
+        run(64, 64, 640, (360,), wg=64, tile=3, pool=True)
+        run(128, 128, 320, (180,), wg=64, tile=3)
+        run(256, 256, 160, (90,), wg=64, tile=3)
+        run(512, 512, 80, (45,), wg=64, tile=3)
+        print("the same layers, product shapes")
+        run(512, 512, 80, (45, 360), wg=128)
+        run(256, 256, 160, (90, 360), wg=128)
+        run(128, 128, 320, (180, 360), wg=128)
+        run(64, 64, 640, (360,))
+        run(64, 64, 640, (360,), pool=True)
     if "--half-tiles" in sys.argv:   # 128-pixel tiles: half the LDS and accumulators per workgroup, more workgroups per CU
         print("half-size tiles (8x16)")
         run(64, 64, 640, (360,), tile=3)

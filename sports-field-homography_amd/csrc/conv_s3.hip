@@ -1207,6 +1207,14 @@ extern "C" int sfh_conv_s3_fwd(const sfh_conv_desc* dp, void* stream_) {
     SFH_S3CASE_W8(2, 1, SFH_TILE_32x8, 2, 8, 32, 8)
   }
 #undef SFH_S3CASE_W8
+  // 128-pixel x 128-cout workgroups (1 x 4 waves, half-size tile) with TWO LDS buffers of 24.5 KB: 151 VGPRs, i.e. three
+  // workgroups per CU, each with the next stage's DMA under its own MFMAs and one barrier per stage.  Explicit request only
+  // (wg_couts = 128 with a half-size tile): +3 % on 128- and 256-channel layers at 180x320 / 90x160, -2 .. -5 % on
+  // 512-channel ones (profiles/r03_conv_rate_probe_w8half.txt) - the engine asks for it where it wins.
+  if (w8_ok && d.wg_couts == 128 && d.ksize == 3 && d.stride == 1 && !d.stats_partial) {
+    if (d.tile == SFH_TILE_8x16) return launch_s3<S3Cfg<3, 1, 1, 16, 8, 16, 2, 4, 1>, true>(d, stream);
+    if (d.tile == SFH_TILE_16x8) return launch_s3<S3Cfg<3, 1, 2, 8, 16, 8, 2, 4, 1>, true>(d, stream);
+  }
 #define SFH_S3CASE(KS, ST, TILE, SH, SW, TH, TW)                      \
   if (d.ksize == KS && d.stride == ST && d.tile == TILE) {             \
     if (d.src_fmt == SFH_FMT_H2) {                                     \
