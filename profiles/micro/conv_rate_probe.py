@@ -54,12 +54,12 @@ if __name__ == "__main__":
         run(128, 128, 320, (45, 90, 180, 360), wg=wg)
         run(64, 64, 640, (90, 180, 360), wg=wg)
         run(64, 64, 640, (360,), wg=wg, pool=True)
-    if "--w8-half" in sys.argv:   # variant build with -DSFH_EXPERIMENT_W8_HALF_DB: 128-pixel x 128-cout workgroups, double-buffered
+    if "--w8-half" in sys.argv:   # 128-pixel x 128-cout double-buffered workgroups (wg=128 + half-size tile) against the other shapes
         print("128 x 128 workgroups, two LDS buffers (tile 8x16)")
         run(512, 512, 80, (45, 360), wg=128, tile=3)
         run(256, 256, 160, (90, 360), wg=128, tile=3)
         run(128, 128, 320, (180, 360), wg=128, tile=3)
-        print("128 x 64 workgroups, two LDS buffers (tile 8x16)")
+        print("128 x 64 workgroups (tile 8x16; double-buffered only in the experiment build recorded in r03_conv_rate_probe_w8half.txt)")
         run(64, 64, 640, (360,), wg=64, tile=3)
         run(64, 64, 640, (360,), wg=64, tile=3, pool=True)
         run(128, 128, 320, (180,), wg=64, tile=3)
