@@ -305,6 +305,7 @@ class ConvTimer:
 
 
 _W8_HALF = os.environ.get("SFH_W8_HALF", "1") != "0"
+_W8_HALF_ROUNDS = float(os.environ.get("SFH_W8_HALF_ROUNDS", "3"))   # rounds of 512 resident workgroups from which the shape is requested
 
 
 class LaunchOrder:
@@ -611,7 +612,7 @@ class PackedConv:
                     and stats is None and not (ksplit and ksplit > 1) and self.cout % 128 == 0
                     and 128 <= self.c0 + self.c1 <= 256):
                 nt = -(-(batch * (ho + zr)) // 8) * -(-wo // 16)
-                if nt * (self.cout // 128) >= 4 * _WG_SLOTS:
+                if nt * (self.cout // 128) >= _W8_HALF_ROUNDS * _WG_SLOTS:
                     d.tile, wg_couts = _lib.TILE_8x16, 128
         else:
             d.tile = choose_tile(batch, ho, wo, self.stride, zr)
