@@ -65,6 +65,11 @@ if __name__ == "__main__":
         run(128, 128, 320, (180,), wg=64, tile=3)
         run(256, 256, 160, (90,), wg=64, tile=3)
         run(512, 512, 80, (45,), wg=64, tile=3)
+        print("64 -> 128 (d1.0): 128 x 128 double-buffered against the product shape")
+        run(64, 128, 320, (180,), wg=128, tile=3)
+        run(64, 128, 320, (180,))
+        run(64, 128, 320, (180,), wg=128, tile=3)
+        run(64, 128, 320, (180,))
         print("the same layers, product shapes")
         run(512, 512, 80, (45, 360), wg=128)
         run(256, 256, 160, (90, 360), wg=128)

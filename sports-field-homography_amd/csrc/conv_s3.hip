@@ -1168,7 +1168,10 @@ extern "C" int sfh_conv_s3_fwd(const sfh_conv_desc* dp, void* stream_) {
   const int nst_all = (d.c0 + (d.src1 ? d.c1 : 0)) / 32;
   const bool w8_ok = d.stride == 1 && (d.ksize == 3 || d.ksize == 2) && d.cout % 128 == 0 && !d.head_w && nst_all >= 4 &&
                      (d.ksize != 2 || (d.cout / 4) % 128 == 0) && d.src_fmt == SFH_FMT_H2;
-  SFH_REQUIRE(d.wg_couts == 0 || d.wg_couts == 64 || (d.wg_couts == 128 && w8_ok),
+  // the 128-pixel x 128-cout double-buffered shape (below) also takes short K (two stages)
+  const bool w8h_ok = d.stride == 1 && d.ksize == 3 && d.cout % 128 == 0 && !d.head_w && nst_all >= 2 && d.src_fmt == SFH_FMT_H2 &&
+                      (d.tile == SFH_TILE_8x16 || d.tile == SFH_TILE_16x8);
+  SFH_REQUIRE(d.wg_couts == 0 || d.wg_couts == 64 || (d.wg_couts == 128 && (w8_ok || w8h_ok)),
               "conv_s3_fwd: wg_couts=%d is not available for this launch (see sfh_conv_desc.wg_couts)", d.wg_couts);
   if (d.stats_partial) {
     SFH_REQUIRE(d.src_fmt == SFH_FMT_H2 && d.dst_fmt == SFH_FMT_F32 && d.ksize == 3 && d.stride == 1 && !d.relu && !d.residual &&
@@ -1211,7 +1214,7 @@ extern "C" int sfh_conv_s3_fwd(const sfh_conv_desc* dp, void* stream_) {
   // workgroups per CU, each with the next stage's DMA under its own MFMAs and one barrier per stage.  Explicit request only
   // (wg_couts = 128 with a half-size tile): +3 % on 128- and 256-channel layers at 180x320 / 90x160, -2 .. -5 % on
   // 512-channel ones (profiles/r03_conv_rate_probe_w8half.txt) - the engine asks for it where it wins.
-  if (w8_ok && d.wg_couts == 128 && d.ksize == 3 && d.stride == 1 && !d.stats_partial) {
+  if (w8h_ok && d.wg_couts == 128 && !d.stats_partial) {
     if (d.tile == SFH_TILE_8x16) return launch_s3<S3Cfg<3, 1, 1, 16, 8, 16, 2, 4, 1>, true>(d, stream);
     if (d.tile == SFH_TILE_16x8) return launch_s3<S3Cfg<3, 1, 2, 8, 16, 8, 2, 4, 1>, true>(d, stream);
   }

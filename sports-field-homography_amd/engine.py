@@ -607,10 +607,10 @@ class PackedConv:
         elif self.s3:
             d.tile = choose_tile_s3(batch, ho, wo, self.stride, zr, self.cout // 64, self.ksize)
             # 128 x 128 double-buffered workgroups (conv_s3.hip): measured +3 % for 128 / 256 input channels on grids of many
-            # rounds, slower for longer K or few rounds (profiles/r03_conv_rate_probe_w8half.txt)
+            # rounds (64 -> 128: +4 %), slower for longer K or few rounds (profiles/r03_conv_rate_probe_w8half.txt)
             if (_W8_HALF and self.fmt == "h2" and self.ksize == 3 and self.stride == 1 and wg_couts == 0 and head is None
                     and stats is None and not (ksplit and ksplit > 1) and self.cout % 128 == 0
-                    and 128 <= self.c0 + self.c1 <= 256):
+                    and 64 <= self.c0 + self.c1 <= 256):
                 nt = -(-(batch * (ho + zr)) // 8) * -(-wo // 16)
                 if nt * (self.cout // 128) >= _W8_HALF_ROUNDS * _WG_SLOTS:
                     d.tile, wg_couts = _lib.TILE_8x16, 128
