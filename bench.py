@@ -58,13 +58,15 @@ def usable_cores():
 
 
 def pmc_traffic(tag):
-    """HBM bytes per launch of the dominant kernel, from the committed rocprofv3 --pmc passes
-    (profiles/pmc_traffic.json, produced by profiles/collect_pmc.sh); None if absent."""
+    """(HBM bytes per launch of the dominant kernel, where the figure comes from): NOT measured in this run - read from
+    the committed rocprofv3 --pmc passes (profiles/pmc_traffic.json, produced by profiles/collect_pmc.sh, which runs this
+    same command under the counters in separate passes); (None, None) if absent."""
     try:
         d = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-        return d[tag]["hbm_bytes_per_launch"]
+        src = "profiles/pmc_traffic.json (%s, committed; rocprofv3 --pmc passes of this command, not this run)" % d.get("round", "r03")
+        return d[tag]["hbm_bytes_per_launch"], src
     except (OSError, KeyError, ValueError):
-        return None
+        return None, None
 
 
 def self_launch(n):
@@ -133,6 +135,8 @@ def train_bench(args):
         opt.step()
         return loss
 
+    torch.cuda.empty_cache()
+    torch.cuda.reset_peak_memory_stats()      # peak_mem_gib is this config's own (other configs ran in this process before)
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
@@ -224,6 +228,21 @@ def extra_configs(args):
     res["C5_1280x720_batch16_pitch_template_poi"] = {
         "value": round(B * n / el, 2), "unit": "frames/s", "ms_per_step": round(el / n * 1e3, 2), "steps": n, "warmup": 2,
         "workload": "predict(consistency=True, project_poi=True), 1280x720, batch 16, pitch_mask_v3_nc4_hd template, 33-point POI"}
+    # the homography warp at this size against HBM (SURVEY 8d algorithmic bytes), launches alone on the chip
+    from sfh_amd import engine
+    tm = engine.ConvTimer()
+    engine.PackedConv.timer = tm
+    with torch.no_grad():
+        for _ in range(3):
+            net.predict(x, consistency=True, project_poi=True)
+    torch.cuda.synchronize()
+    engine.PackedConv.timer = None
+    wv = tm.summary().get("warp")
+    if wv:
+        tbs = wv[1] / (wv[2] * 1e-3) / 1e12
+        res["C5_1280x720_batch16_pitch_template_poi"]["warp"] = {
+            "launches": wv[0], "bound": "hbm", "us_per_launch": round(wv[2] * 1e3 / wv[0], 2),
+            "algorithmic_bytes_per_launch": int(wv[1] / wv[0]), "tb_per_s": round(tbs, 3), "frac": round(tbs / HBM_PEAK_TBS, 4)}
     del net, x, court, poi
     torch.cuda.empty_cache()
     a = copy.copy(args)
@@ -384,9 +403,10 @@ def main():
     peak = {"bf16x6": BF16X6_PEAK_TFLOPS, "f16x3": F16X3_PEAK_TFLOPS}.get(prec, FP32_MFMA_PEAK_TFLOPS)
     x6 = nprod is not None
     half = "fp16" if prec == "f16x3" else "bf16"
+    traffic, traffic_src = pmc_traffic("doubleconv3x3") if (W, H, B) == (640, 360, 16) else (None, None)
     roofline = {"bound": "mfma", "achieved": round(achieved, 2), "peak": round(peak, 1),
                 "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
-                "traffic": pmc_traffic("doubleconv3x3") if (W, H, B) == (640, 360, 16) else None,
+                "traffic": traffic, "traffic_source": traffic_src,
                 "peak_basis": (f"2500 TFLOP/s dense {half} MFMA / {nprod} {half} products per fp32-grade product; the "
                                f"launches execute {nprod}x the algorithmic FLOPs on the {half} matrix cores "
                                f"(= {achieved * (nprod or 1):.0f} TFLOP/s of {half} MFMA work, "
@@ -410,6 +430,7 @@ def main():
     # every timed kernel group against the roofline that bounds it: conv groups against the matrix peak of the mode
     # (algorithmic FLOPs), the homography warp against HBM (algorithmic bytes, SURVEY 8d: B*h*w*4 + Ht*Wt*4 + 36*B)
     other = {}
+    executed = (tm2 if alone is not None else timer).executed()
     for t, v in (alone[0] if alone is not None else summ).items():      # (pipelined run: from the unpipelined pass, see above)
         if t == "warp":
             tbs = v[1] / (v[2] * 1e-3) / 1e12
@@ -420,6 +441,11 @@ def main():
             tf = v[1] / (v[2] * 1e-3) / 1e12
             other[t] = {"launches": v[0], "bound": "mfma", "tflops": round(tf, 2), "frac": round(tf / peak, 4),
                         "ms_per_step": round(v[2] / args.steps, 3)}
+            if t in executed:      # credited with the reference's work, executes less (composed 2x2 Up conv: 8/9)
+                ex = executed[t] / (v[2] * 1e-3) / 1e12
+                other[t].update({"frac_basis": "credited = the u-half of the reference's 3x3 conv (9 taps x C; the ConvTranspose2d "
+                                               "it also replaces is not credited); executed = 4 taps x 2C on the low-resolution tensor",
+                                 "executed_tflops": round(ex, 2), "executed_frac": round(ex / peak, 4)})
     step_gflop = STEP_GFLOP_PER_FRAME_640x360 * (W * H) / (640.0 * 360.0) * B
     whole_tf = step_gflop * 1e9 * args.steps / elapsed / 1e12    # per GPU: every rank runs its own batch per step
 
@@ -470,6 +496,9 @@ def main():
             "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "value_predict_sync": (round(B * args.steps / alone[1], 2) if alone is not None else round(fps, 2)) if world == 1 else None,
+            "value_predict_sync_note": "frames/s of the drop-in predict() called per batch (no predict_async pipelining), "
+                                       "same kernels, timed right after the headline region; N = 1 only",
             "dtype": {"bf16x6": "bf16x6->f32 (3-way bf16 split operands, 6 bf16 MFMA products, fp32 accumulate; fp32-equivalent)",
                       "f16x3": "f16x3->f32 (2-way fp16 split operands = 22 significand bits, 3 fp16 MFMA products, fp32 "
                                "accumulate; end-to-end error at the level of an fp32 run, see DESIGN.md section 2)"}.get(prec, "f32"),

@@ -242,6 +242,37 @@ def _pack2(am):
     return np.packbits(np.unpackbits(am[..., None], axis=-1)[..., 6:].reshape(B, -1), axis=-1)
 
 
+LINE_FRAMES = (0, 7, 15)                       # frames whose seam lines are stored point by point
+LINE_ROWS = (0, 1, 7, 8, 15, 16, 31, 32, -2, -1)   # first / last rows of 8-, 16- and 32-row workgroup tiles, frame borders
+LINE_COLS = (0, 1, 7, 8, 15, 16, 31, 32, -2, -1)
+
+
+def _coverage_vectors(logits):
+    """Quantities every logit enters (round 4; the 4::16 sub-sample touches no tile-edge or frame-border pixel):
+    the sum of every 8x8 block of every channel of every frame (fp64 -> fp32), and, for three frames, complete rows /
+    columns at the first and last lines of the 8 / 16 / 32-pixel workgroup tiles and at the frame borders."""
+    B, C, H, W = logits.shape
+    assert H % 8 == 0 and W % 8 == 0
+    bs = logits.double().reshape(B, C, H // 8, 8, W // 8, 8).sum(dim=(3, 5)).float().numpy()
+    fr = [f for f in LINE_FRAMES if f < B]
+    rows = [r % H for r in LINE_ROWS]
+    cols = [c % W for c in LINE_COLS]
+    sel = logits[fr]
+    return dict(logits_blocksum8=bs, line_frames=np.array(fr, np.int32), line_rows=np.array(rows, np.int32),
+                line_cols=np.array(cols, np.int32), logits_rows=sel[:, :, rows, :].numpy().copy(),
+                logits_cols=sel[:, :, :, cols].numpy().copy())
+
+
+def _save_checked(path, out):
+    """np.savez_compressed, after checking that every array the committed file already holds is reproduced
+    bit for bit (the vectors are deterministic; a difference means the generator or its inputs moved)."""
+    if os.path.exists(path):
+        old = np.load(path)
+        for k in old.files:
+            assert k in out and np.array_equal(old[k], out[k]), f"{os.path.basename(path)}: '{k}' is not reproduced"
+    np.savez_compressed(path, **out)
+
+
 MARGIN_BINS = np.array([0, 1e-5, 2e-5, 5e-5, 1e-4, 2e-4, 5e-4, 1e-3, 2e-3, 5e-3, 1e-2, 1e-1, 1, 1e3], np.float64)
 LOW_MARGIN = 1e-2   # pixels whose top-2 logit margin is below this are listed individually
 
@@ -271,7 +302,7 @@ def _predict_golden(up_mod, rn_mod, x, court, poi, wh, chunk):
                 low_margin_value=margin[low].astype(np.float32),
                 margin_hist=np.stack([np.histogram(margin[b], MARGIN_BINS)[0] for b in range(B)]).astype(np.int32),
                 margin_bins=MARGIN_BINS, logits_sub=logits[:, :, 4::16, 4::16].numpy().copy(),
-                warp_mask_2bit=_pack2(wm.numpy().astype(np.uint8)))
+                warp_mask_2bit=_pack2(wm.numpy().astype(np.uint8)), **_coverage_vectors(logits))
 
 
 def make_c2_golden(up_mod, rn_mod):
@@ -284,7 +315,7 @@ def make_c2_golden(up_mod, rn_mod):
         court = synth.load_court_template("ncaa_nc4_640x360", 4, B)
         poi = synth.load_court_poi("pitch", B)
         out = _predict_golden(up_mod, rn_mod, x, court, poi, (640, 360), 4)
-    np.savez_compressed(os.path.join(GOLD, "c2_640x360_b16.npz"), **out)
+    _save_checked(os.path.join(GOLD, "c2_640x360_b16.npz"), out)
     print("c2 golden: consist", out["consist"], "margin hist", out["margin_hist"].sum(0))
 
 
@@ -298,7 +329,7 @@ def make_c5_golden(up_mod, rn_mod):
         court = synth.load_court_template("pitch_v3_nc4_1280x720", 4, B)
         poi = synth.load_court_poi("pitch", B)
         out = _predict_golden(up_mod, rn_mod, x, court, poi, (1280, 720), 1)
-    np.savez_compressed(os.path.join(GOLD, "c5_1280x720_b16.npz"), **out)
+    _save_checked(os.path.join(GOLD, "c5_1280x720_b16.npz"), out)
     print("c5 golden: theta", out["theta"].reshape(B, 9)[:2], "consist", out["consist"])
 
 
@@ -332,7 +363,8 @@ def make_c3_b16_golden(up_mod, rn_mod):
             names.append(k)
             out[f"buf.{k}"] = b.numpy().copy()
     out["buffers"] = np.array(names)
-    np.savez_compressed(os.path.join(GOLD, "c3_fwd_640x360_b16.npz"), **out)
+    out.update(_coverage_vectors(logits))
+    _save_checked(os.path.join(GOLD, "c3_fwd_640x360_b16.npz"), out)
     print("c3 b16 golden:", {k: float(v) for k, v in ls.items()}, len(names), "BatchNorm buffers")
 
 

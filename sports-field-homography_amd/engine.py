@@ -103,6 +103,10 @@ def s3_empty(b, h, w, c, device):
     return torch.empty(s3_shape(b, h, w, c), dtype=torch.bfloat16, device=device)
 
 
+class FP16RangeExhausted(RuntimeError):
+    """an "f16x3" activation tensor is saturated and its exponent cannot be lowered any further"""
+
+
 class H2Ranges:
     """Exponents and range words of the H2 (two-plane fp16, "f16x3") activation tensors of one model.
 
@@ -118,6 +122,7 @@ class H2Ranges:
     LIMIT = _lib.H2_LIMIT_BITS
     NONFINITE = 0x7F800000
     DEFAULT = _lib.H2_ACT_EXP
+    MIN_EXP = -64
 
     def __init__(self, device, capacity=1024):
         self.device = device
@@ -182,15 +187,26 @@ class H2Ranges:
         bad = [n for n, b in bits.items() if b > self.LIMIT]
         return bad, any(bits[n] >= self.NONFINITE for n in bad)
 
-    def lower(self, name, bits):
-        """Pick the exponent that puts the observed maximum into [2^12, 2^13) (8x headroom).  -> the key."""
-        key, _ = self.slot[name]
-        e = self.exps.get(key, self.DEFAULT)
-        vmax = _bits_to_float(bits) * 2.0 ** -e
-        new = 13 - math.frexp(vmax)[1]                 # frexp: vmax = m * 2^x, 0.5 <= m < 1
-        new = max(-64, min(new, e - 1))
-        self.exps[key] = new
-        return key
+    def lower(self, bad, bits):
+        """Lower the exponents of the saturated tensors `bad` (names; bits = read()'s dict): ONE decision per exponent
+        key - a conv output and its pooled copy share word and key, a skip tensor and its up tensor share a key - from
+        the largest word of the key's tensors, converted with the exponent that was in force when the words were
+        written.  The new exponent puts the observed maximum into [2^12, 2^13) (8x headroom).  -> the set of keys.
+        Raises FP16RangeExhausted if a key cannot go lower (the caller falls back to the three-plane operands)."""
+        worst = {}
+        for n in bad:
+            key = self.slot[n][0]
+            worst[key] = max(worst.get(key, 0), bits[n])
+        before = {key: self.exps.get(key, self.DEFAULT) for key in worst}
+        for key, b in worst.items():
+            e = before[key]
+            vmax = _bits_to_float(b) * 2.0 ** -e
+            new = 13 - math.frexp(vmax)[1]                 # frexp: vmax = m * 2^x, 0.5 <= m < 1
+            new = max(self.MIN_EXP, min(new, e - 1))
+            if new >= e:
+                raise FP16RangeExhausted(f"H2 tensor group {key!r} is saturated at the lowest exponent {e}")
+            self.exps[key] = new
+        return set(worst)
 
     def reset_words(self):
         self.words.zero_()
@@ -298,9 +314,19 @@ class ConvTimer:
     def summary(self):
         """-> {tag: (launches, total_flops, total_ms)}; call after a device synchronize."""
         out = {}
-        for tag, flops, e0, e1 in self.records:
+        for rec in self.records:
+            tag, flops, e0, e1 = rec[:4]
             n, f, t = out.get(tag, (0, 0.0, 0.0))
             out[tag] = (n + 1, f + flops, t + e0.elapsed_time(e1))
+        return out
+
+    def executed(self):
+        """-> {tag: FLOPs the launches EXECUTED} where that differs from the algorithmic work they are credited with
+        (the composed 2x2 Up conv runs 4 taps x 2C channels for the reference's 9 taps x C)."""
+        out = {}
+        for rec in self.records:
+            if len(rec) > 4 and rec[4] is not None:
+                out[rec[0]] = out.get(rec[0], 0.0) + rec[4]
         return out
 
 
@@ -704,9 +730,11 @@ class PackedConv:
             cin = self.stem_cin if self.ksize == 4 else self.c0 + self.c1
             flops = 2.0 * batch * ho * wo * self.cout_real * kk * cin
             fpp = getattr(self, "flops_per_out_pixel", None)
+            executed = None
             if fpp is not None:   # fused Up conv: credited with the u-half of the reference's 3x3 conv only
+                executed = flops  # what the 2x2 conv over the low-resolution tensor really multiplies (8/9 of the credit)
                 flops = fpp * batch * (2 * ho) * (2 * wo)
-            tm.records.append((self.tag, flops, e0, e1))
+            tm.records.append((self.tag, flops, e0, e1, executed))
         return dst
 
 

@@ -190,10 +190,9 @@ class Reconstructor(nn.Module):
         # last two makes this walk the tree again - and only a list that really differs forces new engines
         # (constructing an unrelated module elsewhere, e.g. a loss with a weight buffer, changes nothing here).
         lst = self.__dict__.get("_stamp_tensors")
-        ptrs = 0
+        ptrs = None
         if lst is not None:
-            for t in lst:
-                ptrs += t.data_ptr()
+            ptrs = hash(tuple([t.data_ptr() for t in lst]))     # order-sensitive: two storage moves cannot cancel
         if (lst is None or self.__dict__.get("_stamp_regs") != _REGISTRATIONS[0]
                 or ptrs != self.__dict__.get("_stamp_ptrs")):
             new = list(self.parameters()) + list(self.buffers())
@@ -202,7 +201,7 @@ class Reconstructor(nn.Module):
                 self._weights_generation += 1      # a replaced tensor may carry any _version: force a new stamp
             lst = self.__dict__["_stamp_tensors"] = new
             self.__dict__["_stamp_regs"] = _REGISTRATIONS[0]
-            self.__dict__["_stamp_ptrs"] = sum(t.data_ptr() for t in lst)
+            self.__dict__["_stamp_ptrs"] = hash(tuple([t.data_ptr() for t in lst]))
         dev = None
         ver = 0
         for t in lst:
@@ -279,24 +278,33 @@ class Reconstructor(nn.Module):
         if (self._forced_precision or self.precision) != "f16x3" or rg is None or not self.range_guard:
             return ret
         un, rn = self._engines
+
+        def three_plane_rerun():
+            self._forced_precision = "bf16x6"
+            try:
+                return self._chunked(lambda xi, o: self._run_phases(make_phases(xi, o)), x, base=off)
+            finally:
+                self._forced_precision = None
+
         for _ in range(256):
             bits = rg.read()                     # one read-back of ~100 words per call
             bad, nonfinite = rg.saturated(bits)
             if not bad:
                 return ret
             rg.reset_words()
+            self._pipe_mark_stale()              # batches of predict_async() in flight wrote the same words
             if nonfinite:
                 self.range_fallbacks += 1
                 if self.range_fallbacks == 1:
                     import warnings
                     warnings.warn("sfh_amd: a non-finite activation in the 'f16x3' mode; the batch was re-run with "
                                   "precision 'bf16x6', which carries NaN / Inf to the outputs like the reference")
-                self._forced_precision = "bf16x6"
-                try:
-                    return self._chunked(lambda xi, o: self._run_phases(make_phases(xi, o)), x, base=off)
-                finally:
-                    self._forced_precision = None
-            keys = {rg.lower(n, bits[n]) for n in bad}
+                return three_plane_rerun()
+            try:
+                keys = rg.lower(bad, bits)       # one decision per exponent key
+            except E.FP16RangeExhausted:
+                self.range_fallbacks += 1        # finite, but beyond 2^64 * 65504: outside the two-plane format for good
+                return three_plane_rerun()
             self.range_rescales += 1
             k = un.first_step(keys) if un is not None else None
             if k is not None:
@@ -310,6 +318,25 @@ class Reconstructor(nn.Module):
             ret = tail(r, theta)
         raise RuntimeError("sfh_amd: the fp16 range guard did not converge")
 
+    def _pipe_mark_stale(self):
+        """The range words are shared by every pass of this model.  Whoever finds a saturated tensor and zeroes the words
+        must also invalidate the predict_async() batches still in flight: their own check would read zeros and hand
+        out clamped outputs as valid.  Their result() then recomputes them with the exponents as they are by then."""
+        p = self.__dict__.get("_pipe")
+        if p is not None and p["inflight"]:
+            for o in p["inflight"]:
+                o.stale = True
+            p["inflight"].clear()
+
+    def _pipe_wait_reads(self):
+        """Batches of predict_async() may still be reading the STN-input buffers and the ResNet workspace on the side
+        stream: order the caller's stream behind them before a synchronous pass writes those buffers."""
+        p = self.__dict__.get("_pipe")
+        if p is not None:
+            for ev in p["stem_read"]:
+                if ev is not None:
+                    torch.cuda.current_stream(p["device"]).wait_event(ev)
+
     def range_overflowed(self, reset=True):
         """For callers that pipeline batches with `range_guard = False`: True if an activation tensor of the "f16x3"
         mode was saturated since the last reset (synchronises).  With reset, the exponents of those tensors are
@@ -320,10 +347,12 @@ class Reconstructor(nn.Module):
         bits = rg.read()
         bad, _ = rg.saturated(bits)
         if bad and reset:
-            for n in bad:
-                if bits[n] < rg.NONFINITE:
-                    rg.lower(n, bits[n])
+            try:
+                rg.lower([n for n in bad if bits[n] < rg.NONFINITE], bits)
+            except E.FP16RangeExhausted:
+                pass                             # the batches that follow meet it again; predict() then takes bf16x6
             rg.reset_words()
+            self._pipe_mark_stale()
         return bool(bad)
 
     def h2_headroom(self):
@@ -417,6 +446,7 @@ class Reconstructor(nn.Module):
                 return o
             return (lambda resume=None: self._run_unet(x, resume=resume, want_uv=self.unet_uv),
                     lambda r, resume=None: None, tail)
+        self._pipe_wait_reads()
         o = self._chunked(lambda xi, off: self._guarded(phases, xi, off), x)
         return o["logits"], o["x_top"], o.get("uv")
 
@@ -471,6 +501,7 @@ class Reconstructor(nn.Module):
             return training.train_forward(self, x)
         if x.shape[0] == 0:
             return self._empty_outputs(x, predict=False)
+        self._pipe_wait_reads()
         return self._chunked(self._forward_one, x)
 
     def _forward_one(self, x, off):
@@ -505,11 +536,7 @@ class Reconstructor(nn.Module):
         self._require_eval("predict")
         if x.shape[0] == 0:
             return self._empty_outputs(x, predict=True, consistency=consistency, project_poi=project_poi)
-        p = self.__dict__.get("_pipe")
-        if p is not None:       # batches of predict_async() may still be reading the buffers this call is about to write
-            for ev in p["stem_read"]:
-                if ev is not None:
-                    torch.cuda.current_stream(p["device"]).wait_event(ev)
+        self._pipe_wait_reads()
         return self._chunked(self._predict_one, x, consistency, project_poi)
 
     def predict_async(self, x, consistency=True, project_poi=False):
@@ -575,12 +602,12 @@ class Reconstructor(nn.Module):
         torch.cuda.synchronize(p["device"])
         rg.reset_words()
         if not nonfinite:
-            for n in bad:
-                rg.lower(n, bits[n])
-            self.range_rescales += 1
-        for o in p["inflight"]:
-            o.stale = True
-        p["inflight"].clear()
+            try:
+                rg.lower(bad, bits)
+                self.range_rescales += 1
+            except E.FP16RangeExhausted:
+                pass                             # predict() of the recomputation takes the three-plane operands
+        self._pipe_mark_stale()
         return False
 
     def _empty_outputs(self, x, predict, consistency=False, project_poi=False):

@@ -1142,6 +1142,7 @@ class TrainStep:
         x = E._f32c(x, "input frames")
         f = run_forward(net, tape, x)
         logits, theta, poi, warp = f["logits"], f["theta"], f["poi"], f["warp_mask"]
+        self.last_outputs = {"logits": logits, "theta": theta, "poi": poi, "warp_mask": warp}   # of the step just run
         ww, wh = net.warp_size
         if (wh, ww) != (H, W):
             raise NotImplementedError("TrainStep needs warp_size == frame size (the losses compare per pixel)")

@@ -389,7 +389,7 @@ def test_resnet_stn_golden(E, golden_blocks, name, key, seed, precision):
         if not bad:
             break
         rg.reset_words()
-        theta = eng.rerun(eng.first_step({rg.lower(n, bits[n]) for n in bad}))
+        theta = eng.rerun(eng.first_step(rg.lower(bad, bits)))
         rescales += 1
         assert rescales < 40
     assert _maxerr(theta.cpu(), g[key]) < 1e-4

@@ -32,9 +32,9 @@ class _Ranges:
         bad = [n for n, b in bits.items() if b > 0x477FE000]
         return bad, any(bits[n] >= self.NONFINITE for n in bad)
 
-    def lower(self, name, bits):
-        self.lowered.append(name)
-        return name
+    def lower(self, bad, bits):
+        self.lowered.extend(bad)
+        return set(bad)
 
     def reset_words(self):
         self.zeroed += 1
@@ -186,7 +186,7 @@ def test_h2_ranges_bookkeeping():
     bits = rg.read()
     bad, nonfinite = rg.saturated(bits)
     assert bad == ["up4.up"] and not nonfinite
-    assert rg.lower("up4.up", bits["up4.up"]) == "inc.out"
+    assert rg.lower(bad, bits) == {"inc.out"}
     e = rg.exp("inc.out")
     assert e == rg.exp("inc.pool") == rg.exp("up4.up") == -4 and 2.0 ** 12 <= 75000.0 * 2.0 ** e < 2.0 ** 13
     assert rg.exp("down1.mid") == 2 and abs(rg.peak["down1.mid"] - 25.0) < 1e-6
@@ -194,6 +194,32 @@ def test_h2_ranges_bookkeeping():
     rg.reset_words()
     w[rg.slot["down1.mid"][1]] = 0x7F800000
     assert rg.saturated(rg.read()) == (["down1.mid"], True)
+
+
+def test_h2_ranges_lower_decides_once_per_exponent_key():
+    """A conv output and its pooled copy share word AND key, a skip tensor and its up tensor share a key: however many
+    saturated names point at a key, its exponent is lowered ONCE, from the largest word, converted with the exponent
+    the words were written under (a second conversion under the new exponent would give away 4 more bits for good)."""
+    import numpy as np
+    from sfh_amd import engine as E
+    rg = E.H2Ranges(torch.device("cpu"), capacity=8)
+    rg.register("inc.out")
+    rg.register("inc.pool", key="inc.out", word_of="inc.out")
+    rg.register("up4.up", key="inc.out")
+    w = rg.words.numpy().view("uint32")
+    w[rg.slot["inc.out"][1]] = np.float32(1.0e5).view("uint32")      # u = v * 2^2 = 1e5 in inc.out (and inc.pool)
+    w[rg.slot["up4.up"][1]] = np.float32(7.0e4).view("uint32")       # also saturated, smaller
+    bits = rg.read()
+    bad, _ = rg.saturated(bits)
+    assert sorted(bad) == ["inc.out", "inc.pool", "up4.up"]
+    assert rg.lower(bad, bits) == {"inc.out"}
+    # |v| = 25000 -> [2^12, 2^13) at e = -2 (twice-lowered it would end at -6)
+    assert rg.exp("inc.out") == rg.exp("inc.pool") == rg.exp("up4.up") == -2
+    assert 2.0 ** 12 <= 25000.0 * 2.0 ** -2 < 2.0 ** 13
+    # at the lowest exponent a saturated tensor cannot be helped: the caller is told at once
+    rg.exps["inc.out"] = rg.MIN_EXP
+    with pytest.raises(E.FP16RangeExhausted):
+        rg.lower(["inc.out"], {"inc.out": int(np.float32(1.0e5).view("uint32"))})
 
 
 def test_weight_exponent_puts_the_largest_weight_below_2_to_14():
