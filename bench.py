@@ -281,6 +281,9 @@ def main():
     ap.add_argument("--no-pipeline", action="store_true",
                     help="call predict() per step instead of predict_async() (two batches in flight: the ResNet-STN + warp of "
                          "batch k on a side stream under the UNet of batch k + 1)")
+    ap.add_argument("--device", default="cuda", choices=["cuda", "cpu"],
+                    help="cpu: rehearsal of the multi-rank plumbing in the CPU tests (tests/test_sharding.py, gloo, a stand-in "
+                         "model); the printed value then measures nothing")
     ap.add_argument("--no-extra-configs", action="store_true",
                     help="skip the short C3 (training step) and C5 (1280x720) measurements appended at N=1")
     args = ap.parse_args()
@@ -304,8 +307,13 @@ def main():
         if args.dist_backend != "gloo":
             raise SystemExit("--share-gpu is a rehearsal mode and needs --dist-backend gloo (RCCL wants one GPU per rank)")
         local_rank = 0
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    on_gpu = args.device == "cuda"
+    if not on_gpu and args.dist_backend != "gloo":
+        raise SystemExit("--device cpu is a rehearsal mode and needs --dist-backend gloo")
+    if on_gpu:
+        torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank) if on_gpu else torch.device("cpu")
+    sync = torch.cuda.synchronize if on_gpu else (lambda: None)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.dist_backend == "nccl":
@@ -334,11 +342,15 @@ def main():
     gather = sharding.ResultGather(world, B, dev, depth=2) if world > 1 else None
 
     pending = []    # predict_async handles: at most two batches in flight
+    last = {}       # slot + theta of the newest gathered step (checked after the timed region)
+
+    def exchange(out):
+        if gather is not None:
+            last["slot"], last["theta"] = gather.submit(out["theta"], out.get("consist_score")), out["theta"]
 
     def finish(h):
         out = h.result()
-        if gather is not None:
-            gather.submit(out["theta"], out.get("consist_score"))
+        exchange(out)
         return out
 
     def step(k, last=False):
@@ -347,8 +359,7 @@ def main():
         x = frames[k % nbatches]
         if args.no_pipeline:
             out = net.predict(x, consistency=args.consistency, project_poi=args.consistency)
-            if gather is not None:
-                gather.submit(out["theta"], out.get("consist_score"))
+            exchange(out)
             return out
         pending.append(net.predict_async(x, consistency=args.consistency, project_poi=args.consistency))
         out = None
@@ -359,7 +370,7 @@ def main():
     with torch.no_grad():
         for k in range(args.warmup):
             step(k, last=(k == args.warmup - 1))
-        torch.cuda.synchronize()
+        sync()
         if world > 1:
             dist.barrier()
         timer = engine.ConvTimer()
@@ -367,11 +378,22 @@ def main():
         t0 = time.perf_counter()
         for k in range(args.steps):
             out = step(k, last=(k == args.steps - 1))      # the K-th call drains the pipeline: exactly K batches are timed
-        torch.cuda.synchronize()
+        sync()
         if world > 1:
             dist.barrier()
         elapsed = time.perf_counter() - t0
         engine.PackedConv.timer = None
+
+    # the exchange step, checked once outside the timed region: every rank holds world * B gathered rows, and its own
+    # rows are the theta it computed in the last step
+    gather_check = None
+    if gather is not None:
+        th_all, _ = gather.result(last["slot"])
+        ok = torch.tensor([int(tuple(th_all.shape) == (world * B, 1, 3, 3)
+                               and torch.equal(th_all[rank * B:(rank + 1) * B], last["theta"]))], device=dev)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        gather_check = {"rows_per_rank": int(th_all.shape[0]), "own_rows_equal_own_theta_on_every_rank": bool(ok.item()),
+                        "bytes_per_step_per_rank": 40 * B}
 
     # the same K steps once more WITHOUT the pipeline: per-kernel durations of launches that run alone on the chip (under
     # the pipeline the ResNet-STN launches of batch k share the CUs with the UNet launches of batch k + 1, so every launch
@@ -384,7 +406,7 @@ def main():
             t1 = time.perf_counter()
             for k in range(args.steps):
                 net.predict(frames[k % nbatches], consistency=args.consistency, project_poi=args.consistency)
-            torch.cuda.synchronize()
+            sync()
             el2 = time.perf_counter() - t1
             engine.PackedConv.timer = None
         alone = (tm2.summary(), el2)
@@ -519,6 +541,7 @@ def main():
                            "frac": round(whole_tf / peak, 4),
                            "note": "UNet + ResNet34-STN algorithmic FLOPs of a batch / ms_per_step, against the matrix peak of the mode"},
             "cpu_baseline": cpu_baseline,
+            "gather_check": gather_check,
             "kernel_groups": other,
             "kernel_groups_measured_in": ("the unpipelined pass after the timed region (launches alone on the chip)"
                                           if alone is not None else "the timed region"),

@@ -732,7 +732,8 @@ class PackedConv:
             fpp = getattr(self, "flops_per_out_pixel", None)
             executed = None
             if fpp is not None:   # fused Up conv: credited with the u-half of the reference's 3x3 conv only
-                executed = flops  # what the 2x2 conv over the low-resolution tensor really multiplies (8/9 of the credit)
+                # what the composed conv really multiplies: 4 quadrants x 4 taps x all low-resolution channels (8/9 of the credit)
+                executed = 2.0 * batch * ho * wo * self.cout * 4 * self.c0
                 flops = fpp * batch * (2 * ho) * (2 * wo)
             tm.records.append((self.tag, flops, e0, e1, executed))
         return dst
@@ -773,6 +774,8 @@ class UNetEngine:
         # seeding 14.58 / 14.70, {3,4} seeded 14.58 / 14.66, {2,3,4} 14.60 / 14.57, all four 14.43 / 14.56
         self.up_swap = {int(c) for c in os.environ.get("SFH_UP_SWAP", "1234") if c.isdigit()}
         self.up_seed = {}          # level -> the skip-half conv starts from the partial (sfh_conv_desc.acc_init)
+        # level -> frames per band of the fused Up block's two launches (0 / absent: the whole batch per launch)
+        self.up_bands = {int(a): int(b) for a, b in (t.split(":") for t in os.environ.get("SFH_UP_BANDS", "").split(",") if t)}
         if precision not in PRECISIONS:
             raise ValueError(f"precision={precision!r}: expected one of {sorted(PRECISIONS)}")
         self.device = device
@@ -931,7 +934,7 @@ class UNetEngine:
 
                 def level(y=y, ny=ny, skip=skip, nskip=nskip, part=part, mid=mid, nmid=nmid, fu=fu, sk=sk,
                           up_dst=up_dst, hs=hs, ws_=ws_, hy=hy, wy=wy, ey=ey, ex=ex, swap=i in self.up_swap,
-                          seed=self.up_seed.get(i, False)):
+                          seed=self.up_seed.get(i, False), bands=self.up_bands.get(i, 0)):
                     if swap and seed:
                         # as below, but the partial is written in the skip-half conv's ACCUMULATOR units (divided by its
                         # scale) and that conv STARTS from it (sfh_conv_desc.acc_init): sixteen loads in its prologue
@@ -945,9 +948,14 @@ class UNetEngine:
                         if getattr(fu, "_seed_key", None) != key:
                             div = sk.scale.repeat(4)
                             fu._seed_scale, fu._seed_border, fu._seed_key = fu.scale / div, fu.shift_border / div, key
-                        fu.run(y, B, hy + ey, wy + ex, part, up_dst=up_dst, scale=fu._seed_scale,
-                               shift_border=fu._seed_border, **a_fu)
-                        sk.run(skip, B, hs, ws_, mid, acc_init=part, **a_sk)
+                        # frame bands (experiment, SFH_UP_BANDS="4:4" = level 4 in bands of 4 frames): the two launches of a
+                        # band run back to back, so that the band's fp32 partial is read back from the Infinity Cache
+                        nb_ = bands if bands else B
+                        for b0 in range(0, B, nb_):
+                            b1 = min(B, b0 + nb_)
+                            fu.run(y[b0:b1], b1 - b0, hy + ey, wy + ex, part[b0:b1], up_dst=up_dst, scale=fu._seed_scale,
+                                   shift_border=fu._seed_border, **a_fu)
+                            sk.run(skip[b0:b1], b1 - b0, hs, ws_, mid[b0:b1], acc_init=part[b0:b1], **a_sk)
                     elif swap:
                         # composed 2x2 conv first: it writes the 4 B fp32 partial instead of reading one and writing
                         # 6 B of S3; the MFMA-bound skip-half 3x3 conv then absorbs the residual, the ReLU and the split

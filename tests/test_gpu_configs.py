@@ -33,7 +33,10 @@ torch.set_num_threads(max(1, min(16, os.cpu_count() or 1)))
 
 FLIP_MARGIN = 2e-4                               # golden top-2 margin below which an arg-max pixel may differ
 FLIP_CAP = {(640, 360): 16, (1280, 720): 48}     # ... and how many of the batch's pixels may (3.69 M / 14.7 M)
-BLOCKSUM_TOL = 4e-3                              # |sum over an 8x8 block of (logit - golden)|; 64 x 5e-4 would be 3.2e-2
+# |sum over an 8x8 block of (logit - golden)|.  The accumulation-order error of neighbouring pixels is correlated (same
+# weights, similar inputs), so block sums move by up to 64 x 7e-5 = 4.3e-3 in EVERY mode (measured: f16x3 3.0e-3, exact
+# bf16x6 operands 4.3e-3); a seam error of 1e-3 along one row of a block adds 8e-3.  (64 x the per-pixel bound = 3.2e-2.)
+BLOCKSUM_TOL = 8e-3
 
 
 def _record(tag, **kw):

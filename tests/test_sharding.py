@@ -175,3 +175,87 @@ def test_result_gather_single_process():
     g = sharding.ResultGather(1, 2, "cpu")
     th, sc = g.result(g.submit(torch.ones(2, 1, 3, 3), torch.tensor([3.0, 4.0])))
     assert th.shape == (2, 1, 3, 3) and sc.tolist() == [3.0, 4.0]
+
+
+class _StandInReconstructor(torch.nn.Module):
+    """Takes Reconstructor's place in bench.main() on the CPU: theta is a pure function of the frames (their mean per
+    frame), so that the gathered rows can be checked against what each rank computed."""
+    precision = "f16x3"
+    range_fallbacks = range_rescales = 0
+
+    def __init__(self, court_img, court_poi, **kw):
+        super().__init__()
+        self.w = torch.nn.Parameter(torch.zeros(1))
+
+    def predict(self, x, consistency=True, project_poi=False):
+        n = x.shape[0]
+        theta = x.reshape(n, -1).mean(1).reshape(n, 1, 1, 1) + torch.arange(9.0).reshape(1, 1, 3, 3)
+        out = {"theta": theta.float(), "logits": torch.zeros(n, 4, 2, 2)}
+        if consistency:
+            out["consist_score"] = theta.reshape(n, 9)[:, 0] * 0.5
+        return out
+
+    def predict_async(self, x, consistency=True, project_poi=False):
+        out = self.predict(x, consistency, project_poi)
+
+        class _H:
+            def result(self_inner):
+                return out
+        return _H()
+
+    def invalidate_engines(self):
+        pass
+
+
+def _bench_main_worker(rank, world, port, q):
+    import contextlib
+    import importlib.util
+    import io
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK=str(rank),
+                      WORLD_SIZE=str(world))
+    import sfh_amd.reconstructor as R
+    from sfh_amd import synth
+    R.Reconstructor = _StandInReconstructor
+    # small frames: the plumbing is what runs here, not the workload
+    real = synth.synth_frames_u8
+    synth.synth_frames_u8 = lambda B, H, W, seed=0: real(B, 36, 64, seed=seed)
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    sys.argv = ["bench.py", "--gpus", str(world), "--steps", "3", "--warmup", "1", "--device", "cpu", "--dist-backend", "gloo",
+                "--no-cpu-baseline", "--no-extra-configs"]
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        bench.main()
+    lines = [ln for ln in buf.getvalue().splitlines() if ln.startswith("{")]
+    q.put((rank, json.loads(lines[-1]) if lines else None))
+
+
+def test_bench_main_two_ranks_gloo_reports_the_whole_job():
+    """bench.py's own main() under WORLD_SIZE=2 (gloo, CPU, a stand-in model): ONE JSON line, from rank 0, with
+    n_gpus 2, a global batch of 32 frames, weak scaling, value = frames of BOTH ranks per second, and the exchange
+    step verified inside the run - every rank holds 2 x 16 gathered rows and its own rows equal its own theta."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000) + 131
+    procs = [ctx.Process(target=_bench_main_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=240) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[1] is None                          # only rank 0 prints
+    line = res[0]
+    assert line["n_gpus"] == 2 and line["steps"] == 3 and line["warmup"] == 1 and line["scaling"] == "weak"
+    assert line["config"]["global_batch"] == 32 and line["config"]["frames_per_gpu_per_step"] == 16
+    assert "frame-sharded x2" in line["config"]["parallelism"] and "gloo" in line["config"]["parallelism"]
+    assert line["metric"].startswith("frames/sec at 640x360 batch=16") and line["unit"] == "frames/s"
+    # whole-job throughput: 2 ranks x 16 frames x 3 steps over the (max over ranks) elapsed time
+    assert abs(line["value"] - 2 * 16 * 3 / (line["ms_per_step"] * 3e-3)) < 0.02 * line["value"]
+    assert line["gather_check"] == {"rows_per_rank": 32, "own_rows_equal_own_theta_on_every_rank": True,
+                                    "bytes_per_step_per_rank": 640}
+    assert line["cpu_baseline"] is None and line["other_configs"] is None and line["vs_baseline"] is None
