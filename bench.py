@@ -185,6 +185,34 @@ def _timed_predicts(net, x, n, warm, pipeline, **kw):
         return time.perf_counter() - t0
 
 
+def e2e_bench(net, B, W, H, src_wh, steps, warmup):
+    """predict.py's loop shape end to end (predict.py:57-122): uint8 HWC frames in PINNED HOST memory -> H2D on a copy
+    stream -> /255 + HWC->CHW (+ integer INTER_AREA downscale) on the GPU -> predict_async -> uint8 arg-max mask, uint8
+    warp mask, theta, consistency score -> D2H into pinned host arrays, two batches in flight (sfh_amd.pipeline).
+    -> (frames/s, ms per batch): PCIe-inclusive, never the headline `value`."""
+    import torch
+    from sfh_amd import synth
+    from sfh_amd.pipeline import FramePipeline
+    sw, sh = src_wh
+    pipe = FramePipeline(net, B, (sh, sw), req_outputs=("theta", "warp_mask", "segm_mask"), consistency=True)
+    host = [torch.from_numpy(synth.synth_frames_u8(B, sh, sw, seed=500 + k)).pin_memory() for k in range(2)]
+
+    def run(n):
+        got = 0
+        for res in pipe.run(host[k % 2] for k in range(n)):
+            got += res["theta"].shape[0]
+        return got
+    with torch.no_grad():
+        run(warmup)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        got = run(steps)
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+    assert got == B * steps
+    return B * steps / el, el / steps * 1e3
+
+
 def extra_configs(args):
     """BASELINE configs 3 and 5 on this GPU, a few steps each (driver-observed numbers for every
     single-GPU config in one default run): C5 = predict() with consistency + POI on 16 frames of
@@ -205,6 +233,18 @@ def extra_configs(args):
     net.load_state_dict(synth.synth_state_dict(net.state_dict(), 0))
     net.to(dev).eval()
     x = synth.frames_to_float(synth.synth_frames_u8(B, H, W, seed=0)).to(dev)
+    # the headline workload END TO END (host uint8 frames in, host results out; PCIe inclusive), next to the same loop
+    # device to device measured right before it on this device
+    n = 10
+    d2d = _timed_predicts(net, x, n, 3, True, consistency=True)
+    for tag, src in (("E2E_640x360_batch16", (W, H)), ("E2E_1920x1080_to_640x360_batch16", (3 * W, 3 * H))):
+        fps, ms = e2e_bench(net, B, W, H, src, n, 3)
+        res[tag] = {"value": round(fps, 2), "unit": "frames/s", "ms_per_step": round(ms, 3), "steps": n, "warmup": 3,
+                    "device_to_device_frames_per_s": round(B * n / d2d, 2), "fraction_of_device_to_device": round(fps * d2d / (B * n), 4),
+                    "workload": ("uint8 HWC %dx%d frames in pinned host memory -> H2D (copy stream) -> /255 + CHW%s -> predict_async("
+                                 "consistency=True) -> uint8 arg-max mask + uint8 warp mask + theta + score -> D2H (pinned), two batches "
+                                 "in flight (sfh_amd.pipeline.FramePipeline; predict.py:57-122)")
+                                % (src[0], src[1], "" if src == (W, H) else " + 3x3 INTER_AREA downscale on the GPU")}
     for prec in ("bf16x6", "fp32"):
         net.precision = prec
         n = 4

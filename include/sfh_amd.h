@@ -261,6 +261,11 @@ int sfh_u8hwc_to_f32nchw(const uint8_t* src, float* dst, int batch, int C, int H
  * OpenCV's 2x2 area fast path.  Other scale factors are not covered. */
 int sfh_u8hwc_area2_to_f32nchw(const uint8_t* src, float* dst, int batch, int C, int H, int W, void* stream);
 
+/* Any integer downscale factor k = 2 .. 16 of the same call (1920x1080 -> 640x360 is k = 3): src uint8 (B,kH,kW,C) ->
+ * dst (B,C,H,W).  k = 2 is the special case above; otherwise OpenCV's resizeAreaFast_ rule: the k x k block summed in int,
+ * times the float 1.f / (k * k), rounded half to even, saturated to 0 .. 255, then / 255 (utils/dataset.py:312-330). */
+int sfh_u8hwc_areak_to_f32nchw(const uint8_t* src, float* dst, int batch, int C, int H, int W, int k, void* stream);
+
 /* (B, C, H, W) fp32 -> (B, H, W, cs) fp32, channels >= C zero-filled. */
 int sfh_nchw_to_nhwc(const float* src, float* dst, int batch, int C, int H, int W, int cs,
                      void* stream);
@@ -299,6 +304,12 @@ int sfh_outconv_fwd(const float* x, int cin, const float* w, const float* bias, 
 int sfh_homography_warp_fwd(const float* theta, const float* tmpl, int64_t tmpl_bstride,
                             int ht, int wt, int batch, int h, int w, int mode,
                             float out_scale, float* out_f32, int32_t* out_i32, void* stream);
+/* The same launch with the rows one wave walks given by the caller (1 .. 64; 0 = the launcher's own choice, i.e.
+ * sfh_homography_warp_fwd): a wave covers 64 * J consecutive pixels of rows_per_wave rows.  Results do not depend on
+ * it; exists for the tuning sweep (profiles/warp_sweep.py) and the tests that walk every row count. */
+int sfh_homography_warp_fwd_rows(const float* theta, const float* tmpl, int64_t tmpl_bstride,
+                                 int ht, int wt, int batch, int h, int w, int mode,
+                                 float out_scale, float* out_f32, int32_t* out_i32, int rows_per_wave, void* stream);
 
 /* Test hook (never on the product path): exhaustive GPU sweep of the two exact-division shortcuts of the
  * warp kernel against the IEEE divisions they replace - 1/z for every float with 2^-64 <= |z| <= 2^64, and

@@ -70,6 +70,7 @@ SIGNATURES = {
     "sfh_fold_bn": (C.c_int, [_p, _p, _p, _p, _p, C.c_float, C.c_int, C.c_int, _p, _p, _p]),
     "sfh_u8hwc_to_f32nchw": (C.c_int, [_p, _p, C.c_int, C.c_int, C.c_int, C.c_int, _p]),
     "sfh_u8hwc_area2_to_f32nchw": (C.c_int, [_p, _p, C.c_int, C.c_int, C.c_int, C.c_int, _p]),
+    "sfh_u8hwc_areak_to_f32nchw": (C.c_int, [_p, _p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _p]),
     "sfh_nchw_to_nhwc": (C.c_int, [_p, _p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _p]),
     "sfh_nhwc_to_nchw": (C.c_int, [_p, _p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _p]),
     "sfh_resize_nchw": (C.c_int, [_p, _p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _p]),
@@ -79,6 +80,8 @@ SIGNATURES = {
     "sfh_selftest_warp_arith": (C.c_int, [_p, _p]),
     "sfh_homography_warp_fwd": (C.c_int, [_p, _p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int,
                                           C.c_int, C.c_int, C.c_float, _p, _p, _p]),
+    "sfh_homography_warp_fwd_rows": (C.c_int, [_p, _p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int,
+                                               C.c_int, C.c_int, C.c_float, _p, _p, C.c_int, _p]),
     "sfh_poi_project_fwd": (C.c_int, [_p, _p, C.c_int, C.c_int, C.c_int, _p, _p]),
     "sfh_ce_workspace_floats": (C.c_int64, [C.c_int, C.c_int, C.c_int]),
     "sfh_consistency_ce_fwd": (C.c_int, [_p, _p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,

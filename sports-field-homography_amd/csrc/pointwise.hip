@@ -54,6 +54,32 @@ __global__ void u8hwc_area2_to_f32nchw_kernel(const uint8_t* __restrict__ src, f
   }
 }
 
+// The same for any other integer factor k (1920x1080 -> 640x360 is k = 3): OpenCV's resizeAreaFast_ sums the k x k block in
+// int and stores saturate_cast<uchar>(sum * scale) with scale = 1.f / (k * k) evaluated in float, i.e. the float product
+// rounded half to even (lrint).  The 2x2 case above is OpenCV's own special case ((a + b + c + d + 2) >> 2), not this rule.
+__global__ void u8hwc_areak_to_f32nchw_kernel(const uint8_t* __restrict__ src, float* __restrict__ dst, int C, int H,
+                                              int W, int k, float scale, long npix) {
+  const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;   // one output pixel
+  if (p >= npix) return;
+  const int HW = H * W;
+  const long b = p / HW;
+  const int i = (int)(p - b * HW), y = i / W, x = i - y * W;
+  const long rs = (long)k * W * C;  // source row stride in bytes
+  const uint8_t* s = src + (b * k * H + (long)k * y) * rs + (long)k * x * C;
+  float* d = dst + b * (long)C * HW + i;
+  int sum[4] = {0, 0, 0, 0};
+  for (int dy = 0; dy < k; ++dy)
+    for (int dx = 0; dx < k; ++dx) {
+      const uint8_t* q = s + dy * rs + (long)dx * C;
+      for (int c = 0; c < C; ++c) sum[c] += (int)q[c];
+    }
+  for (int c = 0; c < C; ++c) {
+    int v = __float2int_rn(__fmul_rn((float)sum[c], scale));
+    v = v < 0 ? 0 : (v > 255 ? 255 : v);
+    d[(long)c * HW] = (float)v / 255.0f;
+  }
+}
+
 __global__ void nhwc_to_nchw_kernel(const float* __restrict__ src, float* __restrict__ dst,
                                     int C, int HW, int cs, long npix) {
   const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -643,6 +669,17 @@ extern "C" int sfh_u8hwc_area2_to_f32nchw(const uint8_t* src, float* dst, int ba
   hipLaunchKernelGGL(u8hwc_area2_to_f32nchw_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0,
                      (hipStream_t)stream, src, dst, C, H, W, npix);
   return sfh_check_launch("u8hwc_area2_to_f32nchw_kernel");
+}
+
+extern "C" int sfh_u8hwc_areak_to_f32nchw(const uint8_t* src, float* dst, int batch, int C, int H, int W, int k,
+                                          void* stream) {
+  SFH_REQUIRE(src && dst && batch > 0 && C > 0 && C <= 4 && H > 0 && W > 0 && k >= 2 && k <= 16,
+              "u8hwc_areak_to_f32nchw: bad argument (k=%d must be 2 .. 16)", k);
+  if (k == 2) return sfh_u8hwc_area2_to_f32nchw(src, dst, batch, C, H, W, stream);
+  const long npix = (long)batch * H * W;
+  hipLaunchKernelGGL(u8hwc_areak_to_f32nchw_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0,
+                     (hipStream_t)stream, src, dst, C, H, W, k, 1.f / (float)(k * k), npix);
+  return sfh_check_launch("u8hwc_areak_to_f32nchw_kernel");
 }
 
 extern "C" int sfh_nhwc_to_nchw(const float* src, float* dst, int batch, int C, int H, int W, int cs,

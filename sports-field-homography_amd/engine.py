@@ -1318,8 +1318,9 @@ def f32_to_s3(t):
 def frames_u8_to_input(frames_u8, target_size=None):
     """uint8 (B,H,W,C) decoded frames on the GPU -> float32 (B,C,H,W) in [0,1], bit-identical to the
     reference dataset's `img.transpose((2,0,1)) / 255` (utils/dataset.py:154-159).  target_size = (W, H):
-    like VideoDataset.preprocess_img (utils/dataset.py:310-330) the frames are resized first; on the GPU
-    only the exact 2x downscale (cv2.INTER_AREA's 2x2 fast path, e.g. 1280x720 -> 640x360) is covered."""
+    like VideoDataset.preprocess_img (utils/dataset.py:310-330) the frames are resized first; on the GPU the
+    integer downscale factors 2 .. 16 are covered (cv2.INTER_AREA's block averages: 1280x720 -> 640x360 is the 2x2
+    special case, 1920x1080 -> 640x360 the 3x3 one)."""
     lib = _lib.load()
     if frames_u8.dtype != torch.uint8 or frames_u8.dim() != 4 or not frames_u8.is_cuda:
         raise ValueError("expected a uint8 (B,H,W,C) tensor on the GPU")
@@ -1327,11 +1328,13 @@ def frames_u8_to_input(frames_u8, target_size=None):
     B, H, W, C = f.shape
     if target_size is not None and (int(target_size[0]), int(target_size[1])) != (W, H):
         tw, th = int(target_size[0]), int(target_size[1])
-        if (2 * tw, 2 * th) != (W, H):
-            raise NotImplementedError(f"GPU frame resize {W}x{H} -> {tw}x{th}: only the exact 2x downscale is on the "
-                                      "HIP path; resize on the host as utils/dataset.py does")
+        k = W // tw if tw > 0 else 0
+        if k < 2 or k > 16 or (k * tw, k * th) != (W, H):
+            raise NotImplementedError(f"GPU frame resize {W}x{H} -> {tw}x{th}: only integer downscale factors 2 .. 16 "
+                                      "(cv2.INTER_AREA's block-average cases) are on the HIP path; resize on the host as "
+                                      "utils/dataset.py does")
         out = torch.empty((B, C, th, tw), dtype=torch.float32, device=f.device)
-        _lib.check(lib.sfh_u8hwc_area2_to_f32nchw(_ptr(f), _ptr(out), B, C, th, tw, _stream()), "u8hwc_area2_to_f32nchw")
+        _lib.check(lib.sfh_u8hwc_areak_to_f32nchw(_ptr(f), _ptr(out), B, C, th, tw, k, _stream()), "u8hwc_areak_to_f32nchw")
         return out
     out = torch.empty((B, C, H, W), dtype=torch.float32, device=f.device)
     _lib.check(lib.sfh_u8hwc_to_f32nchw(_ptr(f), _ptr(out), B, C, H, W, _stream()), "u8hwc_to_f32nchw")
@@ -1372,8 +1375,9 @@ def nchw_to_nhwc(t, cs=None):
 
 
 def homography_warp(theta, template, h, w, nearest, scale=None, want_f32=True, want_i32=False,
-                    shared_template=False):
-    """theta (B,1,3,3)|(B,3,3); template (>=B,1,ht,wt).  Returns (f32 or None, i32 or None)."""
+                    shared_template=False, rows_per_wave=0):
+    """theta (B,1,3,3)|(B,3,3); template (>=B,1,ht,wt).  Returns (f32 or None, i32 or None).
+    rows_per_wave: 0 = the launcher's choice; 1 .. 64 for the tuning sweep / tests (same results)."""
     lib = _lib.load()
     theta = _f32c(theta.reshape(-1, 3, 3).contiguous(), "theta")
     template = _f32c(template, "court template")
@@ -1390,9 +1394,14 @@ def homography_warp(theta, template, h, w, nearest, scale=None, want_f32=True, w
     if tm is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    _lib.check(lib.sfh_homography_warp_fwd(_ptr(theta), _ptr(template), bstride, ht, wt, B, h, w,
-                                           0 if nearest else 1, float(scale if scale is not None else 1.0),
-                                           _ptr(out_f), _ptr(out_i), _stream()), "homography_warp")
+    if rows_per_wave:
+        _lib.check(lib.sfh_homography_warp_fwd_rows(_ptr(theta), _ptr(template), bstride, ht, wt, B, h, w,
+                                                    0 if nearest else 1, float(scale if scale is not None else 1.0),
+                                                    _ptr(out_f), _ptr(out_i), int(rows_per_wave), _stream()), "homography_warp")
+    else:
+        _lib.check(lib.sfh_homography_warp_fwd(_ptr(theta), _ptr(template), bstride, ht, wt, B, h, w,
+                                               0 if nearest else 1, float(scale if scale is not None else 1.0),
+                                               _ptr(out_f), _ptr(out_i), _stream()), "homography_warp")
     if tm is not None:
         e1.record()
         # algorithmic BYTES: every output once, the template once (per frame if not shared), theta

@@ -1,0 +1,133 @@
+"""Frames in, results out: the GPU side of the reference's inference loop as one double-buffered pipeline.
+
+The reference's ``predict.py`` runs three processes (predict.py:45-122,250-255): a DataLoader that decodes and
+preprocesses frames on the host (utils/dataset.py:145-161,310-330), ``Workers.predict`` (frames ``.to(device)``,
+``net.predict``) and ``Workers.transfer_gpu_to_cpu`` (``preds_to_masks`` + ``.cpu().numpy()`` of every requested
+output).  ``FramePipeline`` is the device part of that loop in ONE process with HIP streams instead of processes:
+
+    host uint8 HWC frames (pinned) --copy stream--> GPU uint8 --HIP--> /255, HWC->CHW (+ integer INTER_AREA downscale)
+        --> Reconstructor.predict_async (UNet on the caller's stream, ResNet-STN / warp / CE on its side stream)
+        --> uint8 arg-max mask, uint8 warp mask, theta, consistency score, POI --copy stream--> pinned host arrays
+
+Two slots alternate: while batch k computes, batch k + 1 uploads and batch k - 1 downloads.  Everything a batch needs
+on the host arrives in its own pinned buffers; ``get()`` waits for that batch's download event only.
+
+Outputs and dtypes are those of predict.py:92-118 (``outputs.transfer_gpu_to_cpu`` is the synchronous version):
+``segm_mask`` uint8 (B,H,W), ``warp_mask`` uint8 (B,H,W), ``theta`` float32 (B,1,3,3), ``consist_score`` float32 (B,),
+``poi`` float32 (B,N,2).
+"""
+import numpy as np
+import torch
+
+from . import engine as E
+from . import outputs as O
+
+
+class FramePipeline:
+    def __init__(self, net, batch, frame_hw, req_outputs=("theta", "warp_mask"), consistency=False, channels=3):
+        """net: a Reconstructor on the GPU in eval mode; frame_hw = (H, W) of the DECODED frames (a multiple of
+        net.unet_size by an integer factor, or equal to it); req_outputs as predict.py's --req_outputs."""
+        self.net, self.B = net, int(batch)
+        self.req = set(req_outputs)
+        self.consistency = bool(consistency) or "consistency" in self.req
+        self.poi = "poi" in self.req
+        p = next(net.parameters())
+        if p.device.type != "cuda":
+            raise RuntimeError("FramePipeline needs the model on the GPU (no CPU fallback)")
+        self.dev = dev = p.device
+        H, W = int(frame_hw[0]), int(frame_hw[1])
+        tw, th = net.unet_size
+        self.target = None if (W, H) == (tw, th) else (tw, th)
+        wh, ww = net._warp_hw
+        nc = net.mask_classes
+        self.h2d, self.d2h = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+        pin = lambda shape, dt: torch.empty(shape, dtype=dt).pin_memory()
+        self.slots = []
+        for _ in range(2):
+            s = {"u8": torch.empty((self.B, H, W, channels), dtype=torch.uint8, device=dev),
+                 "uploaded": None, "consumed": None, "downloaded": None, "handle": None, "host": {}, "dev": None}
+            if "segm_mask" in self.req:
+                s["host"]["segm_mask"] = pin((self.B, net.target_size[1], net.target_size[0]), torch.uint8)
+            if "warp_mask" in self.req and net.warper:
+                s["host"]["warp_mask"] = pin((self.B, wh, ww), torch.uint8)
+            if "theta" in self.req:
+                s["host"]["theta"] = pin((self.B, 1, 3, 3), torch.float32)
+            if self.consistency and net.warper and net.use_unet:
+                s["host"]["consist_score"] = pin((self.B,), torch.float32)
+            if self.poi:
+                s["host"]["poi"] = pin((self.B,) + tuple(net.court_poi.shape[1:]), torch.float32)
+            self.slots.append(s)
+        self.k = 0
+        self._nc = nc
+
+    def submit(self, frames_u8_host):
+        """frames_u8_host: uint8 (B,H,W,C) host tensor (pinned for a truly asynchronous upload).  Enqueues upload,
+        preprocessing and the forward pass of this batch and returns its ticket; nothing here waits for the GPU."""
+        s = self.slots[self.k % 2]
+        self.k += 1
+        if s["handle"] is not None:
+            raise RuntimeError("FramePipeline: collect() the batch submitted two calls ago before reusing its slot")
+        cur = torch.cuda.current_stream(self.dev)
+        with torch.cuda.stream(self.h2d):
+            if s["consumed"] is not None:
+                self.h2d.wait_event(s["consumed"])       # the preprocessing kernel that read this buffer last is done
+            s["u8"].copy_(frames_u8_host, non_blocking=True)
+            s["uploaded"] = torch.cuda.Event()
+            s["uploaded"].record(self.h2d)
+        cur.wait_event(s["uploaded"])
+        x = E.frames_u8_to_input(s["u8"], self.target)
+        s["consumed"] = torch.cuda.Event()
+        s["consumed"].record(cur)
+        s["handle"] = self.net.predict_async(x, consistency=self.consistency, project_poi=self.poi)
+        return s
+
+    def collect(self, ticket):
+        """Enqueue post-processing and the download of a submitted batch (call it after submitting the NEXT batch, so
+        that this batch's ResNet-STN / warp ran under that one's UNet).  Returns at once; get() waits."""
+        s = ticket
+        out = s["handle"].result()                       # orders the current stream behind the batch
+        s["handle"] = None
+        cur = torch.cuda.current_stream(self.dev)
+        devout = {}
+        if "segm_mask" in s["host"]:
+            devout["segm_mask"] = O.format_masks(out["logits"], "gray", self._nc)          # uint8 arg-max (postprocess.py:7-18)
+        if "warp_mask" in s["host"]:
+            devout["warp_mask"] = O.format_masks(out["warp_mask"].contiguous(), "gray", self._nc)   # int32 -> uint8 on the GPU
+        for k in ("theta", "consist_score", "poi"):
+            if k in s["host"]:
+                devout[k] = out[k]
+        ready = torch.cuda.Event()
+        ready.record(cur)
+        with torch.cuda.stream(self.d2h):
+            self.d2h.wait_event(ready)
+            for k, t in devout.items():
+                s["host"][k].copy_(t, non_blocking=True)
+                t.record_stream(self.d2h)
+            s["downloaded"] = torch.cuda.Event()
+            s["downloaded"].record(self.d2h)
+        s["dev"] = devout
+        return s
+
+    def get(self, ticket):
+        """-> {name: numpy array} of a collected batch (views of the slot's pinned buffers: valid until the slot is
+        submitted again, copy what must live longer)."""
+        ticket["downloaded"].synchronize()
+        ticket["dev"] = None
+        return {k: v.numpy() for k, v in ticket["host"].items()}
+
+    def run(self, batches):
+        """Generator over host uint8 batches -> result dicts (copies), two batches in flight."""
+        prev = None
+        done = None
+        for fr in batches:
+            t = self.submit(fr)
+            if done is not None:
+                yield {k: np.array(v) for k, v in self.get(done).items()}
+                done = None
+            if prev is not None:
+                done = self.collect(prev)
+            prev = t
+        if done is not None:
+            yield {k: np.array(v) for k, v in self.get(done).items()}
+        if prev is not None:
+            yield {k: np.array(v) for k, v in self.get(self.collect(prev)).items()}

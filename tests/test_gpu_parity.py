@@ -994,6 +994,31 @@ def test_u8_frame_area2_downscale(E):
         E.frames_u8_to_input(torch.from_numpy(fr).cuda(), target_size=(30, 20))
 
 
+@pytest.mark.parametrize("k,hw", [(3, (360, 640)), (3, (15, 22)), (4, (11, 18)), (5, (7, 9))])
+def test_u8_frame_integer_area_downscale(E, k, hw):
+    """1920x1080 -> 640x360 (k = 3) and other integer factors: OpenCV's INTER_AREA block average, then /255
+    (utils/dataset.py:310-330), against the numpy restatement oracle/post_ref.resize_area_int; every possible block
+    sum of the 3x3 case is also checked against exact rational rounding where no tie is near."""
+    from oracle import post_ref
+    h, w = hw
+    B = 2
+    fr = synth.synth_frames_u8(B, h * k, w * k, seed=11 + k)
+    fr[0, :k, :k] = 255                      # saturating block
+    fr[0, :k, k:2 * k] = 0
+    area = np.stack([post_ref.resize_area_int(f, k) for f in fr])
+    want = torch.from_numpy((area.transpose(0, 3, 1, 2) / 255)).type(torch.FloatTensor)
+    got = E.frames_u8_to_input(torch.from_numpy(fr).cuda(), target_size=(w, h))
+    torch.cuda.synchronize()
+    assert tuple(got.shape) == (B, 3, h, w)
+    assert torch.equal(got.cpu(), want)
+    assert float(got[0, :, 0, 0].min()) == 1.0 and float(got[0, :, 0, 1].max()) == 0.0
+    # the restatement itself: mean of the block rounded to nearest (no block sum / k^2 of these sizes hits .5 exactly
+    # unless k is even)
+    if k % 2:
+        exact = np.floor(fr.reshape(B, h, k, w, k, 3).astype(np.int64).sum(axis=(2, 4)) / (k * k) + 0.5).astype(np.uint8)
+        assert np.array_equal(area, exact)
+
+
 def test_model_api_errors(E):
     from sfh_amd.reconstructor import Reconstructor
     net, sd, court, poi = _model((112, 90))

@@ -8,6 +8,8 @@ import pytest
 import torch
 
 from sfh_amd import outputs
+from sfh_amd import outputs as O
+from sfh_amd import synth
 from oracle import post_ref, torch_ref
 
 
@@ -133,3 +135,33 @@ def test_transfer_gpu_to_cpu_keys():
     assert np.array_equal(out["warp_mask"], preds["warp_mask"].cpu().numpy().astype(np.uint8))
     with pytest.raises(NotImplementedError):
         outputs.preds_to_masks(preds["logits"][:, :1].contiguous(), 1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("scale", [1, 3])
+def test_frame_pipeline_gives_predict_s_outputs(scale):
+    """sfh_amd.pipeline.FramePipeline (host uint8 frames in, host arrays out, two batches in flight) returns, for every
+    batch, exactly what frames_u8_to_input -> predict() -> transfer_gpu_to_cpu returns for it - also when the decoded
+    frames are 3x the network size (INTER_AREA downscale on the GPU)."""
+    from sfh_amd import engine as E
+    from sfh_amd.pipeline import FramePipeline
+    from sfh_amd.reconstructor import Reconstructor
+    w, h, B = 112, 90, 2
+    court = synth.load_court_template("ncaa_nc4_640x360", 4, B)[:, :, :h, :w].contiguous()
+    poi = synth.load_court_poi("pitch", B)
+    net = Reconstructor(court.cuda(), poi.cuda(), target_size=(w, h), unet_size=(w, h), warp_size=(w, h), warp_with_nearest=True)
+    net.load_state_dict(synth.synth_state_dict(net.state_dict(), 19))
+    net.cuda().eval()
+    batches = [torch.from_numpy(synth.synth_frames_u8(B, h * scale, w * scale, seed=40 + k)).pin_memory() for k in range(5)]
+    req = ("theta", "warp_mask", "segm_mask", "poi")
+    pipe = FramePipeline(net, B, (h * scale, w * scale), req_outputs=req, consistency=True)
+    with torch.no_grad():
+        got = list(pipe.run(iter(batches)))
+        assert len(got) == len(batches)
+        for fr, res in zip(batches, got):
+            x = E.frames_u8_to_input(fr.cuda(), (w, h) if scale != 1 else None)
+            want = O.transfer_gpu_to_cpu(net.predict(x, consistency=True, project_poi=True), set(req), 4)
+            assert set(res) == {"theta", "warp_mask", "segm_mask", "poi", "consist_score"}
+            for k in res:
+                assert res[k].dtype == want[k].dtype and np.array_equal(res[k], want[k]), k
+            assert res["segm_mask"].dtype == np.uint8 and res["warp_mask"].dtype == np.uint8
