@@ -221,6 +221,19 @@ int sfh_h2_to_f32(const void* src, float* dst, int64_t rows, int W, int cs, int 
 int sfh_conv3x3_c4_fwd(const sfh_conv_desc* d, void* stream);
 int sfh_pack_c4_weights(const float* w, float* packed, int cin, int cout, void* stream);
 
+/* The same first layer on the fp16 matrix cores ("f16x3": two fp16 planes per operand, three products, fp32 accumulation;
+ * unet/unet_parts.py:15).  The frame is split ONCE by sfh_frame_to_h2 into the FH2 frame tensor, 16 bytes per pixel =
+ * [fp16 plane 0 of channels 0..3 | fp16 plane 1 of channels 0..3] of x * 2^act_exp (format as SFH_FMT_H2: saturating,
+ * `range` receives the largest |x * 2^act_exp|, `overflow` is OR-ed with 1 on saturation; both optional); dst_nhwc4
+ * (optional) receives the fp32 NHWC copy with 4 stored channels that sfh_nchw_to_nhwc would write.
+ * sfh_conv3x3_c4h2_fwd: src0 = the FH2 tensor (B,H,W) x 16 bytes, wpacked from sfh_pack_c4h2_weights (planes of
+ * w * 2^wexp; the caller multiplies `scale` by 2^-(wexp + act_exp)), dst H2 or fp32; descriptor fields as sfh_conv_fwd. */
+int sfh_frame_to_h2(const float* src_nchw, float* dst_nhwc4, void* dst_fh2, int batch, int C, int H, int W, int act_exp,
+                    uint32_t* overflow, uint32_t* range, void* stream);
+int64_t sfh_packed_c4h2_weight_bytes(int cout);
+int sfh_pack_c4h2_weights(const float* w, void* packed, int cin, int cout, int wexp, void* stream);
+int sfh_conv3x3_c4h2_fwd(const sfh_conv_desc* d, void* stream);
+
 /* Number of floats of the packed weight buffer for a conv with the given geometry. */
 int64_t sfh_packed_weight_floats(int ksize, int c0, int c1, int cout_virtual);
 

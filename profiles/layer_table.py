@@ -6,7 +6,7 @@ paths = [a for a in sys.argv[1:] if a.endswith(".csv")]
 rows = list(csv.DictReader(open(max(paths, key=os.path.getmtime))))
 B = int(sys.argv[-1]) if len(sys.argv) > 2 and sys.argv[-1].isdigit() else 16
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
-idx = [i for i, r in enumerate(rows) if 'nchw_to_nhwc' in r['Kernel_Name']]
+idx = [i for i, r in enumerate(rows) if 'nchw_to_nhwc' in r['Kernel_Name'] or 'frame_to_h2' in r['Kernel_Name']]
 step = rows[idx[-1]:]
 def gm(cin, cout, h, w, k=9): return cin * cout * h * w * k / 1e9
 L = [("inc.0", gm(3, 64, 360, 640)), ("inc.3", gm(64, 64, 360, 640)),
@@ -27,7 +27,7 @@ if any('S3Cfg<2,' in r['Kernel_Name'] for r in step):
                   ("u3.fuse", gm(128, 128, 180, 320)), ("u3.skip", gm(128, 128, 180, 320)), ("u3.3", gm(128, 128, 180, 320)),
                   ("u4.fuse", gm(64, 64, 360, 640)), ("u4.skip", gm(64, 64, 360, 640)), ("u4.3", gm(64, 64, 360, 640))]
 dur = lambda r: (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e6
-is_conv = lambda n: 'conv_mfma' in n or 'conv_s3' in n or 'conv3x3_c4' in n or 'stem7x7' in n
+is_conv = lambda n: 'conv_mfma' in n or 'conv_s3' in n or 'conv3x3_c4' in n or 'stem7x7' in n   # (c4: also conv3x3_c4h2)
 convs = [r for r in step if is_conv(r['Kernel_Name'])]
 tot = 0
 for (nm, g), r in zip(L, convs[:len(L)]):

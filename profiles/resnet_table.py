@@ -1,7 +1,7 @@
 """Per-kernel times of the ResNet-STN part of the last step in a rocprofv3 kernel trace."""
 import csv, re, sys
 rows = list(csv.DictReader(open(sys.argv[1]))); rows.sort(key=lambda r: int(r['Start_Timestamp']))
-idx = [i for i, r in enumerate(rows) if 'nchw_to_nhwc' in r['Kernel_Name']]
+idx = [i for i, r in enumerate(rows) if 'nchw_to_nhwc' in r['Kernel_Name'] or 'frame_to_h2' in r['Kernel_Name']]
 step = rows[idx[-1]:]
 k = [i for i, r in enumerate(step) if 'outconv' in r['Kernel_Name'] or 'stem7x7' in r['Kernel_Name']][0]
 tot = 0

@@ -372,10 +372,12 @@ class PackedConv:
     _shared_scale = False       # `scale` is a tensor shared with other layers (training): never rewritten in place
 
     def __init__(self, weight, bias, bn, ksize, c0, c1=0, relu=True, transposed=False, stride=1,
-                 stem_cin=0, tag="conv", s3=False, fmt=None, wexp=None, shared_unit_scale=False):
+                 stem_cin=0, tag="conv", s3=False, fmt=None, wexp=None, shared_unit_scale=False, frame_h2=False):
         """fmt="s3" (or s3=True): sources are split-bf16 (S3) tensors and the contraction runs as six bf16 MFMAs
         per product; fmt="h2": two-plane fp16 (H2) sources, three fp16 MFMAs per product (both sfh_conv_s3_fwd);
-        otherwise fp32 sources and fp32 MFMA (sfh_conv_fwd)."""
+        otherwise fp32 sources and fp32 MFMA (sfh_conv_fwd).  frame_h2 (with fmt=None, a 3x3 conv over <= 4 channels: the
+        UNet's first layer): the source is the FH2 frame tensor of sfh_frame_to_h2 - held as a float32 (B,H,W,4) tensor, 16
+        bytes per pixel - and the contraction runs as three fp16 MFMAs per product (sfh_conv3x3_c4h2_fwd)."""
         lib = _lib.load()
         self.tag = tag
         self.fmt = fmt if fmt is not None else ("s3" if s3 else None)
@@ -409,7 +411,19 @@ class PackedConv:
         # 3x3 conv over <= 4 input channels (the UNet's first layer): tap-packed kernel
         self.c4 = (not self.s3 and not stem_cin and not transposed and ksize == 3 and stride == 1
                    and c1 == 0 and c0 <= 4)
-        if self.c4:
+        self.c4h2 = bool(frame_h2) and self.c4
+        if frame_h2 and not self.c4:
+            raise ValueError("frame_h2 is the first-layer kernel: a 3x3 stride-1 conv over at most 4 channels, fmt=None")
+        if self.c4h2:
+            import math
+            wmax = float(w.abs().max())
+            if not math.isfinite(wmax):
+                raise ValueError("conv weight holds non-finite values")
+            wx = max(-100, min(100, 14 - math.frexp(wmax)[1])) if wmax > 0 else 0    # max |w| * 2^wx in [2^13, 2^14)
+            self.escale = 2.0 ** -(wx + _lib.H2_ACT_EXP)
+            self.wpacked = torch.empty(lib.sfh_packed_c4h2_weight_bytes(self.cout), dtype=torch.uint8, device=dev)
+            _lib.check(lib.sfh_pack_c4h2_weights(_ptr(w), _ptr(self.wpacked), c0, self.cout, wx, _stream()), "pack_c4h2_weights")
+        elif self.c4:
             self.wpacked = torch.empty((self.cout // 64) * 9 * 256, dtype=torch.float32, device=dev)
             _lib.check(lib.sfh_pack_c4_weights(_ptr(w), _ptr(self.wpacked), c0, self.cout, _stream()), "pack_c4_weights")
         elif self.s3:
@@ -586,7 +600,7 @@ class PackedConv:
         is - the table then receives sum g and sum g * xhat (sfh_conv_desc.bwd_z)."""
         lib = _lib.load()
         d = ConvDesc()
-        if self.fmt == "h2" and exp_src is not None:
+        if (self.fmt == "h2" or getattr(self, "c4h2", False)) and exp_src is not None:
             self._fold_exp_src(int(exp_src))
         d.h2_exp_src = self.exp_src
         if exp_dst is not None:
@@ -715,7 +729,7 @@ class PackedConv:
         if self.c4:
             if src0.shape[-1] != 4 or pool0 or dst_pool is not None:
                 raise ValueError("the <=4-channel first-layer kernel needs an fp32 NHWC source with 4 stored channels")
-            fwd = lib.sfh_conv3x3_c4_fwd
+            fwd = lib.sfh_conv3x3_c4h2_fwd if self.c4h2 else lib.sfh_conv3x3_c4_fwd
         tm = PackedConv.timer
         if tm is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -790,9 +804,13 @@ class UNetEngine:
         self._last_out = None
         L = {}
 
+        # "f16x3": the 3-channel first layer too runs on the fp16 matrix cores, from a frame tensor split once (FH2)
+        self.frame_h2 = fmt == "h2" and os.environ.get("SFH_INC0_H2", "1") != "0"
+
         def dc(name, block, c0, c1=0, first_fmt=fmt):
             (cv1, bn1), (cv2, bn2) = block.convs()
-            L[name + ".0"] = PackedConv(cv1.weight, cv1.bias, bn1, 3, c0, c1, tag="doubleconv3x3", fmt=first_fmt)
+            L[name + ".0"] = PackedConv(cv1.weight, cv1.bias, bn1, 3, c0, c1, tag="doubleconv3x3", fmt=first_fmt,
+                                        frame_h2=(self.frame_h2 and first_fmt is None and c0 <= 4))
             L[name + ".3"] = PackedConv(cv2.weight, cv2.bias, bn2, 3, cv1.out_channels, tag="doubleconv3x3", fmt=fmt)
 
         dc("inc", net.inc, 3, first_fmt=None)  # 3-channel input: fp32 kernel (writes the split format itself)
@@ -874,7 +892,20 @@ class UNetEngine:
             fn()
 
         xin = ws.get("xin", (B, H, W, 4))
-        do((), lambda: _lib.check(lib.sfh_nchw_to_nhwc(_ptr(x), _ptr(xin), B, 3, H, W, 4, _stream()), "nchw_to_nhwc"))
+        first = (xin, None)
+        if self.frame_h2:
+            # one pass writes the fp32 NHWC frame (the fused head reads it) AND its two fp16 planes, 16 bytes per pixel,
+            # held as a float32 (B,H,W,4) tensor; "frame" has an exponent and a range word like every H2 tensor
+            fh2 = ws.get("frame_h2", (B, H, W, 4))
+            rg.register("frame")
+            ovf = self.overflow
+            do(("frame",), lambda: _lib.check(lib.sfh_frame_to_h2(
+                _ptr(x), _ptr(xin), _ptr(fh2), B, 3, H, W, rg.exp("frame"),
+                ctypes.c_void_p(ovf.data_ptr()) if ovf is not None else None,
+                ctypes.c_void_p(rg.word_ptr("frame")) if rg.word_ptr("frame") else None, _stream()), "frame_to_h2"))
+            first = (fh2, "frame")
+        else:
+            do((), lambda: _lib.check(lib.sfh_nchw_to_nhwc(_ptr(x), _ptr(xin), B, 3, H, W, 4, _stream()), "nchw_to_nhwc"))
 
         s3, fmt = self.s3, self.fmt
 
@@ -899,7 +930,7 @@ class UNetEngine:
 
         # encoder: in bf16x6 mode every Down's MaxPool2d(2) is written by the producer's epilogue;
         # in fp32 mode it is applied while the consumer loads its halo (pool0)
-        f0, p0 = dconv("inc", (xin, None), H, W, 64, want_pool=True)
+        f0, p0 = dconv("inc", first, H, W, 64, want_pool=True)
         feats, pooled = [f0], [p0]
         h, w = H, W
         for i in range(1, 5):

@@ -557,7 +557,9 @@ class Reconstructor(nn.Module):
         dev = x.device
         if p is None or p["device"] != dev:
             with torch.cuda.device(dev):
-                p = self.__dict__["_pipe"] = {"device": dev, "side": torch.cuda.Stream(dev), "copy": torch.cuda.Stream(dev),
+                # experiment knob: HIP priority of the side stream (negative = higher than the caller's default stream)
+                prio = int(os.environ.get("SFH_SIDE_PRIO", "0"))
+                p = self.__dict__["_pipe"] = {"device": dev, "side": torch.cuda.Stream(dev, priority=prio), "copy": torch.cuda.Stream(dev),
                                               "slot": 0, "stem_read": [None, None], "inflight": []}
         cur = torch.cuda.current_stream(dev)
         slot = p["slot"]

@@ -70,6 +70,73 @@ def test_double_conv_golden(E, golden_blocks, tile):
     assert _maxerr(_nchw(y), g["dc_64_128_m64.y"]) < 5e-5
 
 
+def _frame_h2(x_nchw, exp=2):
+    """the FH2 frame tensor of sfh_frame_to_h2 (held as float32 (B,H,W,4): 16 bytes per pixel) + the fp32 NHWC copy"""
+    import ctypes
+    from sfh_amd import _lib
+    lib = _lib.load()
+    B, C, H, W = x_nchw.shape
+    x = x_nchw.contiguous().cuda()
+    nhwc4 = torch.empty((B, H, W, 4), device="cuda")
+    fh2 = torch.empty((B, H, W, 4), device="cuda")
+    word = torch.zeros(1, dtype=torch.int32, device="cuda")
+    p = lambda t: ctypes.c_void_p(t.data_ptr())
+    _lib.check(lib.sfh_frame_to_h2(p(x), p(nhwc4), p(fh2), B, C, H, W, exp, None, p(word),
+                                   ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "frame_to_h2")
+    return fh2, nhwc4, word
+
+
+@pytest.mark.parametrize("hw", [(20, 24), (45, 80), (37, 70)])
+def test_first_layer_on_the_fp16_matrix_cores(E, golden_blocks, hw):
+    """DoubleConv's first conv (3 -> 64, unet/unet_parts.py:15) in "f16x3" arithmetic (sfh_conv3x3_c4h2_fwd over the FH2
+    frame tensor): against the reference-class golden, against the fp32-MFMA kernel it replaces on odd sizes (tile
+    seams, frame borders, the zero rows between frames), and a NaN pixel reaches exactly its 3x3 neighbourhood - the
+    padding taps 9 .. 15 of the K axis must not pull neighbours in through zero weights."""
+    g = golden_blocks
+    m, _ = _mods_to_cuda(modules.DoubleConv(3, 64), 11)
+    (cv1, bn1), (cv2, bn2) = m.convs()
+    lh = E.PackedConv(cv1.weight, cv1.bias, bn1, 3, 3, frame_h2=True)
+    lf = E.PackedConv(cv1.weight, cv1.bias, bn1, 3, 3)
+    l2 = E.PackedConv(cv2.weight, cv2.bias, bn2, 3, 64, fmt="h2")
+    assert lh.c4h2 and lf.c4 and not lf.c4h2
+    if hw == (20, 24):
+        x = torch.from_numpy(g["dc_3_64.x"])
+    else:
+        x = torch.rand((3, 3) + hw, generator=torch.Generator().manual_seed(hw[0]))
+    B, _, H, W = x.shape
+    fh2, nhwc4, word = _frame_h2(x)
+    assert torch.equal(nhwc4[..., :3].cpu(), x.permute(0, 2, 3, 1)) and float(nhwc4[..., 3].abs().max()) == 0.0
+    mid_h = E.split_empty("h2", B, H, W, 64, "cuda")
+    mid_f = E.split_empty("h2", B, H, W, 64, "cuda")
+    lh.run(fh2, B, H, W, mid_h)
+    lf.run(nhwc4, B, H, W, mid_f)
+    yh = torch.empty((B, H, W, 64), device="cuda")
+    yf = torch.empty((B, H, W, 64), device="cuda")
+    a, b = E.s3_to_f32(mid_h), E.s3_to_f32(mid_f)
+    torch.cuda.synchronize()
+    assert float((a - b).abs().max()) < 2e-5 * max(1.0, float(b.abs().max()))
+    assert abs(float(word.view(torch.float32).item()) - 4.0 * float(x.abs().max())) < 1e-5   # the range word: max |x| * 2^2
+    if hw == (20, 24):
+        l2.run(mid_h, B, H, W, yh)
+        torch.cuda.synchronize()
+        assert _maxerr(_nchw(yh), g["dc_3_64.y"]) < 2e-5
+    # fp32 destination of the same kernel, and the NaN footprint
+    lh.run(fh2, B, H, W, yh)
+    xn = x.clone()
+    xn[1, 2, 7, 9] = float("nan")
+    fh2n, _, wn = _frame_h2(xn)
+    lh.run(fh2n, B, H, W, yf)
+    torch.cuda.synchronize()
+    assert float((yh - a).abs().max()) < 1e-5 * max(1.0, float(a.abs().max()))
+    assert int(wn.item()) >= 0x7F800000 or int(wn.item()) < 0        # the range word holds a non-finite pattern
+    # the H2 split SATURATES a NaN (the range word reports it and the model re-runs in bf16x6); what this kernel must
+    # guarantee is locality: outputs outside the pixel's 3x3 neighbourhood are those of the clean frame
+    changed = ((yf - yh).abs().amax(dim=3) > 0).cpu()
+    where = changed.nonzero()
+    assert len(where) > 0 and (where[:, 0] == 1).all()
+    assert int(where[:, 1].min()) >= 6 and int(where[:, 1].max()) <= 8 and int(where[:, 2].min()) >= 8 and int(where[:, 2].max()) <= 10
+
+
 # ---------------------------------------------------------------- split-bf16 (S3) conv path
 def _run_double_conv_s3(E, block, x_nhwc, B, H, W, c0, src1=None, c1=0, pad1=(0, 0), tile=None, pool=False, fmt="s3"):
     (cv1, bn1), (cv2, bn2) = block.convs()
