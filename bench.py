@@ -321,6 +321,9 @@ def main():
     ap.add_argument("--no-pipeline", action="store_true",
                     help="call predict() per step instead of predict_async() (two batches in flight: the ResNet-STN + warp of "
                          "batch k on a side stream under the UNet of batch k + 1)")
+    ap.add_argument("--no-alone-pass", action="store_true",
+                    help="skip the unpipelined pass behind the timed region (kernel_groups then come from the pipelined region): "
+                         "for a profiler trace of the pipelined region only")
     ap.add_argument("--device", default="cuda", choices=["cuda", "cpu"],
                     help="cpu: rehearsal of the multi-rank plumbing in the CPU tests (tests/test_sharding.py, gloo, a stand-in "
                          "model); the printed value then measures nothing")
@@ -439,7 +442,7 @@ def main():
     # the pipeline the ResNet-STN launches of batch k share the CUs with the UNet launches of batch k + 1, so every launch
     # of the timed region above takes longer than it would alone although the batch takes less)
     alone = None
-    if not args.no_pipeline:
+    if not args.no_pipeline and not args.no_alone_pass:
         with torch.no_grad():
             tm2 = engine.ConvTimer()
             engine.PackedConv.timer = tm2

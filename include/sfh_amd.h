@@ -317,13 +317,6 @@ int sfh_outconv_fwd(const float* x, int cin, const float* w, const float* bias, 
 int sfh_homography_warp_fwd(const float* theta, const float* tmpl, int64_t tmpl_bstride,
                             int ht, int wt, int batch, int h, int w, int mode,
                             float out_scale, float* out_f32, int32_t* out_i32, void* stream);
-/* The same launch with the rows one wave walks given by the caller (1 .. 64; 0 = the launcher's own choice, i.e.
- * sfh_homography_warp_fwd): a wave covers 64 * J consecutive pixels of rows_per_wave rows.  Results do not depend on
- * it; exists for the tuning sweep (profiles/warp_sweep.py) and the tests that walk every row count. */
-int sfh_homography_warp_fwd_rows(const float* theta, const float* tmpl, int64_t tmpl_bstride,
-                                 int ht, int wt, int batch, int h, int w, int mode,
-                                 float out_scale, float* out_f32, int32_t* out_i32, int rows_per_wave, void* stream);
-
 /* Test hook (never on the product path): exhaustive GPU sweep of the two exact-division shortcuts of the
  * warp kernel against the IEEE divisions they replace - 1/z for every float with 2^-64 <= |z| <= 2^64, and
  * create_meshgrid's (i/(n-1) - 0.5)*2 for every 0 <= i < n <= 16385.  mismatches: DEVICE int64[2].        */

@@ -9,12 +9,15 @@ TAG=${1:-r01}
 ROOTD=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOTD/gpurun_out
 mkdir -p $OUT
-rm -rf $OUT/${TAG}_trace $OUT/${TAG}_trace_np $OUT/${TAG}_fetch $OUT/${TAG}_write $OUT/${TAG}_mfma
+rm -rf $OUT/${TAG}_trace $OUT/${TAG}_trace_pipe $OUT/${TAG}_trace_np $OUT/${TAG}_fetch $OUT/${TAG}_write $OUT/${TAG}_mfma
 cd /tmp && export TMPDIR=/tmp
 ARGS="--steps 3 --warmup 1 --no-cpu-baseline --no-extra-configs"
 # the default command (two batches in flight): kernel stats that bench.py's roofline.avg_launch_ms must agree with
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_trace -- python3 $ROOTD/bench.py $ARGS > $OUT/${TAG}_trace.log 2>&1
 echo "trace done"
+# the pipelined region ONLY (no unpipelined pass behind it): every launch counted ran with two batches in flight
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_trace_pipe -- python3 $ROOTD/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-extra-configs --no-alone-pass > $OUT/${TAG}_trace_pipe.log 2>&1
+echo "trace (pipelined region only) done"
 # one predict() per step: launches alone on the chip, in order (per-layer table; the counter passes below serialise anyway)
 ARGS="$ARGS --no-pipeline"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_trace_np -- python3 $ROOTD/bench.py $ARGS > $OUT/${TAG}_trace_np.log 2>&1

@@ -27,7 +27,7 @@ def rows(kind):
     rr.sort(key=lambda r: int(r["Start_Timestamp"]))
     in_resnet = False
     for r in rr:
-        if "nchw_to_nhwc" in r["Kernel_Name"]:
+        if "nchw_to_nhwc" in r["Kernel_Name"] or "frame_to_h2" in r["Kernel_Name"]:   # first kernel of a step
             in_resnet = False
         elif "space_to_depth" in r["Kernel_Name"] or "stem7x7" in r["Kernel_Name"]:
             in_resnet = True
@@ -46,6 +46,8 @@ def group(name, resnet=False):
         return {"3": "s3_conv3x3", "2": "s3_up2x2"}.get(m.group(1), "s3_conv1x1")
     if "stem7x7" in name:
         return "s3_stem7x7"
+    if "conv3x3_c4" in name:
+        return "first_layer_c4"
     for k in ("warp_kernel", "outconv", "maxpool", "avgpool", "space_to_depth", "nchw_to_nhwc", "pack_weights", "fold_bn", "ce_"):
         if k in name:
             return k
@@ -83,6 +85,7 @@ if "s3_conv3x3" in out:   # the DoubleConv launches of the default (bf16x6) mode
     out["doubleconv3x3"] = out["s3_conv3x3"]
 elif "fp32_conv3x3" in out:
     out["doubleconv3x3"] = out["fp32_conv3x3"]
+out["round"] = tag
 json.dump(out, open(os.path.join(here, "pmc_traffic.json"), "w"), indent=1)
 print("\n".join(lines))
 
@@ -110,12 +113,15 @@ for g, d in sorted(mf.items()):
 open(os.path.join(here, f"{tag}_pmc_mfma_busy.txt"), "w").write("\n".join(ml) + "\n")
 print("\n".join(ml))
 
-# kernel stats summary copy
-ks = sorted(glob.glob(os.path.join(src, f"{tag}_trace", "*", "*_kernel_stats.csv")), key=os.path.getmtime)
-if ks:
-    rr = list(csv.DictReader(open(ks[-1])))
-    sl = [f"# {tag}: rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline",
-          f"{'calls':>6s} {'total ms':>10s} {'avg us':>10s} {'%':>6s}  kernel"]
-    for r in rr:
-        sl.append(f"{r['Calls']:>6s} {int(r['TotalDurationNs'])/1e6:10.3f} {float(r['AverageNs'])/1e3:10.1f} {float(r['Percentage']):6.2f}  {r['Name'][:150]}")
-    open(os.path.join(here, f"{tag}_kernel_stats.txt"), "w").write("\n".join(sl) + "\n")
+# kernel stats summary copies: the default command (pipelined region + the unpipelined pass behind it), and the
+# pipelined region alone (--no-alone-pass: two batches in flight for every launch counted)
+for sub, name, cmd in (("trace", "kernel_stats", "--steps 3 --warmup 1 --no-cpu-baseline --no-extra-configs"),
+                       ("trace_pipe", "kernel_stats_pipelined", "--steps 5 --warmup 1 --no-cpu-baseline --no-extra-configs --no-alone-pass")):
+    ks = sorted(glob.glob(os.path.join(src, f"{tag}_{sub}", "*", "*_kernel_stats.csv")), key=os.path.getmtime)
+    if ks:
+        rr = list(csv.DictReader(open(ks[-1])))
+        sl = [f"# {tag}: rocprofv3 --kernel-trace --stats -- python3 bench.py {cmd}",
+              f"{'calls':>6s} {'total ms':>10s} {'avg us':>10s} {'%':>6s}  kernel"]
+        for r in rr:
+            sl.append(f"{r['Calls']:>6s} {int(r['TotalDurationNs'])/1e6:10.3f} {float(r['AverageNs'])/1e3:10.1f} {float(r['Percentage']):6.2f}  {r['Name'][:150]}")
+        open(os.path.join(here, f"{tag}_{name}.txt"), "w").write("\n".join(sl) + "\n")

@@ -17,9 +17,7 @@ HBM_PEAK_GBS = 8000.0
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--iters", type=int, default=50)
-    ap.add_argument("--rows", default="0", help="comma list of rows per wave to time (0 = the launcher's choice)")
     args = ap.parse_args()
-    rows_list = [int(r) for r in args.rows.split(",")]
     import torch
     from sfh_amd import engine, synth
 
@@ -34,9 +32,9 @@ def main():
             idx = torch.randint(0, len(synth.REALISTIC_THETAS), (B,), generator=g)
             theta = torch.tensor(synth.REALISTIC_THETAS, dtype=torch.float32)[idx]
             theta = (theta + 1e-3 * torch.randn(B, 3, 3, generator=g)).to(dev)
-            for mode, nearest, rpw in [(m, n, r) for (m, n) in (("nearest->i32", True), ("bilinear->f32", False)) for r in rows_list]:
+            for mode, nearest in (("nearest->i32", True), ("bilinear->f32", False)):
                 kw = dict(nearest=nearest, scale=4.0 if nearest else None, want_f32=not nearest,
-                          want_i32=nearest, shared_template=True, rows_per_wave=rpw)
+                          want_i32=nearest, shared_template=True)
                 for _ in range(3):
                     engine.homography_warp(theta, tmpl, H, W, **kw)
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -48,7 +46,7 @@ def main():
                 us = e0.elapsed_time(e1) * 1e3 / args.iters
                 nbytes = B * H * W * 4 + H * W * 4 + B * 36
                 gbs = nbytes / (us * 1e-6) / 1e9
-                rows.append({"size": f"{W}x{H}", "batch": B, "mode": mode, "rows_per_wave": rpw or "auto", "us_per_launch": round(us, 2),
+                rows.append({"size": f"{W}x{H}", "batch": B, "mode": mode, "us_per_launch": round(us, 2),
                              "algorithmic_bytes": nbytes, "GB/s": round(gbs, 1),
                              "frac_of_8TB/s": round(gbs / HBM_PEAK_GBS, 4)})
                 print(json.dumps(rows[-1]), flush=True)

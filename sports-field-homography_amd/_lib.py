@@ -84,8 +84,6 @@ SIGNATURES = {
     "sfh_selftest_warp_arith": (C.c_int, [_p, _p]),
     "sfh_homography_warp_fwd": (C.c_int, [_p, _p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int,
                                           C.c_int, C.c_int, C.c_float, _p, _p, _p]),
-    "sfh_homography_warp_fwd_rows": (C.c_int, [_p, _p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int,
-                                               C.c_int, C.c_int, C.c_float, _p, _p, C.c_int, _p]),
     "sfh_poi_project_fwd": (C.c_int, [_p, _p, C.c_int, C.c_int, C.c_int, _p, _p]),
     "sfh_ce_workspace_floats": (C.c_int64, [C.c_int, C.c_int, C.c_int]),
     "sfh_consistency_ce_fwd": (C.c_int, [_p, _p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,

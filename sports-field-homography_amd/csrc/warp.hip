@@ -13,9 +13,12 @@
 // in front of warp2_body.
 #include <hip/amd_detail/amd_hip_unsafe_atomics.h>
 
-#include <type_traits>
-
 #include "common.h"
+
+// waves a launch should put on the chip before a thread takes more rows (experiment knob of profiles/build_variant.py)
+#ifndef SFH_WARP_MIN_WAVES
+#define SFH_WARP_MIN_WAVES 16384
+#endif
 
 namespace {
 
@@ -103,7 +106,6 @@ __device__ __forceinline__ float tap_ld(__amdgpu_buffer_rsrc_t rs, unsigned off)
 }
 
 constexpr unsigned kTapOOB = 0xFFFFFFFCu;   // beyond any descriptor's num_records: the load returns 0
-constexpr long kWarpMinWaves = 4096;        // waves a launch should keep on the chip (four per SIMD) when rows per wave are chosen
 
 // rx, ry integral-valued floats -> byte offset of the tap or kTapOOB.  LEVEL 0 tolerates NaN / inf.
 template <int LEVEL>
@@ -120,8 +122,8 @@ __device__ __forceinline__ unsigned tap_off(float rx, float ry, int wt, int ht) 
 }
 
 // OUT: 0 = int32 mask only (predict), 1 = float only (forward / training), 2 = both
-template <int MODE, int J, int OUT, int LEVEL, bool SMALL, bool NOLOAD = false>
-__device__ __forceinline__ void warp2_body(const float (&t)[9], int b, int lane, int c0, int r0, int rpw,
+template <int MODE, int J, int RPT, int OUT, int LEVEL, bool SMALL, bool NOLOAD = false>
+__device__ __forceinline__ void warp2_body(const float (&t)[9], int b, int lane, int c0, int r0,
                                            const float* __restrict__ tmpl, long tmpl_bstride,
                                            int ht, int wt, int h, int w, float rdw, float rdh, float out_scale,
                                            float* __restrict__ out_f, int32_t* __restrict__ out_i) {
@@ -136,12 +138,12 @@ __device__ __forceinline__ void warp2_body(const float (&t)[9], int b, int lane,
     a6[j] = __fmul_rn(t[6], xn);
     coff[j] = c < w ? (unsigned)c * 4u : kTapOOB;
   }
-  // lane rr holds the row constants of row r0 + rr (rpw <= 64 rows per wave; lanes beyond the frame: clamped, unused)
-  const float ynl = norm_axis2<SMALL>(r0 + lane < h ? r0 + lane : h - 1, h, rdh);
+  // lane rr holds the row constants of row r0 + rr
+  const float ynl = norm_axis2<SMALL>(r0 + (lane & (RPT - 1)), h, rdh);
   const float c1l = __fmul_rn(t[1], ynl), c4l = __fmul_rn(t[4], ynl), c7l = __fmul_rn(t[7], ynl);
   const __amdgpu_buffer_rsrc_t rt = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float*>(tmpl + (long)b * tmpl_bstride), 0, ht * wt * 4, 0x00020000);
-  const int nrows = (h - r0 < rpw) ? h - r0 : rpw;
+  const int nrows = (h - r0 < RPT) ? h - r0 : RPT;
   const long rowbase = ((long)b * h + r0) * w;
   const __amdgpu_buffer_rsrc_t rof = __builtin_amdgcn_make_buffer_rsrc(
       OUT != 0 ? out_f + rowbase : nullptr, 0, OUT != 0 ? nrows * w * 4 : 0, 0x00020000);
@@ -150,12 +152,10 @@ __device__ __forceinline__ void warp2_body(const float (&t)[9], int b, int lane,
   const float sx = 0.5f * (float)wt, sy = 0.5f * (float)ht;
   constexpr int NT = MODE == 0 ? 1 : 4;
   unsigned off[J][NT];
-  // two register sets that alternate (the row loop below is unrolled by two): taps and weights of the row in flight
-  float wgt[2][J][NT], tv[2][J][NT];
+  float wgt[J][NT], tv[J][NT];
 
-  // tap offsets (and bilinear weights, into set `ws`) of row r0 + rr
-  auto coords = [&](int rr, auto ws_tag) {
-    constexpr int WS = decltype(ws_tag)::value;
+  // tap offsets (and bilinear weights) of row r0 + rr
+  auto coords = [&](int rr) {
     const float c1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, c1l), rr));
     const float c4 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, c4l), rr));
     const float c7 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, c7l), rr));
@@ -175,10 +175,10 @@ __device__ __forceinline__ void warp2_body(const float (&t)[9], int b, int lane,
         const float x0 = floorf(px), y0 = floorf(py);
         const float wx1 = __fsub_rn(px, x0), wx0 = __fsub_rn(1.0f, wx1);
         const float wy1 = __fsub_rn(py, y0), wy0 = __fsub_rn(1.0f, wy1);
-        wgt[WS][j][0] = __fmul_rn(wy0, wx0);
-        wgt[WS][j][1] = __fmul_rn(wy0, wx1);
-        wgt[WS][j][2] = __fmul_rn(wy1, wx0);
-        wgt[WS][j][3] = __fmul_rn(wy1, wx1);
+        wgt[j][0] = __fmul_rn(wy0, wx0);
+        wgt[j][1] = __fmul_rn(wy0, wx1);
+        wgt[j][2] = __fmul_rn(wy1, wx0);
+        wgt[j][3] = __fmul_rn(wy1, wx1);
         if (LEVEL == 0) {
           off[j][0] = tap_off<0>(x0, y0, wt, ht);
           off[j][1] = tap_off<0>(x0 + 1.f, y0, wt, ht);
@@ -202,70 +202,68 @@ __device__ __forceinline__ void warp2_body(const float (&t)[9], int b, int lane,
   // Software pipeline over the rows: the taps of row rr+1 are issued BEFORE the stores of row rr and are
   // consumed one row of coordinate arithmetic later - the wait for them never covers a younger store
   // (loads and stores share the in-order vmcnt counter) and their latency overlaps the thread's own work.
-  auto issue_taps = [&](auto ws_tag) {
-    constexpr int WS = decltype(ws_tag)::value;
+  auto issue_taps = [&]() {
 #pragma unroll
     for (int j = 0; j < J; ++j)
 #pragma unroll
-      for (int k = 0; k < NT; ++k)
-        tv[WS][j][k] = NOLOAD ? __builtin_bit_cast(float, off[j][k] & 0x3fffffffu) : tap_ld(rt, off[j][k]);
+      for (int k = 0; k < NT; ++k) tv[j][k] = NOLOAD ? __builtin_bit_cast(float, off[j][k] & 0x3fffffffu) : tap_ld(rt, off[j][k]);
   };
-  // one row: coordinates of the NEXT row (set NX), values of this row from set CU, taps of the next row, stores
-  auto row = [&](int rr, auto cu_tag, auto nx_tag) {
-    constexpr int CU = decltype(cu_tag)::value;
-    coords(rr + 1 < 64 ? rr + 1 : 63, nx_tag);     // the row behind the wave's last: harmless, its taps are never stored
+  coords(0);
+  issue_taps();
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int rr = 0; rr < RPT; ++rr) {
+    // no early exit for rows beyond the frame (their coordinates are computed and discarded): a `break` here
+    // lets the optimiser sink the prefetched taps back into the next row's block
     float val[J];
+    float w0[J][NT];
+    if (MODE == 1) {
+#pragma unroll
+      for (int j = 0; j < J; ++j)
+#pragma unroll
+        for (int k = 0; k < NT; ++k) w0[j][k] = wgt[j][k];
+    }
+    if (rr + 1 < RPT) coords(rr + 1);     // a row beyond the frame: harmless, its taps are never stored
 #pragma unroll
     for (int j = 0; j < J; ++j) {
-      val[j] = tv[CU][j][0];
+      val[j] = tv[j][0];
       if (MODE == 1) {
-        val[j] = __fmul_rn(tv[CU][j][0], wgt[CU][j][0]);
-        val[j] = __fadd_rn(val[j], __fmul_rn(tv[CU][j][1], wgt[CU][j][1]));
-        val[j] = __fadd_rn(val[j], __fmul_rn(tv[CU][j][2], wgt[CU][j][2]));
-        val[j] = __fadd_rn(val[j], __fmul_rn(tv[CU][j][3], wgt[CU][j][3]));
+        val[j] = __fmul_rn(tv[j][0], w0[j][0]);
+        val[j] = __fadd_rn(val[j], __fmul_rn(tv[j][1], w0[j][1]));
+        val[j] = __fadd_rn(val[j], __fmul_rn(tv[j][2], w0[j][2]));
+        val[j] = __fadd_rn(val[j], __fmul_rn(tv[j][3], w0[j][3]));
       }
     }
-    issue_taps(nx_tag);
+    if (rr + 1 < RPT) issue_taps();
     __builtin_amdgcn_sched_barrier(0);    // the scheduler would sink these loads to their uses one row later
-    const int soff = rr * w * 4;
+    // A row beyond the frame is skipped explicitly (its offset rides in the scalar operand; on gfx950 the
+    // descriptor's range check was observed to cover vector + scalar offset, but nothing here depends on it).
+    // Wave-uniform branch around the stores only, so the prefetched taps above stay where they are.
+    if (rr < nrows) {
+      const int soff = rr * w * 4;
 #pragma unroll
-    for (int j = 0; j < J; ++j) {
-      if (OUT != 0) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val[j]), rof, (int)coff[j], soff, 0);
-      if (OUT != 1)
-        __builtin_amdgcn_raw_buffer_store_b32((unsigned)(int32_t)__fmul_rn(val[j], out_scale), roi, (int)coff[j], soff, 0);
+      for (int j = 0; j < J; ++j) {
+        if (OUT != 0) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val[j]), rof, (int)coff[j], soff, 0);
+        if (OUT != 1)
+          __builtin_amdgcn_raw_buffer_store_b32((unsigned)(int32_t)__fmul_rn(val[j], out_scale), roi, (int)coff[j], soff, 0);
+      }
     }
     __builtin_amdgcn_sched_barrier(0);
-  };
-  using I0 = std::integral_constant<int, 0>;
-  using I1 = std::integral_constant<int, 1>;
-  coords(0, I0{});
-  issue_taps(I0{});
-  __builtin_amdgcn_sched_barrier(0);
-  // A RUNTIME loop over the wave's rows (round 4; the row count was a template parameter of 2 / 4 / 8 before): the
-  // per-wave prologue - theta, the 3 * J column products, J meshgrid divisions, descriptors: ~130 wave instructions,
-  // 8 of the 42 vector instructions per pixel at two rows per wave (profiles/r02_warp_pmc.txt) - is spread over up
-  // to 64 rows.  Unrolled by two with alternating register sets: rolled once, the compiler copied the prefetched taps
-  // into the consumer's registers at the END of the iteration that requested them, i.e. waited for them at once.
-  // The loop body is branch-free (pairs of rows; an odd last row runs behind it).
-  int rr = 0;
-  for (; rr + 1 < nrows; rr += 2) {
-    row(rr, I0{}, I1{});
-    row(rr + 1, I1{}, I0{});
   }
-  if (rr < nrows) row(rr, I0{}, I1{});
 }
 
-template <int MODE, int J, int OUT, bool NOLOAD = false>
+template <int MODE, int J, int RPT, int OUT, bool NOLOAD = false>
 __global__ __launch_bounds__(256) void warp2_kernel(const float* __restrict__ theta,
                                                     const float* __restrict__ tmpl, long tmpl_bstride,
-                                                    int ht, int wt, int h, int w, int rpw, float rdw, float rdh, float out_scale,
+                                                    int ht, int wt, int h, int w, float rdw, float rdh, float out_scale,
                                                     float* __restrict__ out_f, int32_t* __restrict__ out_i) {
   // rdw = 1/(w-1), rdh = 1/(h-1) rounded to nearest (the launcher computes them: wave-uniform IEEE divisions
-  // would cost every thread two dozen instructions); rpw = rows per wave, 1 .. 64
+  // would cost every thread two dozen instructions)
+  static_assert((RPT & (RPT - 1)) == 0 && RPT <= 64, "RPT: power of two");
   const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int b = blockIdx.z;
   const int c0 = blockIdx.x * (64 * J) + lane;
-  const int r0 = (blockIdx.y * 4 + wv) * rpw;
+  const int r0 = (blockIdx.y * 4 + wv) * RPT;
   if (r0 >= h) return;
   float t[9];
 #pragma unroll
@@ -277,7 +275,7 @@ __global__ __launch_bounds__(256) void warp2_kernel(const float* __restrict__ th
   const float zs = fabsf(t[6]) + fabsf(t[7]) + fabsf(t[8]);
   const bool live = (fabsf(t[8]) - fabsf(t[6]) - fabsf(t[7])) > 1e-6f * zs + 1e-7f;   // => |Z| > 1e-8 everywhere
 #define SFH_WARP2_GO(LEVEL, SMALL) \
-  warp2_body<MODE, J, OUT, LEVEL, SMALL, NOLOAD>(t, b, lane, c0, r0, rpw, tmpl, tmpl_bstride, ht, wt, h, w, rdw, rdh, out_scale, out_f, out_i)
+  warp2_body<MODE, J, RPT, OUT, LEVEL, SMALL, NOLOAD>(t, b, lane, c0, r0, tmpl, tmpl_bstride, ht, wt, h, w, rdw, rdh, out_scale, out_f, out_i)
   if (fin && w <= 16384 && h <= 16384) {
     if (live) SFH_WARP2_GO(2, true); else SFH_WARP2_GO(1, true);
   } else {
@@ -462,10 +460,9 @@ __global__ void poi_bwd_theta_kernel(const float* __restrict__ theta, const floa
 
 }  // namespace
 
-namespace {
-// rows_per_wave: 0 = chosen here, else 1 .. 64 (tuning / tests)
-int warp_fwd_launch(const float* theta, const float* tmpl, int64_t tmpl_bstride, int ht, int wt, int batch, int h, int w,
-                    int mode, float out_scale, float* out_f32, int32_t* out_i32, int rows_per_wave, hipStream_t stream) {
+extern "C" int sfh_homography_warp_fwd(const float* theta, const float* tmpl, int64_t tmpl_bstride,
+                                       int ht, int wt, int batch, int h, int w, int mode,
+                                       float out_scale, float* out_f32, int32_t* out_i32, void* stream) {
   SFH_REQUIRE(theta && tmpl && (out_f32 || out_i32), "homography_warp: null pointer");
   SFH_REQUIRE(batch > 0 && batch <= 65535 && h > 1 && w > 1 && ht > 0 && wt > 0,
               "homography_warp: bad geometry b=%d h=%d w=%d ht=%d wt=%d", batch, h, w, ht, wt);
@@ -473,56 +470,42 @@ int warp_fwd_launch(const float* theta, const float* tmpl, int64_t tmpl_bstride,
   SFH_REQUIRE(tmpl_bstride == 0 || tmpl_bstride >= (int64_t)ht * wt, "homography_warp: bad template stride");
   SFH_REQUIRE((int64_t)ht * wt <= (1 << 22) && w <= (1 << 20) && h <= (1 << 20),
               "homography_warp: template %dx%d (at most 4 Mi pixels: exact fp32 tap index) or frame %dx%d too large", wt, ht, w, h);
-  SFH_REQUIRE(rows_per_wave >= 0 && rows_per_wave <= 64, "homography_warp: rows_per_wave=%d (0 = automatic, 1 .. 64)", rows_per_wave);
   const float rdw = 1.0f / (float)(w - 1), rdh = 1.0f / (float)(h - 1);   // IEEE single divisions
-  // Wave shape: 64*J consecutive pixels x rpw rows.  J = 5 when the row splits into 320-pixel segments
+  // Wave shape: 64*J consecutive pixels x RPT rows.  J = 5 when the row splits into 320-pixel segments
   // (640, 1280, 1920 ...), else 4; bilinear (4 taps and 4 weights per pixel in flight): J = 2.
-  // rpw: 8 rows, fewer (4, 2) while the launch would otherwise put less than kWarpMinWaves waves on the chip (the
-  // prologue of a wave costs as much as four rows of one of its columns).  Measured (profiles/r04_warp_rows_sweep.txt):
-  // 8 .. 16 rows are the optimum at every size; beyond that the waves resident at one time write rows that lie far
-  // apart and the launch slows down again (64 rows: -25 % at 640x360 x 1024) although the instruction count still falls.
+  // RPT: the largest of 8 / 4 / 2 that still leaves about eight waves per SIMD on 256 CUs.
   const int J = mode == 1 ? 2 : ((w % 320 == 0) ? 5 : 4);
   const long segs = (long)sfh_cdiv(w, 64 * J) * batch;
-  int rpw = rows_per_wave;
-  if (rpw == 0) {
-    rpw = 8;
-    while (rpw > 2 && segs * sfh_cdiv(h, rpw) < kWarpMinWaves) rpw >>= 1;
-  }
+  int rpt = mode == 1 ? 4 : 8;
+  while (rpt > 2 && segs * sfh_cdiv(h, rpt) < SFH_WARP_MIN_WAVES) rpt >>= 1;
   const int out = (out_f32 && out_i32) ? 2 : (out_f32 ? 1 : 0);
-  const dim3 grid((unsigned)sfh_cdiv(w, 64 * J), (unsigned)sfh_cdiv(h, 4 * rpw), (unsigned)batch);
-#define SFH_WARP_LAUNCH(MODE, JJ, OO)                                                                    \
-  hipLaunchKernelGGL((warp2_kernel<MODE, JJ, OO>), grid, dim3(256), 0, stream, theta, tmpl, \
-                     (long)tmpl_bstride, ht, wt, h, w, rpw, rdw, rdh, out_scale, out_f32, out_i32)
-#define SFH_WARP_OUT(MODE, JJ)                    \
-  do {                                            \
-    if (out == 0) SFH_WARP_LAUNCH(MODE, JJ, 0);   \
-    else if (out == 1) SFH_WARP_LAUNCH(MODE, JJ, 1); \
-    else SFH_WARP_LAUNCH(MODE, JJ, 2);            \
+  const dim3 grid((unsigned)sfh_cdiv(w, 64 * J), (unsigned)sfh_cdiv(h, 4 * rpt), (unsigned)batch);
+#define SFH_WARP_LAUNCH(MODE, JJ, RR, OO)                                                                    \
+  hipLaunchKernelGGL((warp2_kernel<MODE, JJ, RR, OO>), grid, dim3(256), 0, (hipStream_t)stream, theta, tmpl, \
+                     (long)tmpl_bstride, ht, wt, h, w, rdw, rdh, out_scale, out_f32, out_i32)
+#define SFH_WARP_OUT(MODE, JJ, RR)                    \
+  do {                                                \
+    if (out == 0) SFH_WARP_LAUNCH(MODE, JJ, RR, 0);   \
+    else if (out == 1) SFH_WARP_LAUNCH(MODE, JJ, RR, 1); \
+    else SFH_WARP_LAUNCH(MODE, JJ, RR, 2);            \
+  } while (0)
+#define SFH_WARP_RPT(MODE, JJ)                \
+  do {                                        \
+    if (rpt == 8) SFH_WARP_OUT(MODE, JJ, 8);  \
+    else if (rpt == 4) SFH_WARP_OUT(MODE, JJ, 4); \
+    else SFH_WARP_OUT(MODE, JJ, 2);           \
   } while (0)
   if (mode == 1) {
-    SFH_WARP_OUT(1, 2);
+    if (rpt == 4) SFH_WARP_OUT(1, 2, 4); else SFH_WARP_OUT(1, 2, 2);
   } else if (J == 5) {
-    SFH_WARP_OUT(0, 5);
+    SFH_WARP_RPT(0, 5);
   } else {
-    SFH_WARP_OUT(0, 4);
+    SFH_WARP_RPT(0, 4);
   }
+#undef SFH_WARP_RPT
 #undef SFH_WARP_OUT
 #undef SFH_WARP_LAUNCH
   return sfh_check_launch("warp_kernel");
-}
-}  // namespace
-
-extern "C" int sfh_homography_warp_fwd(const float* theta, const float* tmpl, int64_t tmpl_bstride,
-                                       int ht, int wt, int batch, int h, int w, int mode,
-                                       float out_scale, float* out_f32, int32_t* out_i32, void* stream) {
-  return warp_fwd_launch(theta, tmpl, tmpl_bstride, ht, wt, batch, h, w, mode, out_scale, out_f32, out_i32, 0, (hipStream_t)stream);
-}
-
-extern "C" int sfh_homography_warp_fwd_rows(const float* theta, const float* tmpl, int64_t tmpl_bstride,
-                                            int ht, int wt, int batch, int h, int w, int mode,
-                                            float out_scale, float* out_f32, int32_t* out_i32, int rows_per_wave, void* stream) {
-  return warp_fwd_launch(theta, tmpl, tmpl_bstride, ht, wt, batch, h, w, mode, out_scale, out_f32, out_i32, rows_per_wave,
-                         (hipStream_t)stream);
 }
 
 extern "C" int sfh_selftest_warp_arith(int64_t* mismatches, void* stream) {

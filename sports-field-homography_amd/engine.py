@@ -1406,9 +1406,8 @@ def nchw_to_nhwc(t, cs=None):
 
 
 def homography_warp(theta, template, h, w, nearest, scale=None, want_f32=True, want_i32=False,
-                    shared_template=False, rows_per_wave=0):
-    """theta (B,1,3,3)|(B,3,3); template (>=B,1,ht,wt).  Returns (f32 or None, i32 or None).
-    rows_per_wave: 0 = the launcher's choice; 1 .. 64 for the tuning sweep / tests (same results)."""
+                    shared_template=False):
+    """theta (B,1,3,3)|(B,3,3); template (>=B,1,ht,wt).  Returns (f32 or None, i32 or None)."""
     lib = _lib.load()
     theta = _f32c(theta.reshape(-1, 3, 3).contiguous(), "theta")
     template = _f32c(template, "court template")
@@ -1425,14 +1424,9 @@ def homography_warp(theta, template, h, w, nearest, scale=None, want_f32=True, w
     if tm is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    if rows_per_wave:
-        _lib.check(lib.sfh_homography_warp_fwd_rows(_ptr(theta), _ptr(template), bstride, ht, wt, B, h, w,
-                                                    0 if nearest else 1, float(scale if scale is not None else 1.0),
-                                                    _ptr(out_f), _ptr(out_i), int(rows_per_wave), _stream()), "homography_warp")
-    else:
-        _lib.check(lib.sfh_homography_warp_fwd(_ptr(theta), _ptr(template), bstride, ht, wt, B, h, w,
-                                               0 if nearest else 1, float(scale if scale is not None else 1.0),
-                                               _ptr(out_f), _ptr(out_i), _stream()), "homography_warp")
+    _lib.check(lib.sfh_homography_warp_fwd(_ptr(theta), _ptr(template), bstride, ht, wt, B, h, w,
+                                           0 if nearest else 1, float(scale if scale is not None else 1.0),
+                                           _ptr(out_f), _ptr(out_i), _stream()), "homography_warp")
     if tm is not None:
         e1.record()
         # algorithmic BYTES: every output once, the template once (per frame if not shared), theta

@@ -271,32 +271,6 @@ def test_warp_writes_nothing_outside_its_output(hw, nearest):
         assert float((got - want).abs().max()) < 1e-6
 
 
-@pytest.mark.parametrize("nearest", [True, False])
-def test_warp_rows_per_wave_does_not_change_the_result(nearest):
-    """The warp kernel's wave walks 1 .. 64 rows (a runtime loop, the row constants of row r live in lane r of the wave):
-    every row count - including those that do not divide the frame height and the launcher's own choice - gives the
-    oracle's mask at 360x640 and at an odd size, and leaves the bytes behind the tensor alone."""
-    from sfh_amd import engine as E
-    for (h, w) in ((360, 640), (61, 97)):
-        B = 3
-        th = torch.tensor(synth.REALISTIC_THETAS)[[0, 1, 0]].reshape(B, 1, 3, 3).contiguous()
-        th[2, 0] = torch.eye(3) + 0.03 * torch.randn(3, 3, generator=torch.Generator().manual_seed(h))
-        tmpl = synth.load_court_template("ncaa_nc4_640x360", 4, 1)
-        want = warp_ref.homography_warp(th, tmpl.expand(B, -1, -1, -1), h, w, "nearest" if nearest else "bilinear")
-        thc, tc = th.cuda(), tmpl.cuda()
-        for rpw in (0, 1, 2, 3, 7, 8, 16, 31, 32, 63, 64):
-            of, oi = E.homography_warp(thc, tc, h, w, nearest, scale=4.0, want_f32=True, want_i32=nearest,
-                                       shared_template=True, rows_per_wave=rpw)
-            torch.cuda.synchronize()
-            if nearest:
-                assert torch.equal(of.cpu(), want), (h, w, rpw)
-                assert torch.equal(oi.cpu(), (want * 4).to(torch.int32)), (h, w, rpw)
-            else:
-                assert float((of.cpu() - want).abs().max()) < 1e-6, (h, w, rpw)
-    with pytest.raises(ValueError):
-        E.homography_warp(thc, tc, h, w, nearest, shared_template=True, rows_per_wave=65)
-
-
 def test_warp_huge_and_non_finite_theta_take_the_ieee_path():
     """A wave-uniform test on theta routes |t| > 2^59, inf and NaN to the IEEE-division / NaN-tolerant path of the
     warp kernel (LEVEL 0): exact against the oracle in nearest mode (non-finite coordinates sample 0)."""
