@@ -14,7 +14,7 @@ Two kinds of output:
    deterministic synthetic weights of ``sfh_amd.synth``.  These pin ``oracle/torch_ref.py``.
 
 Usage:  python oracle/make_fixtures.py [--full]     (--full adds the 640x360 end-to-end vector)
-        python oracle/make_fixtures.py --configs c2,c5,c3,c3b16   (BASELINE configs at their stated sizes)
+        python oracle/make_fixtures.py --configs c2,c5,c3,c3b16,c3b16grad   (BASELINE configs at their stated sizes)
 """
 import argparse
 import importlib.util
@@ -368,6 +368,49 @@ def make_c3_b16_golden(up_mod, rn_mod):
     print("c3 b16 golden:", {k: float(v) for k, v in ls.items()}, len(names), "BatchNorm buffers")
 
 
+def make_c3_b16_grad_golden(up_mod, rn_mod):
+    """BASELINE config 3 at its stated batch, WITH the backward pass (round 4): the reference's own classes under
+    ``net.train()`` + torch autograd in fp32 on all 16 frames (about 31 GB of host memory, eight minutes on 8 cores; an fp64
+    run of this size does not fit the container - the fp32-vs-fp64 yardstick stays the B=2 vector), losses of
+    train.py:181-224, then one optimizer step as train.py:88,234-237 does it: ``clip_grad_value_(0.1)`` and
+    ``RMSprop(lr=1e-5, weight_decay=1e-8, momentum=0.9)``.  Stored per parameter: a fixed sample of the gradient, its L2 norm,
+    and the same sample of the weight update (w_after - w_before)."""
+    from oracle import train_ref
+    torch.set_num_threads(os.cpu_count())
+    B, H, W = 16, 360, 640
+    x = synth.frames_to_float(synth.synth_frames_u8(B, H, W, seed=0))
+    court = synth.load_court_template("ncaa_nc4_640x360", 4, B)
+    poi = synth.load_court_poi("pitch", B)
+    batch = c3_batch(B, H, W, poi.shape[1])
+    net = _loaded(_RefNet(up_mod, rn_mod), 0).train()
+    opt = torch.optim.RMSprop(net.parameters(), lr=1e-5, weight_decay=1e-8, momentum=0.9)
+    logits, _, _ = net.unet(x)
+    theta = net.resnet_reg(torch.cat((logits, x), 1))
+    preds = {"logits": logits, "theta": theta, "poi": torch_ref.transform_poi(theta, poi),
+             "warp_mask": torch_ref.warp(theta, court, (W, H), nearest=False)}
+    ls = train_ref.losses(preds, batch)
+    print("losses", {k: float(v) for k, v in ls.items()}, flush=True)
+    opt.zero_grad()
+    ls["total"].backward()
+    out = {f"loss.{k}": np.float64(float(v.detach())) for k, v in ls.items()}
+    names = [k for k, _ in net.named_parameters()]
+    out["names"] = np.array(names)
+    before = {k: p.detach().clone() for k, p in net.named_parameters()}
+    for i, (k, p) in enumerate(net.named_parameters()):
+        g = p.grad.detach().reshape(-1)
+        idx = torch.from_numpy(grad_sample_index(g.numel()))
+        out[f"g.{i}"] = g[idx].numpy().copy()
+        out[f"gnorm.{i}"] = np.float64(float(g.double().norm()))
+    torch.nn.utils.clip_grad_value_(net.parameters(), 0.1)
+    opt.step()
+    for i, (k, p) in enumerate(net.named_parameters()):
+        d = (p.detach() - before[k]).reshape(-1)
+        idx = torch.from_numpy(grad_sample_index(d.numel()))
+        out[f"dw.{i}"] = d[idx].numpy().copy()
+    np.savez_compressed(os.path.join(GOLD, "c3_grads_640x360_b16.npz"), **out)
+    print("c3 b16 gradient golden:", len(names), "parameters,", sum(v.nbytes for v in out.values()) // 1024, "KiB raw")
+
+
 def make_c3_golden(up_mod, rn_mod):
     """BASELINE config 3 at 640x360 (B=2 of the 16): the reference's own classes under ``net.train()``
     (batch-statistics BatchNorm) + autograd, losses of train.py:181-224 (oracle/train_ref.losses), once in
@@ -430,7 +473,8 @@ if __name__ == "__main__":
         rn_mod = _load("ref_resnet", "models/resnet.py")
         if a.configs:
             for c in a.configs.split(","):
-                {"c2": make_c2_golden, "c5": make_c5_golden, "c3": make_c3_golden, "c3b16": make_c3_b16_golden}[c](up_mod, rn_mod)
+                {"c2": make_c2_golden, "c5": make_c5_golden, "c3": make_c3_golden, "c3b16": make_c3_b16_golden,
+                 "c3b16grad": make_c3_b16_grad_golden}[c](up_mod, rn_mod)
             raise SystemExit(0)
         if a.train_only:
             make_train_goldens(up_mod, rn_mod)

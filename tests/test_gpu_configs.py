@@ -506,3 +506,87 @@ def test_c3_training_step_640x360_vs_fp64_reference(precision, monkeypatch):
             beyond_4x_own_fp32_error_rederived_under_gpu_relu_masks=tail,
             table=[(k, float(e), float(e32)) for k, e, e32 in rows])
     assert not worst, worst
+
+
+@pytest.mark.parametrize("precision", ["f16x3", "bf16x6"])  # training precisions
+def test_c3_batch16_gradients_and_weight_update(precision, monkeypatch):
+    """BASELINE config 3 at its stated batch WITH the backward pass and the optimizer step (train.py:155-237): one
+    `TrainStep.step` on 16 frames of 640x360 against the reference's own classes under torch autograd in fp32 on the same
+    16 frames, followed by clip_grad_value_(0.1) and one RMSprop(momentum 0.9) step (oracle/make_fixtures.py:
+    make_c3_b16_grad_golden).  Every parameter gradient: relative L2 distance on a fixed sample within 6x the distance
+    the reference's fp32 run keeps from fp64 (per tensor, or the upper quartile of its stage: the B=2 vector - an fp64 run
+    of 16 frames does not fit the build container); the weight update w_after - w_before: equal to 3 % of the step on at
+    least 99.5 % of the sampled elements whose golden gradient is not vanishing (RMSprop's first step is lr * g / (0.1 |g|
+    + eps): about 10 * lr * sign(g); "not vanishing" = beyond 50x the tensor's measured gradient error, so that the sign is
+    not a matter of rounding: about 6000 of the 60000 sampled elements).  The gradients of a train-mode pass carry percent-level
+    differences between ANY two fp32-grade runs (ReLU / max-pool decisions that flip with the forward rounding): the
+    reference's own fp32 run sits 1.5 % (median over the tensors) from its fp64 run at B=2, and so does this path."""
+    from oracle.fixture_inputs import c3_batch, grad_sample_index
+    from sfh_amd import training
+    from sfh_amd.reconstructor import Reconstructor
+    monkeypatch.setenv("SFH_TRAIN_PRECISION", precision)
+    g = np.load(os.path.join(GOLD, "c3_grads_640x360_b16.npz"))
+    g2 = np.load(os.path.join(GOLD, "c3_train_640x360_b2.npz"))
+    B, H, W = 16, 360, 640
+    court = synth.load_court_template("ncaa_nc4_640x360", 4, B)
+    poi = synth.load_court_poi("pitch", B)
+    net = Reconstructor(court.cuda(), poi.cuda(), target_size=(W, H), unet_size=(W, H), warp_size=(W, H))
+    net.load_state_dict(synth.synth_state_dict(net.state_dict(), 0))
+    net.cuda().train()
+    lr = 1e-5
+    ts = training.TrainStep(net, lr=lr, weight_decay=1e-8, seg_lambda=1.0, rec_lambda=1.0, reproj_lambda=1.0, consist_lambda=1.0)
+    x = synth.frames_to_float(synth.synth_frames_u8(B, H, W, seed=0)).cuda()
+    batch = {k: v.cuda() for k, v in c3_batch(B, H, W, poi.shape[1]).items()}
+    names = [str(n) for n in g["names"]]
+    params = dict(net.named_parameters())
+    assert names == [str(n) for n in g2["names"]] and set(names) == set(params)
+    before = {k: params[k].detach().clone() for k in names}
+    losses = ts.step(x, batch).cpu().numpy()
+    torch.cuda.synchronize()
+    assert ts.range_fallbacks == 0
+    for k, v in zip(("seg", "rec", "consist", "reproj"), losses.tolist()):
+        want = float(g[f"loss.{k}"])
+        assert abs(v - want) < (1e-3 if k == "consist" else 2e-5) * max(1.0, abs(want)), (k, v, want)
+    grads = {ts.names(p): gr for p, gr in zip(ts.params, ts.grads)}
+
+    def stage(k):
+        p = k.split(".")
+        if p[0] != "resnet_reg":
+            return p[0]
+        return "resnet_reg." + (p[1] if p[1].startswith("layer") or p[1] == "reg" else "stem")
+
+    e32_stage = {}
+    for i, k in enumerate(names):
+        if g2[f"stat.{i}"][0] >= 1e-9:
+            e32_stage.setdefault(stage(k), []).append(float(g2[f"stat.{i}"][2]))
+    e32_stage = {k: float(np.quantile(v, 0.75)) for k, v in e32_stage.items()}
+    rows, bad = [], []
+    upd_total = upd_off = 0
+    for i, k in enumerate(names):
+        want = g[f"g.{i}"].astype(np.float64)
+        idx = torch.from_numpy(grad_sample_index(params[k].numel())).cuda()
+        got = grads[k].detach().reshape(-1)[idx].cpu().double().numpy()
+        gn = float(g[f"gnorm.{i}"])
+        ns = np.linalg.norm(want)
+        if gn < 1e-9 or ns < 1e-12 * max(1.0, gn):
+            assert np.abs(got).max() < 1e-6, (k, np.abs(got).max())      # conv bias in front of BatchNorm: exactly zero
+            continue
+        e = float(np.linalg.norm(got - want) / ns)
+        yard = max(float(g2[f"stat.{i}"][2]), e32_stage[stage(k)])
+        rows.append((k, e, yard))
+        if e > 6.0 * yard + 2e-4:       # (floor: the regression head's gradient is reproduced to 1e-5 by the fp32 run itself)
+            bad.append((k, e, yard))
+        # the optimizer step: elements whose golden gradient is clearly non-zero move by ~ 10 * lr * sign(g)
+        dw_want = g[f"dw.{i}"].astype(np.float64)
+        dw_got = (params[k].detach() - before[k]).reshape(-1)[idx].cpu().double().numpy()
+        sel = np.abs(want) > max(1e-5, 50.0 * e * ns / np.sqrt(len(want)))
+        upd_total += int(sel.sum())
+        upd_off += int((np.abs(dw_got - dw_want)[sel] > 0.03 * 10.0 * lr + 1e-7 * np.abs(before[k].reshape(-1)[idx].cpu().numpy())[sel]).sum())
+    errs = np.array([e for _, e, _ in rows])
+    ratios = np.array([e / max(y, 1e-6) for _, e, y in rows])
+    _record(f"C3 step 640x360 B=16 {precision}", tensors=len(rows), median_err_vs_fp32_reference=float(np.median(errs)),
+            max_err_vs_fp32_reference=float(errs.max()), median_ratio_to_fp32_yardstick=float(np.median(ratios)),
+            max_ratio_to_fp32_yardstick=float(ratios.max()), over_bound=[(k, float(e), float(y)) for k, e, y in bad],
+            update_elements_checked=upd_total, update_elements_off=upd_off)
+    assert not bad, bad
+    assert upd_total > 3000 and upd_off <= 0.005 * upd_total, (upd_off, upd_total)
