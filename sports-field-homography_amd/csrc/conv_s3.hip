@@ -964,6 +964,9 @@ int launch_s3(const sfh_conv_desc& d, hipStream_t stream) {
   // variant overlaps each stage's DMA latency with the previous stage's MFMAs
   if constexpr (!DB && C::LDS_BYTES <= 160 * 1024) {
     if (nblocks <= 320) return launch_s3<C, true>(d, stream);
+#ifdef SFH_KS2_DB   // experiment (profiles/build_variant.py): the 64-cout 2x2 up-scatter launches double-buffered, two per CU
+    if (C::KS == 2 && C::NWN == 2 && C::NP == 2) return launch_s3<C, true>(d, stream);
+#endif
   }
   // (an LDS-free variant for 1x1 / transposed convs that streams both operands straight into
   // registers was measured slower: 3.69 ms vs 2.96 ms per step for the four ConvTranspose launches)

@@ -702,7 +702,8 @@ __global__ __launch_bounds__(256) void stem_bwd_data_kernel(const float* __restr
   }
   __syncthreads();
   // a thread owns the pixels x and x + 64 of a row: same column parity, i.e. the same taps (ky, kx) and the same weights -
-  // every 16-byte LDS read of a weight quad feeds two pixels (the kernel was bound by those reads: one per four FMAs)
+  // every 16-byte LDS read of a weight quad feeds two pixels (the kernel was bound by those reads: one per four FMAs).
+  // (Round 4: FOUR pixels per thread measured slower, 1.28 -> 1.36 ms.)
   const int x = blockIdx.x * 128 + (threadIdx.x & 63);
   const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
   const int b = blockIdx.z;
@@ -963,13 +964,13 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
 #pragma unroll
     for (int s = 0; s < NSUB; ++s) acc[t][s] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  for (int tile = split; tile < a.ntiles; tile += a.nsplit) {
+  // global loads of one tile into registers (zero outside the frame / the channel range)
+  f32x4 hv[NHV], zv[4];
+  auto load_tile = [&](int tile) {
     const int tx = tile % a.ntx;
     const int ty = (tile / a.ntx) % a.nty;
     const int b = tile / (a.ntx * a.nty);
     const int y0 = ty * TH, x0 = tx * TW;
-    // ---- issue every global load of the tile first (one latency, not one per iteration)
-    f32x4 hv[NHV], zv[4];
 #pragma unroll
     for (int k = 0; k < NHV; ++k) {
       const int i = tid + k * 256;
@@ -991,6 +992,16 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
       if (y < a.H && x < a.W && m < a.M)
         zv[k] = *reinterpret_cast<const f32x4*>(a.dz + (((long)b * a.H + y) * a.W + x) * a.dz_cs + m);
     }
+  };
+  // Software pipeline over the workgroup's tiles (round 4): the loads of tile t + 1 are requested right behind the
+  // barrier that publishes tile t in LDS and stay in flight during its contraction; before, every tile paid its own
+  // load latency between two barriers (the 3-channel first layer: 1.03 ms for 0.94 GB = 0.9 TB/s).
+  // Only for the small instances (the 3-channel first layer: 36 accumulator registers): with 128+ accumulator registers
+  // the prefetched tile costs occupancy and the 7x7 stem's instance measured 0.63 -> 0.71 ms.
+  constexpr bool PIPE = KK * NSUB <= 9;
+  if (PIPE && split < a.ntiles) load_tile(split);
+  for (int tile = split; tile < a.ntiles; tile += a.nsplit) {
+    if (!PIPE) load_tile(tile);   // every global load of the tile issued first (one latency, not one per iteration)
     __syncthreads();  // previous tile's fragments consumed
 #pragma unroll
     for (int k = 0; k < NHV; ++k) {
@@ -1005,6 +1016,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
       *reinterpret_cast<f32x4*>(zL + p * 64 + 4 * (q ^ ((p & 1) << 2))) = zv[k];
     }
     __syncthreads();
+    if (PIPE && tile + a.nsplit < a.ntiles) load_tile(tile + a.nsplit);
     // ---- contraction over the 64 pixels of the tile, 4 per MFMA
 #pragma unroll 1
     for (int r = 0; r < TH; ++r) {
