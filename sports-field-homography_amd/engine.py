@@ -1079,6 +1079,11 @@ class StemConv:
             self.escale = 2.0 ** -(wexp + _lib.H2_ACT_EXP)
         _lib.check(lib.sfh_pack_stem_weights(_ptr(w), _ptr(self.wpacked), cin, _SPLIT[fmt][2], wexp, _stream()),
                    "pack_stem_weights")
+        self.relu = bn is not None
+        if bn is None:   # training: the raw conv output z (batch-statistics BatchNorm follows as its own pass)
+            self.scale = torch.full((64,), float(self.escale), dtype=torch.float32, device=dev)
+            self.shift = torch.zeros(64, dtype=torch.float32, device=dev)
+            return
         self.scale = torch.empty(64, dtype=torch.float32, device=dev)
         self.shift = torch.empty(64, dtype=torch.float32, device=dev)
         args = [_f32c(t.detach(), "bn tensor") for t in (bn.weight, bn.bias, bn.running_mean, bn.running_var)]
@@ -1089,7 +1094,8 @@ class StemConv:
 
     def run(self, x_nhwc8, B, H, W, dst, exp_src=None, range_word=None):
         """exp_src / range_word (h2 arithmetic): exponent of the split the kernel makes of its fp32 input, and the
-        device word that receives the largest |x * 2^exp_src| (H2Ranges)."""
+        device word that receives the largest |x * 2^exp_src| (H2Ranges).  Built without a BatchNorm (bn=None) the
+        launch writes the raw conv output (no ReLU)."""
         lib = _lib.load()
         d = ConvDesc()
         if self.fmt == "h2" and exp_src is not None and int(exp_src) != self.exp_src:
@@ -1102,7 +1108,7 @@ class StemConv:
         d.src0, d.c0, d.cs0, d.h0, d.w0 = x_nhwc8.data_ptr(), self.cin, 8, H, W
         d.batch, d.H, d.W, d.ksize, d.stride = B, H, W, 7, 2
         d.wpacked, d.scale, d.shift = self.wpacked.data_ptr(), self.scale.data_ptr(), self.shift.data_ptr()
-        d.cout, d.relu = 64, 1
+        d.cout, d.relu = 64, 1 if self.relu else 0
         d.dst, d.dst_cs, d.out_mode = dst.data_ptr(), dst.shape[3], _lib.OUT_NHWC
         d.src_fmt = d.dst_fmt = _lib.FMT_F32
         d.split_arith = _SPLIT[self.fmt][2]

@@ -658,9 +658,14 @@ class ResNetTrainer:
         s2d = _empty((B, H2, W2, 4 * cs), stn_in)
         _lib.check(lib.sfh_space_to_depth2(_ptr(stn_in), _ptr(s2d), B, H, W, cs, st()), "space_to_depth2")
         w0 = rn.conv0.weight.detach()
-        pc = PackedConv(w0, None, None, 4, 4 * cs, relu=False, stem_cin=cin, tag="train_fwd")
         z0 = _empty((B, H2, W2, 64), stn_in)
-        pc.run(s2d, B, H2, W2, z0)
+        if tape.fmt is not None and cs == 8 and w0.shape[0] == 64 and os.environ.get("SFH_TRAIN_STEM7", "1") != "0":
+            # the tap-packed stem kernel of the inference path (csrc/stem.hip: 0.16 ms against 0.63 ms for the 4x4 fp32 conv
+            # over the space-to-depth copy), in the tape's arithmetic, writing the raw conv output z
+            E.StemConv(rn.conv0, None, cin, tag="train_fwd", fmt=tape.fmt, overflow=tape.overflow).run(stn_in, B, H, W, z0)
+        else:
+            pc = PackedConv(w0, None, None, 4, 4 * cs, relu=False, stem_cin=cin, tag="train_fwd")
+            pc.run(s2d, B, H2, W2, z0)
         c1, mi0 = _bn_forward(lib, z0, rn.bn1, True, None, tape, want_s3=False)
         h, w = (H2 - 1) // 2 + 1, (W2 - 1) // 2 + 1
         x = _empty((B, h, w, 64), stn_in)
