@@ -53,7 +53,7 @@ def durations():
 
 sq, fe, wr, dur = counters("sq"), counters("fetch"), counters("write"), durations()
 mean = lambda lst: sum(v for v, _ in lst) / len(lst) if lst else float("nan")
-lines = [f"# {tag}: rocprofv3 passes of the PRODUCT warp kernel (warp2_kernel<mode, J, out>, runtime rows per wave) through the C-ABI: profiles/warp_sweep.py",
+lines = [f"# {tag}: rocprofv3 passes of the PRODUCT warp kernel (warp2_kernel<mode, J, rows per thread, out>: the round-3 kernel) through the C-ABI: profiles/warp_sweep.py",
          "# algorithmic bytes = B*h*w*4 + ht*wt*4 + 36*B; VALU/px = SQ_INSTS_VALU * 64 / pixels; valu_busy = 4 * SQ_ACTIVE_INST_VALU / (1024 SIMDs * GRBM_GUI_ACTIVE / 8)",
          "# hbm = (FETCH_SIZE + WRITE_SIZE) KiB (dword gathers: no doubling); durations from the kernel-trace pass (5 launches behind 3 warm-up launches)",
          "%-9s %-9s %6s %8s %7s %9s %10s %9s %8s" % ("mode", "size", "batch", "avg us", "TB/s", "VALU/px", "valu_busy", "hbm MB", "vs alg")]
