@@ -721,6 +721,44 @@ def _rescaled_checkpoint(sd, factor, pairs):
     return sd2
 
 
+def test_f16x3_frame_beyond_the_fp16_range_lowers_the_frame_exponent(E):
+    """Round 4: the input frame is an H2 tensor too (the first layer runs on the fp16 matrix cores from sfh_frame_to_h2's
+    two-plane copy).  Frames scaled by 2^17 (values up to 131072 against the +-16376 of the default exponent) with the first
+    conv's weights divided by it - the same function: the range word of "frame" reports it, its exponent goes down, the
+    pass repeats from the first launch and stays on the two-plane path; results equal the unscaled run (itself checked against
+    the CPU restatement elsewhere) to rounding; the next batch repeats nothing."""
+    from sfh_amd.reconstructor import Reconstructor
+    B, H, W = 2, 48, 64
+    court = synth.load_court_template("ncaa_nc4_640x360", 4, B)[:, :, :H, :W].contiguous()
+    poi = synth.load_court_poi("pitch", B)
+    net = Reconstructor(court.cuda(), poi.cuda(), target_size=(W, H), unet_size=(W, H), warp_size=(W, H),
+                        warp_with_nearest=True, resnet_input="mask")      # (the STN input holds no frame channels)
+    sd = synth.synth_state_dict(net.state_dict(), 44)
+    x = synth.smooth_frames(B, H, W, seed=44)
+    net.load_state_dict(sd)
+    net.cuda().eval()
+    net.precision = "f16x3"
+    with torch.no_grad():
+        base = net.predict(x.cuda(), consistency=False)
+    assert net.range_rescales == 0 and net._h2_ranges.exp("frame") == 2
+    f = 2.0 ** 17
+    sd2 = dict(sd)
+    sd2["inc.double_conv.0.weight"] = sd["inc.double_conv.0.weight"] / f
+    net.load_state_dict(sd2)
+    xs = (x * f).contiguous()
+    with torch.no_grad(), warnings.catch_warnings():
+        warnings.simplefilter("error")
+        got = net.predict(xs.cuda(), consistency=False)
+    n1 = net.range_rescales
+    assert net.range_fallbacks == 0 and n1 >= 1 and net._h2_ranges.exp("frame") <= 2 - 4
+    # (the unscaled run is the yardstick: the scaling by a power of two changes no product, only the frame's exponent)
+    assert _maxerr(got["logits"].cpu(), base["logits"].cpu()) < 5e-4 and _maxerr(got["theta"].cpu(), base["theta"].cpu()) < 1e-4
+    with torch.no_grad():
+        again = net.predict(xs.cuda(), consistency=False)
+    assert net.range_rescales == n1 and torch.equal(again["logits"], got["logits"])
+    assert net.h2_headroom()["frame"] >= 1.0
+
+
 def test_f16x3_range_guard_rescales_and_resumes(E):
     """A checkpoint whose activations leave the fp16 range of the default H2 exponent (here: BatchNorms scaled by
     2^16 / 2^8 and the convs that read them divided by it - the same function) must neither give saturated results
