@@ -346,6 +346,11 @@ int sfh_mask_format_fwd(const void* src, int src_kind, int nc, int batch, int hs
 /* ResNetSTN pieces (models/resnet.py:235-254). */
 /* MaxPool2d(kernel 3, stride 2, padding 1) on NHWC (B,H,W,C) -> (B,Ho,Wo,C). */
 int sfh_maxpool3x3s2_fwd(const float* x, float* y, int batch, int H, int W, int C, void* stream);
+/* The same pooling written straight into a split tensor (dst_fmt SFH_FMT_H2 with exponent act_exp + the optional overflow /
+ * range words of the format, or SFH_FMT_S3): what sfh_maxpool3x3s2_fwd followed by sfh_f32_to_h2 / sfh_f32_to_s3 gives, in
+ * one pass.  C a multiple of 32. */
+int sfh_maxpool3x3s2_split_fwd(const float* x, void* y, int batch, int H, int W, int C, int dst_fmt, int act_exp,
+                               uint32_t* overflow, uint32_t* range, void* stream);
 /* AdaptiveAvgPool2d(1) + flatten + Linear(C -> nout): x NHWC (B,H,W,C), w (nout,C), feat (B,C) = the
  * pooled features (workspace / second output), out (B,nout). */
 int sfh_avgpool_linear_fwd(const float* x, const float* w, const float* bias, int batch, int H,

@@ -30,6 +30,8 @@ LAYERS = [  # name, cin, cout, H, W, pooled output
     ("u1.3", 512, 512, 45, 80, False), ("u2.3", 256, 256, 90, 160, False), ("u3.3", 128, 128, 180, 320, False),
     ("u4.3", 64, 64, 360, 640, False),
 ]
+if "--c5" in sys.argv:   # the same layers at 1280x720 (BASELINE config 5): every frame size doubled
+    LAYERS = [(n, ci, co, 2 * h, 2 * w, p) for (n, ci, co, h, w, p) in LAYERS]
 COMBOS = [("8x32/64", 0, 64), ("16x16/64", 1, 64), ("32x8/64", 2, 64), ("8x32/128", 0, 128), ("16x16/128", 1, 128),
           ("32x8/128", 2, 128), ("8x16/128db", 3, 128)]
 B = 16

@@ -129,6 +129,7 @@ SIGNATURES = {
     "sfh_packed_stem_weight_bytes": (C.c_int64, []),
     "sfh_pack_stem_weights": (C.c_int, [_p, _p, C.c_int, C.c_int, C.c_int, _p]),
     "sfh_maxpool3x3s2_fwd": (C.c_int, [_p, _p, C.c_int, C.c_int, C.c_int, C.c_int, _p]),
+    "sfh_maxpool3x3s2_split_fwd": (C.c_int, [_p, _p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _p, _p, _p]),
     "sfh_avgpool_linear_fwd": (C.c_int, [_p, _p, _p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _p, _p, _p]),
 }
 

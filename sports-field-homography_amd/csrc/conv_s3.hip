@@ -795,6 +795,63 @@ __global__ __launch_bounds__(256) void f32_to_h2_kernel(const float* __restrict_
   sfh_h2_report(over, overflow, range);
 }
 
+// MaxPool2d(3, stride 2, padding 1) of an fp32 NHWC tensor written straight into a split tensor (ResNetSTN's stem pooling,
+// models/resnet.py:176,243: the pooled tensor is the first one that enters the split domain).  Same values as
+// maxpool3x3s2_kernel followed by f32_to_h2 / f32_to_s3 - the split is monotone, the maximum is taken in fp32 - in one pass
+// and one launch less.  Thread mapping as f32_to_s3_kernel (8 channels of one output pixel); no early exit (sfh_h2_report).
+template <int DFMT>
+__global__ __launch_bounds__(256) void maxpool3x3s2_split_kernel(const float* __restrict__ x, unsigned short* __restrict__ dst,
+                                                                 int H, int W, int Ho, int Wo, int cs, int xchunks, long total,
+                                                                 float scale, unsigned* overflow, unsigned* range) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  const int g = (int)(i & 3), px = (int)((i >> 2) & 15);
+  long r = i >> 6;
+  const int xc = (int)(r % xchunks); r /= xchunks;
+  const int cb = (int)(r % (cs >> 5));
+  const long row = r / (cs >> 5);          // b * Ho + yo
+  const int xo = xc * 16 + px;
+  unsigned over = 0u;
+  if (i < total && xo < Wo) {
+    const long b = row / Ho;
+    const int yo = (int)(row - b * Ho);
+    f32x4 m0 = {-INFINITY, -INFINITY, -INFINITY, -INFINITY}, m1 = m0;
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) {
+      const int yy = 2 * yo - 1 + dy;
+      if (yy < 0 || yy >= H) continue;
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx) {
+        const int xx = 2 * xo - 1 + dx;
+        if (xx < 0 || xx >= W) continue;
+        const float* sp = x + ((b * H + yy) * W + xx) * cs + cb * 32 + g * 8;
+        const f32x4 a = *reinterpret_cast<const f32x4*>(sp), c = *reinterpret_cast<const f32x4*>(sp + 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          m0[j] = sfh_max_nan(m0[j], a[j]);
+          m1[j] = sfh_max_nan(m1[j], c[j]);
+        }
+      }
+    }
+    const long ps = 4L * Wo * 8;  // plane stride in elements
+    if constexpr (DFMT == SFH_FMT_H2) {
+      sfh_u32x2 pa[2], pb[2];
+      sfh_split4_h2(m0, scale, pa, over);
+      sfh_split4_h2(m1, scale, pb, over);
+      const long e = ((((row * (cs >> 5) + cb) * 2) * 4 + g) * Wo + xo) * 8;
+      *reinterpret_cast<u32x4*>(dst + e) = (u32x4){pa[0][0], pa[0][1], pb[0][0], pb[0][1]};
+      *reinterpret_cast<u32x4*>(dst + e + ps) = (u32x4){pa[1][0], pa[1][1], pb[1][0], pb[1][1]};
+    } else {
+      sfh_u32x2 pa[3], pb[3];
+      sfh_split4(m0, pa);
+      sfh_split4(m1, pb);
+      const long e = s3_elem(row, xo, cb * 32 + g * 8, 0, Wo, cs);
+#pragma unroll
+      for (int p = 0; p < 3; ++p) *reinterpret_cast<u32x4*>(dst + e + p * ps) = (u32x4){pa[p][0], pa[p][1], pb[p][0], pb[p][1]};
+    }
+  }
+  if constexpr (DFMT == SFH_FMT_H2) sfh_h2_report(over, overflow, range);
+}
+
 __global__ void h2_to_f32_kernel(const unsigned short* __restrict__ src, float* __restrict__ dst, int W, int cs,
                                  long total, float inv_scale) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1077,6 +1134,24 @@ extern "C" int sfh_f32_to_h2(const float* src, void* dst, int64_t rows, int W, i
   hipLaunchKernelGGL(f32_to_h2_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                      src, (unsigned short*)dst, W, cs, xchunks, total, ldexpf(1.f, act_exp), overflow, range);
   return sfh_check_launch("f32_to_h2_kernel");
+}
+
+extern "C" int sfh_maxpool3x3s2_split_fwd(const float* x, void* y, int batch, int H, int W, int C, int dst_fmt, int act_exp,
+                                          uint32_t* overflow, uint32_t* range, void* stream) {
+  SFH_REQUIRE(x && y && batch > 0 && H > 0 && W > 0 && C > 0 && C % 32 == 0, "maxpool3x3s2_split: C=%d must be a multiple of 32", C);
+  SFH_REQUIRE(dst_fmt == SFH_FMT_H2 || dst_fmt == SFH_FMT_S3, "maxpool3x3s2_split: dst_fmt=%d (S3 or H2)", dst_fmt);
+  SFH_REQUIRE(act_exp >= -64 && act_exp <= 64, "maxpool3x3s2_split: act_exp=%d out of range", act_exp);
+  const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+  const int xchunks = (Wo + 15) / 16;
+  const long total = (long)batch * Ho * (C / 32) * xchunks * 64;
+  const dim3 grid((unsigned)((total + 255) / 256));
+  if (dst_fmt == SFH_FMT_H2)
+    hipLaunchKernelGGL(maxpool3x3s2_split_kernel<SFH_FMT_H2>, grid, dim3(256), 0, (hipStream_t)stream, x, (unsigned short*)y, H,
+                       W, Ho, Wo, C, xchunks, total, ldexpf(1.f, act_exp), overflow, range);
+  else
+    hipLaunchKernelGGL(maxpool3x3s2_split_kernel<SFH_FMT_S3>, grid, dim3(256), 0, (hipStream_t)stream, x, (unsigned short*)y, H,
+                       W, Ho, Wo, C, xchunks, total, 1.f, nullptr, nullptr);
+  return sfh_check_launch("maxpool3x3s2_split_kernel");
 }
 
 extern "C" int sfh_h2_to_f32(const void* src, float* dst, int64_t rows, int W, int cs, int act_exp, void* stream) {

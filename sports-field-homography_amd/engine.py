@@ -1227,8 +1227,6 @@ class ResNetEngine:
                 s2d = s2d3
             do((), lambda s2d=s2d: L["stem"].run(s2d, B, H2, W2, c1))
         h, w = (H2 - 1) // 2 + 1, (W2 - 1) // 2 + 1
-        x = ws.get("pool", (B, h, w, 64))
-        do((), lambda x=x: _lib.check(lib.sfh_maxpool3x3s2_fwd(_ptr(c1), _ptr(x), B, H2, W2, 64, _stream()), "maxpool3x3s2"))
 
         def act(name, hh, ww, c):
             if s3:
@@ -1237,10 +1235,16 @@ class ResNetEngine:
             return ws.get(name, (B, hh, ww, c)), None
 
         nx = None
-        if s3:  # the pooled stem output enters the split domain (small tensor: 1/16 of the frame area)
-            xs, nxs = act("pool.s3", h, w, 64)
-            do((nxs,), lambda x=x, xs=xs, nxs=nxs: _f32_to_split_into(x, xs, self.overflow, rg.exp(nxs), rg.word_ptr(nxs)))
-            x, nx = xs, nxs
+        if s3:  # the pooled stem output enters the split domain: pooling and split in one pass (round 4; two launches before)
+            x, nx = act("pool.s3", h, w, 64)
+            ovf = self.overflow
+            do((nx,), lambda x=x, nx=nx: _lib.check(lib.sfh_maxpool3x3s2_split_fwd(
+                _ptr(c1), _ptr(x), B, H2, W2, 64, _SPLIT[fmt][2], rg.exp(nx),
+                ctypes.c_void_p(ovf.data_ptr()) if (ovf is not None and fmt == "h2") else None,
+                ctypes.c_void_p(rg.word_ptr(nx)) if rg.word_ptr(nx) else None, _stream()), "maxpool3x3s2_split"))
+        else:
+            x = ws.get("pool", (B, h, w, 64))
+            do((), lambda x=x: _lib.check(lib.sfh_maxpool3x3s2_fwd(_ptr(c1), _ptr(x), B, H2, W2, 64, _stream()), "maxpool3x3s2"))
         for name, width, cout, stride, has_down, bottleneck in self.blocks:
             ho, wo = (h - 1) // stride + 1, (w - 1) // stride + 1
 

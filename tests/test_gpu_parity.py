@@ -464,6 +464,37 @@ def test_resnet_stn_golden(E, golden_blocks, name, key, seed, precision):
         assert min(rg.headroom().values()) >= 1.0 and len(rg.peak) > 10
 
 
+@pytest.mark.parametrize("fmt", ["h2", "s3"])
+@pytest.mark.parametrize("hw", [(180, 320), (23, 41), (7, 5)])
+def test_stem_maxpool_written_straight_into_the_split_format(E, fmt, hw):
+    """sfh_maxpool3x3s2_split_fwd (the ResNetSTN's MaxPool2d(3, 2, 1), models/resnet.py:176, pooled and split in one pass)
+    gives the bits of the two-launch path it replaces - and of torch's max_pool2d - also on odd sizes, with a non-default
+    exponent, and it raises the range word like f32_to_h2 does."""
+    import ctypes
+    from sfh_amd import _lib
+    lib = _lib.load()
+    H, W = hw
+    B, C = 2, 64
+    x = torch.randn((B, H, W, C), generator=torch.Generator().manual_seed(H)).mul_(50.0).cuda()
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    p = lambda t: ctypes.c_void_p(t.data_ptr())
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    y32 = torch.empty((B, Ho, Wo, C), device="cuda")
+    _lib.check(lib.sfh_maxpool3x3s2_fwd(p(x), p(y32), B, H, W, C, st), "maxpool")
+    want32 = torch.nn.functional.max_pool2d(x.permute(0, 3, 1, 2), 3, 2, 1).permute(0, 2, 3, 1)
+    assert torch.equal(y32, want32)
+    exp = -1 if fmt == "h2" else 2
+    want = E.f32_to_split(y32, fmt, exp=exp) if fmt == "h2" else E.f32_to_split(y32, fmt)
+    got = E.split_empty(fmt, B, Ho, Wo, C, "cuda")
+    word = torch.zeros(1, dtype=torch.int32, device="cuda")
+    _lib.check(lib.sfh_maxpool3x3s2_split_fwd(p(x), p(got), B, H, W, C, E._SPLIT[fmt][2], exp, None,
+                                              p(word) if fmt == "h2" else None, st), "maxpool_split")
+    torch.cuda.synchronize()
+    assert torch.equal(got.view(torch.int16), want.view(torch.int16))
+    if fmt == "h2":
+        assert abs(float(word.view(torch.float32).item()) - float(y32.abs().max()) * 2.0 ** exp) < 1e-3
+
+
 # ---------------------------------------------------------------- warp / POI / CE
 def _thetas():
     ident = np.eye(3, dtype=np.float32)
