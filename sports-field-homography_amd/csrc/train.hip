@@ -1076,6 +1076,117 @@ int launch_wgrad(WgradArgs a, hipStream_t stream) {
   return sfh_check_launch("wgrad_kernel");
 }
 
+// Backward-filter of a 3x3 conv over at most FOUR input channels (the UNet's first layer: N = 3 stored as 4; round 4).
+// The generic kernel above spends one MFMA per tap on a 16-wide n block of which 4 columns are channels (75 % padding:
+// 0.75 ms, bound by the fp32 matrix pipe).  Here the n axis is (tap, channel): n = 4 * tap + c, 36 real columns in three
+// blocks of 16 - three MFMAs per four pixels instead of nine - and the halo is 16 bytes per pixel (2 KB instead of 35 KB of
+// LDS: four workgroups per CU).  B fragment: lane (j = n in the block, k = pixel) reads x[pixel + tap(n)][c(n)], one
+// ds_read_b32 at a per-lane constant offset; columns 36 .. 47 read a slot that stays zero.
+template <int TH, int TW>
+__global__ __launch_bounds__(256, 4) void wgrad_c4_kernel(const WgradArgs a) {
+  static_assert(TH * TW == 64 && TW % 4 == 0, "64-pixel tiles");
+  constexpr int HR = TH + 2, HW = TW + 2, HPX = HR * HW;
+  __shared__ __attribute__((aligned(16))) float zL[64 * 64];     // dz tile [64 pixels][64 m]
+  __shared__ __attribute__((aligned(16))) f32x4 xL[HPX + 1];     // halo, 4 channels per pixel; slot HPX stays zero
+  const float* xf = reinterpret_cast<const float*>(xL);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l16 = lane & 15, kq = lane >> 4;
+  const int xcd = blockIdx.x & 7, kk_ = blockIdx.x >> 3;
+  const int split = (kk_ / a.mn) * 8 + xcd, mni = kk_ % a.mn;
+  if (split >= a.nsplit) return;
+  const int m0 = mni * 64;
+  int offn[3];
+#pragma unroll
+  for (int nb = 0; nb < 3; ++nb) {
+    const int n = nb * 16 + l16, tap = n >> 2, c = n & 3;
+    offn[nb] = n < 36 ? ((tap / 3) * HW + tap % 3) * 4 + c : -1;
+  }
+  f32x4 acc[3];
+#pragma unroll
+  for (int nb = 0; nb < 3; ++nb) acc[nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  if (tid == 0) xL[HPX] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  f32x4 hv, zv[4];
+  auto load_tile = [&](int tile) {
+    const int tx = tile % a.ntx;
+    const int ty = (tile / a.ntx) % a.nty;
+    const int b = tile / (a.ntx * a.nty);
+    const int y0 = ty * TH, x0 = tx * TW;
+    hv = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (tid < HPX) {
+      const int hr = tid / HW, hc = tid - hr * HW;
+      const int sy = y0 + hr - 1, sx = x0 + hc - 1;
+      if (sy >= 0 && sy < a.H && sx >= 0 && sx < a.W)
+        hv = *reinterpret_cast<const f32x4*>(a.x + (((long)b * a.H + sy) * a.W + sx) * 4);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int i = tid + k * 256;
+      const int q = i & 15, p = i >> 4;
+      const int r = p / TW, c = p - r * TW;
+      const int y = y0 + r, x = x0 + c, m = m0 + 4 * q;
+      zv[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (y < a.H && x < a.W && m < a.M)
+        zv[k] = *reinterpret_cast<const f32x4*>(a.dz + (((long)b * a.H + y) * a.W + x) * a.dz_cs + m);
+    }
+  };
+  if (split < a.ntiles) load_tile(split);
+  for (int tile = split; tile < a.ntiles; tile += a.nsplit) {
+    __syncthreads();  // previous tile's fragments consumed
+    if (tid < HPX) xL[tid] = hv;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int i = tid + k * 256;
+      const int q = i & 15, p = i >> 4;
+      *reinterpret_cast<f32x4*>(zL + p * 64 + 4 * (q ^ ((p & 1) << 2))) = zv[k];
+    }
+    __syncthreads();
+    if (tile + a.nsplit < a.ntiles) load_tile(tile + a.nsplit);   // in flight during the contraction
+#pragma unroll 2
+    for (int r = 0; r < TH; ++r) {
+#pragma unroll
+      for (int c4 = 0; c4 < TW / 4; ++c4) {
+        const int pz = r * TW + c4 * 4 + kq;
+        const float av = zL[pz * 64 + ((wave * 16 + l16) ^ ((pz & 1) << 4))];
+        const int ph4 = (r * HW + c4 * 4 + kq) * 4;     // float index of the window's top-left pixel
+#pragma unroll
+        for (int nb = 0; nb < 3; ++nb) {
+          const float bv = xf[offn[nb] >= 0 ? ph4 + offn[nb] : HPX * 4];
+          acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[nb], 0, 0, 0);
+        }
+      }
+    }
+  }
+  // D[i = 4 * (lane / 16) + r][j = lane % 16]: m = m0 + 16 * wave + i, n = 16 * nb + j = 4 * tap + c
+#pragma unroll
+  for (int nb = 0; nb < 3; ++nb) {
+    const int n = nb * 16 + l16, tap = n >> 2, c = n & 3;
+    if (n >= 36 || c >= a.N) continue;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int m = m0 + wave * 16 + 4 * kq + r;
+      if (m < a.M) unsafeAtomicAdd(a.raw + ((long)m * 9 + tap) * a.raw_n + a.n_off + c, acc[nb][r]);
+    }
+  }
+}
+
+template <int TH, int TW>
+int launch_wgrad_c4(WgradArgs a, hipStream_t stream) {
+  a.ntx = sfh_cdiv(a.W, TW);
+  a.nty = sfh_cdiv(a.H, TH);
+  a.ntiles = a.batch * a.ntx * a.nty;
+  const int mn = sfh_cdiv(a.M, 64);
+  int ns = sfh_cdiv(2048, mn);          // four workgroups per CU: two rounds of 1024
+  if (ns > a.ntiles) ns = a.ntiles;
+  if (ns < 1) ns = 1;
+  if (ns < 8 && a.ntiles >= 8) ns = 8;
+  a.nsplit = ns;
+  a.mt = mn;
+  a.mn = mn;
+  const dim3 grid((unsigned)(sfh_cdiv(ns, 8) * 8 * mn));
+  hipLaunchKernelGGL((wgrad_c4_kernel<TH, TW>), grid, dim3(256), 0, stream, a);
+  return sfh_check_launch("wgrad_c4_kernel");
+}
+
 // tile shape (rows x cols, 64 pixels) with the fewest padded pixels; ties go to the widest
 static int wgrad_tile(int H, int W) {
   const int th[3] = {2, 4, 8}, tw[3] = {32, 16, 8};
@@ -1248,7 +1359,10 @@ extern "C" int sfh_conv_wgrad(const float* dz, int dz_cs, int M, const float* x,
 #define SFH_WG(KS_, NS_)                                         \
   (t == 0 ? launch_wgrad<KS_, NS_, 2, 32>(a, st)                  \
           : (t == 1 ? launch_wgrad<KS_, NS_, 4, 16>(a, st) : launch_wgrad<KS_, NS_, 8, 8>(a, st)))
-  if (ksize == 3 && N <= 16) return SFH_WG(3, 1);  // the network's first layer (3 input channels stored as 4)
+  // the network's first layer (3 input channels stored as 4, one source of the frame's own size): n = (tap, channel)
+  if (ksize == 3 && N <= 4 && x_cs == 4 && xh == H && xw == W && pad_top == 0 && pad_left == 0)
+    return t == 0 ? launch_wgrad_c4<2, 32>(a, st) : (t == 1 ? launch_wgrad_c4<4, 16>(a, st) : launch_wgrad_c4<8, 8>(a, st));
+  if (ksize == 3 && N <= 16) return SFH_WG(3, 1);
   if (ksize == 3) return SFH_WG(3, 4);
   if (ksize == 1) return SFH_WG(1, 4);
   return SFH_WG(4, 2);
