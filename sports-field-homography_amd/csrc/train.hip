@@ -703,7 +703,9 @@ __global__ __launch_bounds__(256) void stem_bwd_data_kernel(const float* __restr
   __syncthreads();
   // a thread owns the pixels x and x + 64 of a row: same column parity, i.e. the same taps (ky, kx) and the same weights -
   // every 16-byte LDS read of a weight quad feeds two pixels (the kernel was bound by those reads: one per four FMAs).
-  // (Round 4: FOUR pixels per thread measured slower, 1.28 -> 1.36 ms.)
+  // (Round 4: FOUR pixels per thread measured slower, 1.28 -> 1.36 ms; waves of ONE column parity - wave-uniform tap loops,
+  // broadcast weight reads - slower still, 1.23 -> 1.88 ms: with lane -> every second column each dz load instruction touches
+  // 64 cache lines instead of 32; the kernel is bound by that gather, not by the LDS weight reads.)
   const int x = blockIdx.x * 128 + (threadIdx.x & 63);
   const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
   const int b = blockIdx.z;
