@@ -308,8 +308,15 @@ class ConvTimer:
     """Optional HIP-event timing of conv launches on the launch stream (used by bench.py for the
     live roofline figure).  Records (tag, algorithmic FLOPs, start event, end event)."""
 
-    def __init__(self):
+    def __init__(self, only=None):
+        """only: set of tags to time (None = every launch).  bench.py times just the dominant kernel's launches inside the
+        headline region - two event records per launch are not free (all 59 timed launches of a step: +0.2 ms) - and every
+        group in the unpipelined pass behind it."""
         self.records = []
+        self.only = None if only is None else set(only)
+
+    def wants(self, tag):
+        return self.only is None or tag in self.only
 
     def summary(self):
         """-> {tag: (launches, total_flops, total_ms)}; call after a device synchronize."""
@@ -731,6 +738,8 @@ class PackedConv:
                 raise ValueError("the <=4-channel first-layer kernel needs an fp32 NHWC source with 4 stored channels")
             fwd = lib.sfh_conv3x3_c4h2_fwd if self.c4h2 else lib.sfh_conv3x3_c4_fwd
         tm = PackedConv.timer
+        if tm is not None and not tm.wants(self.tag):
+            tm = None
         if tm is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -1117,6 +1126,8 @@ class StemConv:
         if tuple(dst.shape) != (B, ho, wo, 64) or tuple(x_nhwc8.shape) != (B, H, W, 8):
             raise ValueError(f"stem: shapes {tuple(x_nhwc8.shape)} -> {tuple(dst.shape)} do not match {(B, ho, wo, 64)}")
         tm = PackedConv.timer
+        if tm is not None and not tm.wants(self.tag):
+            tm = None
         if tm is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -1431,6 +1442,8 @@ def homography_warp(theta, template, h, w, nearest, scale=None, want_f32=True, w
     out_i = torch.empty((B, h, w), dtype=torch.int32, device=theta.device) if want_i32 else None
     bstride = 0 if shared_template else ht * wt
     tm = PackedConv.timer
+    if tm is not None and not tm.wants("warp"):
+        tm = None
     if tm is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
