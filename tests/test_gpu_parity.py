@@ -942,6 +942,56 @@ def test_predict_async_pipeline_gives_predict_s_bits(E):
             assert torch.equal(g[key], w[key]), key
 
 
+def test_forward_and_forward_unet_between_pipelined_batches(E):
+    """Round 4 (review finding): forward() and forward_unet() write the STN-input buffer and the ResNet workspace that a
+    predict_async() batch in flight may still be reading on the side stream - they now wait for those reads like predict()
+    does.  Interleaved with pipelined batches they give their own sequential results, and the batches theirs; and a
+    synchronous call that finds a SATURATED tensor (it zeroes the shared range words) invalidates the batches in flight, whose
+    result() then recomputes them instead of handing out clamped outputs."""
+    from sfh_amd.reconstructor import Reconstructor
+    B, H, W = 2, 48, 64
+    court = synth.load_court_template("ncaa_nc4_640x360", 4, B)[:, :, :H, :W].contiguous()
+    poi = synth.load_court_poi("pitch", B)
+    nets = []
+    sd = None
+    for _ in range(2):
+        net = Reconstructor(court.cuda(), poi.cuda(), target_size=(W, H), unet_size=(W, H), warp_size=(W, H), warp_with_nearest=True)
+        sd = sd or synth.synth_state_dict(net.state_dict(), 72)
+        net.load_state_dict(sd)
+        nets.append(net.cuda().eval())
+    ref, pipe = nets
+    xs = [synth.smooth_frames(B, H, W, seed=200 + k).cuda() for k in range(4)]
+    with torch.no_grad():
+        want_p = [ref.predict(x, consistency=True, project_poi=True) for x in xs]
+        want_f = ref(xs[3])
+        want_u = ref.forward_unet(xs[2])[0]
+        h0 = pipe.predict_async(xs[0], consistency=True, project_poi=True)
+        fw = pipe(xs[3])                                  # forward() while batch 0's ResNet may still run
+        h1 = pipe.predict_async(xs[1], consistency=True, project_poi=True)
+        lg = pipe.forward_unet(xs[2])[0]
+        r0, r1 = h0.result(), h1.result()
+    torch.cuda.synchronize()
+    for got, want in ((r0, want_p[0]), (r1, want_p[1]), (fw, want_f)):
+        assert sorted(got) == sorted(want)
+        for key in want:
+            assert torch.equal(got[key], want[key]), key
+    assert torch.equal(lg, want_u)
+    # a saturating checkpoint: the synchronous predict() in the middle lowers the exponent and zeroes the words; the batch
+    # in flight was computed with the old exponent (clamped values) - its result() must not return that
+    sd2 = _rescaled_checkpoint(sd, 65536.0, [("inc.double_conv.1", ["inc.double_conv.3.weight"])])
+    for n in nets:
+        n.load_state_dict(sd2)
+    with torch.no_grad():
+        want = [ref.predict(x, consistency=True, project_poi=True) for x in xs[:2]]
+        h0 = pipe.predict_async(xs[0], consistency=True, project_poi=True)       # saturates inc.mid, not checked yet
+        mid = pipe.predict(xs[1], consistency=True, project_poi=True)            # finds the word, rescales, resets the words
+        r0 = h0.result()
+    assert pipe.range_rescales >= 1 and pipe.range_fallbacks == 0
+    for got, w in ((mid, want[1]), (r0, want[0])):
+        for key in w:
+            assert torch.equal(got[key], w[key]), key
+
+
 @pytest.mark.parametrize("B,size", [(1, (50, 70)), (3, (33, 47)), (1, (16, 16)), (5, (64, 48))])
 def test_ragged_batches_and_sizes_vs_oracle(E, B, size):
     """Batch sizes 1 / 3 / 5, odd and minimal frame sizes (16x16 is the smallest frame four 2x2 poolings allow),
