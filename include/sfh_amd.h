@@ -58,6 +58,8 @@ extern "C" {
 #define SFH_FMT_F32 0
 #define SFH_FMT_S3 1
 #define SFH_FMT_H2 2
+#define SFH_FMT_FH2 3 /* the frame tensor of sfh_frame_to_h2 (16 bytes per pixel: two fp16 planes of channels 0..3); the only
+                         source format sfh_conv3x3_c4h2_fwd takes, and only that entry takes it */
 #define SFH_H2_ACT_EXP 2
 
 /* Output modes of sfh_conv_fwd. */
@@ -226,7 +228,8 @@ int sfh_pack_c4_weights(const float* w, float* packed, int cin, int cout, void* 
  * [fp16 plane 0 of channels 0..3 | fp16 plane 1 of channels 0..3] of x * 2^act_exp (format as SFH_FMT_H2: saturating,
  * `range` receives the largest |x * 2^act_exp|, `overflow` is OR-ed with 1 on saturation; both optional); dst_nhwc4
  * (optional) receives the fp32 NHWC copy with 4 stored channels that sfh_nchw_to_nhwc would write.
- * sfh_conv3x3_c4h2_fwd: src0 = the FH2 tensor (B,H,W) x 16 bytes, wpacked from sfh_pack_c4h2_weights (planes of
+ * sfh_conv3x3_c4h2_fwd: src0 = the FH2 tensor (B,H,W) x 16 bytes (src_fmt = SFH_FMT_FH2, c0 <= 4, cs0 = 4; a plain fp32 NHWC4
+ * frame - src_fmt SFH_FMT_F32, the source of sfh_conv3x3_c4_fwd - is rejected), h2_exp_src = act_exp, wpacked from sfh_pack_c4h2_weights (planes of
  * w * 2^wexp; the caller multiplies `scale` by 2^-(wexp + act_exp)), dst H2 or fp32; descriptor fields as sfh_conv_fwd. */
 int sfh_frame_to_h2(const float* src_nchw, float* dst_nhwc4, void* dst_fh2, int batch, int C, int H, int W, int act_exp,
                     uint32_t* overflow, uint32_t* range, void* stream);

@@ -14,7 +14,7 @@ Two kinds of output:
    deterministic synthetic weights of ``sfh_amd.synth``.  These pin ``oracle/torch_ref.py``.
 
 Usage:  python oracle/make_fixtures.py [--full]     (--full adds the 640x360 end-to-end vector)
-        python oracle/make_fixtures.py --configs c2,c5,c3,c3b16,c3b16grad   (BASELINE configs at their stated sizes)
+        python oracle/make_fixtures.py --configs c2,c2d,c5,c3,c3b16,c3b16grad   (BASELINE configs at their stated sizes)
 """
 import argparse
 import importlib.util
@@ -277,9 +277,11 @@ MARGIN_BINS = np.array([0, 1e-5, 2e-5, 5e-5, 1e-4, 2e-4, 5e-4, 1e-3, 2e-3, 5e-3,
 LOW_MARGIN = 1e-2   # pixels whose top-2 logit margin is below this are listed individually
 
 
-def _predict_golden(up_mod, rn_mod, x, court, poi, wh, chunk):
+def _predict_golden(up_mod, rn_mod, x, court, poi, wh, chunk, warp_wh=None):
     """Reference classes for UNet / ResNetSTN (eval mode, frames are independent), oracle for the Kornia
-    leg: theta, consistency score, POI, arg-max mask, top-2 margins, sub-sampled logits."""
+    leg: theta, consistency score, POI, arg-max mask, top-2 margins, sub-sampled logits.  warp_wh: (W, H) of the warp
+    when it differs from the UNet's (predict.py:151-155): the consistency CE then reads the warp mask through
+    F.interpolate(..., mode='nearest') as models/reconstructor.py:230-234 does."""
     W, H = wh
     B = x.shape[0]
     net = _loaded(_RefNet(up_mod, rn_mod), 0)
@@ -290,8 +292,11 @@ def _predict_golden(up_mod, rn_mod, x, court, poi, wh, chunk):
         logits[i:i + chunk] = lg
         theta[i:i + chunk] = net.resnet_reg(torch.cat((lg, x[i:i + chunk]), 1))
         print("  frames", i, "...", i + chunk, flush=True)
-    wm = torch_ref.warp(theta, court, (W, H), nearest=True) * 4
-    ce = torch.nn.functional.cross_entropy(logits, wm.long(), reduction="none").mean(dim=(1, 2))
+    wm = torch_ref.warp(theta, court, warp_wh or (W, H), nearest=True) * 4
+    wm_ce = wm
+    if tuple(wm.shape[1:3]) != (H, W):
+        wm_ce = torch.nn.functional.interpolate(wm.unsqueeze(1), size=(H, W), mode="nearest").squeeze(1)
+    ce = torch.nn.functional.cross_entropy(logits, wm_ce.long(), reduction="none").mean(dim=(1, 2))
     p = torch_ref.transform_poi(theta, poi)
     am = torch.argmax(logits, 1).to(torch.uint8).numpy()
     top2 = torch.topk(logits, 2, dim=1).values
@@ -317,6 +322,25 @@ def make_c2_golden(up_mod, rn_mod):
         out = _predict_golden(up_mod, rn_mod, x, court, poi, (640, 360), 4)
     _save_checked(os.path.join(GOLD, "c2_640x360_b16.npz"), out)
     print("c2 golden: consist", out["consist"], "margin hist", out["margin_hist"].sum(0))
+
+
+def make_c2d_golden(up_mod, rn_mod):
+    """predict.py's DEFAULT geometry at full size (round 5): the UNet stays at 640x360 while court_size / warp_size are
+    raised to out_size = 1280x720 (predict.py:151-155), so the warp mask is 1280x720 and the consistency CE reads it
+    through a nearest resize (models/reconstructor.py:226-240).  16 frames, seed-0 weights and frames (the frames,
+    logits and theta of the C2 vector), NCAA template resized NEAREST to 1280x720 (utils/dataset.py:51-53), 33-point POI."""
+    torch.set_num_threads(os.cpu_count())
+    B = 16
+    with torch.no_grad():
+        x = synth.frames_to_float(synth.synth_frames_u8(B, 360, 640, seed=0))
+        court = synth.load_court_template("ncaa_nc4_1280x720", 4, B)
+        poi = synth.load_court_poi("pitch", B)
+        out = _predict_golden(up_mod, rn_mod, x, court, poi, (640, 360), 4, warp_wh=(1280, 720))
+    c2 = np.load(os.path.join(GOLD, "c2_640x360_b16.npz"))
+    assert np.array_equal(c2["theta"], out["theta"]) and np.array_equal(c2["logits_blocksum8"], out["logits_blocksum8"])
+    keep = ("theta", "consist", "poi", "warp_mask_2bit")      # the logit vectors are those of c2_640x360_b16.npz
+    _save_checked(os.path.join(GOLD, "c2d_unet640x360_warp1280x720_b16.npz"), {k: out[k] for k in keep})
+    print("c2d golden: consist", out["consist"])
 
 
 def make_c5_golden(up_mod, rn_mod):
@@ -473,7 +497,7 @@ if __name__ == "__main__":
         rn_mod = _load("ref_resnet", "models/resnet.py")
         if a.configs:
             for c in a.configs.split(","):
-                {"c2": make_c2_golden, "c5": make_c5_golden, "c3": make_c3_golden, "c3b16": make_c3_b16_golden,
+                {"c2": make_c2_golden, "c2d": make_c2d_golden, "c5": make_c5_golden, "c3": make_c3_golden, "c3b16": make_c3_b16_golden,
                  "c3b16grad": make_c3_b16_grad_golden}[c](up_mod, rn_mod)
             raise SystemExit(0)
         if a.train_only:

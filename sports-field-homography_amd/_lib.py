@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get("SFH_AMD_LIB") or os.path.join(_HERE, "libsfh_amd.so")
 
 TILE_8x32, TILE_16x16, TILE_32x8, TILE_8x16, TILE_16x8 = 0, 1, 2, 3, 4
 OUT_NHWC, OUT_UPSCATTER2 = 0, 1
-FMT_F32, FMT_S3, FMT_H2 = 0, 1, 2
+FMT_F32, FMT_S3, FMT_H2, FMT_FH2 = 0, 1, 2, 3
 H2_ACT_EXP = 2   # SFH_H2_ACT_EXP: the default exponent of an H2 tensor
 H2_LIMIT_BITS = 0x477FE000   # bit pattern of 65504.f: sfh_conv_desc.h2_range words above it mean saturation
 

@@ -199,6 +199,11 @@ extern "C" int sfh_conv3x3_c4h2_fwd(const sfh_conv_desc* dp, void* stream_) {
   SFH_REQUIRE(d.dst_fmt == SFH_FMT_H2 || d.dst_fmt == SFH_FMT_F32, "conv3x3_c4h2_fwd: the destination is H2 or fp32 (dst_fmt=%d)", d.dst_fmt);
   SFH_REQUIRE(d.cout > 0 && d.cout % 64 == 0 && d.batch > 0 && d.H > 0 && d.W > 0, "conv3x3_c4h2_fwd: bad geometry");
   SFH_REQUIRE(d.h2_exp_dst >= -64 && d.h2_exp_dst <= 64, "conv3x3_c4h2_fwd: h2_exp_dst=%d out of range (-64 .. 64)", d.h2_exp_dst);
+  SFH_REQUIRE(d.h2_exp_src >= -64 && d.h2_exp_src <= 64, "conv3x3_c4h2_fwd: h2_exp_src=%d out of range (-64 .. 64)", d.h2_exp_src);
+  // the kernel hard-codes 16 bytes per source pixel (two fp16 planes of four channels): anything else would be misread silently
+  SFH_REQUIRE(d.src_fmt == SFH_FMT_FH2, "conv3x3_c4h2_fwd: src_fmt=%d, expected SFH_FMT_FH2 (the frame tensor of sfh_frame_to_h2; "
+              "an fp32 NHWC4 frame belongs to sfh_conv3x3_c4_fwd)", d.src_fmt);
+  SFH_REQUIRE(d.c0 >= 1 && d.c0 <= 4 && d.cs0 == 4, "conv3x3_c4h2_fwd: c0=%d cs0=%d, expected 1..4 channels stored as 4", d.c0, d.cs0);
   C4HGeom g;
   g.Ho = d.H;
   g.Wo = d.W;

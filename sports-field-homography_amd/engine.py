@@ -110,19 +110,30 @@ class FP16RangeExhausted(RuntimeError):
 class H2Ranges:
     """Exponents and range words of the H2 (two-plane fp16, "f16x3") activation tensors of one model.
 
-    An H2 tensor stores v * 2^e and saturates beyond |v| = 65504 * 2^-e (include/sfh_amd.h).  Every tensor NAME has
-    an exponent KEY - tensors that enter one conv as its two sources share a key, and so do a conv output and the
-    pooled copy its producer writes - and a device word that the producing kernels raise (atomic max) to the
-    largest bit pattern of |v * 2^e| they produced, before saturation.  After a forward pass the host reads the
-    words (`read`): a word above H2_LIMIT_BITS means its tensor was saturated, and how far it overshot gives the
-    exponent that fits (`lower`); the engines then repeat the pass from the first step that writes such a tensor.
-    Exponents start at the conventional 2 and only ever go down: the state is sticky, shared by the UNet and ResNet
-    engines of a Reconstructor and kept across engine rebuilds (same model, new weights)."""
+    An H2 tensor stores u = v * 2^e and saturates beyond |v| = 65504 * 2^-e (include/sfh_amd.h); below |u| = 2^-3 its
+    low plane is an fp16 subnormal and the element keeps fewer than 22 bits.  Every tensor NAME has an exponent KEY -
+    tensors that enter one conv as its two sources share a key, and so do a conv output and the pooled copy its
+    producer writes - and a device word that the producing kernels raise (atomic max) to the largest bit pattern of
+    |v * 2^e| they produced, before saturation.  After a forward pass the host reads the words (`read`) and decides
+    in BOTH directions, one decision per key:
+
+    * a word above H2_LIMIT_BITS: the tensor was saturated; how far it overshot gives the exponent that fits (`lower`);
+    * every written word of a key below RAISE_BELOW (= 4: the largest element of the key's tensors sits within 2^5 of
+      the subnormal boundary, so a typical element, an order of magnitude below the peak, has lost bits - a "quiet"
+      layer): the exponent is RAISED so that the peak lands in [2^12, 2^13) like after `lower` (`quiet` / `raise_`).
+
+    The engines then repeat the pass from the first step that writes such a tensor.  Exponents start at the conventional
+    2; the state is sticky, shared by the UNet and ResNet engines of a Reconstructor and kept across engine rebuilds
+    (same model, new weights).  Hysteresis: the words are running maxima since the last reset (a reset happens only
+    together with a decision), so a key is raised only if EVERYTHING since then was quiet, and a key that `lower` has
+    touched is never raised above the exponent `lower` gave it until the weights change (`new_generation`)."""
 
     LIMIT = _lib.H2_LIMIT_BITS
     NONFINITE = 0x7F800000
     DEFAULT = _lib.H2_ACT_EXP
     MIN_EXP = -64
+    MAX_EXP = 48          # |v| down to 2^-36 reaches [2^12, 2^13); the kernels take -64 .. 64
+    RAISE_BELOW = 4.0     # stored peak |v * 2^e| below which a key counts as quiet (see above)
 
     def __init__(self, device, capacity=1024):
         self.device = device
@@ -130,6 +141,7 @@ class H2Ranges:
         self.exps = {}     # key -> exponent (absent = DEFAULT)
         self.slot = {}     # tensor name -> (key, word index)
         self.peak = {}     # tensor name -> largest |v| seen so far (host side, from read())
+        self.ceiling = {}  # key -> exponent `lower` gave it in this weights generation: `raise_` never exceeds it
         self._nwords = 0
 
     def register(self, name, key=None, word_of=None):
@@ -206,7 +218,48 @@ class H2Ranges:
             if new >= e:
                 raise FP16RangeExhausted(f"H2 tensor group {key!r} is saturated at the lowest exponent {e}")
             self.exps[key] = new
+            self.ceiling[key] = new
         return set(worst)
+
+    def quiet(self, bits):
+        """The other direction (bits = read()'s dict of a pass WITHOUT saturated tensors): {key: larger exponent} for
+        every key whose written tensors all peaked below RAISE_BELOW in stored units - the largest word of the key,
+        converted with the exponent in force, goes to [2^12, 2^13).  Tensors whose word is still zero (not written
+        since the reset, or all zeros) say nothing; a key with no written tensor is left alone.  Never above the
+        exponent `lower` gave the key in this weights generation, never above MAX_EXP."""
+        top = {}
+        for n, b in bits.items():
+            s = self.slot.get(n)
+            if s is None or b == 0:
+                continue
+            top[s[0]] = max(top.get(s[0], 0), b)
+        plan = {}
+        for key, b in top.items():
+            if b > self.LIMIT:
+                continue                                   # saturated / non-finite: `lower`'s business
+            stored = _bits_to_float(b)
+            if stored >= self.RAISE_BELOW:
+                continue
+            e = self.exps.get(key, self.DEFAULT)
+            new = 13 - math.frexp(stored * 2.0 ** -e)[1]
+            new = min(new, self.MAX_EXP, self.ceiling.get(key, self.MAX_EXP))
+            if new > e:
+                plan[key] = new
+        return plan
+
+    def raise_(self, plan):
+        """apply quiet()'s plan -> the set of keys (the caller zeroes the words and repeats the pass from the first
+        launch that writes one of them)"""
+        self.exps.update(plan)
+        return set(plan)
+
+    def new_generation(self):
+        """The model's weights changed (or its mode): what the words and the `lower` ceilings say belongs to the old
+        weights.  The exponents stay - they are the best guess for the new weights - and are re-examined in both
+        directions by the first pass."""
+        self.words.zero_()
+        self.ceiling.clear()
+        self.peak.clear()
 
     def reset_words(self):
         self.words.zero_()
@@ -737,6 +790,8 @@ class PackedConv:
             if src0.shape[-1] != 4 or pool0 or dst_pool is not None:
                 raise ValueError("the <=4-channel first-layer kernel needs an fp32 NHWC source with 4 stored channels")
             fwd = lib.sfh_conv3x3_c4h2_fwd if self.c4h2 else lib.sfh_conv3x3_c4_fwd
+            if self.c4h2:
+                d.src_fmt = _lib.FMT_FH2   # the (B,H,W,4) float32 tensor holds sfh_frame_to_h2's 16-byte pixels, not floats
         tm = PackedConv.timer
         if tm is not None and not tm.wants(self.tag):
             tm = None
@@ -1065,9 +1120,11 @@ class StemConv:
     """ResNetSTN stem (7x7 s2 conv + BatchNorm + ReLU) on the tap-packed split-bf16 kernel (csrc/stem.hip):
     reads the fp32 NHWC STN input (8 stored channels) directly, no space-to-depth copy."""
 
-    def __init__(self, conv, bn, cin, tag="resnet", fmt="s3", overflow=None):
+    def __init__(self, conv, bn, cin, tag="resnet", fmt="s3", overflow=None, wexp=None):
         """fmt: arithmetic of the kernel - "s3": the input is split into three bf16 planes, six products; "h2": two
-        fp16 planes, three products (overflow: the engine's fp16-range word)."""
+        fp16 planes, three products (overflow: the engine's fp16-range word; wexp: the weight exponent, max |w| * 2^wexp
+        in [2^13, 2^14), from a caller that has the maximum already - the training tape reads all of them back in one
+        batched synchronisation - else one device read-back here)."""
         lib = _lib.load()
         w = _f32c(conv.weight.detach(), "stem weight")
         if tuple(w.shape) != (64, cin, 7, 7) or cin > 8:
@@ -1078,13 +1135,15 @@ class StemConv:
         self.tag, self.cin, self.fmt, self.overflow = tag, cin, fmt, overflow
         self.exp_src = _lib.H2_ACT_EXP     # h2: the input planes carry x * 2^exp_src (folded into `scale`)
         self.wpacked = torch.empty(lib.sfh_packed_stem_weight_bytes(), dtype=torch.uint8, device=dev)
-        wexp, self.escale = 0, 1.0
+        self.escale = 1.0
+        wexp_given, wexp = wexp, 0
         if fmt == "h2":
-            import math
-            wmax = float(w.abs().max())
-            if not math.isfinite(wmax):
-                raise ValueError("stem weight holds non-finite values")
-            wexp = max(-100, min(100, 14 - math.frexp(wmax)[1])) if wmax > 0 else 0
+            if wexp_given is None:
+                wmax = float(w.abs().max())
+                if not math.isfinite(wmax):
+                    raise ValueError("stem weight holds non-finite values")
+                wexp_given = 14 - math.frexp(wmax)[1] if wmax > 0 else 0
+            wexp = max(-100, min(100, int(wexp_given)))
             self.escale = 2.0 ** -(wexp + _lib.H2_ACT_EXP)
         _lib.check(lib.sfh_pack_stem_weights(_ptr(w), _ptr(self.wpacked), cin, _SPLIT[fmt][2], wexp, _stream()),
                    "pack_stem_weights")

@@ -172,6 +172,7 @@ class Reconstructor(nn.Module):
         self._h2_ranges = None     # engine.H2Ranges: exponents + device range words of the "f16x3" activations
         self._forced_precision = None
         self.range_rescales = 0    # passes repeated from a layer whose output left its fp16 range (exponent lowered)
+        self.range_raises = 0      # passes repeated from a layer whose output sat at the bottom of its range (exponent raised)
         self.range_fallbacks = 0   # batches re-run in "bf16x6" because an activation was not finite
         # False: predict() / forward() skip the 4-byte read-back (a device synchronisation) after every call; a
         # caller that pipelines several batches then asks range_overflowed() itself once it has synchronised
@@ -231,8 +232,11 @@ class Reconstructor(nn.Module):
     def _get_engines(self):
         stamp = self._param_stamp()
         if self._engine_stamp != stamp:
+            old = self._engine_stamp
             self._engines_by_precision = {}
             self._engine_stamp = stamp
+            if old is not None:
+                self._on_new_weights()
         precision = self._forced_precision or self.precision
         eng = self._engines_by_precision.get(precision)
         if eng is None:
@@ -253,6 +257,17 @@ class Reconstructor(nn.Module):
             eng = self._engines_by_precision[precision] = (un, rn)
         self._engines = eng
         return eng
+
+    def _on_new_weights(self):
+        """The stamp moved (new weights, another mode or precision): batches of predict_async() still in flight were
+        computed with the old engines - take their results (and their range checks) now - and what the range words and
+        the `lower` ceilings of the "f16x3" mode hold describes the old weights (engine.H2Ranges.new_generation)."""
+        p = self.__dict__.get("_pipe")
+        if p is not None and p["inflight"]:
+            for h in list(p["inflight"]):
+                h.result()
+        if self._h2_ranges is not None:
+            self._h2_ranges.new_generation()
 
     @staticmethod
     def _run_phases(phases):
@@ -289,23 +304,31 @@ class Reconstructor(nn.Module):
         for _ in range(256):
             bits = rg.read()                     # one read-back of ~100 words per call
             bad, nonfinite = rg.saturated(bits)
-            if not bad:
+            plan = None if bad else rg.quiet(bits)
+            if not bad and not plan:
                 return ret
+            # launches of predict_async() batches still running on the side stream were enqueued with the exponents as
+            # they are now and write the same words: let them finish before the words are zeroed and the exponents move
+            self._pipe_drain()
             rg.reset_words()
             self._pipe_mark_stale()              # batches of predict_async() in flight wrote the same words
-            if nonfinite:
+            if plan:
+                keys = rg.raise_(plan)           # quiet tensors: larger exponents (one decision per key)
+                self.range_raises += 1
+            elif nonfinite:
                 self.range_fallbacks += 1
                 if self.range_fallbacks == 1:
                     import warnings
                     warnings.warn("sfh_amd: a non-finite activation in the 'f16x3' mode; the batch was re-run with "
                                   "precision 'bf16x6', which carries NaN / Inf to the outputs like the reference")
                 return three_plane_rerun()
-            try:
-                keys = rg.lower(bad, bits)       # one decision per exponent key
-            except E.FP16RangeExhausted:
-                self.range_fallbacks += 1        # finite, but beyond 2^64 * 65504: outside the two-plane format for good
-                return three_plane_rerun()
-            self.range_rescales += 1
+            else:
+                try:
+                    keys = rg.lower(bad, bits)   # one decision per exponent key
+                except E.FP16RangeExhausted:
+                    self.range_fallbacks += 1    # finite, but beyond 2^64 * 65504: outside the two-plane format for good
+                    return three_plane_rerun()
+                self.range_rescales += 1
             k = un.first_step(keys) if un is not None else None
             if k is not None:
                 r = run_unet(resume=k)
@@ -328,6 +351,12 @@ class Reconstructor(nn.Module):
                 o.stale = True
             p["inflight"].clear()
 
+    def _pipe_drain(self):
+        """wait for the predict_async() batches in flight (their side-stream launches write the shared range words)"""
+        p = self.__dict__.get("_pipe")
+        if p is not None and p["inflight"]:
+            torch.cuda.synchronize(p["device"])
+
     def _pipe_wait_reads(self):
         """Batches of predict_async() may still be reading the STN-input buffers and the ResNet workspace on the side
         stream: order the caller's stream behind them before a synchronous pass writes those buffers."""
@@ -339,21 +368,27 @@ class Reconstructor(nn.Module):
 
     def range_overflowed(self, reset=True):
         """For callers that pipeline batches with `range_guard = False`: True if an activation tensor of the "f16x3"
-        mode was saturated since the last reset (synchronises).  With reset, the exponents of those tensors are
-        lowered so that the following batches fit; the caller re-submits the batches it had in flight."""
+        mode was saturated since the last reset - or, the other direction, if every tensor of an exponent key stayed at
+        the bottom of its range, where elements lose bits (synchronises).  With reset, the exponents of those tensors
+        are lowered / raised so that the following batches fit; the caller re-submits the batches it had in flight."""
         rg = self._h2_ranges
         if rg is None:
             return False
         bits = rg.read()
         bad, _ = rg.saturated(bits)
-        if bad and reset:
-            try:
-                rg.lower([n for n in bad if bits[n] < rg.NONFINITE], bits)
-            except E.FP16RangeExhausted:
-                pass                             # the batches that follow meet it again; predict() then takes bf16x6
+        plan = None if bad else rg.quiet(bits)
+        if (bad or plan) and reset:
+            self._pipe_drain()
+            if plan:
+                rg.raise_(plan)
+            else:
+                try:
+                    rg.lower([n for n in bad if bits[n] < rg.NONFINITE], bits)
+                except E.FP16RangeExhausted:
+                    pass                         # the batches that follow meet it again; predict() then takes bf16x6
             rg.reset_words()
             self._pipe_mark_stale()
-        return bool(bad)
+        return bool(bad or plan)
 
     def h2_headroom(self):
         """{activation tensor: factor between its fp16 range and the largest magnitude seen} ("f16x3" mode)"""
@@ -374,8 +409,9 @@ class Reconstructor(nn.Module):
     def _require_eval(self, what):
         if self.training:
             raise NotImplementedError(
-                f"{what} in training mode (batch-statistics BatchNorm + backward kernels, SURVEY.md §8 "
-                "row f2) is not implemented on the HIP path; call .eval() first")
+                f"{what}() is an eval-mode entry point (running-statistics BatchNorm, as in the reference's predict.py); "
+                "call .eval() first.  Training runs through forward(): net.train(); net(x) gives outputs that carry the "
+                "HIP backward pass (sfh_amd.training)")
 
     def _needs_resize(self, x):
         """True when forward_unet has to resize its input or output (models/reconstructor.py:134-156)."""
@@ -598,12 +634,16 @@ class Reconstructor(nn.Module):
             p["copy"].wait_event(h.done)
             bits = rg.read()            # synchronises the copy stream only: the next batch's UNet keeps running
         bad, nonfinite = rg.saturated(bits)
-        if not bad:
+        plan = None if bad else rg.quiet(bits)
+        if not bad and not plan:
             return True
         # drain, fix the exponents, and let every batch in flight (this one included) be recomputed synchronously
         torch.cuda.synchronize(p["device"])
         rg.reset_words()
-        if not nonfinite:
+        if plan:
+            rg.raise_(plan)
+            self.range_raises += 1
+        elif not nonfinite:
             try:
                 rg.lower(bad, bits)
                 self.range_rescales += 1

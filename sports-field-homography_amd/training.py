@@ -662,7 +662,8 @@ class ResNetTrainer:
         if tape.fmt is not None and cs == 8 and w0.shape[0] == 64 and os.environ.get("SFH_TRAIN_STEM7", "1") != "0":
             # the tap-packed stem kernel of the inference path (csrc/stem.hip: 0.16 ms against 0.63 ms for the 4x4 fp32 conv
             # over the space-to-depth copy), in the tape's arithmetic, writing the raw conv output z
-            E.StemConv(rn.conv0, None, cin, tag="train_fwd", fmt=tape.fmt, overflow=tape.overflow).run(stn_in, B, H, W, z0)
+            E.StemConv(rn.conv0, None, cin, tag="train_fwd", fmt=tape.fmt, overflow=tape.overflow,
+                       wexp=tape.wexp_of(rn.conv0.weight)).run(stn_in, B, H, W, z0)
         else:
             pc = PackedConv(w0, None, None, 4, 4 * cs, relu=False, stem_cin=cin, tag="train_fwd")
             pc.run(s2d, B, H2, W2, z0)

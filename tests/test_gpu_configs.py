@@ -11,7 +11,7 @@ restatement oracle/warp_ref.py, see its header for the pin status):
   reference's own fp32 run has against fp64; and the forward pass + losses + BatchNorm running statistics at the
   stated batch of 16 (batch-statistics BatchNorm depends on it) against the reference classes' fp32 run.
 
-Measured figures are appended to gpurun_out/parity_r04.jsonl when that directory exists (they are quoted
+Measured figures are appended to gpurun_out/parity_r05.jsonl when that directory exists (they are quoted
 in DESIGN.md).
 """
 import json
@@ -43,7 +43,7 @@ def _record(tag, **kw):
     out = os.path.join(os.path.dirname(HERE), "gpurun_out")
     print(tag, json.dumps({k: v for k, v in kw.items() if k != "table"}))
     if os.path.isdir(out):
-        with open(os.path.join(out, "parity_r04.jsonl"), "a") as f:
+        with open(os.path.join(out, "parity_r05.jsonl"), "a") as f:
             f.write(json.dumps(dict(case=tag, **kw)) + "\n")
 
 
@@ -151,6 +151,60 @@ def test_c2_640x360_batch16_golden(precision):
     torch.cuda.synchronize()
     assert out["warp_mask"].dtype == torch.int32 and tuple(out["warp_mask"].shape) == (16, 360, 640)
     _check_predict(f"C2 640x360 B=16 {precision}", out, g, court, (640, 360), 16)
+
+
+@pytest.mark.parametrize("precision", ["f16x3", "bf16x6"])
+def test_c2d_predict_py_default_geometry_unet640x360_warp1280x720(precision):
+    """predict.py's DEFAULT geometry at full size (round 5): `court_size` / `warp_size` are raised to out_size = 1280x720
+    while the UNet stays at 640x360 (predict.py:151-155), so `warp_mask` is (16, 720, 1280) and the consistency CE reads
+    it through a nearest resize to the logits' size (models/reconstructor.py:226-240).  Golden from the reference's classes
+    (oracle/make_fixtures.py --configs c2d; logits / theta are those of the C2 vector): theta, the 1280x720 warp mask,
+    the consistency score through the resized mask, POI; all of C2's logit checks as well."""
+    from oracle import torch_ref
+    from sfh_amd.reconstructor import Reconstructor
+    g2 = np.load(os.path.join(GOLD, "c2_640x360_b16.npz"))
+    g = np.load(os.path.join(GOLD, "c2d_unet640x360_warp1280x720_b16.npz"))
+    B, W, H, WW, WH = 16, 640, 360, 1280, 720
+    court = synth.load_court_template("ncaa_nc4_1280x720", 4, B)
+    poi = synth.load_court_poi("pitch", B)
+    net = Reconstructor(court.cuda(), poi.cuda(), target_size=(W, H), unet_size=(W, H), warp_size=(WW, WH), warp_with_nearest=True)
+    net.precision = precision
+    net.load_state_dict(synth.synth_state_dict(net.state_dict(), 0))
+    net.cuda().eval()
+    x = synth.frames_to_float(synth.synth_frames_u8(B, H, W, seed=0))
+    with torch.no_grad():
+        out = net.predict(x.cuda(), consistency=True, project_poi=True)
+        piped = net.predict_async(x.cuda(), consistency=True, project_poi=True).result()
+    torch.cuda.synchronize()
+    assert out["warp_mask"].dtype == torch.int32 and tuple(out["warp_mask"].shape) == (B, WH, WW)
+    assert tuple(out["logits"].shape) == (B, 4, H, W) and tuple(out["consist_score"].shape) == (B,)
+    assert all(torch.equal(piped[k], out[k]) for k in out)
+    theta, logits = out["theta"].cpu(), out["logits"].cpu()
+    dtheta = float((theta - torch.from_numpy(g["theta"])).abs().max())
+    dpoi = float((out["poi"].cpu() - torch.from_numpy(g["poi"])).abs().max())
+    dblock, drow, dcol = _coverage_errors(logits, g2, B)
+    assert dtheta < 1e-4 and dpoi < 1e-4 and dblock < BLOCKSUM_TOL and drow < 5e-4 and dcol < 5e-4
+    # the 1280x720 nearest warp of the GPU's OWN theta: exact on every pixel; against the golden theta's mask: moves only
+    # with the 1e-7-level theta difference
+    wm = out["warp_mask"].cpu()
+    want = (warp_ref.homography_warp(theta, court, WH, WW, "nearest") * 4).to(torch.int32)
+    nexact = int((wm != want).sum())
+    assert nexact == 0, nexact
+    wm_ref = _unpack2(g["warp_mask_2bit"], (B, WH, WW))
+    warp_vs_golden = float((wm.numpy() != wm_ref).mean())
+    assert warp_vs_golden < 2e-3
+    # consistency through the nearest-resized mask: against the golden, and exactly the reference's formula on the GPU's
+    # own logits and mask (F.interpolate nearest + cross_entropy on the CPU)
+    dcons = float((out["consist_score"].cpu() - torch.from_numpy(g["consist"])).abs().max())
+    assert dcons < 2e-3 + 20.0 * warp_vs_golden, (dcons, warp_vs_golden)
+    m = torch.nn.functional.interpolate(wm.float().unsqueeze(1), size=(H, W), mode="nearest").squeeze(1).long()
+    own = torch.nn.functional.cross_entropy(logits, m, reduction="none").mean(dim=(1, 2))
+    down = float((out["consist_score"].cpu() - own).abs().max())
+    assert down < 2e-5, down
+    assert net.range_fallbacks == 0 and net.range_rescales == 0 and net.range_raises == 0
+    _record(f"C2d unet 640x360 warp 1280x720 B=16 {precision}", frames=B, max_abs_dtheta=dtheta, max_abs_dpoi=dpoi,
+            max_abs_dblocksum8=dblock, max_abs_dconsist=dcons, max_abs_dconsist_vs_torch_on_own_outputs=down,
+            warp_mismatch_vs_oracle_of_gpu_theta=nexact, warp_mismatch_frac_vs_golden_theta=warp_vs_golden)
 
 
 @pytest.mark.parametrize("precision", ["f16x3", "bf16x6"])

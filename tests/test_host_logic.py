@@ -23,6 +23,7 @@ class _Ranges:
     def __init__(self, reads):
         self.reads = [dict(r) for r in reads]
         self.lowered = []
+        self.raised = []
         self.zeroed = 0
 
     def read(self):
@@ -35,6 +36,14 @@ class _Ranges:
     def lower(self, bad, bits):
         self.lowered.extend(bad)
         return set(bad)
+
+    def quiet(self, bits):
+        """names whose word is an ordinary float below 4.0 (the scripted reads use tiny integers for "fine")"""
+        return {n: 24 for n, b in bits.items() if 0x30000000 <= b < 0x40800000}
+
+    def raise_(self, plan):
+        self.raised.extend(sorted(plan))
+        return set(plan)
 
     def reset_words(self):
         self.zeroed += 1
@@ -127,6 +136,104 @@ def test_range_guard_lowers_the_exponent_and_resumes_from_the_layer():
     calls.clear()
     net.predict(x)
     assert [c[0] for c in calls] == ["unet", "stn", "tail"] and net.range_rescales == 2
+
+
+QUIET = 0x3A800000                    # bit pattern of 2^-10: far below the 4.0 under which a tensor counts as quiet
+
+
+def test_range_guard_raises_the_exponent_of_a_quiet_tensor_and_resumes_from_the_layer():
+    """The other direction (round 5): a tensor whose largest stored element sits at the bottom of the fp16 range loses
+    bits in its low plane without saturating anything.  Its exponent goes UP and the pass resumes at the launch that
+    writes it, exactly like after a saturation; a saturated tensor in the same read-back wins (one decision per pass)."""
+    x = torch.empty((16, 3, 720, 1280))
+    net, calls = _net((1280, 720))
+    net.precision = "f16x3"
+    net._h2_ranges = rg = _Ranges([{"down2.mid": QUIET, "inc.out": 5}, {"rn.layer3.0.out": QUIET, "down2.mid": 0x45800000}, {}])
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        out = net.predict(x)
+    assert [c[0] + ("" if c[4] is None else f"@{c[4]}") for c in calls] == [
+        "unet", "stn", "tail", "unet@5", "stn", "tail", "stn@7", "tail"]
+    assert rg.raised == ["down2.mid", "rn.layer3.0.out"] and rg.lowered == [] and rg.zeroed == 2
+    assert net.range_raises == 2 and net.range_rescales == 0 and net.range_fallbacks == 0 and out["theta"].shape[0] == 16
+    # saturated and quiet tensors in one read-back: the saturated one is handled first, the quiet one in the next round
+    net._h2_ranges = rg = _Ranges([{"down2.mid": BIG, "inc.out": QUIET}, {"inc.out": QUIET}, {}])
+    calls.clear()
+    net.predict(x)
+    assert rg.lowered == ["down2.mid"] and rg.raised == ["inc.out"]
+    assert [c[0] + ("" if c[4] is None else f"@{c[4]}") for c in calls] == [
+        "unet", "stn", "tail", "unet@5", "stn", "tail", "unet@1", "stn", "tail"]
+    # guard off: range_overflowed() reports and fixes quiet tensors too
+    net.range_guard = False
+    net._h2_ranges = rg = _Ranges([{"inc.out": QUIET}, {}])
+    calls.clear()
+    net.predict(x)
+    assert [c[0] for c in calls] == ["unet", "stn", "tail"]
+    assert net.range_overflowed() is True and rg.raised == ["inc.out"] and rg.zeroed == 1 and net.range_overflowed() is False
+
+
+def test_h2_ranges_raise_quiet_keys():
+    """engine.H2Ranges.quiet / raise_: a key whose written tensors all peak below 4.0 in stored units goes to
+    [2^12, 2^13); unwritten words say nothing; `lower`'s exponent is a ceiling until the weights change."""
+    import numpy as np
+    from sfh_amd import engine as E
+    rg = E.H2Ranges(torch.device("cpu"), capacity=8)
+    rg.register("inc.out")
+    rg.register("inc.pool", key="inc.out", word_of="inc.out")
+    rg.register("up4.up", key="inc.out")
+    rg.register("down1.mid")
+    rg.register("down1.out")
+    rg.register("frame")
+    w = rg.words.numpy().view("uint32")
+
+    def put(name, u):
+        w[rg.slot[name][1]] = np.float32(u).view("uint32")
+    # |v| peaks at 2^-12 in down1.mid: stored 2^-10 at the default exponent 2 -> e = 24 puts it at 2^12
+    put("down1.mid", 2.0 ** -10)
+    # a key with two written tensors: the larger one decides, and it is not quiet (stored 40 >= 4)
+    put("inc.out", 0.5)
+    put("up4.up", 40.0)
+    # the frame of an ordinary video: peak 1.0 = stored 4.0, exactly at the boundary: left alone
+    put("frame", 4.0)
+    bits = rg.read()
+    assert rg.saturated(bits) == ([], False)
+    plan = rg.quiet(bits)
+    assert plan == {"down1.mid": 24}
+    assert rg.raise_(plan) == {"down1.mid"} and rg.exp("down1.mid") == 24 and rg.exp("down1.out") == 2
+    assert 2.0 ** 12 <= 2.0 ** -12 * 2.0 ** rg.exp("down1.mid") < 2.0 ** 13
+    # the words of the repeated pass: nothing quiet any more (down1.out, never written, is not a reason to act)
+    rg.reset_words()
+    put("down1.mid", 2.0 ** 12)
+    put("inc.out", 0.5)
+    put("up4.up", 40.0)
+    assert rg.quiet(rg.read()) == {}
+    # both tensors of a key quiet: raised from the LARGER of the two, once
+    rg.reset_words()
+    put("inc.out", 2.0 ** -4)           # |v| = 2^-6
+    put("up4.up", 2.0 ** -7)
+    plan = rg.quiet(rg.read())
+    assert plan == {"inc.out": 18} and 2.0 ** 12 <= 2.0 ** -6 * 2.0 ** 18 < 2.0 ** 13
+    rg.raise_(plan)
+    assert rg.exp("inc.pool") == rg.exp("up4.up") == 18
+    # hysteresis: a key that a saturation brought down is not raised beyond that exponent in this weights generation
+    rg.reset_words()
+    put("inc.out", 1.0e5)               # |v| = 1e5 * 2^-18 = 0.38: saturated at e = 18
+    bits = rg.read()
+    bad, _ = rg.saturated(bits)
+    rg.lower(bad, bits)
+    e = rg.exp("inc.out")
+    assert e == 14 and rg.ceiling["inc.out"] == 14
+    rg.reset_words()
+    put("inc.out", 2.0 ** -3)           # a very quiet batch afterwards
+    assert rg.quiet(rg.read()) == {}    # would be 28, capped by the ceiling 14 = no change
+    rg.new_generation()                 # new weights: the ceiling belongs to the old ones
+    assert int(rg.words.abs().sum()) == 0 and rg.exp("inc.out") == 14
+    put("inc.out", 2.0 ** -3)
+    assert rg.quiet(rg.read()) == {"inc.out": 14 + 15}
+    # tiny tensors stop at MAX_EXP; an all-zero tensor (word 0) is left alone
+    rg.reset_words()
+    put("down1.out", 2.0 ** -120)
+    assert rg.quiet(rg.read()) == {"down1.out": rg.MAX_EXP}
 
 
 def test_range_guard_reruns_a_non_finite_batch_in_bf16x6_and_rechunks():
