@@ -69,6 +69,139 @@ def pmc_traffic(tag):
         return None, None
 
 
+class PowerSampler:
+    """Socket power of one GPU while a region runs: a thread reads the amdgpu hwmon file (micro-watts; a plain file read,
+    no subprocess) every `period` seconds.  None everywhere if the box exposes no such file for this device."""
+
+    def __init__(self, pci_bus_id=None, period=0.02):
+        import glob
+        self.path, self.samples, self.period, self._stop, self._thr = None, [], period, False, None
+        cands = []
+        for hw in sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*")):
+            for name in ("power1_average", "power1_input"):
+                f = os.path.join(hw, name)
+                if os.path.exists(f):
+                    cands.append((os.path.realpath(os.path.join(hw, "..", "..")), f))
+                    break
+        if pci_bus_id is not None:
+            want = str(pci_bus_id).lower()
+            cands = [c for c in cands if os.path.basename(c[0]).lower().endswith(want)] or cands[:0]
+        if len(cands) >= 1:
+            self.path = cands[0][1]
+
+    def _read(self):
+        try:
+            return int(open(self.path).read().strip()) * 1e-6
+        except (OSError, ValueError):
+            return None
+
+    def __enter__(self):
+        if self.path is None:
+            return self
+        import threading
+
+        def loop():
+            while not self._stop:
+                v = self._read()
+                if v is not None:
+                    self.samples.append(v)
+                time.sleep(self.period)
+        self._thr = threading.Thread(target=loop, daemon=True)
+        self._thr.start()
+        return self
+
+    def __exit__(self, *exc):
+        self._stop = True
+        if self._thr is not None:
+            self._thr.join(timeout=1.0)
+        return False
+
+    def summary(self):
+        if not self.samples:
+            return None
+        v = sorted(self.samples)
+        return {"samples": len(v), "mean_w": round(sum(v) / len(v), 1), "max_w": round(v[-1], 1), "min_w": round(v[0], 1),
+                "source": self.path}
+
+
+def device_calibration(dev, ms_target=30.0):
+    """What THIS device sustains, so that lines from different devices of the pool compare (they differ by up to 4 % in the
+    clock they hold under an MFMA-dense load): a register-resident v_mfma_f32_16x16x32_f16 loop over every CU for about
+    `ms_target` ms (sfh_probe_mfma_f16: random fp16 mantissas, two workgroups per CU, four rounds) -> TFLOP/s of fp16 MFMA
+    work, the clock the chip held INSIDE the kernel (s_memtime / s_memrealtime) and the socket power while it ran."""
+    import ctypes
+    import torch
+    from sfh_amd import _lib
+    lib = _lib.load()
+    props = torch.cuda.get_device_properties(dev)
+    wgs = 2 * 4 * int(props.multi_processor_count)
+    out = torch.empty(wgs * 256, dtype=torch.float32, device=dev)
+    clk = torch.zeros(2, dtype=torch.int64, device=dev)
+    st = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    p = lambda t: ctypes.c_void_p(t.data_ptr())
+
+    def run(iters):
+        clk.zero_()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        _lib.check(lib.sfh_probe_mfma_f16(int(iters), wgs, p(out), p(clk), st), "probe_mfma_f16")
+        e1.record()
+        e1.synchronize()
+        return e0.elapsed_time(e1)
+    ms = run(300)                                   # warm-up, and the rate to size the timed launch from
+    iters = max(300, min(1 << 18, int(300 * ms_target / max(ms, 1e-3))))
+    bus = None
+    try:
+        bus = "%04x:%02x:%02x.0" % (props.pci_domain_id, props.pci_bus_id, props.pci_device_id)
+    except AttributeError:
+        pass
+    with PowerSampler(bus, period=0.004) as ps:
+        ms = run(iters)
+    c = clk.cpu().tolist()
+    flops = wgs * 4.0 * iters * 64 * 2 * 16 * 16 * 32
+    return {"kernel": "register-resident v_mfma_f32_16x16x32_f16 loop, random fp16 mantissas, %d workgroups of 4 waves" % wgs,
+            "ms": round(ms, 3), "mfma_f16_tflops": round(flops / (ms * 1e-3) / 1e12, 1),
+            "frac_of_2500": round(flops / (ms * 1e-3) / 1e12 / BF16_MFMA_PEAK_TFLOPS, 4),
+            "in_kernel_clock_ghz": round(0.1 * c[0] / c[1], 3) if c[1] else None,
+            "power": ps.summary(), "device": props.name, "compute_units": int(props.multi_processor_count),
+            "pci": bus}
+
+
+def c2_parity(net, dev):
+    """The headline workload's parity figures IN the bench line (N = 1, 640x360, batch 16): predict() on the seed-0 batch
+    against the golden vector of the reference's own classes (tests/golden/c2_640x360_b16.npz, data only): arg-max pixels
+    that differ and the largest golden top-2 margin among them, max |d theta|, sub-sampled logits."""
+    import numpy as np
+    import torch
+    from sfh_amd import synth
+    path = os.path.join(ROOT, "tests", "golden", "c2_640x360_b16.npz")
+    if not os.path.exists(path):
+        return None
+    g = np.load(path)
+    B, H, W = 16, 360, 640
+    x = synth.frames_to_float(synth.synth_frames_u8(B, H, W, seed=0)).to(dev)
+    with torch.no_grad():
+        out = net.predict(x, consistency=True, project_poi=True)
+    logits = out["logits"].cpu()
+    am = logits.argmax(1).numpy().astype(np.uint8)
+    bits = np.unpackbits(g["argmax_2bit"], axis=-1).reshape(B, H, W, 2)
+    am_ref = (bits[..., 0] * 2 + bits[..., 1]).astype(np.uint8)
+    diff = np.argwhere(am != am_ref)
+    margin = np.full((B, H * W), np.inf, np.float32)
+    margin[g["low_margin_frame"], g["low_margin_pixel"]] = g["low_margin_value"]
+    margin = margin.reshape(B, H, W)
+    dm = margin[diff[:, 0], diff[:, 1], diff[:, 2]] if len(diff) else np.zeros(0, np.float32)
+    return {"against": "tests/golden/c2_640x360_b16.npz (the reference's own UNet / ResNetSTN classes on torch CPU fp32, 16 frames)",
+            "argmax_pixels": int(B * H * W), "argmax_differ": int(len(diff)),
+            "largest_golden_top2_margin_among_differing": float(dm.max()) if len(diff) else 0.0,
+            "max_abs_dtheta": float((out["theta"].cpu() - torch.from_numpy(g["theta"])).abs().max()),
+            "max_abs_dlogits_every_16th_pixel": float((logits[:, :, 4::16, 4::16] - torch.from_numpy(g["logits_sub"])).abs().max()),
+            "max_abs_dpoi": float((out["poi"].cpu() - torch.from_numpy(g["poi"])).abs().max()),
+            "max_abs_dconsist": float((out["consist_score"].cpu() - torch.from_numpy(g["consist"])).abs().max()),
+            "note": "north_star asks for bit-exact arg-max: met up to summation order - every differing pixel is a near-tie of "
+                    "the golden logits (margin above), the fp32-MFMA mode flips the same pixels (DESIGN.md section 5)"}
+
+
 def self_launch(n):
     """`python bench.py --gpus N` without a launcher: start N ranks (one process per GPU) through
     torch.distributed.run as a CHILD process and relay its output.  This process never touches the GPU
@@ -245,6 +378,20 @@ def extra_configs(args):
                                  "consistency=True) -> uint8 arg-max mask + uint8 warp mask + theta + score -> D2H (pinned), two batches "
                                  "in flight (sfh_amd.pipeline.FramePipeline; predict.py:57-122)")
                                 % (src[0], src[1], "" if src == (W, H) else " + 3x3 INTER_AREA downscale on the GPU")}
+    # predict.py's default geometry (predict.py:151-155): UNet at 640x360, court / warp raised to out_size 1280x720, the
+    # consistency CE through the nearest-resized mask, 33-point POI
+    court_hd = synth.load_court_template("ncaa_nc4_1280x720", 4, B).to(dev)
+    net_d = Reconstructor(court_hd, poi, target_size=(W, H), unet_size=(W, H), warp_size=(2 * W, 2 * H), warp_with_nearest=True)
+    net_d.load_state_dict(synth.synth_state_dict(net_d.state_dict(), 0))
+    net_d.to(dev).eval()
+    n = 6
+    el = _timed_predicts(net_d, x, n, 2, not args.no_pipeline, consistency=True, project_poi=True)
+    res["C2d_unet640x360_warp1280x720_batch16"] = {
+        "value": round(B * n / el, 2), "unit": "frames/s", "ms_per_step": round(el / n * 1e3, 3), "steps": n, "warmup": 2,
+        "workload": "predict.py's default geometry: predict(consistency=True, project_poi=True), UNet 640x360, court / warp 1280x720 "
+                    "(NCAA template resized NEAREST), consistency through the nearest-resized warp mask, batch 16"}
+    del net_d, court_hd
+    torch.cuda.empty_cache()
     for prec in ("bf16x6", "fp32"):
         net.precision = prec
         n = 4
@@ -306,7 +453,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=16,
                     help="frames of the same workload timed on the host cores for cpu_baseline (about 10 s)")
-    ap.add_argument("--consistency", action="store_true", help="also compute consist_score + poi")
+    ap.add_argument("--consistency", action="store_true",
+                    help="also compute consist_score + poi (N > 1 always computes consist_score: BASELINE config 4 gathers it)")
     ap.add_argument("--train", action="store_true",
                     help="BASELINE config 3 instead of the headline: one training step (forward, losses, "
                          "backward, clip, RMSprop) per batch; prints its own JSON line")
@@ -365,6 +513,8 @@ def main():
             dist.init_process_group(backend="gloo")
 
     B, W, H = args.batch, args.width, args.height
+    # BASELINE config 4 (N > 1) names theta + consistency: the sharded run computes the score that its gather carries
+    cons = bool(args.consistency or world > 1)
     tmpl_name = "ncaa_nc4_640x360" if (W, H) == (640, 360) else "pitch_v3_nc4_1280x720"
     court = synth.load_court_template(tmpl_name, 4, B).to(dev)
     if tuple(court.shape[2:]) != (H, W):
@@ -401,15 +551,17 @@ def main():
         that the small launches behind the UNet (ResNet-STN, warp, CE) run under the next batch's UNet; `last` drains."""
         x = frames[k % nbatches]
         if args.no_pipeline:
-            out = net.predict(x, consistency=args.consistency, project_poi=args.consistency)
+            out = net.predict(x, consistency=cons, project_poi=args.consistency)
             exchange(out)
             return out
-        pending.append(net.predict_async(x, consistency=args.consistency, project_poi=args.consistency))
+        pending.append(net.predict_async(x, consistency=cons, project_poi=args.consistency))
         out = None
         while len(pending) > (0 if last else 1):
             out = finish(pending.pop(0))
         return out
 
+    calib = device_calibration(dev) if on_gpu else None
+    bus = calib.get("pci") if calib else None
     with torch.no_grad():
         for k in range(args.warmup):
             step(k, last=(k == args.warmup - 1))
@@ -422,13 +574,19 @@ def main():
         will_time_alone = not args.no_pipeline and not args.no_alone_pass
         timer = engine.ConvTimer(only={"doubleconv3x3"} if will_time_alone else None)
         engine.PackedConv.timer = timer
+        power = PowerSampler(bus) if on_gpu else None
         t0 = time.perf_counter()
+        if power is not None:
+            power.__enter__()
         for k in range(args.steps):
             out = step(k, last=(k == args.steps - 1))      # the K-th call drains the pipeline: exactly K batches are timed
         sync()
+        own_elapsed = time.perf_counter() - t0             # this rank's own K steps (before it waits for the others)
         if world > 1:
             dist.barrier()
         elapsed = time.perf_counter() - t0
+        if power is not None:
+            power.__exit__()
         engine.PackedConv.timer = None
 
     # the exchange step, checked once outside the timed region: every rank holds world * B gathered rows, and its own
@@ -448,19 +606,38 @@ def main():
     alone = None
     if not args.no_pipeline and not args.no_alone_pass:
         with torch.no_grad():
-            tm2 = engine.ConvTimer()
-            engine.PackedConv.timer = tm2
+            # (a) the drop-in predict() rate: no event timers in this pass (two records per launch on 59 launches cost 0.2 ms)
             t1 = time.perf_counter()
             for k in range(args.steps):
-                net.predict(frames[k % nbatches], consistency=args.consistency, project_poi=args.consistency)
+                net.predict(frames[k % nbatches], consistency=cons, project_poi=args.consistency)
             sync()
             el2 = time.perf_counter() - t1
+            # (b) the same steps with every launch timed: per-kernel durations alone on the chip
+            tm2 = engine.ConvTimer()
+            engine.PackedConv.timer = tm2
+            for k in range(args.steps):
+                net.predict(frames[k % nbatches], consistency=cons, project_poi=args.consistency)
+            sync()
             engine.PackedConv.timer = None
         alone = (tm2.summary(), el2)
     el = torch.tensor([elapsed], device=dev, dtype=torch.float64)
     if world > 1:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
     elapsed = el.item()
+    # per-rank figures: each rank's own step time and what its device sustains - a 4 % spread between the pool's devices
+    # would otherwise read as a scaling loss (value = all frames / the SLOWEST rank's time)
+    mine = {"rank": rank, "ms_per_step": round(own_elapsed / args.steps * 1e3, 3),
+            "device": calib["device"] if calib else str(dev),
+            "mfma_f16_tflops": calib["mfma_f16_tflops"] if calib else None,
+            "in_kernel_clock_ghz": calib["in_kernel_clock_ghz"] if calib else None,
+            "power_w_timed_region": (power.summary() or {}).get("mean_w") if power is not None else None}
+    ranks = [mine]
+    if world > 1:
+        ranks = [None] * world
+        dist.all_gather_object(ranks, mine)
+    rms = sorted(r["ms_per_step"] for r in ranks)
+    per_rank = {"ms_per_step_min": rms[0], "ms_per_step_median": rms[len(rms) // 2] if len(rms) % 2 else
+                round(0.5 * (rms[len(rms) // 2 - 1] + rms[len(rms) // 2]), 3), "ms_per_step_max": rms[-1], "ranks": ranks}
     frames_total = B * args.steps * world
     fps = frames_total / elapsed
 
@@ -483,6 +660,12 @@ def main():
                                if x6 else "157.3 TFLOP/s dense fp32 MFMA (v_mfma_f32_16x16x4_f32)"),
                 "kernel": ((f"conv_s3_kernel<3x3, {'2 fp16' if prec == 'f16x3' else '3 bf16'} planes> (DoubleConv, split operands)")
                            if x6 else "conv_mfma_kernel<3x3,s1> (DoubleConv)"),
+                # algorithmic FLOPs / time against the dense MFMA peak of the dtype the launches execute in (no
+                # division by the products per element): `frac` is the executed-work figure (matrix-pipe utilisation)
+                "frac_algorithmic": round(achieved / (BF16_MFMA_PEAK_TFLOPS if x6 else FP32_MFMA_PEAK_TFLOPS), 4),
+                "frac_meaning": ("frac = executed %s MFMA work / 2500 TFLOP/s (= achieved x %d / 2500: what north_star calls MFMA "
+                                 "utilisation); frac_algorithmic = achieved / 2500 (SURVEY 8d's definition)" % (half, nprod)) if x6 else
+                                "fp32 MFMA: executed = algorithmic work",
                 "launches": n,
                 "avg_launch_ms": round(ms / max(n, 1), 4),
                 "algorithmic_gflop_per_launch": round(fl / max(n, 1) / 1e9, 2),
@@ -524,19 +707,20 @@ def main():
         ncpu = min(usable_cores(), int(os.environ.get("SFH_CPU_THREADS", "64")))
         torch.set_num_threads(ncpu)
         nf = min(args.cpu_frames, B)
-        xc = frames[0][:nf].cpu()
         sd_cpu = {k: v.cpu() for k, v in sd.items()}
         court_c, poi_c = court.cpu(), poi.cpu()
+        samples, dth = [], 0.0
         with torch.no_grad():
-            torch_ref.predict(xc[:1], sd_cpu, court_c, poi_c, warp_size=(W, H), unet_size=(W, H),
+            torch_ref.predict(frames[0][:1].cpu(), sd_cpu, court_c, poi_c, warp_size=(W, H), unet_size=(W, H),
                               target_size=(W, H), consistency=False)  # warm-up (1 frame)
-            t0 = time.perf_counter()
-            ref = torch_ref.predict(xc, sd_cpu, court_c, poi_c, warp_size=(W, H), unet_size=(W, H),
-                                    target_size=(W, H), consistency=False)
-            cpu_s = time.perf_counter() - t0
-        with torch.no_grad():
-            got = net.predict(frames[0][:nf], consistency=False)
-        dth = (got["theta"].cpu() - ref["theta"]).abs().max().item()
+            for k in range(min(2, nbatches)):       # two different batches, reported separately and together
+                xc = frames[k][:nf].cpu()
+                t0 = time.perf_counter()
+                ref = torch_ref.predict(xc, sd_cpu, court_c, poi_c, warp_size=(W, H), unet_size=(W, H),
+                                        target_size=(W, H), consistency=False)
+                samples.append(time.perf_counter() - t0)
+                got = net.predict(frames[k][:nf], consistency=False)
+                dth = max(dth, (got["theta"].cpu() - ref["theta"]).abs().max().item())
         model = ""
         try:
             for line in open("/proc/cpuinfo"):
@@ -545,13 +729,17 @@ def main():
                     break
         except OSError:
             pass
-        cpu_baseline = {"value": round(nf / cpu_s, 4), "unit": "frames/s", "cores": ncpu, "kind": "port",
-                        "sample": f"{nf} frames of the same {W}x{H} workload, 1 warm-up frame, "
+        cpu_baseline = {"value": round(nf * len(samples) / sum(samples), 4), "unit": "frames/s", "cores": ncpu, "kind": "port",
+                        "sample": f"{len(samples)} batches of {nf} frames of the same {W}x{H} workload, 1 warm-up frame, "
                                   f"torch {torch.__version__} CPU fp32, {ncpu} threads, {model}",
+                        "per_batch_frames_per_s": [round(nf / t, 4) for t in samples],
                         "max_abs_dtheta_gpu_vs_cpu": dth}
 
     # the other single-GPU BASELINE configs, a few steps each, AFTER the headline region (N = 1 only): the
     # headline fields above are not touched by them
+    parity = None
+    if rank == 0 and world == 1 and on_gpu and (W, H, B) == (640, 360, 16) and prec in ("f16x3", "bf16x6", "fp32"):
+        parity = c2_parity(net, dev)
     other_configs = None
     if rank == 0 and world == 1 and not args.no_extra_configs and (W, H, B) == (640, 360, 16):
         del frames, out
@@ -574,13 +762,14 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"predict(): UNet seg + ResNet34-STN + nearest warp, {W}x{H}, "
                                    f"batch {B}/GPU, req_outputs=theta,warp_mask"
-                                   + (",consistency,poi" if args.consistency else ""),
+                                   + (",consistency,poi" if args.consistency else ",consistency" if cons else ""),
                        "frames_per_gpu_per_step": B, "global_batch": B * world,
                        "pipeline": ("none: predict() per step" if args.no_pipeline else
                                     "predict_async(): two batches in flight, ResNet-STN + warp of batch k on a side stream under the UNet of batch k + 1"),
                        "precision": prec, "range_fallbacks": int(getattr(net, "range_fallbacks", 0)),
                        "range_rescales": int(getattr(net, "range_rescales", 0)),
-                       "parallelism": (f"frame-sharded x{world}, all_gather(theta) over "
+                       "range_raises": int(getattr(net, "range_raises", 0)),
+                       "parallelism": (f"frame-sharded x{world}, all_gather_into_tensor(theta + consist_score) over "
                                        + ("RCCL" if args.dist_backend == "nccl" else "gloo (REHEARSAL, ranks share a GPU)" if args.share_gpu else "gloo")
                                        if world > 1 else "single GPU")},
             "roofline": roofline,
@@ -588,6 +777,9 @@ def main():
                            "frac": round(whole_tf / peak, 4),
                            "note": "UNet + ResNet34-STN algorithmic FLOPs of a batch / ms_per_step, against the matrix peak of the mode"},
             "cpu_baseline": cpu_baseline,
+            "parity": parity,
+            "device_calibration": dict(calib, power_timed_region=(power.summary() if power is not None else None)) if calib else None,
+            "per_rank": per_rank,
             "gather_check": gather_check,
             "kernel_groups": other,
             "kernel_groups_measured_in": ("the unpipelined pass after the timed region (launches alone on the chip)"

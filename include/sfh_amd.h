@@ -525,6 +525,13 @@ int64_t sfh_packed_stem_weight_bytes(void);
 int sfh_pack_stem_weights(const float* w, void* packed, int cin, int fmt, int wexp, void* stream);   /* fmt: SFH_FMT_S3, or
     SFH_FMT_H2 (planes of w * 2^wexp; the caller folds 2^-(wexp + h2_exp_src) into the layer's scale) */
 
+/* Device calibration probe (bench.py `device_calibration`; not on the hot path): `workgroups` x 4 waves each run `iters` x 64
+ * register-resident v_mfma_f32_16x16x32_f16 (fp16 operands with random mantissas): executed FLOPs = workgroups * 4 * iters *
+ * 64 * 2 * 16 * 16 * 32.  out: workgroups * 256 floats (sink); clk: two 64-bit words zeroed by the caller - sums of the
+ * shader-clock cycles (s_memtime) and of the 100 MHz ticks (s_memrealtime) the sampled waves spent in the loop, so the clock
+ * the chip HELD inside the kernel is 100 MHz * clk[0] / clk[1].  The caller times the launch with events on `stream`. */
+int sfh_probe_mfma_f16(int iters, int workgroups, float* out, uint64_t* clk, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -131,6 +131,7 @@ SIGNATURES = {
     "sfh_maxpool3x3s2_fwd": (C.c_int, [_p, _p, C.c_int, C.c_int, C.c_int, C.c_int, _p]),
     "sfh_maxpool3x3s2_split_fwd": (C.c_int, [_p, _p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _p, _p, _p]),
     "sfh_avgpool_linear_fwd": (C.c_int, [_p, _p, _p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _p, _p, _p]),
+    "sfh_probe_mfma_f16": (C.c_int, [C.c_int, C.c_int, _p, _p, _p]),
 }
 
 _lib = None

@@ -10,7 +10,13 @@ output).  ``FramePipeline`` is the device part of that loop in ONE process with 
         --> uint8 arg-max mask, uint8 warp mask, theta, consistency score, POI --copy stream--> pinned host arrays
 
 Two slots alternate: while batch k computes, batch k + 1 uploads and batch k - 1 downloads.  Everything a batch needs
-on the host arrives in its own pinned buffers; ``get()`` waits for that batch's download event only.
+on the host arrives in its slot's pinned buffers; ``get()`` waits for that batch's download event only.
+
+Every batch has its own TICKET (slot, generation, its own upload / download events).  The order a caller must keep is
+checked, not assumed: ``submit`` refuses a slot whose previous batch was not collected; ``collect`` refuses to download
+into host buffers whose previous batch was never fetched with ``get``; ``get`` refuses a ticket whose host buffers have
+meanwhile been given to a later batch.  ``wait_uploaded(ticket)`` (or ``ticket.uploaded``) tells when the caller's host
+frame buffer has been read and may be refilled.
 
 Outputs and dtypes are those of predict.py:92-118 (``outputs.transfer_gpu_to_cpu`` is the synchronous version):
 ``segm_mask`` uint8 (B,H,W), ``warp_mask`` uint8 (B,H,W), ``theta`` float32 (B,1,3,3), ``consist_score`` float32 (B,),
@@ -21,6 +27,16 @@ import torch
 
 from . import engine as E
 from . import outputs as O
+
+
+class Ticket:
+    """one submitted batch: which slot it uses, its generation on that slot, its own events"""
+    __slots__ = ("slot", "gen", "uploaded", "downloaded", "handle", "dev", "fetched")
+
+    def __init__(self, slot, gen):
+        self.slot, self.gen = slot, gen
+        self.uploaded = self.downloaded = self.handle = self.dev = None
+        self.fetched = False
 
 
 class FramePipeline:
@@ -44,8 +60,10 @@ class FramePipeline:
         pin = lambda shape, dt: torch.empty(shape, dtype=dt).pin_memory()
         self.slots = []
         for _ in range(2):
+            # pending: the ticket submitted on this slot and not yet collected; collected: the ticket whose results the host
+            # buffers hold (or are receiving)
             s = {"u8": torch.empty((self.B, H, W, channels), dtype=torch.uint8, device=dev),
-                 "uploaded": None, "consumed": None, "downloaded": None, "handle": None, "host": {}, "dev": None}
+                 "consumed": None, "host": {}, "pending": None, "collected": None, "gen": 0}
             if "segm_mask" in self.req:
                 s["host"]["segm_mask"] = pin((self.B, net.target_size[1], net.target_size[0]), torch.uint8)
             if "warp_mask" in self.req and net.warper:
@@ -62,31 +80,46 @@ class FramePipeline:
 
     def submit(self, frames_u8_host):
         """frames_u8_host: uint8 (B,H,W,C) host tensor (pinned for a truly asynchronous upload).  Enqueues upload,
-        preprocessing and the forward pass of this batch and returns its ticket; nothing here waits for the GPU."""
+        preprocessing and the forward pass of this batch and returns its Ticket; nothing here waits for the GPU.  The host
+        buffer is read asynchronously: refill it only after wait_uploaded(ticket)."""
         s = self.slots[self.k % 2]
         self.k += 1
-        if s["handle"] is not None:
+        if s["pending"] is not None:
             raise RuntimeError("FramePipeline: collect() the batch submitted two calls ago before reusing its slot")
+        s["gen"] += 1
+        t = Ticket(s, s["gen"])
         cur = torch.cuda.current_stream(self.dev)
         with torch.cuda.stream(self.h2d):
             if s["consumed"] is not None:
                 self.h2d.wait_event(s["consumed"])       # the preprocessing kernel that read this buffer last is done
             s["u8"].copy_(frames_u8_host, non_blocking=True)
-            s["uploaded"] = torch.cuda.Event()
-            s["uploaded"].record(self.h2d)
-        cur.wait_event(s["uploaded"])
+            t.uploaded = torch.cuda.Event()
+            t.uploaded.record(self.h2d)
+        cur.wait_event(t.uploaded)
         x = E.frames_u8_to_input(s["u8"], self.target)
         s["consumed"] = torch.cuda.Event()
         s["consumed"].record(cur)
-        s["handle"] = self.net.predict_async(x, consistency=self.consistency, project_poi=self.poi)
-        return s
+        t.handle = self.net.predict_async(x, consistency=self.consistency, project_poi=self.poi)
+        s["pending"] = t
+        return t
+
+    def wait_uploaded(self, ticket):
+        """block until the host frame buffer given to submit() has been read: it may be refilled afterwards"""
+        ticket.uploaded.synchronize()
 
     def collect(self, ticket):
         """Enqueue post-processing and the download of a submitted batch (call it after submitting the NEXT batch, so
         that this batch's ResNet-STN / warp ran under that one's UNet).  Returns at once; get() waits."""
-        s = ticket
-        out = s["handle"].result()                       # orders the current stream behind the batch
-        s["handle"] = None
+        t, s = ticket, ticket.slot
+        if s["pending"] is not t:
+            raise RuntimeError("FramePipeline.collect: this ticket is not the batch pending on its slot (collected already, "
+                               "or from another pipeline)")
+        prev = s["collected"]
+        if prev is not None and not prev.fetched:
+            raise RuntimeError("FramePipeline.collect: the slot's host buffers still hold a batch that was never fetched with "
+                               "get(); this download would overwrite it")
+        out = t.handle.result()                          # orders the current stream behind the batch
+        t.handle = None
         cur = torch.cuda.current_stream(self.dev)
         devout = {}
         if "segm_mask" in s["host"]:
@@ -100,20 +133,28 @@ class FramePipeline:
         ready.record(cur)
         with torch.cuda.stream(self.d2h):
             self.d2h.wait_event(ready)
-            for k, t in devout.items():
-                s["host"][k].copy_(t, non_blocking=True)
-                t.record_stream(self.d2h)
-            s["downloaded"] = torch.cuda.Event()
-            s["downloaded"].record(self.d2h)
-        s["dev"] = devout
-        return s
+            for k, v in devout.items():
+                s["host"][k].copy_(v, non_blocking=True)
+                v.record_stream(self.d2h)
+            t.downloaded = torch.cuda.Event()
+            t.downloaded.record(self.d2h)
+        t.dev = devout
+        s["pending"], s["collected"] = None, t
+        return t
 
     def get(self, ticket):
-        """-> {name: numpy array} of a collected batch (views of the slot's pinned buffers: valid until the slot is
-        submitted again, copy what must live longer)."""
-        ticket["downloaded"].synchronize()
-        ticket["dev"] = None
-        return {k: v.numpy() for k, v in ticket["host"].items()}
+        """-> {name: numpy array} of a collected batch (views of the slot's pinned buffers: valid until the NEXT batch of this
+        slot is collected, copy what must live longer)."""
+        t, s = ticket, ticket.slot
+        if t.downloaded is None:
+            raise RuntimeError("FramePipeline.get: collect() this batch first")
+        if s["collected"] is not t:
+            raise RuntimeError(f"FramePipeline.get: the slot's host buffers now hold generation {s['collected'].gen}, this ticket "
+                               f"is generation {t.gen} - fetch a batch before the batch two submissions later is collected")
+        t.downloaded.synchronize()
+        t.dev = None
+        t.fetched = True
+        return {k: v.numpy() for k, v in s["host"].items()}
 
     def run(self, batches):
         """Generator over host uint8 batches -> result dicts (copies), two batches in flight."""

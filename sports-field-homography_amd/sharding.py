@@ -6,7 +6,9 @@ batch shards by frame with NO data-path collective: rank r of W processes frames
 needs on every rank / on rank 0: theta (9 floats) and consist_score (1 float) = 40 B per
 frame.  One process per GPU; backend "nccl" (= RCCL over xGMI) on GPUs, "gloo" in the CPU
 tests.  The payload is latency-bound (5 KB for 128 frames), so a single all_gather per batch
-is used - on the fully connected xGMI mesh RCCL resolves it in one hop.
+is used - ``all_gather_into_tensor`` on ONE (world * n, 10) receive buffer: with the list form RCCL gathers into a
+flat staging buffer and then copies every rank's rows out with a launch per rank; on the fully connected xGMI
+mesh the collective itself resolves in one hop.
 """
 import torch
 import torch.distributed as dist
@@ -47,9 +49,12 @@ def gather_results(theta, consist_score=None, group=None, n_max=None):
     n_max = max(counts)
     if n < n_max:
         rows = torch.cat([rows, rows.new_zeros((n_max - n, 10))], 0)
-    bufs = [torch.empty_like(rows) for _ in range(world)]
-    dist.all_gather(bufs, rows.contiguous(), group=group)
-    allrows = torch.cat([b[:c] for b, c in zip(bufs, counts)], 0)
+    buf = rows.new_empty((world * n_max, 10))
+    dist.all_gather_into_tensor(buf, rows.contiguous(), group=group)
+    if all(c == n_max for c in counts):
+        allrows = buf
+    else:
+        allrows = torch.cat([buf[r * n_max:r * n_max + c] for r, c in enumerate(counts)], 0)
     return allrows[:, :9].reshape(-1, 1, 3, 3), allrows[:, 9].clone()
 
 
@@ -70,8 +75,9 @@ class ResultGather:
         self.world, self.n, self.group = world, n, group
         self.cuda = device.type == "cuda"
         self.side = torch.cuda.Stream(device) if self.cuda else None
+        # one flat receive buffer per slot: rank r's rows land at [r * n, (r + 1) * n) - a single collective, no copy-out
         self.slots = [{"rows": torch.zeros((n, 10), dtype=torch.float32, device=device),
-                       "bufs": [torch.empty((n, 10), dtype=torch.float32, device=device) for _ in range(world)],
+                       "buf": torch.empty((world * n, 10), dtype=torch.float32, device=device),
                        "done": None} for _ in range(depth)]
         self.k = 0
 
@@ -87,16 +93,16 @@ class ResultGather:
         if consist_score is not None:
             slot["rows"][:, 9] = consist_score
         if self.world == 1 or not dist.is_initialized():
-            slot["bufs"][0].copy_(slot["rows"])
+            slot["buf"].copy_(slot["rows"])
             return slot
         if not self.cuda:
-            dist.all_gather(slot["bufs"], slot["rows"], group=self.group)
+            dist.all_gather_into_tensor(slot["buf"], slot["rows"], group=self.group)
             return slot
         ready = torch.cuda.Event()
         ready.record()
         with torch.cuda.stream(self.side):
             self.side.wait_event(ready)
-            dist.all_gather(slot["bufs"], slot["rows"], group=self.group)
+            dist.all_gather_into_tensor(slot["buf"], slot["rows"], group=self.group)
             slot["done"] = torch.cuda.Event()
             slot["done"].record()
         return slot
@@ -105,8 +111,8 @@ class ResultGather:
         """(theta_all (world*n,1,3,3), score_all (world*n,)) in rank order"""
         if self.cuda and slot["done"] is not None:
             torch.cuda.current_stream().wait_event(slot["done"])
-        rows = torch.cat(slot["bufs"], 0)
-        return rows[:, :9].reshape(-1, 1, 3, 3), rows[:, 9].clone()
+        rows = slot["buf"]
+        return rows[:, :9].reshape(-1, 1, 3, 3).clone(), rows[:, 9].clone()    # (copies: the slot is reused two steps later)
 
 
 def predict_sharded(net, frames, consistency=True, group=None):

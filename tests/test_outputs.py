@@ -165,3 +165,52 @@ def test_frame_pipeline_gives_predict_s_outputs(scale):
             for k in res:
                 assert res[k].dtype == want[k].dtype and np.array_equal(res[k], want[k]), k
             assert res["segm_mask"].dtype == np.uint8 and res["warp_mask"].dtype == np.uint8
+
+
+@pytest.mark.gpu
+def test_frame_pipeline_tickets_enforce_the_slot_order():
+    """Round 5 (review finding): a batch's ticket is its own object (slot, generation, own events).  The orders that would
+    silently hand out another batch's data raise instead: fetching a ticket whose host buffers were given to the batch two
+    submissions later, collecting into buffers whose batch was never fetched, reusing a slot that was not collected; and
+    wait_uploaded() says when the caller's pinned frame buffer may be refilled."""
+    from sfh_amd.pipeline import FramePipeline
+    from sfh_amd.reconstructor import Reconstructor
+    w, h, B = 112, 90, 2
+    court = synth.load_court_template("ncaa_nc4_640x360", 4, B)[:, :, :h, :w].contiguous()
+    poi = synth.load_court_poi("pitch", B)
+    net = Reconstructor(court.cuda(), poi.cuda(), target_size=(w, h), unet_size=(w, h), warp_size=(w, h), warp_with_nearest=True)
+    net.load_state_dict(synth.synth_state_dict(net.state_dict(), 19))
+    net.cuda().eval()
+    fr = [torch.from_numpy(synth.synth_frames_u8(B, h, w, seed=60 + k)).pin_memory() for k in range(4)]
+    pipe = FramePipeline(net, B, (h, w), req_outputs=("theta",))
+    with torch.no_grad():
+        t0 = pipe.submit(fr[0])
+        t1 = pipe.submit(fr[1])
+        assert t0 is not t1 and t0.slot is not t1.slot and (t0.gen, t1.gen) == (1, 1)
+        with pytest.raises(RuntimeError, match="collect"):
+            pipe.submit(fr[2])                       # slot 0 still holds batch 0
+        with pytest.raises(RuntimeError, match="collect"):
+            pipe.get(t0)                             # not collected yet
+        pipe.collect(t0)
+        with pytest.raises(RuntimeError, match="pending"):
+            pipe.collect(t0)                         # twice
+        t2 = pipe.submit(fr[2])                      # slot 0 again: a NEW ticket, generation 2
+        assert t2 is not t0 and t2.slot is t0.slot and t2.gen == 2
+        pipe.wait_uploaded(t2)
+        buf = fr[2].clone()
+        fr[2].zero_()                                # refilling the host buffer after wait_uploaded() changes nothing
+        th0 = np.array(pipe.get(t0)["theta"])        # run()'s own order: fetch batch k after submitting batch k + 2
+        pipe.collect(t1)
+        with pytest.raises(RuntimeError, match="never fetched"):
+            t3 = pipe.submit(fr[3])
+            pipe.collect(t2)                         # fine: batch 0 was fetched
+            pipe.collect(t3)                         # slot 1's buffers still hold batch 1, never fetched
+        th1 = np.array(pipe.get(t1)["theta"])
+        pipe.collect(t3)
+        with pytest.raises(RuntimeError, match="generation"):
+            pipe.get(t1)                             # its buffers now belong to batch 3
+        th2, th3 = np.array(pipe.get(t2)["theta"]), np.array(pipe.get(t3)["theta"])
+        from sfh_amd import engine as E
+        for f, th in zip((fr[0], fr[1], buf, fr[3]), (th0, th1, th2, th3)):
+            want = net.predict(E.frames_u8_to_input(f.cuda()), consistency=False)["theta"].cpu().numpy()
+            assert np.array_equal(th, want)

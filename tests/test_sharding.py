@@ -181,7 +181,7 @@ class _StandInReconstructor(torch.nn.Module):
     """Takes Reconstructor's place in bench.main() on the CPU: theta is a pure function of the frames (their mean per
     frame), so that the gathered rows can be checked against what each rank computed."""
     precision = "f16x3"
-    range_fallbacks = range_rescales = 0
+    range_fallbacks = range_rescales = range_raises = 0
 
     def __init__(self, court_img, court_poi, **kw):
         super().__init__()
@@ -259,3 +259,12 @@ def test_bench_main_two_ranks_gloo_reports_the_whole_job():
     assert line["gather_check"] == {"rows_per_rank": 32, "own_rows_equal_own_theta_on_every_rank": True,
                                     "bytes_per_step_per_rank": 640}
     assert line["cpu_baseline"] is None and line["other_configs"] is None and line["vs_baseline"] is None
+    # round 5: BASELINE config 4 gathers theta + consistency - with N > 1 the score is computed without --consistency
+    assert "consistency" in line["config"]["workload"] and "all_gather_into_tensor" in line["config"]["parallelism"]
+    # per-rank figures next to the whole-job value: own step time of every rank (the value uses the slowest)
+    pr = line["per_rank"]
+    assert [r["rank"] for r in pr["ranks"]] == [0, 1]
+    assert pr["ms_per_step_min"] <= pr["ms_per_step_median"] <= pr["ms_per_step_max"] <= line["ms_per_step"] * 1.001
+    assert all(set(r) >= {"ms_per_step", "device", "mfma_f16_tflops", "in_kernel_clock_ghz", "power_w_timed_region"} for r in pr["ranks"])
+    assert "frac_algorithmic" in line["roofline"] and "device_calibration" in line and "parity" in line
+    assert line["config"]["range_raises"] == 0
