@@ -83,9 +83,9 @@ class FramePipeline:
         preprocessing and the forward pass of this batch and returns its Ticket; nothing here waits for the GPU.  The host
         buffer is read asynchronously: refill it only after wait_uploaded(ticket)."""
         s = self.slots[self.k % 2]
-        self.k += 1
         if s["pending"] is not None:
             raise RuntimeError("FramePipeline: collect() the batch submitted two calls ago before reusing its slot")
+        self.k += 1
         s["gen"] += 1
         t = Ticket(s, s["gen"])
         cur = torch.cuda.current_stream(self.dev)
