@@ -426,12 +426,15 @@ def extra_configs(args):
             net.predict(x, consistency=True, project_poi=True)
     torch.cuda.synchronize()
     engine.PackedConv.timer = None
-    wv = tm.summary().get("warp")
-    if wv:
-        tbs = wv[1] / (wv[2] * 1e-3) / 1e12
-        res["C5_1280x720_batch16_pitch_template_poi"]["warp"] = {
-            "launches": wv[0], "bound": "hbm", "us_per_launch": round(wv[2] * 1e3 / wv[0], 2),
-            "algorithmic_bytes_per_launch": int(wv[1] / wv[0]), "tb_per_s": round(tbs, 3), "frac": round(tbs / HBM_PEAK_TBS, 4)}
+    for wtag in ("warp", "warp+ce"):
+        wv = tm.summary().get(wtag)
+        if wv:
+            tbs = wv[1] / (wv[2] * 1e-3) / 1e12
+            res["C5_1280x720_batch16_pitch_template_poi"][wtag] = {
+                "launches": wv[0], "bound": "hbm", "us_per_launch": round(wv[2] * 1e3 / wv[0], 2),
+                "algorithmic_bytes_per_launch": int(wv[1] / wv[0]), "tb_per_s": round(tbs, 3), "frac": round(tbs / HBM_PEAK_TBS, 4),
+                "kernel": ("warpce_kernel: nearest warp + consistency CE in one launch (logits + mask + template bytes)"
+                           if wtag == "warp+ce" else "warp2_kernel")}
     del net, x, court, poi
     torch.cuda.empty_cache()
     a = copy.copy(args)
@@ -686,11 +689,21 @@ def main():
     other = {}
     executed = (tm2 if alone is not None else timer).executed()
     for t, v in (alone[0] if alone is not None else summ).items():      # (pipelined run: from the unpipelined pass, see above)
-        if t == "warp":
+        if t in ("warp", "warp+ce"):
             tbs = v[1] / (v[2] * 1e-3) / 1e12
             other[t] = {"launches": v[0], "bound": "hbm", "us_per_launch": round(v[2] * 1e3 / v[0], 2),
                         "algorithmic_bytes_per_launch": int(v[1] / v[0]), "tb_per_s": round(tbs, 3),
                         "frac": round(tbs / HBM_PEAK_TBS, 4), "ms_per_step": round(v[2] / args.steps, 4)}
+            if t == "warp":
+                # north_star's >= 60 % HBM roofline on grid_sample, stated where it can and cannot hold
+                other[t].update({
+                    "ceiling_frac": 0.47 if (W, H, B) == (640, 360, 16) else None,
+                    "ceiling_basis": "a STORE-ONLY kernel of this launch's shape reaches 0.47 of 8 TB/s at 640x360 x 16 (15.7 MB = 2 us of "
+                                     "traffic behind ~6 us of launch and ramp: profiles/r02_warp_variants.txt); the warp itself is vector-issue "
+                                     "bound at 32-40 instructions per pixel (0.51-0.58 at batch 1024, profiles/r04_warp_pmc.txt)",
+                    "target_met_as": "warp + consistency CE fused (sfh_warp_consistency_fwd, predict(consistency=True)): 0.64 of 8 TB/s at "
+                                     "640x360 x 16 and 0.75 at 1280x720 x 16 for the fused kernel alone, 0.50 / 0.64 with its one-wave-per-frame "
+                                     "final launch (profiles/r05_warpce_pmc.txt); live figure of this run: other_configs.C5...['warp+ce']"})
         else:
             tf = v[1] / (v[2] * 1e-3) / 1e12
             other[t] = {"launches": v[0], "bound": "mfma", "tflops": round(tf, 2), "frac": round(tf / peak, 4),

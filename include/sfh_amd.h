@@ -338,6 +338,18 @@ int64_t sfh_ce_workspace_floats(int batch, int H, int W);
 int sfh_consistency_ce_fwd(const float* logits, const int32_t* mask, int batch, int nc, int H,
                            int W, int hm, int wm, float* partial, float* score, void* stream);
 
+/* The two calls above fused for predict()'s usual case (warp_size == the logits' size, nearest mode, 4 classes;
+ * models/reconstructor.py:223-240): out_i32 (B,h,w) = trunc(warp * out_scale) bit-identical to sfh_homography_warp_fwd, and
+ * score (B) = mean over the pixels of cross_entropy(logits[:, :, y, x], out_i32[y, x]) - every wave scores the pixels it warps
+ * while the class ids are still in registers, the logits (B,nc,h,w) are streamed once, the mask is never read back.  Two
+ * launches (the fused kernel + a one-wave-per-frame sum of its partials in fp64, fixed order: deterministic) instead of three.
+ * partial: workspace of sfh_warp_consistency_workspace_floats(batch, h, w) floats.  Other class counts / a mask of another
+ * size: the two separate entries.                                                                                       */
+int64_t sfh_warp_consistency_workspace_floats(int batch, int h, int w);
+int sfh_warp_consistency_fwd(const float* theta, const float* tmpl, int64_t tmpl_bstride, int ht, int wt, int batch, int h,
+                             int w, float out_scale, const float* logits, int nc, int32_t* out_i32, float* partial,
+                             float* score, void* stream);
+
 /* Output masks as predict.py writes them (predict.py:286-315; utils/postprocess.py:7-61):
  * src is int32 class ids (src_kind 0, e.g. predict()'s warp_mask), uint8 ids (1) or fp32 logits
  * NCHW (2: argmax over nc classes, first maximum wins); nearest resize (hs,ws)->(hd,wd) with

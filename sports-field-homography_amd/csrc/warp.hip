@@ -284,6 +284,173 @@ __global__ __launch_bounds__(256) void warp2_kernel(const float* __restrict__ th
 #undef SFH_WARP2_GO
 }
 
+// ---------------------------------------------------------------------------------------------
+// Nearest warp + consistency score in ONE launch (round 5; models/reconstructor.py:223-240 with warp_size == the logits'
+// size): each wave warps its 64*J x RPT pixels exactly as warp2_body<0, ...> does (same instruction sequence for the
+// coordinates, so the mask is bit-identical), keeps the class ids in registers, streams the NC logit planes of those pixels
+// ONCE (coalesced 256-byte wave loads, prefetched one row ahead like the taps) and accumulates
+//     logsumexp(logits[:, p]) - logits[mask[p], p]
+// per lane; every wave leaves its sum in `partial`, and a second, tiny launch (warpce_final_kernel: one wave per frame) adds a
+// frame's partials up in a fixed order in fp64 and writes the mean.  (The single-launch form - the last block of a frame,
+// found through a device counter, does that sum - was built first and measured 2x SLOWER than the separate kernels, 68 us
+// against 38 at 640x360 x 16: on this chip a device-scope release fence writes the XCD's L2 back, because the eight L2s are
+// not coherent with each other, and every block paid for one; profiles/r05_warpce_sweep.txt.)
+// Traffic = logits (4 * NC B / pixel) + mask (4 B / pixel) + one template: 74.6 MB at 640x360 x 16, 298 MB at 1280x720 x 16,
+// against 15.7 / 62.7 MB for the warp alone and a second pass over mask + logits for the separate CE kernels.
+template <int J, int RPT, int NC, int LEVEL, bool SMALL>
+__device__ __forceinline__ float warpce_body(const float (&t)[9], int b, int lane, int c0, int r0,
+                                             const float* __restrict__ tmpl, long tmpl_bstride, int ht, int wt, int h, int w,
+                                             float rdw, float rdh, float out_scale, const float* __restrict__ logits,
+                                             int32_t* __restrict__ out_i) {
+  float a0[J], a3[J], a6[J];
+  unsigned coff[J];
+#pragma unroll
+  for (int j = 0; j < J; ++j) {
+    const int c = c0 + 64 * j;
+    const float xn = norm_axis2<SMALL>(c < w ? c : w - 1, w, rdw);
+    a0[j] = __fmul_rn(t[0], xn);
+    a3[j] = __fmul_rn(t[3], xn);
+    a6[j] = __fmul_rn(t[6], xn);
+    coff[j] = c < w ? (unsigned)c * 4u : kTapOOB;
+  }
+  const float ynl = norm_axis2<SMALL>(r0 + (lane & (RPT - 1)), h, rdh);
+  const float c1l = __fmul_rn(t[1], ynl), c4l = __fmul_rn(t[4], ynl), c7l = __fmul_rn(t[7], ynl);
+  const __amdgpu_buffer_rsrc_t rt = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(tmpl + (long)b * tmpl_bstride), 0, ht * wt * 4, 0x00020000);
+  const int nrows = (h - r0 < RPT) ? h - r0 : RPT;
+  const long rowbase = ((long)b * h + r0) * w;
+  const __amdgpu_buffer_rsrc_t roi = __builtin_amdgcn_make_buffer_rsrc(out_i + rowbase, 0, nrows * w * 4, 0x00020000);
+  // the NC logit planes of this frame: plane k, row r at byte (k * h + r) * w * 4 (below 4 GiB: checked by the launcher)
+  const __amdgpu_buffer_rsrc_t rl = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(logits + (long)b * NC * h * w), 0, NC * h * w * 4, 0x00020000);
+  const float sx = 0.5f * (float)wt, sy = 0.5f * (float)ht;
+  unsigned off[J];
+  float tv[J], lg[2][J][NC];
+
+  auto coords = [&](int rr) {
+    const float c1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, c1l), rr));
+    const float c4 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, c4l), rr));
+    const float c7 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, c7l), rr));
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+      const float X = __fadd_rn(__fadd_rn(a0[j], c1), t[2]);
+      const float Y = __fadd_rn(__fadd_rn(a3[j], c4), t[5]);
+      const float Z = __fadd_rn(__fadd_rn(a6[j], c7), t[8]);
+      const float r = recip_rn<LEVEL>(__fadd_rn(Z, 1e-8f));
+      const float s = (LEVEL == 2 || fabsf(Z) > 1e-8f) ? r : 1.0f;
+      const float px = __builtin_fmaf(__fadd_rn(__fmul_rn(s, X), 1.0f), sx, -0.5f);
+      const float py = __builtin_fmaf(__fadd_rn(__fmul_rn(s, Y), 1.0f), sy, -0.5f);
+      off[j] = tap_off<LEVEL>(rintf(px), rintf(py), wt, ht);
+    }
+  };
+  auto issue_taps = [&]() {
+#pragma unroll
+    for (int j = 0; j < J; ++j) tv[j] = tap_ld(rt, off[j]);
+  };
+  // logits of row r0 + rr into register set `set` (rows beyond the frame: the scalar offset stays inside the frame's planes
+  // or beyond the descriptor - either way the values are never used)
+  auto issue_logits = [&](int rr, int set) {
+    const int row = r0 + rr < h ? r0 + rr : h - 1;
+#pragma unroll
+    for (int k = 0; k < NC; ++k) {
+      const int soff = (k * h + row) * w * 4;
+#pragma unroll
+      for (int j = 0; j < J; ++j)
+        lg[set][j][k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rl, (int)coff[j], soff, 0));
+    }
+  };
+  float sum = 0.f;
+  coords(0);
+  issue_taps();
+  issue_logits(0, 0);
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int rr = 0; rr < RPT; ++rr) {
+    float val[J];
+    if (rr + 1 < RPT) coords(rr + 1);
+#pragma unroll
+    for (int j = 0; j < J; ++j) val[j] = tv[j];
+    if (rr + 1 < RPT) {
+      issue_taps();
+      issue_logits(rr + 1, (rr + 1) & 1);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (rr < nrows) {
+      const int soff = rr * w * 4;
+#pragma unroll
+      for (int j = 0; j < J; ++j) {
+        const int32_t cls = (int32_t)__fmul_rn(val[j], out_scale);
+        __builtin_amdgcn_raw_buffer_store_b32((unsigned)cls, roi, (int)coff[j], soff, 0);
+        // cross entropy of this pixel: logsumexp - logit of the warped class (a class outside 0 .. NC-1 contributes the
+        // logsumexp alone, as xt = 0 in ce_partial_kernel)
+        const float (&v)[NC] = lg[rr & 1][j];
+        float m = v[0];
+#pragma unroll
+        for (int k = 1; k < NC; ++k) m = fmaxf(m, v[k]);
+        float se = 0.f, xt = 0.f;
+#pragma unroll
+        for (int k = 0; k < NC; ++k) {
+          se += __expf(v[k] - m);
+          xt = (cls == k) ? v[k] : xt;
+        }
+        const float ce = (m + __logf(se)) - xt;
+        sum += (coff[j] != kTapOOB) ? ce : 0.f;
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  return sum;
+}
+
+template <int J, int RPT, int NC>
+__global__ __launch_bounds__(256) void warpce_kernel(const float* __restrict__ theta, const float* __restrict__ tmpl,
+                                                     long tmpl_bstride, int ht, int wt, int h, int w, float rdw, float rdh,
+                                                     float out_scale, const float* __restrict__ logits,
+                                                     int32_t* __restrict__ out_i, float* __restrict__ partial) {
+  const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int b = blockIdx.z;
+  const int c0 = blockIdx.x * (64 * J) + lane;
+  const int r0 = (blockIdx.y * 4 + wv) * RPT;
+  float sum = 0.f;
+  if (r0 < h) {
+    float t[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) t[k] = theta[b * 9 + k];
+    bool fin = true;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) fin &= fabsf(t[k]) <= 0x1p59f;
+    const float zs = fabsf(t[6]) + fabsf(t[7]) + fabsf(t[8]);
+    const bool live = (fabsf(t[8]) - fabsf(t[6]) - fabsf(t[7])) > 1e-6f * zs + 1e-7f;
+#define SFH_WARPCE_GO(LEVEL, SMALL) \
+  sum = warpce_body<J, RPT, NC, LEVEL, SMALL>(t, b, lane, c0, r0, tmpl, tmpl_bstride, ht, wt, h, w, rdw, rdh, out_scale, logits, out_i)
+    if (fin && w <= 16384 && h <= 16384) {
+      if (live) SFH_WARPCE_GO(2, true); else SFH_WARPCE_GO(1, true);
+    } else {
+      SFH_WARPCE_GO(0, false);
+    }
+#undef SFH_WARPCE_GO
+  }
+  // wave partial (fp32 lane sums of at most J * RPT pixels, fp64 across the lanes); waves beyond the frame write zero
+  double ds = (double)sum;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) ds += __shfl_down(ds, o);
+  if (lane == 0) {
+    const unsigned nwv = gridDim.x * gridDim.y * 4u;
+    partial[(size_t)b * nwv + (blockIdx.y * gridDim.x + blockIdx.x) * 4u + (unsigned)wv] = (float)ds;
+  }
+}
+
+// one wave per frame: sum of the frame's wave partials in a fixed order, fp64 -> mean cross entropy
+__global__ __launch_bounds__(64) void warpce_final_kernel(const float* __restrict__ partial, int nwv, double inv_hw,
+                                                          float* __restrict__ score) {
+  const int b = blockIdx.x;
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < nwv; i += 64) acc += (double)partial[(size_t)b * nwv + i];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o);
+  if (threadIdx.x == 0) score[b] = (float)(acc * inv_hw);
+}
+
 // Exhaustive arithmetic self-tests (called by tests/, never by the product path): count the inputs on which
 // the fast forms above differ from the IEEE divisions they replace.
 __global__ void selftest_recip_kernel(unsigned lo, unsigned long long count, unsigned long long* bad) {
@@ -506,6 +673,46 @@ extern "C" int sfh_homography_warp_fwd(const float* theta, const float* tmpl, in
 #undef SFH_WARP_OUT
 #undef SFH_WARP_LAUNCH
   return sfh_check_launch("warp_kernel");
+}
+
+extern "C" int64_t sfh_warp_consistency_workspace_floats(int batch, int h, int w) {
+  if (batch <= 0 || h <= 1 || w <= 1) return -1;
+  const int J = (w % 320 == 0) ? 5 : 4;
+  // one float per wave; the smallest rows-per-thread the launcher may choose gives the most waves
+  return (int64_t)batch * sfh_cdiv(w, 64 * J) * sfh_cdiv(h, 4 * 2) * 4;
+}
+
+extern "C" int sfh_warp_consistency_fwd(const float* theta, const float* tmpl, int64_t tmpl_bstride, int ht, int wt,
+                                        int batch, int h, int w, float out_scale, const float* logits, int nc,
+                                        int32_t* out_i32, float* partial, float* score, void* stream) {
+  SFH_REQUIRE(theta && tmpl && logits && out_i32 && partial && score, "warp_consistency: null pointer");
+  SFH_REQUIRE(batch > 0 && batch <= 65535 && h > 1 && w > 1 && ht > 0 && wt > 0,
+              "warp_consistency: bad geometry b=%d h=%d w=%d ht=%d wt=%d", batch, h, w, ht, wt);
+  SFH_REQUIRE(nc == 4, "warp_consistency: nc=%d (the fused kernel is built for 4 classes; use sfh_homography_warp_fwd + "
+              "sfh_consistency_ce_fwd otherwise)", nc);
+  SFH_REQUIRE(tmpl_bstride == 0 || tmpl_bstride >= (int64_t)ht * wt, "warp_consistency: bad template stride");
+  SFH_REQUIRE((int64_t)ht * wt <= (1 << 22) && w <= (1 << 20) && h <= (1 << 20) && (int64_t)nc * h * w * 4 < 0x7FFFFFF0LL,
+              "warp_consistency: template %dx%d or frame %dx%d too large", wt, ht, w, h);
+  const float rdw = 1.0f / (float)(w - 1), rdh = 1.0f / (float)(h - 1);
+  const int J = (w % 320 == 0) ? 5 : 4;
+  const long segs = (long)sfh_cdiv(w, 64 * J) * batch;
+  int rpt = 8;
+  while (rpt > 2 && segs * sfh_cdiv(h, rpt) < SFH_WARP_MIN_WAVES) rpt >>= 1;
+  const dim3 grid((unsigned)sfh_cdiv(w, 64 * J), (unsigned)sfh_cdiv(h, 4 * rpt), (unsigned)batch);
+#define SFH_WCE(JJ, RR)                                                                                             \
+  hipLaunchKernelGGL((warpce_kernel<JJ, RR, 4>), grid, dim3(256), 0, (hipStream_t)stream, theta, tmpl,                \
+                     (long)tmpl_bstride, ht, wt, h, w, rdw, rdh, out_scale, logits, out_i32, partial)
+  if (J == 5) {
+    if (rpt == 8) SFH_WCE(5, 8); else if (rpt == 4) SFH_WCE(5, 4); else SFH_WCE(5, 2);
+  } else {
+    if (rpt == 8) SFH_WCE(4, 8); else if (rpt == 4) SFH_WCE(4, 4); else SFH_WCE(4, 2);
+  }
+#undef SFH_WCE
+  int rc = sfh_check_launch("warpce_kernel");
+  if (rc) return rc;
+  hipLaunchKernelGGL(warpce_final_kernel, dim3((unsigned)batch), dim3(64), 0, (hipStream_t)stream, partial,
+                     (int)(grid.x * grid.y * 4u), 1.0 / ((double)h * (double)w), score);
+  return sfh_check_launch("warpce_final_kernel");
 }
 
 extern "C" int sfh_selftest_warp_arith(int64_t* mismatches, void* stream) {

@@ -1517,6 +1517,42 @@ def homography_warp(theta, template, h, w, nearest, scale=None, want_f32=True, w
     return out_f, out_i
 
 
+def warp_consistency(theta, template, logits, scale, shared_template=False):
+    """predict()'s nearest warp (* mask_classes -> int32) AND the consistency score in one launch (sfh_warp_consistency_fwd):
+    the warp has the logits' size, 4 classes.  -> (warp_mask int32 (B,h,w), score float32 (B,)); the mask is bit-identical to
+    homography_warp()'s."""
+    lib = _lib.load()
+    theta = _f32c(theta.reshape(-1, 3, 3).contiguous(), "theta")
+    template = _f32c(template, "court template")
+    logits = _f32c(logits, "logits")
+    B, nc, h, w = logits.shape
+    if theta.shape[0] != B:
+        raise ValueError(f"{theta.shape[0]} homographies for {B} frames of logits")
+    if template.dim() != 4 or template.shape[1] != 1:
+        raise ValueError(f"court template must be (B,1,H,W), got {tuple(template.shape)}")
+    if template.shape[0] < B and not shared_template:
+        raise ValueError(f"batch {B} exceeds the court template batch {template.shape[0]}")
+    ht, wt = template.shape[2], template.shape[3]
+    dev = theta.device
+    out_i = torch.empty((B, h, w), dtype=torch.int32, device=dev)
+    partial = torch.empty(lib.sfh_warp_consistency_workspace_floats(B, h, w), dtype=torch.float32, device=dev)
+    score = torch.empty(B, dtype=torch.float32, device=dev)
+    tm = PackedConv.timer
+    if tm is not None and not tm.wants("warp+ce"):
+        tm = None
+    if tm is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    _lib.check(lib.sfh_warp_consistency_fwd(_ptr(theta), _ptr(template), 0 if shared_template else ht * wt, ht, wt, B, h, w,
+                                            float(scale), _ptr(logits), nc, _ptr(out_i), _ptr(partial), _ptr(score),
+                                            _stream()), "warp_consistency")
+    if tm is not None:
+        e1.record()
+        # algorithmic BYTES: the logits once, the mask once, the template once (per frame if not shared), theta
+        tm.records.append(("warp+ce", float(B * h * w * 4 * (nc + 1) + (1 if shared_template else B) * ht * wt * 4 + 36 * B), e0, e1))
+    return out_i, score
+
+
 def poi_project(theta, poi, normalize=True):
     lib = _lib.load()
     theta = _f32c(theta.reshape(-1, 3, 3).contiguous(), "theta")

@@ -177,6 +177,9 @@ class Reconstructor(nn.Module):
         # False: predict() / forward() skip the 4-byte read-back (a device synchronisation) after every call; a
         # caller that pipelines several batches then asks range_overflowed() itself once it has synchronised
         self.range_guard = True
+        # predict(consistency=True) with a nearest warp of the logits' size: warp + consistency CE as one kernel (False: the two
+        # separate kernels; env SFH_FUSE_WARP_CE=0)
+        self.fuse_warp_ce = os.environ.get("SFH_FUSE_WARP_CE", "1") != "0"
         self._engine_stamp = None
         self._weights_generation = 0
         self._tmpl_shared = None   # (data_ptr, shape) -> bool cache
@@ -702,12 +705,21 @@ class Reconstructor(nn.Module):
                     tmpl = self.court_img[off:off + bs]
                     if tmpl.shape[0] < bs:
                         raise ValueError(f"batch {bs} exceeds the court template batch {self.court_img.shape[0]}")
-                    # warp * mask_classes -> int32, fused in the kernel (reference: :223,240)
-                    _, wm = E.homography_warp(theta, tmpl.contiguous(), h, w, self.warp_with_nearest,
-                                              scale=float(self.mask_classes), want_f32=False, want_i32=True,
-                                              shared_template=self._template_is_shared(self.court_img, bs))
-                    if consistency and self.use_unet:
-                        ret['consist_score'] = E.consistency_ce(ret['logits'], wm)
+                    shared = self._template_is_shared(self.court_img, bs)
+                    lgt = ret.get('logits')
+                    if (consistency and self.use_unet and self.warp_with_nearest and self.fuse_warp_ce
+                            and self.mask_classes == 4 and tuple(lgt.shape[1:]) == (4, h, w)):
+                        # the usual case: warp and consistency score in ONE launch - every wave scores the pixels it warps
+                        # while their class ids are in registers, the logits are streamed once (reference: :223-240)
+                        wm, ret['consist_score'] = E.warp_consistency(theta, tmpl.contiguous(), lgt, float(self.mask_classes),
+                                                                      shared_template=shared)
+                    else:
+                        # warp * mask_classes -> int32, fused in the kernel (reference: :223,240)
+                        _, wm = E.homography_warp(theta, tmpl.contiguous(), h, w, self.warp_with_nearest,
+                                                  scale=float(self.mask_classes), want_f32=False, want_i32=True,
+                                                  shared_template=shared)
+                        if consistency and self.use_unet:
+                            ret['consist_score'] = E.consistency_ce(lgt, wm)
                     ret['warp_mask'] = wm
                 if project_poi:
                     ret['poi'] = self.transform_poi(theta, self.court_poi[off:])
