@@ -282,6 +282,19 @@ int sfh_u8hwc_area2_to_f32nchw(const uint8_t* src, float* dst, int batch, int C,
  * times the float 1.f / (k * k), rounded half to even, saturated to 0 .. 255, then / 255 (utils/dataset.py:312-330). */
 int sfh_u8hwc_areak_to_f32nchw(const uint8_t* src, float* dst, int batch, int C, int H, int W, int k, void* stream);
 
+/* The same call for ANY downscale (both factors >= 1, at least one not an integer: e.g. 1920x1080 -> 1024x576): OpenCV's
+ * generic INTER_AREA path, resizeArea_ over the per-axis tables of computeResizeAreaTab (published imgproc/resize.cpp): every
+ * destination pixel is sum_j beta_j * (sum_k alpha_k * S[sy_j][sx_k]) in float, products and sums individually rounded in
+ * table order, then rounded half to even, saturated to 0 .. 255, / 255.
+ * sfh_resize_area_tab (HOST code, no GPU): the table of one axis - for destination index d the entries ofs[d] .. ofs[d+1]-1 give
+ * source index si[] and weight alpha[]; ofs has dsize + 1 ints, si / alpha room for `cap` entries (2 * dsize + ssize always
+ * suffices); returns the number of entries, or -1 (bad sizes, dsize > ssize, cap too small).
+ * sfh_u8hwc_area_to_f32nchw: src uint8 (B,Hs,Ws,C) -> dst float32 (B,C,Hd,Wd); the six table arrays are DEVICE pointers. */
+int sfh_resize_area_tab(int ssize, int dsize, int32_t* ofs, int32_t* si, float* alpha, int cap);
+int sfh_u8hwc_area_to_f32nchw(const uint8_t* src, float* dst, int batch, int C, int Hs, int Ws, int Hd, int Wd,
+                              const int32_t* xofs, const int32_t* xsi, const float* xalpha, const int32_t* yofs,
+                              const int32_t* ysi, const float* ybeta, void* stream);
+
 /* (B, C, H, W) fp32 -> (B, H, W, cs) fp32, channels >= C zero-filled. */
 int sfh_nchw_to_nhwc(const float* src, float* dst, int batch, int C, int H, int W, int cs,
                      void* stream);

@@ -48,6 +48,54 @@ def resize_area_int(img, k):
     return np.clip(np.rint(blocks.astype(np.float32) * scale), 0, 255).astype(np.uint8)
 
 
+def _area_tab(ssize, dsize):
+    """computeResizeAreaTab of OpenCV's published imgproc/resize.cpp: [(di, si, alpha)] with scale = 1 / (dsize / ssize) in
+    double, alpha rounded to float."""
+    import math
+    scale = 1.0 / (dsize / ssize)
+    tab = []
+    for dx in range(dsize):
+        fsx1 = dx * scale
+        fsx2 = fsx1 + scale
+        cell = min(scale, ssize - fsx1)
+        sx1, sx2 = math.ceil(fsx1), math.floor(fsx2)
+        sx2 = min(sx2, ssize - 1)
+        sx1 = min(sx1, sx2)
+        if sx1 - fsx1 > 1e-3:
+            tab.append((dx, sx1 - 1, np.float32((sx1 - fsx1) / cell)))
+        for sx in range(sx1, sx2):
+            tab.append((dx, sx, np.float32(1.0 / cell)))
+        if fsx2 - sx2 > 1e-3:
+            tab.append((dx, sx2, np.float32(min(min(fsx2 - sx2, 1.0), cell) / cell)))
+    return tab
+
+
+def resize_area(img, out_size):
+    """cv2.resize(img, (wd, hd), interpolation=cv2.INTER_AREA) on a uint8 (H,W[,C]) array for a DOWNSCALE whose factors are not
+    both integers (utils/dataset.py:312-316 with e.g. 1920x1080 frames and a 1024x576 target).  Restated from OpenCV's published
+    generic path: ResizeArea_<uchar, float> - per source row of a destination row buf[dx] += S[sx] * alpha over the x table
+    (float, in table order), sum[dx] = beta * buf[dx] for the first row and += for the others, saturate_cast<uchar> (round
+    half to even) at the end.  OpenCV is absent here: parity unpinned for this rule."""
+    wd, hd = out_size
+    hs, ws = img.shape[:2]
+    assert img.dtype == np.uint8 and wd <= ws and hd <= hs
+    im = img.reshape(hs, ws, -1).astype(np.float32)
+    xtab, ytab = _area_tab(ws, wd), _area_tab(hs, hd)
+    out = np.zeros((hd, wd, im.shape[2]), np.float32)
+    started = np.zeros(hd, bool)
+    for dy, sy, beta in ytab:
+        buf = np.zeros((wd, im.shape[2]), np.float32)
+        for dx, sx, alpha in xtab:
+            buf[dx] = buf[dx] + im[sy, sx] * alpha              # float32 product, float32 sum, in table order
+        if not started[dy]:
+            out[dy] = beta * buf
+            started[dy] = True
+        else:
+            out[dy] = out[dy] + beta * buf
+    res = np.clip(np.rint(out), 0, 255).astype(np.uint8)
+    return res.reshape((hd, wd) + img.shape[2:])
+
+
 def format_masks(ids, mask_type, n_classes, out_size):
     """predict.py:286-315 on a uint8 id mask batch (B,H,W)."""
     if mask_type == "rgb":

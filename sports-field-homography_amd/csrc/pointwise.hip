@@ -1,6 +1,8 @@
 // pointwise.hip - the bandwidth-bound kernels around the conv stack (all HBM-roofline work):
 // layout conversion, BatchNorm folding, OutConv (+argmax, +STN input assembly),
 // consistency cross-entropy, ResNet max-pool and avg-pool+Linear.
+#include <math.h>
+
 #include "common.h"
 
 namespace {
@@ -75,6 +77,45 @@ __global__ void u8hwc_areak_to_f32nchw_kernel(const uint8_t* __restrict__ src, f
     }
   for (int c = 0; c < C; ++c) {
     int v = __float2int_rn(__fmul_rn((float)sum[c], scale));
+    v = v < 0 ? 0 : (v > 255 ? 255 : v);
+    d[(long)c * HW] = (float)v / 255.0f;
+  }
+}
+
+// Generic INTER_AREA downscale (non-integer factors): OpenCV's resizeArea_ with the per-axis tables of computeResizeAreaTab.
+// One thread per destination pixel; per source row j of its y entries: buf = ((0 + S*a0) + S*a1) + ... over its x entries,
+// sum = beta0 * buf0, then sum += beta_j * buf_j - products and sums individually rounded, in table order, as the row-buffer
+// loop of resizeArea_ does (no FMA contraction: the file is built with -ffp-contract=off and the intrinsics pin it).
+__global__ void u8hwc_area_to_f32nchw_kernel(const uint8_t* __restrict__ src, float* __restrict__ dst, int C, int Hs, int Ws,
+                                             int Hd, int Wd, const int* __restrict__ xofs, const int* __restrict__ xsi,
+                                             const float* __restrict__ xalpha, const int* __restrict__ yofs,
+                                             const int* __restrict__ ysi, const float* __restrict__ ybeta, long npix) {
+  const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= npix) return;
+  const int HW = Hd * Wd;
+  const long b = p / HW;
+  const int i = (int)(p - b * HW), y = i / Wd, x = i - y * Wd;
+  const uint8_t* s = src + b * (long)Hs * Ws * C;
+  float sum[4] = {0.f, 0.f, 0.f, 0.f};
+  const int x0 = xofs[x], x1 = xofs[x + 1];
+  for (int j = yofs[y]; j < yofs[y + 1]; ++j) {
+    const uint8_t* row = s + (long)ysi[j] * Ws * C;
+    float buf[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int k = x0; k < x1; ++k) {
+      const uint8_t* q = row + (long)xsi[k] * C;
+      const float a = xalpha[k];
+      for (int c = 0; c < C; ++c) buf[c] = __fadd_rn(buf[c], __fmul_rn((float)q[c], a));
+    }
+    const float beta = ybeta[j];
+    if (j == yofs[y]) {
+      for (int c = 0; c < C; ++c) sum[c] = __fmul_rn(beta, buf[c]);
+    } else {
+      for (int c = 0; c < C; ++c) sum[c] = __fadd_rn(sum[c], __fmul_rn(beta, buf[c]));
+    }
+  }
+  float* d = dst + b * (long)C * HW + i;
+  for (int c = 0; c < C; ++c) {
+    int v = __float2int_rn(sum[c]);
     v = v < 0 ? 0 : (v > 255 ? 255 : v);
     d[(long)c * HW] = (float)v / 255.0f;
   }
@@ -680,6 +721,53 @@ extern "C" int sfh_u8hwc_areak_to_f32nchw(const uint8_t* src, float* dst, int ba
   hipLaunchKernelGGL(u8hwc_areak_to_f32nchw_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0,
                      (hipStream_t)stream, src, dst, C, H, W, k, 1.f / (float)(k * k), npix);
   return sfh_check_launch("u8hwc_areak_to_f32nchw_kernel");
+}
+
+// computeResizeAreaTab of OpenCV's imgproc/resize.cpp, restated (host code): scale = 1 / (dsize / ssize) in double
+extern "C" int sfh_resize_area_tab(int ssize, int dsize, int32_t* ofs, int32_t* si, float* alpha, int cap) {
+  if (!ofs || !si || !alpha || ssize <= 0 || dsize <= 0 || dsize > ssize) return -1;
+  const double scale = 1.0 / ((double)dsize / (double)ssize);
+  int k = 0;
+  for (int dx = 0; dx < dsize; ++dx) {
+    ofs[dx] = k;
+    const double fsx1 = dx * scale, fsx2 = fsx1 + scale;
+    const double cell = scale < ssize - fsx1 ? scale : ssize - fsx1;
+    int sx1 = (int)ceil(fsx1), sx2 = (int)floor(fsx2);
+    if (sx2 > ssize - 1) sx2 = ssize - 1;
+    if (sx1 > sx2) sx1 = sx2;
+    if (sx1 - fsx1 > 1e-3) {
+      if (k >= cap) return -1;
+      si[k] = sx1 - 1;
+      alpha[k++] = (float)((sx1 - fsx1) / cell);
+    }
+    for (int sx = sx1; sx < sx2; ++sx) {
+      if (k >= cap) return -1;
+      si[k] = sx;
+      alpha[k++] = (float)(1.0 / cell);
+    }
+    if (fsx2 - sx2 > 1e-3) {
+      if (k >= cap) return -1;
+      double a = fsx2 - sx2;
+      if (a > 1.0) a = 1.0;
+      if (a > cell) a = cell;
+      si[k] = sx2;
+      alpha[k++] = (float)(a / cell);
+    }
+  }
+  ofs[dsize] = k;
+  return k;
+}
+
+extern "C" int sfh_u8hwc_area_to_f32nchw(const uint8_t* src, float* dst, int batch, int C, int Hs, int Ws, int Hd, int Wd,
+                                         const int32_t* xofs, const int32_t* xsi, const float* xalpha, const int32_t* yofs,
+                                         const int32_t* ysi, const float* ybeta, void* stream) {
+  SFH_REQUIRE(src && dst && xofs && xsi && xalpha && yofs && ysi && ybeta, "u8hwc_area_to_f32nchw: null pointer");
+  SFH_REQUIRE(batch > 0 && C > 0 && C <= 4 && Hd > 0 && Wd > 0 && Hs >= Hd && Ws >= Wd,
+              "u8hwc_area_to_f32nchw: bad geometry %dx%d -> %dx%d (a downscale, at most 4 channels)", Ws, Hs, Wd, Hd);
+  const long npix = (long)batch * Hd * Wd;
+  hipLaunchKernelGGL(u8hwc_area_to_f32nchw_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     src, dst, C, Hs, Ws, Hd, Wd, xofs, xsi, xalpha, yofs, ysi, ybeta, npix);
+  return sfh_check_launch("u8hwc_area_to_f32nchw_kernel");
 }
 
 extern "C" int sfh_nhwc_to_nchw(const float* src, float* dst, int batch, int C, int H, int W, int cs,

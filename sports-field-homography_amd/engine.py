@@ -1426,12 +1426,34 @@ def f32_to_s3(t):
     return out
 
 
+_AREA_TABS = {}
+
+
+def _area_tab(ssize, dsize, device):
+    """device copies of one axis' INTER_AREA table (sfh_resize_area_tab: OpenCV's computeResizeAreaTab), cached per size pair"""
+    key = (ssize, dsize, str(device))
+    t = _AREA_TABS.get(key)
+    if t is None:
+        import numpy as np
+        lib = _lib.load()
+        cap = 2 * dsize + ssize
+        ofs, si, al = np.zeros(dsize + 1, np.int32), np.zeros(cap, np.int32), np.zeros(cap, np.float32)
+        n = lib.sfh_resize_area_tab(ssize, dsize, ofs.ctypes.data_as(ctypes.c_void_p), si.ctypes.data_as(ctypes.c_void_p),
+                                    al.ctypes.data_as(ctypes.c_void_p), cap)
+        if n < 0:
+            raise ValueError(f"no INTER_AREA table for {ssize} -> {dsize}")
+        t = _AREA_TABS[key] = tuple(torch.from_numpy(a).to(device) for a in (ofs, si[:max(n, 1)].copy(), al[:max(n, 1)].copy()))
+    return t
+
+
 def frames_u8_to_input(frames_u8, target_size=None):
     """uint8 (B,H,W,C) decoded frames on the GPU -> float32 (B,C,H,W) in [0,1], bit-identical to the
     reference dataset's `img.transpose((2,0,1)) / 255` (utils/dataset.py:154-159).  target_size = (W, H):
-    like VideoDataset.preprocess_img (utils/dataset.py:310-330) the frames are resized first; on the GPU the
-    integer downscale factors 2 .. 16 are covered (cv2.INTER_AREA's block averages: 1280x720 -> 640x360 is the 2x2
-    special case, 1920x1080 -> 640x360 the 3x3 one)."""
+    like VideoDataset.preprocess_img (utils/dataset.py:310-330) frames WIDER than the target are resized first with
+    cv2.INTER_AREA's rules: the integer factors 2 .. 16 take OpenCV's block-average fast paths (1280x720 -> 640x360 is the
+    2x2 special case, 1920x1080 -> 640x360 the 3x3 one), any other downscale (both factors >= 1, e.g. 1920x1080 -> 1024x576
+    or 1600x900 -> 640x360) the generic area tables (round 5).  Frames narrower than the target (the reference switches to
+    INTER_LINEAR there) are not on the HIP path."""
     lib = _lib.load()
     if frames_u8.dtype != torch.uint8 or frames_u8.dim() != 4 or not frames_u8.is_cuda:
         raise ValueError("expected a uint8 (B,H,W,C) tensor on the GPU")
@@ -1439,13 +1461,22 @@ def frames_u8_to_input(frames_u8, target_size=None):
     B, H, W, C = f.shape
     if target_size is not None and (int(target_size[0]), int(target_size[1])) != (W, H):
         tw, th = int(target_size[0]), int(target_size[1])
-        k = W // tw if tw > 0 else 0
-        if k < 2 or k > 16 or (k * tw, k * th) != (W, H):
-            raise NotImplementedError(f"GPU frame resize {W}x{H} -> {tw}x{th}: only integer downscale factors 2 .. 16 "
-                                      "(cv2.INTER_AREA's block-average cases) are on the HIP path; resize on the host as "
-                                      "utils/dataset.py does")
+        if tw <= 0 or th <= 0 or W <= tw or H < th:
+            raise NotImplementedError(f"GPU frame resize {W}x{H} -> {tw}x{th}: only downscales (cv2.INTER_AREA, the reference's choice "
+                                      "for frames wider than the target) are on the HIP path; resize on the host as utils/dataset.py does")
         out = torch.empty((B, C, th, tw), dtype=torch.float32, device=f.device)
-        _lib.check(lib.sfh_u8hwc_areak_to_f32nchw(_ptr(f), _ptr(out), B, C, th, tw, k, _stream()), "u8hwc_areak_to_f32nchw")
+        k = W // tw
+        if 2 <= k <= 16 and (k * tw, k * th) == (W, H):
+            _lib.check(lib.sfh_u8hwc_areak_to_f32nchw(_ptr(f), _ptr(out), B, C, th, tw, k, _stream()), "u8hwc_areak_to_f32nchw")
+            return out
+        if (tw * (W // tw), th * (H // th)) == (W, H):
+            # integer factors that differ per axis, or beyond 16: OpenCV's resizeAreaFast_ with an (kx, ky) block - not built
+            raise NotImplementedError(f"GPU frame resize {W}x{H} -> {tw}x{th}: integer factors {W // tw} x {H // th} (unequal or "
+                                      "above 16) are not on the HIP path")
+        xo, xs, xa = _area_tab(W, tw, f.device)
+        yo, ys, yb = _area_tab(H, th, f.device)
+        _lib.check(lib.sfh_u8hwc_area_to_f32nchw(_ptr(f), _ptr(out), B, C, H, W, th, tw, _ptr(xo), _ptr(xs), _ptr(xa), _ptr(yo),
+                                                 _ptr(ys), _ptr(yb), _stream()), "u8hwc_area_to_f32nchw")
         return out
     out = torch.empty((B, C, H, W), dtype=torch.float32, device=f.device)
     _lib.check(lib.sfh_u8hwc_to_f32nchw(_ptr(f), _ptr(out), B, C, H, W, _stream()), "u8hwc_to_f32nchw")

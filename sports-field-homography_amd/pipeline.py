@@ -5,7 +5,7 @@ preprocesses frames on the host (utils/dataset.py:145-161,310-330), ``Workers.pr
 ``net.predict``) and ``Workers.transfer_gpu_to_cpu`` (``preds_to_masks`` + ``.cpu().numpy()`` of every requested
 output).  ``FramePipeline`` is the device part of that loop in ONE process with HIP streams instead of processes:
 
-    host uint8 HWC frames (pinned) --copy stream--> GPU uint8 --HIP--> /255, HWC->CHW (+ integer INTER_AREA downscale)
+    host uint8 HWC frames (pinned) --copy stream--> GPU uint8 --HIP--> /255, HWC->CHW (+ INTER_AREA downscale)
         --> Reconstructor.predict_async (UNet on the caller's stream, ResNet-STN / warp / CE on its side stream)
         --> uint8 arg-max mask, uint8 warp mask, theta, consistency score, POI --copy stream--> pinned host arrays
 
@@ -41,8 +41,8 @@ class Ticket:
 
 class FramePipeline:
     def __init__(self, net, batch, frame_hw, req_outputs=("theta", "warp_mask"), consistency=False, channels=3):
-        """net: a Reconstructor on the GPU in eval mode; frame_hw = (H, W) of the DECODED frames (a multiple of
-        net.unet_size by an integer factor, or equal to it); req_outputs as predict.py's --req_outputs."""
+        """net: a Reconstructor on the GPU in eval mode; frame_hw = (H, W) of the DECODED frames (net.unet_size, or any
+        larger size: cv2.INTER_AREA's downscale runs on the GPU, engine.frames_u8_to_input); req_outputs as predict.py's --req_outputs."""
         self.net, self.B = net, int(batch)
         self.req = set(req_outputs)
         self.consistency = bool(consistency) or "consistency" in self.req

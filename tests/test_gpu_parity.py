@@ -1339,8 +1339,45 @@ def test_u8_frame_area2_downscale(E):
     got = E.frames_u8_to_input(torch.from_numpy(fr).cuda(), target_size=(36, 22))
     torch.cuda.synchronize()
     assert torch.equal(got.cpu(), want)
-    with pytest.raises(NotImplementedError):
-        E.frames_u8_to_input(torch.from_numpy(fr).cuda(), target_size=(30, 20))
+    with pytest.raises(NotImplementedError):      # frames narrower than the target: the reference switches to INTER_LINEAR
+        E.frames_u8_to_input(torch.from_numpy(fr).cuda(), target_size=(80, 50))
+    with pytest.raises(NotImplementedError):      # unequal integer factors (3 x 2): OpenCV's fast path with a 3x2 block, not built
+        E.frames_u8_to_input(torch.from_numpy(fr).cuda(), target_size=(24, 22))
+
+
+@pytest.mark.parametrize("src,dst", [((1080, 1920), (576, 1024)), ((900, 1600), (360, 640)), ((50, 77), (21, 30)), ((45, 64), (44, 63)),
+                                     ((720, 1280), (480, 854))])
+def test_u8_frame_non_integer_area_downscale(E, src, dst):
+    """Round 5: any downscale, not only integer factors (1920x1080 -> 1024x576, 1600x900 -> 640x360, ...): OpenCV's generic
+    INTER_AREA path (computeResizeAreaTab + resizeArea_), then /255 (utils/dataset.py:310-330), bit for bit against the numpy
+    restatement oracle/post_ref.resize_area; the per-axis tables of the C-ABI's host helper against the oracle's own."""
+    import ctypes
+    from oracle import post_ref
+    from sfh_amd import _lib
+    (hs, ws), (hd, wd) = src, dst
+    B = 2
+    fr = synth.synth_frames_u8(B, hs, ws, seed=23)
+    fr[0, :8, :8] = 255
+    fr[0, :8, 8:16] = 0
+    area = np.stack([post_ref.resize_area(f, (wd, hd)) for f in fr])
+    want = torch.from_numpy((area.transpose(0, 3, 1, 2) / 255)).type(torch.FloatTensor)
+    got = E.frames_u8_to_input(torch.from_numpy(fr).cuda(), target_size=(wd, hd))
+    torch.cuda.synchronize()
+    assert tuple(got.shape) == (B, 3, hd, wd)
+    assert torch.equal(got.cpu(), want)
+    # an area average stays within the range of its sources and keeps a constant image constant
+    flat = np.full((1, hs, ws, 3), 137, np.uint8)
+    assert torch.equal(E.frames_u8_to_input(torch.from_numpy(flat).cuda(), target_size=(wd, hd)).cpu(),
+                       torch.full((1, 3, hd, wd), 137 / 255, dtype=torch.float32))
+    lib = _lib.load()
+    for ss, ds in ((ws, wd), (hs, hd)):
+        cap = 2 * ds + ss
+        ofs, si, al = np.zeros(ds + 1, np.int32), np.zeros(cap, np.int32), np.zeros(cap, np.float32)
+        n = lib.sfh_resize_area_tab(ss, ds, ofs.ctypes.data_as(ctypes.c_void_p), si.ctypes.data_as(ctypes.c_void_p),
+                                    al.ctypes.data_as(ctypes.c_void_p), cap)
+        tab = post_ref._area_tab(ss, ds)
+        assert n == len(tab)
+        assert [(d, int(si[k]), float(al[k])) for d in range(ds) for k in range(ofs[d], ofs[d + 1])] == [(d, s_, float(a)) for d, s_, a in tab]
 
 
 @pytest.mark.parametrize("k,hw", [(3, (360, 640)), (3, (15, 22)), (4, (11, 18)), (5, (7, 9))])
