@@ -217,6 +217,13 @@ int sfh_f32_to_h2(const float* src, void* dst, int64_t rows, int W, int cs, int 
                   uint32_t* range, void* stream);
 int sfh_h2_to_f32(const void* src, float* dst, int64_t rows, int W, int cs, int act_exp, void* stream);
 
+/* The same 3x3 stride-1 convolution on two-plane fp16 operands for launches whose grid of 256-pixel x 64-cout workgroups
+ * leaves the chip under-filled (ResNet layer4 at batch 16, small batches): tiles of 12 x 20 pixels x 32 couts, halo and weight
+ * fragments through LDS.  Same descriptor, same packed weights (sfh_pack_h2_weights), same accumulation order per output -
+ * results are bit-identical to sfh_conv_s3_fwd's.  Restrictions: src_fmt H2, one source, ksize 3, stride 1, plain NHWC output
+ * (H2 or fp32), optional residual of the destination's format + ReLU, no pooled output / head / acc_init / split-K / statistics. */
+int sfh_conv_small_fwd(const sfh_conv_desc* d, void* stream);
+
 /* First UNet layer (inc.double_conv.0, unet/unet_parts.py:15; 3 input channels stored as 4):
  * tap-packed fp32 MFMA kernel, k = channel, one MFMA k-step per tap.  Same descriptor/epilogue as
  * sfh_conv_fwd; wpacked from sfh_pack_c4_weights ((cout/64)*9*256 floats), w is OIHW (cout,cin<=4,3,3). */

@@ -68,6 +68,7 @@ SIGNATURES = {
     "sfh_packed_c4h2_weight_bytes": (C.c_int64, [C.c_int]),
     "sfh_pack_c4h2_weights": (C.c_int, [_p, _p, C.c_int, C.c_int, C.c_int, _p]),
     "sfh_conv3x3_c4h2_fwd": (C.c_int, [C.POINTER(ConvDesc), _p]),
+    "sfh_conv_small_fwd": (C.c_int, [C.POINTER(ConvDesc), _p]),
     "sfh_packed_weight_floats": (C.c_int64, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "sfh_pack_conv_weights": (C.c_int, [_p, _p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _p]),
     "sfh_space_to_depth2": (C.c_int, [_p, _p, C.c_int, C.c_int, C.c_int, C.c_int, _p]),

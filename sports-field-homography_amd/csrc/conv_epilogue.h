@@ -130,6 +130,13 @@ struct sfh_cfg_stats { static constexpr bool value = false; };
 template <class CFG>
 struct sfh_cfg_stats<CFG, decltype((void)CFG::STATS)> { static constexpr bool value = CFG::STATS; };
 
+// a kernel configuration whose tile holds fewer real pixel groups than its waves cover says so with `static constexpr int NGRP`
+// (conv_small.hip: 15 groups in a 16-group layout); groups >= NGRP are never stored
+template <class CFG, class = void>
+struct sfh_cfg_ngrp { static constexpr int value = 1 << 30; };
+template <class CFG>
+struct sfh_cfg_ngrp<CFG, decltype((void)CFG::NGRP)> { static constexpr int value = CFG::NGRP; };
+
 constexpr unsigned kSfhOOB = 0xFFFFFFF0u;  // byte offset that the buffer range check rejects
 
 // CFG supplies SUBX, SH, SW, FLATROWS; G supplies Ho, Wo, rows_total, rows_per_img, rows_magic.
@@ -203,7 +210,7 @@ __device__ __forceinline__ void sfh_conv_epilogue(const sfh_conv_desc& d, const 
     const int oy = sy * CFG::SH + lq / CFG::SW, ox = sx * CFG::SW + lq % CFG::SW;
     const int x = x0 + ox;
     int b, y;
-    bool ok = x < g.Wo;
+    bool ok = x < g.Wo && s < sfh_cfg_ngrp<CFG>::value;
     if (CFG::FLATROWS) {
       const int r = r0 + oy;
       b = (int)__umulhi((unsigned)r, g.rows_magic);

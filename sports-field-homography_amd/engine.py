@@ -390,6 +390,11 @@ class ConvTimer:
         return out
 
 
+# conv_small.hip (12 x 20-pixel x 32-cout workgroups, halo + weights through LDS; bit-identical results) for 3x3 stride-1 H2
+# launches whose standard grid fills at most _SMALL_MAP_MAX of the 256 CUs: ResNet layer4 at batch 16 (192 workgroups -> 256:
+# 79 -> 50 us per launch, profiles/r05_small_map_probe.txt), small batches.  SFH_SMALL_MAP=0 switches it off.
+_SMALL_MAP = os.environ.get("SFH_SMALL_MAP", "1") != "0"
+_SMALL_MAP_MAX = int(os.environ.get("SFH_SMALL_MAP_MAX", "224"))
 _W8_HALF = os.environ.get("SFH_W8_HALF", "1") != "0"
 _W8_HALF_ROUNDS = float(os.environ.get("SFH_W8_HALF_ROUNDS", "3"))   # rounds of 512 resident workgroups from which the shape is requested
 
@@ -643,7 +648,8 @@ class PackedConv:
 
     def run(self, src0, batch, H, W, dst, src1=None, pool0=False, pad1=(0, 0), residual=None, tile=None,
             dst_pool=None, up_dst=None, head=None, wg_couts=0, exp_src=None, exp_dst=None, exp_res=None,
-            range_word=None, ksplit=0, slabs=None, acc_init=None, scale=None, shift_border=None, stats=None, bwd=None):
+            range_word=None, ksplit=0, slabs=None, acc_init=None, scale=None, shift_border=None, stats=None, bwd=None,
+            small=None):
         """src0/src1: NHWC float32 tensors, or split tensors of the layer's format (S3 bfloat16 / H2 float16);
         dst/residual/dst_pool: float32 NHWC or the same split format (by dtype).  H, W: conv input frame.
         H2 tensors: exp_src / exp_dst / exp_res = exponents of the sources / dst and dst_pool / an H2 residual
@@ -657,7 +663,10 @@ class PackedConv:
         power of two - the epilogue adds the per-wave sums of z and z^2 for batch-statistics BatchNorm into it
         (sfh_conv_desc.stats_partial; PackedConv.stats_ok says whether a layer qualifies).  bwd (with stats, this launch
         being a backward-data conv): (z, mean_invstd, gamma, beta) of the BatchNorm + ReLU layer whose only gradient dst
-        is - the table then receives sum g and sum g * xhat (sfh_conv_desc.bwd_z)."""
+        is - the table then receives sum g and sum g * xhat (sfh_conv_desc.bwd_z).
+        small: True / False forces / forbids the small-map kernel (sfh_conv_small_fwd: plain 3x3 stride-1 H2 launches, same
+        bits); None: the engine's rule - the standard grid would leave more than an eighth of the CUs without a workgroup and
+        the finer tiling gives at least 1.2x the workgroups."""
         lib = _lib.load()
         d = ConvDesc()
         if (self.fmt == "h2" or getattr(self, "c4h2", False)) and exp_src is not None:
@@ -786,6 +795,19 @@ class PackedConv:
                     "splitk_finish")
             if _chan(dst) != self.cout:
                 raise ValueError("split-K writes all channels of dst")
+        small_ok = (self.fmt == "h2" and self.ksize == 3 and self.stride == 1 and not self.transposed and src1 is None
+                    and dst_pool is None and head is None and acc_init is None and stats is None and not (ksplit and ksplit > 1)
+                    and not d.residual_f32 and sb is None and not self.c4)
+        if small and not small_ok:
+            raise ValueError("the small-map kernel takes a plain 3x3 stride-1 H2 conv (one source, no pooled output / head / "
+                             "acc_init / statistics / split-K)")
+        if small is None and small_ok and _SMALL_MAP and wg_couts == 0 and tile is None:
+            th, tw = next((a, b) for t_, a, b in _TILES + _TILES_S3_HALF if t_ == d.tile)
+            std = -(-(batch * (ho + zr)) // th) * -(-wo // tw) * (self.cout // 64)
+            fine = batch * -(-ho // 12) * -(-wo // 20) * (self.cout // 32)
+            small = std <= _SMALL_MAP_MAX and fine * 5 >= std * 6
+        if small:
+            fwd = lib.sfh_conv_small_fwd
         if self.c4:
             if src0.shape[-1] != 4 or pool0 or dst_pool is not None:
                 raise ValueError("the <=4-channel first-layer kernel needs an fp32 NHWC source with 4 stored channels")

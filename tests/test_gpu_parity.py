@@ -192,6 +192,66 @@ def test_s3_split_is_exact(E):
     assert torch.equal(rec, x)
 
 
+@pytest.mark.parametrize("case", [(16, 12, 20, 512, 512), (3, 23, 40, 256, 128), (2, 45, 80, 64, 64), (5, 7, 9, 32, 192),
+                                  (1, 25, 41, 96, 64), (16, 22, 40, 1024, 64)])
+def test_conv_small_map_kernel_gives_the_standard_kernel_s_bits(E, case):
+    """Round 5: sfh_conv_small_fwd (12x20-pixel x 32-cout workgroups, 15 pixel groups of 4x4, halo AND weights through LDS; for
+    launches whose standard grid leaves the chip under-filled: ResNet layer4 at batch 16) against conv_s3_kernel on the same
+    operands and the same packed weights: every output accumulates the same products in the same order => identical bits.
+    H2 destination with an H2 residual + ReLU, fp32 destination without; frames that are whole tiles (12x20), partial tiles in
+    both directions (23x40, 45x80, 7x9, 25x41), stored channels beyond the used ones; both LDS-buffering variants (grids of
+    at most / more than 256 workgroups); the range word reports the same maximum; and against an fp64 conv."""
+    B, H, W, cin, cout = case
+    g = synth._rng(7, f"small{case}")
+    x = torch.from_numpy(g.normal(0, 1, (B, H, W, cin + 32)).astype(np.float32)).cuda()     # 32 stored channels the conv ignores
+    w = torch.from_numpy((g.normal(0, 1, (cout, cin, 3, 3)) * (2.0 / (9 * cin)) ** 0.5).astype(np.float32)).cuda()
+    b = torch.from_numpy(g.normal(0, 0.1, (cout,)).astype(np.float32)).cuda()
+    res = torch.from_numpy(g.normal(0, 1, (B, H, W, cout)).astype(np.float32)).cuda()
+    bn = torch.nn.BatchNorm2d(cout).cuda().eval()
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5)
+        bn.running_mean.uniform_(-0.2, 0.2)
+        bn.running_var.uniform_(0.5, 1.5)
+    pc = E.PackedConv(w, b, bn, 3, cin, fmt="h2")
+    xs, rs = E.f32_to_split(x, "h2"), E.f32_to_split(res, "h2")
+    outs, words = {}, {}
+    for small in (False, True):
+        y = E.split_empty("h2", B, H, W, cout, "cuda")
+        word = torch.zeros(1, dtype=torch.int32, device="cuda")
+        pc.run(xs, B, H, W, y, residual=rs, small=small, range_word=word.data_ptr(), exp_src=2, exp_dst=1, exp_res=2)
+        yf = torch.empty((B, H, W, cout), device="cuda")
+        pc.relu = False
+        pc.run(xs, B, H, W, yf, small=small, exp_src=2)
+        pc.relu = True
+        torch.cuda.synchronize()
+        outs[small], words[small] = (y.clone(), yf), int(word.item())
+    assert torch.equal(outs[True][0], outs[False][0]) and torch.equal(outs[True][1], outs[False][1])
+    assert words[True] == words[False] and words[True] > 0
+    xin = x[..., :cin].cpu().double().permute(0, 3, 1, 2)
+    z = torch.nn.functional.conv2d(xin, w.cpu().double(), b.cpu().double(), padding=1)
+    bnd = bn.double().cpu()
+    want = bnd(z)
+    tol = 3e-5 if cin <= 512 else 1e-4      # (fp32 accumulation over K = 9 * cin products; the bit-equality above is the test)
+    assert _maxerr(_nchw(outs[True][1]).double(), want) < tol
+    want_r = torch.relu(want + E.s3_to_f32(rs).cpu().double().permute(0, 3, 1, 2))
+    assert _maxerr(_nchw(E.s3_to_f32(outs[True][0], 1)).double(), want_r) < tol
+    bn.float().cuda()
+    # the engine's own rule: only grids that leave more than an eighth of the CUs idle AND gain workgroups from the finer tiling
+    if case == (16, 12, 20, 512, 512):
+        calls = []
+        lib = E._lib.load()
+        real = lib.sfh_conv_small_fwd
+        try:
+            E._lib._lib.sfh_conv_small_fwd = lambda *a: (calls.append(1), real(*a))[1]
+            pc.run(xs, B, H, W, E.split_empty("h2", B, H, W, cout, "cuda"))
+        finally:
+            E._lib._lib.sfh_conv_small_fwd = real
+        assert calls == [1]            # ResNet layer4 at batch 16: 192 standard workgroups -> the small-map kernel
+    with pytest.raises(ValueError):
+        pc.run(xs, B, H, W, E.split_empty("h2", B, H, W, cout, "cuda"), small=True,
+               dst_pool=E.split_empty("h2", B, H // 2, W // 2, cout, "cuda"))
+
+
 @pytest.mark.parametrize("tile", [0, 1, 2])
 @pytest.mark.parametrize("hw", [(17, 23), (45, 80), (22, 40)])
 def test_conv_h2_eight_wave_workgroup_matches_four_wave(E, tile, hw):
