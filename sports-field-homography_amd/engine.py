@@ -391,10 +391,12 @@ class ConvTimer:
 
 
 # conv_small.hip (12 x 20-pixel x 32-cout workgroups, halo + weights through LDS; bit-identical results) for 3x3 stride-1 H2
-# launches whose standard grid fills at most _SMALL_MAP_MAX of the 256 CUs: ResNet layer4 at batch 16 (192 workgroups -> 256:
-# 79 -> 50 us per launch, profiles/r05_small_map_probe.txt), small batches.  SFH_SMALL_MAP=0 switches it off.
+# launches whose standard grid is at most one workgroup per CU, i.e. one wave per SIMD (_SMALL_MAP_MAX workgroups): ResNet layer4
+# at batch 16 (192 workgroups -> 256: 79 -> 50 us per launch, profiles/r05_small_map_probe.txt), layer3 (240 -> 512: equal
+# alone, +0.2 % under the pipeline), small batches.  Same-device A/B (profiles/r05_ab_small_map.txt): 13.31 -> 13.19 ms per batch
+# with the threshold at 224 (layer4 only), 13.09 at 256.  SFH_SMALL_MAP=0 switches it off.
 _SMALL_MAP = os.environ.get("SFH_SMALL_MAP", "1") != "0"
-_SMALL_MAP_MAX = int(os.environ.get("SFH_SMALL_MAP_MAX", "224"))
+_SMALL_MAP_MAX = int(os.environ.get("SFH_SMALL_MAP_MAX", "256"))
 _W8_HALF = os.environ.get("SFH_W8_HALF", "1") != "0"
 _W8_HALF_ROUNDS = float(os.environ.get("SFH_W8_HALF_ROUNDS", "3"))   # rounds of 512 resident workgroups from which the shape is requested
 
@@ -665,8 +667,8 @@ class PackedConv:
         being a backward-data conv): (z, mean_invstd, gamma, beta) of the BatchNorm + ReLU layer whose only gradient dst
         is - the table then receives sum g and sum g * xhat (sfh_conv_desc.bwd_z).
         small: True / False forces / forbids the small-map kernel (sfh_conv_small_fwd: plain 3x3 stride-1 H2 launches, same
-        bits); None: the engine's rule - the standard grid would leave more than an eighth of the CUs without a workgroup and
-        the finer tiling gives at least 1.2x the workgroups."""
+        bits); None: the engine's rule - the standard grid is at most one workgroup per CU (one wave per SIMD)
+        and the finer tiling gives at least 1.2x the workgroups."""
         lib = _lib.load()
         d = ConvDesc()
         if (self.fmt == "h2" or getattr(self, "c4h2", False)) and exp_src is not None:
