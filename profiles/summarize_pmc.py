@@ -44,6 +44,8 @@ def group(name, resnet=False):
         if resnet:
             return "s3_resnet"
         return {"3": "s3_conv3x3", "2": "s3_up2x2"}.get(m.group(1), "s3_conv1x1")
+    if "conv_small_kernel" in name:      # round 5: the small-map 3x3 kernel (ResNet layer3 / layer4 at batch 16)
+        return "s3_resnet" if resnet else "s3_conv3x3"
     if "stem7x7" in name:
         return "s3_stem7x7"
     if "conv3x3_c4" in name:
