@@ -207,7 +207,9 @@ extern "C" int sfh_conv_small_fwd(const sfh_conv_desc* dp, void* stream_) {
   SFH_REQUIRE(nblocks < (1L << 31), "conv_small_fwd: grid too large");
   hipStream_t stream = (hipStream_t)stream_;
   // at most one workgroup per CU (256 CUs): two LDS buffers, the DMA of stage s + 1 under the MFMAs of stage s
-  if ((long)g.ntiles * g.nblk <= 256) {
+  // (sfh_conv_desc.wg_couts, which has no other meaning here, overrides: 1 = one buffer, 2 = two buffers)
+  SFH_REQUIRE(d.wg_couts >= 0 && d.wg_couts <= 2, "conv_small_fwd: wg_couts=%d (0 = the launcher decides, 1 = one LDS buffer, 2 = two)", d.wg_couts);
+  if (d.wg_couts == 2 || (d.wg_couts == 0 && (long)g.ntiles * g.nblk <= 256)) {
     sfh_allow_big_lds((const void*)conv_small_kernel<true>);
     hipLaunchKernelGGL(conv_small_kernel<true>, dim3((unsigned)nblocks), dim3(256), 2 * SmallCfg::BUF * 16, stream, d, g);
   } else {
