@@ -358,8 +358,9 @@ int64_t sfh_ce_workspace_floats(int batch, int H, int W);
 int sfh_consistency_ce_fwd(const float* logits, const int32_t* mask, int batch, int nc, int H,
                            int W, int hm, int wm, float* partial, float* score, void* stream);
 
-/* The two calls above fused for predict()'s usual case (warp_size == the logits' size, nearest mode, 4 classes;
- * models/reconstructor.py:223-240): out_i32 (B,h,w) = trunc(warp * out_scale) bit-identical to sfh_homography_warp_fwd, and
+/* The two calls above fused for predict()'s usual cases (nearest mode, 4 classes; the logits (B,nc,hl,wl) have the warp's size,
+ * or exactly half of it in both directions - predict.py's default geometry, where the reference scores through the nearest-
+ * resized mask, i.e. logit pixel (y, x) against mask pixel (2y, 2x); models/reconstructor.py:223-240): out_i32 (B,h,w) = trunc(warp * out_scale) bit-identical to sfh_homography_warp_fwd, and
  * score (B) = mean over the pixels of cross_entropy(logits[:, :, y, x], out_i32[y, x]) - every wave scores the pixels it warps
  * while the class ids are still in registers, the logits (B,nc,h,w) are streamed once, the mask is never read back.  Two
  * launches (the fused kernel + a one-wave-per-frame sum of its partials in fp64, fixed order: deterministic) instead of three.
@@ -367,8 +368,8 @@ int sfh_consistency_ce_fwd(const float* logits, const int32_t* mask, int batch, 
  * size: the two separate entries.                                                                                       */
 int64_t sfh_warp_consistency_workspace_floats(int batch, int h, int w);
 int sfh_warp_consistency_fwd(const float* theta, const float* tmpl, int64_t tmpl_bstride, int ht, int wt, int batch, int h,
-                             int w, float out_scale, const float* logits, int nc, int32_t* out_i32, float* partial,
-                             float* score, void* stream);
+                             int w, float out_scale, const float* logits, int nc, int hl, int wl, int32_t* out_i32,
+                             float* partial, float* score, void* stream);
 
 /* Output masks as predict.py writes them (predict.py:286-315; utils/postprocess.py:7-61):
  * src is int32 class ids (src_kind 0, e.g. predict()'s warp_mask), uint8 ids (1) or fp32 logits

@@ -137,7 +137,7 @@ SIGNATURES = {
     "sfh_probe_mfma_f16": (C.c_int, [C.c_int, C.c_int, _p, _p, _p]),
     "sfh_warp_consistency_workspace_floats": (C.c_int64, [C.c_int, C.c_int, C.c_int]),
     "sfh_warp_consistency_fwd": (C.c_int, [_p, _p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, _p, C.c_int,
-                                           _p, _p, _p, _p]),
+                                           C.c_int, C.c_int, _p, _p, _p, _p]),
 }
 
 _lib = None

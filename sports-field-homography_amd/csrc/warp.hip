@@ -297,13 +297,16 @@ __global__ __launch_bounds__(256) void warp2_kernel(const float* __restrict__ th
 // not coherent with each other, and every block paid for one; profiles/r05_warpce_sweep.txt.)
 // Traffic = logits (4 * NC B / pixel) + mask (4 B / pixel) + one template: 74.6 MB at 640x360 x 16, 298 MB at 1280x720 x 16,
 // against 15.7 / 62.7 MB for the warp alone and a second pass over mask + logits for the separate CE kernels.
-template <int J, int RPT, int NC, int LEVEL, bool SMALL>
+// LS = 1: the logits have the warp's size.  LS = 2: the warp is twice the logits' size in both directions (predict.py's default
+// geometry: UNet 640x360, warp 1280x720); the reference scores through F.interpolate(mask, mode='nearest'), i.e. logit pixel
+// (y, x) against mask pixel (2y, 2x): the lanes at even x of the even rows score, the others only warp.
+template <int J, int RPT, int NC, int LS, int LEVEL, bool SMALL>
 __device__ __forceinline__ float warpce_body(const float (&t)[9], int b, int lane, int c0, int r0,
                                              const float* __restrict__ tmpl, long tmpl_bstride, int ht, int wt, int h, int w,
                                              float rdw, float rdh, float out_scale, const float* __restrict__ logits,
                                              int32_t* __restrict__ out_i) {
   float a0[J], a3[J], a6[J];
-  unsigned coff[J];
+  unsigned coff[J], loff[J];
 #pragma unroll
   for (int j = 0; j < J; ++j) {
     const int c = c0 + 64 * j;
@@ -312,6 +315,7 @@ __device__ __forceinline__ float warpce_body(const float (&t)[9], int b, int lan
     a3[j] = __fmul_rn(t[3], xn);
     a6[j] = __fmul_rn(t[6], xn);
     coff[j] = c < w ? (unsigned)c * 4u : kTapOOB;
+    loff[j] = (c < w && (c % LS) == 0) ? (unsigned)(c / LS) * 4u : kTapOOB;     // the logit pixel this lane scores, if any
   }
   const float ynl = norm_axis2<SMALL>(r0 + (lane & (RPT - 1)), h, rdh);
   const float c1l = __fmul_rn(t[1], ynl), c4l = __fmul_rn(t[4], ynl), c7l = __fmul_rn(t[7], ynl);
@@ -320,9 +324,11 @@ __device__ __forceinline__ float warpce_body(const float (&t)[9], int b, int lan
   const int nrows = (h - r0 < RPT) ? h - r0 : RPT;
   const long rowbase = ((long)b * h + r0) * w;
   const __amdgpu_buffer_rsrc_t roi = __builtin_amdgcn_make_buffer_rsrc(out_i + rowbase, 0, nrows * w * 4, 0x00020000);
-  // the NC logit planes of this frame: plane k, row r at byte (k * h + r) * w * 4 (below 4 GiB: checked by the launcher)
+  // the NC logit planes of this frame (hl x wl = the warp's size / LS): plane k, row r at byte (k * hl + r) * wl * 4 (below
+  // 4 GiB: checked by the launcher)
+  const int hl = h / LS, wl = w / LS;
   const __amdgpu_buffer_rsrc_t rl = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float*>(logits + (long)b * NC * h * w), 0, NC * h * w * 4, 0x00020000);
+      const_cast<float*>(logits + (long)b * NC * hl * wl), 0, NC * hl * wl * 4, 0x00020000);
   const float sx = 0.5f * (float)wt, sy = 0.5f * (float)ht;
   unsigned off[J];
   float tv[J], lg[2][J][NC];
@@ -347,22 +353,25 @@ __device__ __forceinline__ float warpce_body(const float (&t)[9], int b, int lan
 #pragma unroll
     for (int j = 0; j < J; ++j) tv[j] = tap_ld(rt, off[j]);
   };
-  // logits of row r0 + rr into register set `set` (rows beyond the frame: the scalar offset stays inside the frame's planes
-  // or beyond the descriptor - either way the values are never used)
-  auto issue_logits = [&](int rr, int set) {
-    const int row = r0 + rr < h ? r0 + rr : h - 1;
+  // logits for warp row r0 + rr (a scoring row: rr % LS == 0; r0 is a multiple of RPT, which is even) into register set
+  // (rr / LS) & 1 (rows beyond the frame: the scalar offset stays inside the frame's planes or beyond the descriptor - either
+  // way the values are never used)
+  auto issue_logits = [&](int rr) {
+    if (rr % LS != 0) return;
+    const int set = (rr / LS) & 1;
+    const int row = (r0 + rr < h ? r0 + rr : h - 1) / LS;
 #pragma unroll
     for (int k = 0; k < NC; ++k) {
-      const int soff = (k * h + row) * w * 4;
+      const int soff = (k * hl + row) * wl * 4;
 #pragma unroll
       for (int j = 0; j < J; ++j)
-        lg[set][j][k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rl, (int)coff[j], soff, 0));
+        lg[set][j][k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rl, (int)loff[j], soff, 0));
     }
   };
   float sum = 0.f;
   coords(0);
   issue_taps();
-  issue_logits(0, 0);
+  issue_logits(0);
   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
   for (int rr = 0; rr < RPT; ++rr) {
@@ -372,7 +381,7 @@ __device__ __forceinline__ float warpce_body(const float (&t)[9], int b, int lan
     for (int j = 0; j < J; ++j) val[j] = tv[j];
     if (rr + 1 < RPT) {
       issue_taps();
-      issue_logits(rr + 1, (rr + 1) & 1);
+      issue_logits(rr + 1);
     }
     __builtin_amdgcn_sched_barrier(0);
     if (rr < nrows) {
@@ -381,9 +390,10 @@ __device__ __forceinline__ float warpce_body(const float (&t)[9], int b, int lan
       for (int j = 0; j < J; ++j) {
         const int32_t cls = (int32_t)__fmul_rn(val[j], out_scale);
         __builtin_amdgcn_raw_buffer_store_b32((unsigned)cls, roi, (int)coff[j], soff, 0);
+        if (rr % LS != 0) continue;      // (compile time: rr is an unrolled loop index)
         // cross entropy of this pixel: logsumexp - logit of the warped class (a class outside 0 .. NC-1 contributes the
         // logsumexp alone, as xt = 0 in ce_partial_kernel)
-        const float (&v)[NC] = lg[rr & 1][j];
+        const float (&v)[NC] = lg[(rr / LS) & 1][j];
         float m = v[0];
 #pragma unroll
         for (int k = 1; k < NC; ++k) m = fmaxf(m, v[k]);
@@ -394,7 +404,7 @@ __device__ __forceinline__ float warpce_body(const float (&t)[9], int b, int lan
           xt = (cls == k) ? v[k] : xt;
         }
         const float ce = (m + __logf(se)) - xt;
-        sum += (coff[j] != kTapOOB) ? ce : 0.f;
+        sum += (loff[j] != kTapOOB) ? ce : 0.f;
       }
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -402,7 +412,7 @@ __device__ __forceinline__ float warpce_body(const float (&t)[9], int b, int lan
   return sum;
 }
 
-template <int J, int RPT, int NC>
+template <int J, int RPT, int NC, int LS>
 __global__ __launch_bounds__(256) void warpce_kernel(const float* __restrict__ theta, const float* __restrict__ tmpl,
                                                      long tmpl_bstride, int ht, int wt, int h, int w, float rdw, float rdh,
                                                      float out_scale, const float* __restrict__ logits,
@@ -422,7 +432,7 @@ __global__ __launch_bounds__(256) void warpce_kernel(const float* __restrict__ t
     const float zs = fabsf(t[6]) + fabsf(t[7]) + fabsf(t[8]);
     const bool live = (fabsf(t[8]) - fabsf(t[6]) - fabsf(t[7])) > 1e-6f * zs + 1e-7f;
 #define SFH_WARPCE_GO(LEVEL, SMALL) \
-  sum = warpce_body<J, RPT, NC, LEVEL, SMALL>(t, b, lane, c0, r0, tmpl, tmpl_bstride, ht, wt, h, w, rdw, rdh, out_scale, logits, out_i)
+  sum = warpce_body<J, RPT, NC, LS, LEVEL, SMALL>(t, b, lane, c0, r0, tmpl, tmpl_bstride, ht, wt, h, w, rdw, rdh, out_scale, logits, out_i)
     if (fin && w <= 16384 && h <= 16384) {
       if (live) SFH_WARPCE_GO(2, true); else SFH_WARPCE_GO(1, true);
     } else {
@@ -683,13 +693,16 @@ extern "C" int64_t sfh_warp_consistency_workspace_floats(int batch, int h, int w
 }
 
 extern "C" int sfh_warp_consistency_fwd(const float* theta, const float* tmpl, int64_t tmpl_bstride, int ht, int wt,
-                                        int batch, int h, int w, float out_scale, const float* logits, int nc,
+                                        int batch, int h, int w, float out_scale, const float* logits, int nc, int hl, int wl,
                                         int32_t* out_i32, float* partial, float* score, void* stream) {
   SFH_REQUIRE(theta && tmpl && logits && out_i32 && partial && score, "warp_consistency: null pointer");
   SFH_REQUIRE(batch > 0 && batch <= 65535 && h > 1 && w > 1 && ht > 0 && wt > 0,
               "warp_consistency: bad geometry b=%d h=%d w=%d ht=%d wt=%d", batch, h, w, ht, wt);
   SFH_REQUIRE(nc == 4, "warp_consistency: nc=%d (the fused kernel is built for 4 classes; use sfh_homography_warp_fwd + "
               "sfh_consistency_ce_fwd otherwise)", nc);
+  SFH_REQUIRE((hl == h && wl == w) || (2 * hl == h && 2 * wl == w),
+              "warp_consistency: logits %dx%d against a warp of %dx%d (the same size, or exactly half of it in both directions)", wl, hl, w, h);
+  const int ls = h / hl;
   SFH_REQUIRE(tmpl_bstride == 0 || tmpl_bstride >= (int64_t)ht * wt, "warp_consistency: bad template stride");
   SFH_REQUIRE((int64_t)ht * wt <= (1 << 22) && w <= (1 << 20) && h <= (1 << 20) && (int64_t)nc * h * w * 4 < 0x7FFFFFF0LL,
               "warp_consistency: template %dx%d or frame %dx%d too large", wt, ht, w, h);
@@ -700,8 +713,14 @@ extern "C" int sfh_warp_consistency_fwd(const float* theta, const float* tmpl, i
   while (rpt > 2 && segs * sfh_cdiv(h, rpt) < SFH_WARP_MIN_WAVES) rpt >>= 1;
   const dim3 grid((unsigned)sfh_cdiv(w, 64 * J), (unsigned)sfh_cdiv(h, 4 * rpt), (unsigned)batch);
 #define SFH_WCE(JJ, RR)                                                                                             \
-  hipLaunchKernelGGL((warpce_kernel<JJ, RR, 4>), grid, dim3(256), 0, (hipStream_t)stream, theta, tmpl,                \
-                     (long)tmpl_bstride, ht, wt, h, w, rdw, rdh, out_scale, logits, out_i32, partial)
+  do {                                                                                                              \
+    if (ls == 1)                                                                                                    \
+      hipLaunchKernelGGL((warpce_kernel<JJ, RR, 4, 1>), grid, dim3(256), 0, (hipStream_t)stream, theta, tmpl,         \
+                         (long)tmpl_bstride, ht, wt, h, w, rdw, rdh, out_scale, logits, out_i32, partial);           \
+    else                                                                                                            \
+      hipLaunchKernelGGL((warpce_kernel<JJ, RR, 4, 2>), grid, dim3(256), 0, (hipStream_t)stream, theta, tmpl,         \
+                         (long)tmpl_bstride, ht, wt, h, w, rdw, rdh, out_scale, logits, out_i32, partial);           \
+  } while (0)
   if (J == 5) {
     if (rpt == 8) SFH_WCE(5, 8); else if (rpt == 4) SFH_WCE(5, 4); else SFH_WCE(5, 2);
   } else {
@@ -711,7 +730,7 @@ extern "C" int sfh_warp_consistency_fwd(const float* theta, const float* tmpl, i
   int rc = sfh_check_launch("warpce_kernel");
   if (rc) return rc;
   hipLaunchKernelGGL(warpce_final_kernel, dim3((unsigned)batch), dim3(64), 0, (hipStream_t)stream, partial,
-                     (int)(grid.x * grid.y * 4u), 1.0 / ((double)h * (double)w), score);
+                     (int)(grid.x * grid.y * 4u), 1.0 / ((double)hl * (double)wl), score);
   return sfh_check_launch("warpce_final_kernel");
 }
 

@@ -1574,15 +1574,19 @@ def homography_warp(theta, template, h, w, nearest, scale=None, want_f32=True, w
     return out_f, out_i
 
 
-def warp_consistency(theta, template, logits, scale, shared_template=False):
-    """predict()'s nearest warp (* mask_classes -> int32) AND the consistency score in one launch (sfh_warp_consistency_fwd):
-    the warp has the logits' size, 4 classes.  -> (warp_mask int32 (B,h,w), score float32 (B,)); the mask is bit-identical to
-    homography_warp()'s."""
+def warp_consistency(theta, template, logits, scale, shared_template=False, warp_hw=None):
+    """predict()'s nearest warp (* mask_classes -> int32) AND the consistency score fused (sfh_warp_consistency_fwd): 4 classes;
+    the warp (warp_hw = (h, w), default the logits' size) has the logits' size or exactly twice it in both directions
+    (predict.py's default geometry: the score then goes through the nearest-resized mask, as the reference's).
+    -> (warp_mask int32 (B,h,w), score float32 (B,)); the mask is bit-identical to homography_warp()'s."""
     lib = _lib.load()
     theta = _f32c(theta.reshape(-1, 3, 3).contiguous(), "theta")
     template = _f32c(template, "court template")
     logits = _f32c(logits, "logits")
-    B, nc, h, w = logits.shape
+    B, nc, hl, wl = logits.shape
+    h, w = (hl, wl) if warp_hw is None else (int(warp_hw[0]), int(warp_hw[1]))
+    if (h, w) not in ((hl, wl), (2 * hl, 2 * wl)):
+        raise ValueError(f"warp {w}x{h} against logits {wl}x{hl}: the fused kernel takes the same size or exactly twice it")
     if theta.shape[0] != B:
         raise ValueError(f"{theta.shape[0]} homographies for {B} frames of logits")
     if template.dim() != 4 or template.shape[1] != 1:
@@ -1601,12 +1605,12 @@ def warp_consistency(theta, template, logits, scale, shared_template=False):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
     _lib.check(lib.sfh_warp_consistency_fwd(_ptr(theta), _ptr(template), 0 if shared_template else ht * wt, ht, wt, B, h, w,
-                                            float(scale), _ptr(logits), nc, _ptr(out_i), _ptr(partial), _ptr(score),
+                                            float(scale), _ptr(logits), nc, hl, wl, _ptr(out_i), _ptr(partial), _ptr(score),
                                             _stream()), "warp_consistency")
     if tm is not None:
         e1.record()
         # algorithmic BYTES: the logits once, the mask once, the template once (per frame if not shared), theta
-        tm.records.append(("warp+ce", float(B * h * w * 4 * (nc + 1) + (1 if shared_template else B) * ht * wt * 4 + 36 * B), e0, e1))
+        tm.records.append(("warp+ce", float(B * (hl * wl * 4 * nc + h * w * 4) + (1 if shared_template else B) * ht * wt * 4 + 36 * B), e0, e1))
     return out_i, score
 
 

@@ -708,11 +708,13 @@ class Reconstructor(nn.Module):
                     shared = self._template_is_shared(self.court_img, bs)
                     lgt = ret.get('logits')
                     if (consistency and self.use_unet and self.warp_with_nearest and self.fuse_warp_ce
-                            and self.mask_classes == 4 and tuple(lgt.shape[1:]) == (4, h, w)):
-                        # the usual case: warp and consistency score in ONE launch - every wave scores the pixels it warps
-                        # while their class ids are in registers, the logits are streamed once (reference: :223-240)
+                            and self.mask_classes == 4 and tuple(lgt.shape[1:]) in ((4, h, w), (4, h // 2, w // 2))
+                            and (h % 2 == 0 and w % 2 == 0 or tuple(lgt.shape[2:]) == (h, w))):
+                        # the usual cases - the warp has the logits' size, or twice it (predict.py's default geometry) - warp and
+                        # consistency score fused: every wave scores the pixels it warps while their class ids are in registers,
+                        # the logits are streamed once (reference: :223-240)
                         wm, ret['consist_score'] = E.warp_consistency(theta, tmpl.contiguous(), lgt, float(self.mask_classes),
-                                                                      shared_template=shared)
+                                                                      shared_template=shared, warp_hw=(h, w))
                     else:
                         # warp * mask_classes -> int32, fused in the kernel (reference: :223,240)
                         _, wm = E.homography_warp(theta, tmpl.contiguous(), h, w, self.warp_with_nearest,

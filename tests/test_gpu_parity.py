@@ -664,6 +664,37 @@ def test_warp_consistency_fused_kernel(E, size, shared):
     assert _maxerr(score, sep) < 1e-5
 
 
+@pytest.mark.parametrize("size", [(1280, 720), (194, 122), (640, 90)])
+def test_warp_consistency_fused_kernel_with_a_warp_twice_the_logits_size(E, size):
+    """predict.py's default geometry (predict.py:151-155): the warp is twice the logits' size, the reference scores through
+    F.interpolate(mask, mode='nearest') - logit pixel (y, x) against mask pixel (2y, 2x).  The fused kernel warps every pixel and
+    lets the lanes at even x of the even rows score: mask bit-identical to the oracle's warp, score equal to torch's
+    cross_entropy through the nearest-resized mask and to the separate kernels'."""
+    w, h = size
+    theta = _thetas()
+    B = theta.shape[0]
+    if (w, h) == (1280, 720):
+        tmpl = synth.load_court_template("ncaa_nc4_1280x720", 4, B)
+    else:
+        ids = synth._rng(3, "tmpl2").integers(0, 4, (h + 3, w + 5))
+        tmpl = torch.from_numpy(ids.astype(np.float32) / 4.0)[None, None].repeat(B, 1, 1, 1)
+    g = synth._rng(12, f"wce2_{w}x{h}")
+    logits = torch.from_numpy(g.normal(0, 3, (B, 4, h // 2, w // 2)).astype(np.float32))
+    want_mask = (warp_ref.homography_warp(theta, tmpl, h, w, "nearest") * 4).to(torch.int32)
+    m = torch.nn.functional.interpolate(want_mask.float().unsqueeze(1), size=(h // 2, w // 2), mode="nearest").squeeze(1).long()
+    assert torch.equal(m, want_mask[:, ::2, ::2].long())
+    want = torch.nn.functional.cross_entropy(logits, m, reduction="none").mean(dim=(1, 2))
+    lg, th, tm = logits.cuda(), theta.cuda(), tmpl.cuda()
+    wm, score = E.warp_consistency(th, tm, lg, 4.0, shared_template=True, warp_hw=(h, w))
+    _, wm2 = E.homography_warp(th, tm, h, w, True, scale=4.0, want_f32=False, want_i32=True, shared_template=True)
+    sep = E.consistency_ce(lg, wm2)
+    torch.cuda.synchronize()
+    assert torch.equal(wm.cpu(), want_mask) and torch.equal(wm, wm2)
+    assert _maxerr(score.cpu(), want) < 1e-5 and _maxerr(score, sep) < 1e-5
+    with pytest.raises(ValueError):
+        E.warp_consistency(th, tm, lg, 4.0, shared_template=True, warp_hw=(h // 2 + 1, w // 2))
+
+
 def test_predict_uses_the_fused_warp_consistency_kernel_and_matches_the_separate_kernels(E):
     """predict(consistency=True) with a nearest warp of the logits' size takes the fused kernel; `fuse_warp_ce = False` (or a
     bilinear warp, or a warp of another size) the two separate ones: same mask bits, scores within 1e-5, same keys."""
