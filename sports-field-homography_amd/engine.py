@@ -336,6 +336,18 @@ def choose_tile_s3(batch, ho, wo, stride, zrows, nblk, ksize=3, wg_slots=_WG_SLO
     return best[1]
 
 
+def choose_small_map(batch, ho, wo, zr, cout, tile_id, max_wgs=None):
+    """Should a plain 3x3 stride-1 H2 launch take the small-map kernel (csrc/conv_small.hip: 12x20-pixel x 32-cout workgroups)
+    instead of conv_s3_kernel with workgroup tile `tile_id`?  Yes when the standard grid is at most one workgroup per CU - one
+    wave per SIMD: the launch then takes what its busiest SIMD takes, and only finer work units shorten it - AND the finer tiling
+    gives at least 1.2x the workgroups.  At batch 16 and 640x360: ResNet layer4 (192 -> 256 workgroups: 79 -> 50 us) and layer3
+    (240 -> 512: equal alone, better under the pipeline); at batch 1 most of the net."""
+    th, tw = next((a, b) for t_, a, b in _TILES + _TILES_S3_HALF if t_ == tile_id)
+    std = -(-(batch * (ho + zr)) // th) * -(-wo // tw) * (cout // 64)
+    fine = batch * -(-ho // 12) * -(-wo // 20) * (cout // 32)
+    return std <= (_SMALL_MAP_MAX if max_wgs is None else max_wgs) and fine * 5 >= std * 6
+
+
 def choose_ksplit(batch, ho, wo, stride, cout, nstages, ksize=3, wg_slots=_WG_SLOTS):
     """Split-K factor for a conv whose (pixel tile, 64-cout block) grid fills at most a QUARTER of the chip's
     workgroup slots (small batches: one frame of 640x360 has 4-60 workgroups per ResNet layer): the largest factor
@@ -805,10 +817,7 @@ class PackedConv:
             raise ValueError("the small-map kernel takes a plain 3x3 stride-1 H2 conv (one source, no pooled output / head / "
                              "acc_init / statistics / split-K)")
         if small is None and small_ok and _SMALL_MAP and wg_couts == 0 and tile is None:
-            th, tw = next((a, b) for t_, a, b in _TILES + _TILES_S3_HALF if t_ == d.tile)
-            std = -(-(batch * (ho + zr)) // th) * -(-wo // tw) * (self.cout // 64)
-            fine = batch * -(-ho // 12) * -(-wo // 20) * (self.cout // 32)
-            small = std <= _SMALL_MAP_MAX and fine * 5 >= std * 6
+            small = choose_small_map(batch, ho, wo, zr, self.cout, d.tile)
         if small:
             fwd = lib.sfh_conv_small_fwd
             d.wg_couts = _SMALL_MAP_BUFFERS      # 0: the launcher decides (two LDS buffers for grids of at most 256 workgroups)

@@ -379,3 +379,26 @@ def test_engine_stamp_ignores_unrelated_modules_and_notices_sub_module_casts():
     live = {id(t) for t in list(net.parameters()) + list(net.buffers())}
     assert {id(t) for t in net.__dict__["_stamp_tensors"]} == live
     assert net._param_stamp() == s2
+
+
+def test_small_map_kernel_rule():
+    """engine.choose_small_map: the finer 12x20 x 32-cout tiling only for launches whose standard grid is at most one workgroup
+    per CU and that gain at least 1.2x the workgroups from it."""
+    from sfh_amd import engine as E
+
+    def rule(batch, ho, wo, cout, cin_unused=None):
+        zr = 1 + ((ho + 1) & 1)
+        tile = E.choose_tile_s3(batch, ho, wo, 1, zr, cout // 64)
+        return E.choose_small_map(batch, ho, wo, zr, cout, tile)
+    # 640x360, batch 16: ResNet layer4 (192 standard workgroups) and layer3 (240) take it, layer2 / layer1 and the UNet do not
+    assert rule(16, 12, 20, 512) and rule(16, 23, 40, 256)
+    assert not rule(16, 45, 80, 128) and not rule(16, 90, 160, 64)
+    assert not rule(16, 22, 40, 1024) and not rule(16, 45, 80, 512) and not rule(16, 360, 640, 64)
+    # 1280x720, batch 16: layer4 is 23x40 with 512 channels: 480 standard workgroups - stays
+    assert not rule(16, 23, 40, 512)
+    # one frame: most of the net is under-filled
+    assert rule(1, 45, 80, 512) and rule(1, 22, 40, 1024) and rule(1, 90, 160, 256)
+    # never when the finer tiling does not add workgroups: four 12x20 frames x 64 couts = 8 standard workgroups (16x16 tiles) and 8 fine ones
+    assert E.choose_small_map(4, 12, 20, 2, 64, E._lib.TILE_16x16) is False
+    # the threshold is a parameter (experiments): with 224, layer3's 240 standard workgroups stay on the standard kernel
+    assert E.choose_small_map(16, 23, 40, 1, 256, E._lib.TILE_32x8, max_wgs=224) is False
