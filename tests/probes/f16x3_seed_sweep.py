@@ -20,7 +20,7 @@ poi = synth.load_court_poi("pitch", B)
 sys.path.insert(0, ROOT)
 import bench  # noqa: E402   (usable_cores: the cgroup's CPU quota, not the host's core count)
 torch.set_num_threads(min(bench.usable_cores(), 16))
-OUT = open(os.path.join(ROOT, "gpurun_out", "r02h_f16x3_seed_sweep.txt"), "w")
+OUT = open(os.path.join(ROOT, "gpurun_out", "f16x3_seed_sweep.txt"), "w")
 
 
 def emit(line):
