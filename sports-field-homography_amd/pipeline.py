@@ -29,6 +29,23 @@ from . import engine as E
 from . import outputs as O
 
 
+# ONE copy stream per device, shared by every FramePipeline of the process, for uploads AND downloads.  HIP multiplexes streams
+# onto a handful of hardware queues (four by default) in creation order: with an upload stream and a download stream per pipeline
+# object, every second pipeline a process created got streams that share a queue with the model's compute / side streams, and its
+# copies then waited behind kernels (measured: 13.2 ms per batch from the first pipeline, 14.2 from the second, 13.3 from the third
+# ...; 13.7 / 16.0 with 1920x1080 frames; GPU_MAX_HW_QUEUES=8 removes the alternation: profiles/micro/e2e_parity_probe.py).  The
+# two directions need no stream of their own: an upload is 0.25-1.9 ms, a download 0.14 ms, per 13 ms batch.
+_COPY_STREAMS = {}
+
+
+def _copy_stream(dev):
+    key = (dev.type, dev.index if dev.index is not None else torch.cuda.current_device())
+    st = _COPY_STREAMS.get(key)
+    if st is None:
+        st = _COPY_STREAMS[key] = torch.cuda.Stream(dev)
+    return st
+
+
 class Ticket:
     """one submitted batch: which slot it uses, its generation on that slot, its own events"""
     __slots__ = ("slot", "gen", "uploaded", "downloaded", "handle", "dev", "fetched")
@@ -56,7 +73,7 @@ class FramePipeline:
         self.target = None if (W, H) == (tw, th) else (tw, th)
         wh, ww = net._warp_hw
         nc = net.mask_classes
-        self.h2d, self.d2h = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+        self.h2d = self.d2h = _copy_stream(dev)
         pin = lambda shape, dt: torch.empty(shape, dtype=dt).pin_memory()
         self.slots = []
         for _ in range(2):
