@@ -51,6 +51,21 @@ torch.nn.modules.module.register_module_buffer_registration_hook(_count_registra
 torch.nn.modules.module.register_module_module_registration_hook(_count_registration)
 
 
+# predict_async()'s two extra streams, ONE pair per device for every model of the process: HIP multiplexes streams onto a handful
+# of hardware queues (four by default) in creation order, and streams that share a queue serialise - a pair per model object
+# would make the overlap of every second or third model a process creates depend on which queue its side stream happened to land
+# on (sfh_amd.pipeline measured exactly that with per-object copy streams: profiles/micro/e2e_parity_probe.py).
+_PIPE_STREAMS = {}
+
+
+def _pipe_streams(dev, prio):
+    key = (dev.index if dev.index is not None else torch.cuda.current_device(), prio)
+    st = _PIPE_STREAMS.get(key)
+    if st is None:
+        st = _PIPE_STREAMS[key] = (torch.cuda.Stream(dev, priority=prio), torch.cuda.Stream(dev))
+    return st
+
+
 class _Done:
     """handle of a batch that was computed synchronously"""
 
@@ -598,7 +613,8 @@ class Reconstructor(nn.Module):
             with torch.cuda.device(dev):
                 # experiment knob: HIP priority of the side stream (negative = higher than the caller's default stream)
                 prio = int(os.environ.get("SFH_SIDE_PRIO", "0"))
-                p = self.__dict__["_pipe"] = {"device": dev, "side": torch.cuda.Stream(dev, priority=prio), "copy": torch.cuda.Stream(dev),
+                side, copy = _pipe_streams(dev, prio)
+                p = self.__dict__["_pipe"] = {"device": dev, "side": side, "copy": copy,
                                               "slot": 0, "stem_read": [None, None], "inflight": []}
         cur = torch.cuda.current_stream(dev)
         slot = p["slot"]
