@@ -288,6 +288,9 @@ int sfh_u8hwc_area2_to_f32nchw(const uint8_t* src, float* dst, int batch, int C,
  * dst (B,C,H,W).  k = 2 is the special case above; otherwise OpenCV's resizeAreaFast_ rule: the k x k block summed in int,
  * times the float 1.f / (k * k), rounded half to even, saturated to 0 .. 255, then / 255 (utils/dataset.py:312-330). */
 int sfh_u8hwc_areak_to_f32nchw(const uint8_t* src, float* dst, int batch, int C, int H, int W, int k, void* stream);
+/* Integer factors that differ per axis, or exceed 16 (kx horizontal, ky vertical, 1 .. 64 each): the same resizeAreaFast_ rule
+ * with a kx x ky block - the block summed in int, times the float 1.f / (kx * ky), rounded half to even.  src (B,ky*H,kx*W,C). */
+int sfh_u8hwc_areaxy_to_f32nchw(const uint8_t* src, float* dst, int batch, int C, int H, int W, int kx, int ky, void* stream);
 
 /* The same call for ANY downscale (both factors >= 1, at least one not an integer: e.g. 1920x1080 -> 1024x576): OpenCV's
  * generic INTER_AREA path, resizeArea_ over the per-axis tables of computeResizeAreaTab (published imgproc/resize.cpp): every

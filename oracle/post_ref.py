@@ -33,18 +33,19 @@ def resize_nearest(img, out_size):
     return img[sy][:, sx]
 
 
-def resize_area_int(img, k):
-    """cv2.resize(img, (W // k, H // k), interpolation=cv2.INTER_AREA) on a uint8 (H,W[,C]) array whose size is an exact
-    multiple of k (utils/dataset.py:312-316: the video path's downscale).  Restated from OpenCV's published
+def resize_area_int(img, k, ky=None):
+    """cv2.resize(img, (W // k, H // ky), interpolation=cv2.INTER_AREA) (ky = k unless given) on a uint8 (H,W[,C]) array whose size is an exact
+    multiple of (ky, k) (utils/dataset.py:312-316: the video path's downscale).  Restated from OpenCV's published
     imgproc/resize.cpp: k = 2 is ResizeAreaFastVec's (a + b + c + d + 2) >> 2; any other integer factor is
     resizeAreaFast_: the k x k block summed in int, saturate_cast<uchar>(sum * scale) with scale = 1.f / (k * k) in
     float, i.e. the float product rounded half to even.  OpenCV is absent here: parity unpinned for this rule."""
-    h, w = img.shape[0] // k, img.shape[1] // k
-    assert img.dtype == np.uint8 and img.shape[0] == h * k and img.shape[1] == w * k
-    blocks = img.reshape((h, k, w, k) + img.shape[2:]).astype(np.int32).sum(axis=(1, 3))
-    if k == 2:
+    ky = k if ky is None else ky
+    h, w = img.shape[0] // ky, img.shape[1] // k
+    assert img.dtype == np.uint8 and img.shape[0] == h * ky and img.shape[1] == w * k
+    blocks = img.reshape((h, ky, w, k) + img.shape[2:]).astype(np.int32).sum(axis=(1, 3))
+    if k == 2 and ky == 2:
         return ((blocks + 2) >> 2).astype(np.uint8)
-    scale = np.float32(1.0) / np.float32(k * k)
+    scale = np.float32(1.0) / np.float32(k * ky)
     return np.clip(np.rint(blocks.astype(np.float32) * scale), 0, 255).astype(np.uint8)
 
 

@@ -76,6 +76,7 @@ SIGNATURES = {
     "sfh_u8hwc_to_f32nchw": (C.c_int, [_p, _p, C.c_int, C.c_int, C.c_int, C.c_int, _p]),
     "sfh_u8hwc_area2_to_f32nchw": (C.c_int, [_p, _p, C.c_int, C.c_int, C.c_int, C.c_int, _p]),
     "sfh_u8hwc_areak_to_f32nchw": (C.c_int, [_p, _p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _p]),
+    "sfh_u8hwc_areaxy_to_f32nchw": (C.c_int, [_p, _p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _p]),
     "sfh_resize_area_tab": (C.c_int, [C.c_int, C.c_int, _p, _p, _p, C.c_int]),
     "sfh_u8hwc_area_to_f32nchw": (C.c_int, [_p, _p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _p, _p, _p, _p, _p, _p, _p]),
     "sfh_nchw_to_nhwc": (C.c_int, [_p, _p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _p]),

@@ -60,17 +60,17 @@ __global__ void u8hwc_area2_to_f32nchw_kernel(const uint8_t* __restrict__ src, f
 // int and stores saturate_cast<uchar>(sum * scale) with scale = 1.f / (k * k) evaluated in float, i.e. the float product
 // rounded half to even (lrint).  The 2x2 case above is OpenCV's own special case ((a + b + c + d + 2) >> 2), not this rule.
 __global__ void u8hwc_areak_to_f32nchw_kernel(const uint8_t* __restrict__ src, float* __restrict__ dst, int C, int H,
-                                              int W, int k, float scale, long npix) {
+                                              int W, int k, int ky, float scale, long npix) {
   const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;   // one output pixel
   if (p >= npix) return;
   const int HW = H * W;
   const long b = p / HW;
   const int i = (int)(p - b * HW), y = i / W, x = i - y * W;
-  const long rs = (long)k * W * C;  // source row stride in bytes
-  const uint8_t* s = src + (b * k * H + (long)k * y) * rs + (long)k * x * C;
+  const long rs = (long)k * W * C;  // source row stride in bytes (k = the horizontal factor, ky the vertical one)
+  const uint8_t* s = src + (b * ky * H + (long)ky * y) * rs + (long)k * x * C;
   float* d = dst + b * (long)C * HW + i;
   int sum[4] = {0, 0, 0, 0};
-  for (int dy = 0; dy < k; ++dy)
+  for (int dy = 0; dy < ky; ++dy)
     for (int dx = 0; dx < k; ++dx) {
       const uint8_t* q = s + dy * rs + (long)dx * C;
       for (int c = 0; c < C; ++c) sum[c] += (int)q[c];
@@ -719,7 +719,18 @@ extern "C" int sfh_u8hwc_areak_to_f32nchw(const uint8_t* src, float* dst, int ba
   if (k == 2) return sfh_u8hwc_area2_to_f32nchw(src, dst, batch, C, H, W, stream);
   const long npix = (long)batch * H * W;
   hipLaunchKernelGGL(u8hwc_areak_to_f32nchw_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0,
-                     (hipStream_t)stream, src, dst, C, H, W, k, 1.f / (float)(k * k), npix);
+                     (hipStream_t)stream, src, dst, C, H, W, k, k, 1.f / (float)(k * k), npix);
+  return sfh_check_launch("u8hwc_areak_to_f32nchw_kernel");
+}
+
+extern "C" int sfh_u8hwc_areaxy_to_f32nchw(const uint8_t* src, float* dst, int batch, int C, int H, int W, int kx, int ky,
+                                           void* stream) {
+  SFH_REQUIRE(src && dst && batch > 0 && C > 0 && C <= 4 && H > 0 && W > 0 && kx >= 1 && kx <= 64 && ky >= 1 && ky <= 64 &&
+                  kx * ky >= 2, "u8hwc_areaxy_to_f32nchw: bad argument (kx=%d, ky=%d: integer factors 1 .. 64, not both 1)", kx, ky);
+  if (kx == ky && kx <= 16) return sfh_u8hwc_areak_to_f32nchw(src, dst, batch, C, H, W, kx, stream);
+  const long npix = (long)batch * H * W;
+  hipLaunchKernelGGL(u8hwc_areak_to_f32nchw_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0,
+                     (hipStream_t)stream, src, dst, C, H, W, kx, ky, 1.f / (float)(kx * ky), npix);
   return sfh_check_launch("u8hwc_areak_to_f32nchw_kernel");
 }
 

@@ -1496,7 +1496,7 @@ def frames_u8_to_input(frames_u8, target_size=None):
     B, H, W, C = f.shape
     if target_size is not None and (int(target_size[0]), int(target_size[1])) != (W, H):
         tw, th = int(target_size[0]), int(target_size[1])
-        if tw <= 0 or th <= 0 or W <= tw or H < th:
+        if tw <= 0 or th <= 0 or W <= tw or H < th:      # (W > tw: the reference's own test for INTER_AREA, utils/dataset.py:314)
             raise NotImplementedError(f"GPU frame resize {W}x{H} -> {tw}x{th}: only downscales (cv2.INTER_AREA, the reference's choice "
                                       "for frames wider than the target) are on the HIP path; resize on the host as utils/dataset.py does")
         out = torch.empty((B, C, th, tw), dtype=torch.float32, device=f.device)
@@ -1505,9 +1505,12 @@ def frames_u8_to_input(frames_u8, target_size=None):
             _lib.check(lib.sfh_u8hwc_areak_to_f32nchw(_ptr(f), _ptr(out), B, C, th, tw, k, _stream()), "u8hwc_areak_to_f32nchw")
             return out
         if (tw * (W // tw), th * (H // th)) == (W, H):
-            # integer factors that differ per axis, or beyond 16: OpenCV's resizeAreaFast_ with an (kx, ky) block - not built
-            raise NotImplementedError(f"GPU frame resize {W}x{H} -> {tw}x{th}: integer factors {W // tw} x {H // th} (unequal or "
-                                      "above 16) are not on the HIP path")
+            # integer factors that differ per axis, or beyond 16: OpenCV's resizeAreaFast_ with a kx x ky block
+            kx, ky = W // tw, H // th
+            if kx > 64 or ky > 64:
+                raise NotImplementedError(f"GPU frame resize {W}x{H} -> {tw}x{th}: integer factors beyond 64 are not on the HIP path")
+            _lib.check(lib.sfh_u8hwc_areaxy_to_f32nchw(_ptr(f), _ptr(out), B, C, th, tw, kx, ky, _stream()), "u8hwc_areaxy_to_f32nchw")
+            return out
         xo, xs, xa = _area_tab(W, tw, f.device)
         yo, ys, yb = _area_tab(H, th, f.device)
         _lib.check(lib.sfh_u8hwc_area_to_f32nchw(_ptr(f), _ptr(out), B, C, H, W, th, tw, _ptr(xo), _ptr(xs), _ptr(xa), _ptr(yo),

@@ -1432,8 +1432,13 @@ def test_u8_frame_area2_downscale(E):
     assert torch.equal(got.cpu(), want)
     with pytest.raises(NotImplementedError):      # frames narrower than the target: the reference switches to INTER_LINEAR
         E.frames_u8_to_input(torch.from_numpy(fr).cuda(), target_size=(80, 50))
-    with pytest.raises(NotImplementedError):      # unequal integer factors (3 x 2): OpenCV's fast path with a 3x2 block, not built
-        E.frames_u8_to_input(torch.from_numpy(fr).cuda(), target_size=(24, 22))
+    # unequal integer factors (3 x 2) and factors beyond 16: OpenCV's fast path with a kx x ky block
+    from oracle import post_ref
+    for (tw, th) in ((24, 22), (36, 11), (4, 2)):
+        kx, ky = 72 // tw, 44 // th
+        area = np.stack([post_ref.resize_area_int(f_, kx, ky) for f_ in fr])
+        want = torch.from_numpy((area.transpose(0, 3, 1, 2) / 255)).type(torch.FloatTensor)
+        assert torch.equal(E.frames_u8_to_input(torch.from_numpy(fr).cuda(), target_size=(tw, th)).cpu(), want), (tw, th)
 
 
 @pytest.mark.parametrize("src,dst", [((1080, 1920), (576, 1024)), ((900, 1600), (360, 640)), ((50, 77), (21, 30)), ((45, 64), (44, 63)),
