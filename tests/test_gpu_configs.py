@@ -644,3 +644,18 @@ def test_c3_batch16_gradients_and_weight_update(precision, monkeypatch):
             update_elements_checked=upd_total, update_elements_off=upd_off)
     assert not bad, bad
     assert upd_total > 3000 and upd_off <= 0.005 * upd_total, (upd_off, upd_total)
+
+
+def test_device_calibration_probe():
+    """bench.py's `device_calibration` (sfh_probe_mfma_f16 through the C-ABI): a register-resident fp16 MFMA loop reports a rate
+    between a fifth of and the full dense peak, and the clock the chip held inside the kernel is a plausible shader clock."""
+    import importlib.util
+    root = os.path.dirname(HERE)
+    spec = importlib.util.spec_from_file_location("bench_for_probe", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    c = bench.device_calibration(torch.device("cuda", 0), ms_target=10.0)
+    assert 500.0 < c["mfma_f16_tflops"] <= 2600.0, c
+    assert 0.8 < c["in_kernel_clock_ghz"] < 2.6, c
+    assert c["compute_units"] >= 64 and c["launches"] == 5
+    assert c["power"] is None or c["power"]["max_w"] > 50.0
