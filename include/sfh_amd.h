@@ -173,6 +173,10 @@ typedef struct sfh_conv_desc {
   const float* bwd_mi;
   const float* bwd_gamma;
   const float* bwd_beta;
+  /* sfh_conv_upfused_fwd only: the packed weights (sfh_pack_h2_weights, ksize 2, 4 * cout virtual couts) and the 4 * cout
+   * epilogue scales of the composed 2x2 conv of a fused Up block (its border-class shifts ride in shift_border). */
+  const float* up_wpacked;
+  const float* up_scale;
 } sfh_conv_desc;
 
 const char* sfh_last_error(void);
@@ -223,6 +227,15 @@ int sfh_h2_to_f32(const void* src, float* dst, int64_t rows, int W, int cs, int 
  * results are bit-identical to sfh_conv_s3_fwd's.  Restrictions: src_fmt H2, one source, ksize 3, stride 1, plain NHWC output
  * (H2 or fp32), optional residual of the destination's format + ReLU, no pooled output / head / acc_init / split-K / statistics. */
 int sfh_conv_small_fwd(const sfh_conv_desc* d, void* stream);
+
+/* The first conv of a fused Up block - conv3x3(cat([skip, ConvTranspose2d(x)])) + BatchNorm + ReLU, unet/unet_parts.py:52-68 - as ONE
+ * launch (round 5 experiment; the two-launch form is sfh_conv_s3_fwd with ksize 2 / SFH_OUT_UPSCATTER2 writing an fp32 partial +
+ * sfh_conv_s3_fwd with acc_init): src0 = the skip tensor (B,H,W,cs0) H2, src1 = the low-resolution x (B,h1,w1,cs1) H2 with
+ * H in {2*h1, 2*h1+1}, W alike; wpacked / scale / shift / relu = the skip-half 3x3 conv's (c0 -> cout); up_wpacked / up_scale /
+ * shift_border = the composed 2x2 conv's (c1 -> 4*cout virtual couts), scale and border shifts expressed in the skip-half's
+ * accumulator units (what the two-launch form passes to its first launch); dst H2 (B,H,W,dst_cs).  Same products in the same
+ * order per output as the two-launch form: bit-identical results.                                                        */
+int sfh_conv_upfused_fwd(const sfh_conv_desc* d, void* stream);
 
 /* First UNet layer (inc.double_conv.0, unet/unet_parts.py:15; 3 input channels stored as 4):
  * tap-packed fp32 MFMA kernel, k = channel, one MFMA k-step per tap.  Same descriptor/epilogue as

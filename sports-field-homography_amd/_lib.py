@@ -38,6 +38,7 @@ class ConvDesc(C.Structure):
         ("wg_couts", _i), ("split_arith", _i), ("ksplit", _i), ("ksplit_stride", C.c_int64), ("acc_init", _p),
         ("stats_partial", _p), ("stats_rows", _i),
         ("bwd_z", _p), ("bwd_mi", _p), ("bwd_gamma", _p), ("bwd_beta", _p),
+        ("up_wpacked", _p), ("up_scale", _p),
     ]
 
     def __init__(self, *args, **kw):
@@ -69,6 +70,7 @@ SIGNATURES = {
     "sfh_pack_c4h2_weights": (C.c_int, [_p, _p, C.c_int, C.c_int, C.c_int, _p]),
     "sfh_conv3x3_c4h2_fwd": (C.c_int, [C.POINTER(ConvDesc), _p]),
     "sfh_conv_small_fwd": (C.c_int, [C.POINTER(ConvDesc), _p]),
+    "sfh_conv_upfused_fwd": (C.c_int, [C.POINTER(ConvDesc), _p]),
     "sfh_packed_weight_floats": (C.c_int64, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "sfh_pack_conv_weights": (C.c_int, [_p, _p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _p]),
     "sfh_space_to_depth2": (C.c_int, [_p, _p, C.c_int, C.c_int, C.c_int, C.c_int, _p]),

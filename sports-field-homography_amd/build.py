@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB = os.path.join(_HERE, "libsfh_amd.so")
 SOURCES = ["capi.hip", "conv_mfma.hip", "conv_s3.hip", "conv_c4h2.hip", "pointwise.hip", "warp.hip", "train.hip", "stem.hip",
-           "wgrad_s3.hip", "probe.hip", "conv_small.hip"]
+           "wgrad_s3.hip", "probe.hip", "conv_small.hip", "conv_upfused.hip"]
 # warp.hip's coordinate arithmetic must not be contracted into FMAs (bit-exact nearest
 # sampling against oracle/warp_ref.py); the flag is harmless elsewhere.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-ffp-contract=off",
@@ -22,7 +22,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-ffp-contract=o
 # (conv_s3.hip with / without the flag: 9.84-9.92 / 9.47-9.61 ms per batch for the DoubleConv launches).
 _NO_SLP = ["-fno-slp-vectorize"]
 EXTRA_FLAGS = {"warp.hip": _NO_SLP, "conv_s3.hip": _NO_SLP, "conv_mfma.hip": _NO_SLP, "stem.hip": _NO_SLP,
-               "conv_c4h2.hip": _NO_SLP, "conv_small.hip": _NO_SLP}
+               "conv_c4h2.hip": _NO_SLP, "conv_small.hip": _NO_SLP, "conv_upfused.hip": _NO_SLP}
 
 
 def _stale(target, deps):

@@ -852,6 +852,49 @@ class PackedConv:
         return dst
 
 
+def run_upfused(fu, sk, skip, ylow, dst, batch, H, W, exp_dst=None, range_word=None):
+    """The first conv of a fused Up block as ONE launch (sfh_conv_upfused_fwd): fu / sk = the composed 2x2 conv and the skip-half
+    3x3 conv of the level (PackedConv.fused_up / the skip-half PackedConv) with fu._seed_scale / fu._seed_border up to date (the
+    composed conv's scale and border shifts in sk's accumulator units, as the two-launch form passes them to its first launch);
+    skip / ylow / dst: H2 tensors.  Bit-identical to fu.run(...part...) followed by sk.run(..., acc_init=part)."""
+    lib = _lib.load()
+    d = ConvDesc()
+    d.src0, d.c0, d.cs0 = skip.data_ptr(), sk.c0, _chan(skip)
+    d.h0, d.w0 = _hw(skip)
+    d.src1, d.c1, d.cs1 = ylow.data_ptr(), fu.c0, _chan(ylow)
+    d.h1, d.w1 = _hw(ylow)
+    d.batch, d.H, d.W, d.ksize, d.stride = batch, H, W, 3, 1
+    d.wpacked, d.scale, d.shift = sk.wpacked.data_ptr(), sk.scale.data_ptr(), sk.shift.data_ptr()
+    d.cout, d.relu = sk.cout, 1
+    d.up_wpacked, d.up_scale = fu.wpacked.data_ptr(), fu._seed_scale.data_ptr()
+    d.shift_border = fu._seed_border.data_ptr()
+    d.dst, d.dst_cs = dst.data_ptr(), _chan(dst)
+    d.src_fmt = d.dst_fmt = _lib.FMT_H2
+    d.out_mode = _lib.OUT_NHWC
+    if exp_dst is not None:
+        d.h2_exp_dst = int(exp_dst)
+    ovf = getattr(sk, "overflow", None)
+    d.h2_overflow = ovf.data_ptr() if ovf is not None else None
+    d.h2_range = range_word if range_word else None
+    if (dst.shape[0],) + _hw(dst) != (batch, H, W) or _hw(skip) != (H, W) or _fmt_of(dst) != "h2" or _fmt_of(skip) != "h2":
+        raise ValueError("run_upfused: skip and dst must be H2 tensors of the output's size")
+    tm = PackedConv.timer
+    if tm is not None and not tm.wants("upfused"):
+        tm = None
+    if tm is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    _lib.check(lib.sfh_conv_upfused_fwd(ctypes.byref(d), _stream()), "conv_upfused_fwd")
+    if tm is not None:
+        e1.record()
+        # credited like the two launches it replaces: the whole reference conv over cat([skip, up]) (9 taps x (c_skip + c_up))
+        c_up = fu.flops_per_out_pixel / (2.0 * sk.cout * 9)
+        # executed: 9 taps x the skip channels + 4 taps x all low-resolution channels (= 8/9 of the u-half's credit)
+        tm.records.append(("upfused", 2.0 * batch * H * W * sk.cout * 9 * (sk.c0 + c_up), e0, e1,
+                           2.0 * batch * H * W * sk.cout * (9 * sk.c0 + 4 * fu.c0)))
+    return dst
+
+
 class _Workspace:
     """Named activation buffers, one per name: a call with another shape (a different batch size, the tail
     chunk of a sub-batched call) replaces the buffer instead of keeping a second full activation set in HBM."""
@@ -889,6 +932,11 @@ class UNetEngine:
         self.up_seed = {}          # level -> the skip-half conv starts from the partial (sfh_conv_desc.acc_init)
         # level -> frames per band of the fused Up block's two launches (0 / absent: the whole batch per launch)
         self.up_bands = {int(a): int(b) for a, b in (t.split(":") for t in os.environ.get("SFH_UP_BANDS", "").split(",") if t)}
+        # levels whose fused Up block runs as ONE kernel (csrc/conv_upfused.hip, round 5; bit-identical to the two-launch
+        # "swap + seed" form).  Same-device A/B at 640x360 x 16 (profiles/r05_ab_up_single.txt), ms per batch pipelined: none 13.13,
+        # {4} 12.93, {3,4} 12.91-12.94, {2,3,4} 12.94, all four 13.15 (at long K a wave per parity class streams too many weights);
+        # 1280x720: none 50.97, {3,4} 49.9.  SFH_UP_SINGLE="" switches it off.
+        self.up_single = {int(c) for c in os.environ.get("SFH_UP_SINGLE", "34") if c.isdigit()}
         if precision not in PRECISIONS:
             raise ValueError(f"precision={precision!r}: expected one of {sorted(PRECISIONS)}")
         self.device = device
@@ -1064,7 +1112,7 @@ class UNetEngine:
 
                 def level(y=y, ny=ny, skip=skip, nskip=nskip, part=part, mid=mid, nmid=nmid, fu=fu, sk=sk,
                           up_dst=up_dst, hs=hs, ws_=ws_, hy=hy, wy=wy, ey=ey, ex=ex, swap=i in self.up_swap,
-                          seed=self.up_seed.get(i, False), bands=self.up_bands.get(i, 0)):
+                          seed=self.up_seed.get(i, False), bands=self.up_bands.get(i, 0), single=i in self.up_single):
                     if swap and seed:
                         # as below, but the partial is written in the skip-half conv's ACCUMULATOR units (divided by its
                         # scale) and that conv STARTS from it (sfh_conv_desc.acc_init): sixteen loads in its prologue
@@ -1080,6 +1128,9 @@ class UNetEngine:
                             fu._seed_scale, fu._seed_border, fu._seed_key = fu.scale / div, fu.shift_border / div, key
                         # frame bands (experiment, SFH_UP_BANDS="4:4" = level 4 in bands of 4 frames): the two launches of a
                         # band run back to back, so that the band's fp32 partial is read back from the Infinity Cache
+                        if single and fu.fmt == "h2" and not bands:
+                            run_upfused(fu, sk, skip, y, mid, B, hs, ws_, a_sk["exp_dst"], a_sk["range_word"])
+                            return
                         nb_ = bands if bands else B
                         for b0 in range(0, B, nb_):
                             b1 = min(B, b0 + nb_)

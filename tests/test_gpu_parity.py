@@ -695,6 +695,38 @@ def test_warp_consistency_fused_kernel_with_a_warp_twice_the_logits_size(E, size
         E.warp_consistency(th, tm, lg, 4.0, shared_template=True, warp_hw=(h // 2 + 1, w // 2))
 
 
+@pytest.mark.parametrize("wh", [(112, 90), (640, 360), (160, 96)])
+def test_single_kernel_up_block_gives_the_two_launch_bits(E, wh):
+    """Round 5 experiment (csrc/conv_upfused.hip, engine knob SFH_UP_SINGLE): the first conv of a fused Up block as ONE kernel -
+    the composed 2x2 conv over the low-resolution tensor and the skip-half 3x3 conv accumulate into the same registers, a wave per
+    output-parity class - against the two-launch form (fp32 partial + acc_init): same products in the same order per output =>
+    identical logits and theta, at every level, incl. the level whose skip tensor is one row larger than twice the low-resolution
+    one (90 -> 45 -> 22: F.pad with diff 1)."""
+    net, sd, court, poi = _model(wh, warp_with_nearest=True)
+    net.load_state_dict(sd)
+    net.cuda().eval()
+    x = synth.smooth_frames(2, wh[1], wh[0], seed=19).cuda()
+    outs = {}
+    for single in ((), (4,), (1, 2, 3, 4)):
+        net.invalidate_engines()
+        un, _ = net._get_engines()
+        un.up_single = set(single)
+        with torch.no_grad():
+            outs[single] = net.predict(x, consistency=False)
+    for single in ((4,), (1, 2, 3, 4)):
+        assert torch.equal(outs[single]["logits"], outs[()]["logits"]), single
+        assert torch.equal(outs[single]["theta"], outs[()]["theta"]), single
+    calls = []
+    real = E.run_upfused
+    E.run_upfused = lambda *a, **k: (calls.append(1), real(*a, **k))[1]
+    try:
+        with torch.no_grad():
+            net.predict(x, consistency=False)
+    finally:
+        E.run_upfused = real
+    assert len(calls) == 4
+
+
 def test_predict_uses_the_fused_warp_consistency_kernel_and_matches_the_separate_kernels(E):
     """predict(consistency=True) with a nearest warp of the logits' size takes the fused kernel; `fuse_warp_ce = False` (or a
     bilinear warp, or a warp of another size) the two separate ones: same mask bits, scores within 1e-5, same keys."""
