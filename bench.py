@@ -710,8 +710,12 @@ def main():
                         "ms_per_step": round(v[2] / args.steps, 3)}
             if t in executed:      # credited with the reference's work, executes less (composed 2x2 Up conv: 8/9)
                 ex = executed[t] / (v[2] * 1e-3) / 1e12
-                other[t].update({"frac_basis": "credited = the u-half of the reference's 3x3 conv (9 taps x C; the ConvTranspose2d "
-                                               "it also replaces is not credited); executed = 4 taps x 2C on the low-resolution tensor",
+                basis = ("credited = the u-half of the reference's 3x3 conv (9 taps x C; the ConvTranspose2d it also replaces is not "
+                         "credited); executed = 4 taps x 2C on the low-resolution tensor") if t != "upfused" else \
+                        ("single-kernel Up block (csrc/conv_upfused.hip: u3, u4): credited = the reference's whole 3x3 conv over skip + "
+                         "up-sampled channels (9 taps x 2C; its ConvTranspose2d is not credited); executed = 9 taps x C on the skip "
+                         "tensor + 4 taps x 2C on the low-resolution tensor; these launches are not in `doubleconv3x3` / `fusedup2x2`")
+                other[t].update({"frac_basis": basis,
                                  "executed_tflops": round(ex, 2), "executed_frac": round(ex / peak, 4)})
     step_gflop = STEP_GFLOP_PER_FRAME_640x360 * (W * H) / (640.0 * 360.0) * B
     whole_tf = step_gflop * 1e9 * args.steps / elapsed / 1e12    # per GPU: every rank runs its own batch per step

@@ -11,21 +11,22 @@ OUT=$ROOTD/gpurun_out
 mkdir -p $OUT
 rm -rf $OUT/${TAG}_trace $OUT/${TAG}_trace_pipe $OUT/${TAG}_trace_np $OUT/${TAG}_fetch $OUT/${TAG}_write $OUT/${TAG}_mfma
 cd /tmp && export TMPDIR=/tmp
+echo "start $(date +%T)"
 ARGS="--steps 3 --warmup 1 --no-cpu-baseline --no-extra-configs"
 # the default command (two batches in flight): kernel stats that bench.py's roofline.avg_launch_ms must agree with
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_trace -- python3 $ROOTD/bench.py $ARGS > $OUT/${TAG}_trace.log 2>&1
-echo "trace done"
+timeout -k 10 420 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_trace -- python3 $ROOTD/bench.py $ARGS > $OUT/${TAG}_trace.log 2>&1
+echo "trace done $(date +%T)"
 # the pipelined region ONLY (no unpipelined pass behind it): every launch counted ran with two batches in flight
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_trace_pipe -- python3 $ROOTD/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-extra-configs --no-alone-pass > $OUT/${TAG}_trace_pipe.log 2>&1
-echo "trace (pipelined region only) done"
+timeout -k 10 420 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_trace_pipe -- python3 $ROOTD/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-extra-configs --no-alone-pass > $OUT/${TAG}_trace_pipe.log 2>&1
+echo "trace (pipelined region only) done $(date +%T)"
 # one predict() per step: launches alone on the chip, in order (per-layer table; the counter passes below serialise anyway)
 ARGS="$ARGS --no-pipeline"
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_trace_np -- python3 $ROOTD/bench.py $ARGS > $OUT/${TAG}_trace_np.log 2>&1
-echo "trace (no pipeline) done"
-timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/${TAG}_fetch -- python3 $ROOTD/bench.py $ARGS > $OUT/${TAG}_fetch.log 2>&1
-echo "fetch done"
-timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/${TAG}_write -- python3 $ROOTD/bench.py $ARGS > $OUT/${TAG}_write.log 2>&1
-echo "write done"
-timeout -k 10 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVES GRBM_GUI_ACTIVE --output-format csv -d $OUT/${TAG}_mfma -- python3 $ROOTD/bench.py $ARGS > $OUT/${TAG}_mfma.log 2>&1
-echo "mfma done"
+timeout -k 10 420 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_trace_np -- python3 $ROOTD/bench.py $ARGS > $OUT/${TAG}_trace_np.log 2>&1
+echo "trace (no pipeline) done $(date +%T)"
+timeout -k 10 420 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/${TAG}_fetch -- python3 $ROOTD/bench.py $ARGS > $OUT/${TAG}_fetch.log 2>&1
+echo "fetch done $(date +%T)"
+timeout -k 10 420 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/${TAG}_write -- python3 $ROOTD/bench.py $ARGS > $OUT/${TAG}_write.log 2>&1
+echo "write done $(date +%T)"
+timeout -k 10 420 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVES GRBM_GUI_ACTIVE --output-format csv -d $OUT/${TAG}_mfma -- python3 $ROOTD/bench.py $ARGS > $OUT/${TAG}_mfma.log 2>&1
+echo "mfma done $(date +%T)"
 ls $OUT/${TAG}_*/*/ | head -40

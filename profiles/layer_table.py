@@ -21,19 +21,27 @@ L = [("inc.0", gm(3, 64, 360, 640)), ("inc.3", gm(64, 64, 360, 640)),
 if any('S3Cfg<2,' in r['Kernel_Name'] for r in step):
     # fused Up blocks (no F.pad at that level): skip-half 3x3 conv + composed 2x2 quadrant conv over the
     # low-resolution tensor, credited with the u-half of the reference's 3x3 conv; no ConvTranspose launch
-    L = L[:10] + [("u1.skip", gm(512, 512, 45, 80)), ("u1.fuse", gm(512, 512, 45, 80)), ("u1.3", gm(512, 512, 45, 80)),
-                  ("u2.skip", gm(256, 256, 90, 160)), ("u2.fuse", gm(256, 256, 90, 160)), ("u2.3", gm(256, 256, 90, 160)),
+    # (u1 / u2: .a / .b in launch order - cfg<2, …> is the composed 2x2 launch, cfg<3, …> the skip half)
+    L = L[:10] + [("u1.a", gm(512, 512, 45, 80)), ("u1.b", gm(512, 512, 45, 80)), ("u1.3", gm(512, 512, 45, 80)),
+                  ("u2.a", gm(256, 256, 90, 160)), ("u2.b", gm(256, 256, 90, 160)), ("u2.3", gm(256, 256, 90, 160)),
                   # u3 / u4: the composed 2x2 conv runs first, the skip-half 3x3 conv finishes (engine.UNetEngine.up_swap)
                   ("u3.fuse", gm(128, 128, 180, 320)), ("u3.skip", gm(128, 128, 180, 320)), ("u3.3", gm(128, 128, 180, 320)),
                   ("u4.fuse", gm(64, 64, 360, 640)), ("u4.skip", gm(64, 64, 360, 640)), ("u4.3", gm(64, 64, 360, 640))]
+if any('conv_upfused' in r['Kernel_Name'] for r in step):
+    # round 5: u3 / u4's first conv is ONE kernel (csrc/conv_upfused.hip), credited with the whole 3x3 conv it stands for
+    names = [n for n, _ in L]
+    for lv, g in (("u3", gm(256, 128, 180, 320)), ("u4", gm(128, 64, 360, 640))):
+        i = names.index(lv + ".fuse")
+        L[i:i + 2] = [(lv + ".one", g)]
+        names = [n for n, _ in L]
 dur = lambda r: (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e6
-is_conv = lambda n: 'conv_mfma' in n or 'conv_s3' in n or 'conv3x3_c4' in n or 'stem7x7' in n   # (c4: also conv3x3_c4h2)
+is_conv = lambda n: 'conv_mfma' in n or 'conv_s3' in n or 'conv_upfused' in n or 'conv_small' in n or 'conv3x3_c4' in n or 'stem7x7' in n   # (c4: also conv3x3_c4h2)
 convs = [r for r in step if is_conv(r['Kernel_Name'])]
 tot = 0
 for (nm, g), r in zip(L, convs[:len(L)]):
     d = dur(r)
     m_ = re.search(r'Cfg<([^>]*)>', r['Kernel_Name'])
-    cfg = m_.group(1) if m_ else 'c4 tap-packed'
+    cfg = m_.group(1) if m_ else ('single-kernel Up' if 'upfused' in r['Kernel_Name'] else 'c4 tap-packed')
     print(f"{nm:6s} cfg<{cfg:22s}> {d:7.3f} ms {2*g*B/d:7.1f} TFLOP/s grid={r.get('Grid_Size_X')} vgpr={r.get('VGPR_Count')} lds={r.get('LDS_Block_Size')}")
     tot += d
 print(f"UNet conv launches: {tot:.3f} ms")

@@ -46,6 +46,8 @@ def group(name, resnet=False):
         return {"3": "s3_conv3x3", "2": "s3_up2x2"}.get(m.group(1), "s3_conv1x1")
     if "conv_small_kernel" in name:      # round 5: the small-map 3x3 kernel (ResNet layer3 / layer4 at batch 16)
         return "s3_resnet" if resnet else "s3_conv3x3"
+    if "conv_upfused_kernel" in name:    # round 5: composed 2x2 + skip-half 3x3 of a fused Up block in one kernel (u3, u4)
+        return "s3_upfused"
     if "stem7x7" in name:
         return "s3_stem7x7"
     if "conv3x3_c4" in name:
