@@ -446,11 +446,30 @@ int sfh_bn_bwd_apply(const float* dy, const float* y, const float* z, const floa
 /* acc[c] += sum_p x[p][c] over a channel slice of a (npix, cs) tensor: conv / transposed-conv bias
  * gradients.                                                                                       */
 int sfh_colsum(const float* x, int64_t npix, int C, int cs, double* acc, void* stream);
+/* First pass of nn.ConvTranspose2d(c, c/2, 2, stride=2).backward (unet/unet_parts.py:52, called from train.py:233):
+ * du (B, 2h, 2w, cout) fp32 -> the space-to-depth tensor s (B, h, w, 4*cout), s[(py*2+px)*cout + co] at (y, x) =
+ * du[2y+py][2x+px][co], written in the split format only (split_fmt SFH_FMT_S3 / SFH_FMT_H2 at the default exponent;
+ * overflow as sfh_bn_apply), and acc[co] += sum of du[..., co] (fp64, the bias gradient) - one pass instead of
+ * sfh_colsum + sfh_space_to_depth2 + sfh_f32_to_h2.  cout % 8 == 0.                                          */
+int sfh_s2d_split_colsum(const float* du, int batch, int h, int w, int cout, void* s_split, int split_fmt,
+                         double* acc, uint32_t* overflow, void* stream);
 /* nn.MaxPool2d(2) (unet/unet_parts.py:33) on NHWC, forward (floor) and backward: the gradient goes to
  * the first maximum of each window in scan order, like ATen; accumulate != 0 adds into dx.          */
 int sfh_maxpool2_fwd(const float* x, float* y, int batch, int H, int W, int C, void* stream);
 int sfh_maxpool2_bwd(const float* x, const float* dy, float* dx, int batch, int H, int W, int C,
                      int accumulate, void* stream);
+/* The encoder's skip tensors in training mode (DoubleConv -> [MaxPool2d(2), Up], unet/unet_parts.py:16-20,33; split formats):
+ * sfh_bn_apply_pool: y = relu(bn(z)) with the statistics in mean_invstd AND maxpool2(y) from one pass over z, both written in
+ *   the split format only (y_s3: (B,H,W,C), pool_s3: (B,H/2,W/2,C); split_fmt / overflow as sfh_bn_apply) - bit for bit the
+ *   planes of sfh_bn_apply -> sfh_maxpool2_fwd -> sfh_f32_to_h2.  C % 32 == 0.
+ * sfh_pool2_bwd_bn_reduce: dx (+)= max-pool routing of dpool (window values recomputed from z; accumulate != 0: dx holds the
+ *   gradient from y's other consumer) and, dx being the layer's total gradient then, acc (2*C doubles, zeroed by the caller)
+ *   += [sum g | sum g * xhat], g = dx * (y > 0): sfh_maxpool2_bwd + sfh_bn_bwd_reduce in one pass.                       */
+int sfh_bn_apply_pool(const float* z, const float* mean_invstd, const float* gamma, const float* beta, int batch, int H,
+                      int W, int C, void* y_s3, void* pool_s3, int split_fmt, uint32_t* overflow, void* stream);
+int sfh_pool2_bwd_bn_reduce(const float* z, const float* mean_invstd, const float* gamma, const float* beta,
+                            const float* dpool, int batch, int H, int W, int C, int accumulate, float* dx, double* acc,
+                            void* stream);
 /* dst (B,h,w,C) (+)= src[b, y+oy, x+ox, c_off:c_off+C], src (B,Hs,Ws,cs), zero outside: the backward of
  * torch.cat / F.pad in Up (unet/unet_parts.py:59-67).                                              */
 int sfh_slice_add(const float* src, int Hs, int Ws, int cs, int c_off, int oy, int ox, float* dst,

@@ -447,6 +447,49 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_s3_kernel(const float* __res
   }
 }
 
+// ------------------------------------------------------------------ ConvTranspose2d(2, stride 2) backward, first pass
+// du (B, 2h, 2w, cout) fp32 -> s (B, h, w, 4 * cout) in the split format ONLY, s[(py * 2 + px) * cout + co] at (y, x) =
+// du[2y + py][2x + px][co] (the 1x1 backward-data conv and the backward-filter kernel of the transposed conv read nothing
+// else), and acc[co] += sum over pixels of du[..., co] - the bias gradient - from the same read.  Replaces colsum +
+// space_to_depth2 + f32_to_h2 (three passes, 20 bytes per element) by one of 8.  Mapping as tr_block_thread, but a block
+// strides over many 64-pixel chunks so that its column sums end in one fp64 atomic per channel and wave.
+template <int NP>
+__global__ __launch_bounds__(256) void s2d_split_colsum_kernel(const float* __restrict__ du, int h, int w, int cout,
+                                                               long npix, long nchunks, int chunk_stride,
+                                                               unsigned short* __restrict__ s_split,
+                                                               double* __restrict__ acc, unsigned* __restrict__ overflow) {
+  const int C4 = 4 * cout, nb = C4 >> 5;
+  const int cb = (int)(blockIdx.x % (unsigned)nb);
+  const int g = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  const int c0 = cb * 32 + g * 8;
+  const int par = c0 / cout, co = c0 - par * cout, py = par >> 1, px = par & 1;
+  double s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned over = 0u;
+  for (long chunk = (long)(blockIdx.x / (unsigned)nb); chunk < nchunks; chunk += chunk_stride) {
+    const long p = chunk * 64 + (threadIdx.x & 63);
+    if (p >= npix) break;
+    const unsigned row = (unsigned)p / (unsigned)w;          // b * h + y   (npix < 2^31: checked by the launcher)
+    const int x = (int)((unsigned)p - row * (unsigned)w);
+    const unsigned b = row / (unsigned)h, y = row - b * (unsigned)h;
+    const float* sp = du + (((long)b * 2 * h + 2 * y + py) * (2L * w) + 2 * x + px) * cout + co;
+    const f32x4 a = *reinterpret_cast<const f32x4*>(sp), bq = *reinterpret_cast<const f32x4*>(sp + 4);
+    const float v[8] = {a[0], a[1], a[2], a[3], bq[0], bq[1], bq[2], bq[3]};
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s[j] += (double)v[j];
+    if constexpr (NP == 3) tr_split8(v, s_split, tr_s3_elem((long)row, x, c0, w, C4), 4L * w * 8);
+    else tr_split8_h2(v, s_split, tr_s3_elem((long)row, x, c0, w, C4, 2), 4L * w * 8, over);
+  }
+  if constexpr (NP == 2)
+    if (overflow && sfh_h2_out_of_range(over)) atomicOr(overflow, 1u);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    double t = s[j];
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) t += __shfl_xor(t, m, 64);
+    if ((threadIdx.x & 63) == 0) unsafeAtomicAdd(&acc[co + j], t);
+  }
+}
+
 // ------------------------------------------------------------------ max-pool 2x2 (floor)
 __global__ __launch_bounds__(256) void maxpool2_fwd_kernel(const float* __restrict__ x, int H, int W, int C,
                                                            int Ho, int Wo, long total4, float* __restrict__ y) {
@@ -507,6 +550,162 @@ __global__ __launch_bounds__(256) void maxpool2_bwd_kernel(const float* __restri
       *d = t;
     } else {
       *d = o[k];
+    }
+  }
+}
+
+// ------------------------------------------------------------------ BatchNorm + ReLU + max-pool 2x2 of a skip tensor
+// The encoder's skip tensors (DoubleConv outputs that feed both MaxPool2d(2) and an Up block, unet/unet_model.py) in
+// training mode, split formats: one pass over the conv output z writes y = relu(bn(z)) AND maxpool2(y), both in the split
+// format only.  The split is monotone and the maximum is taken on the fp32 values, so the pooled planes are bit for bit
+// those of bn_apply -> maxpool2_fwd -> f32_to_h2, without the fp32 copy of y (4 B per element written, 4 read), the pooled
+// fp32 tensor and its conversion pass.  One thread = a 2x2 window (cropped at odd borders: those pixels still get their y)
+// x 8 channels; a wave = 64 consecutive windows of the flattened (B * ceil(H/2), ceil(W/2)) grid x one channel group.
+template <int NP>
+__global__ __launch_bounds__(256) void bn_apply_pool_s3_kernel(const float* __restrict__ z, const float* __restrict__ mi,
+                                                               const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                               int H, int W, int C, long nquads,
+                                                               unsigned short* __restrict__ y_s3, unsigned short* __restrict__ p_s3,
+                                                               unsigned* __restrict__ overflow) {
+  const int nb = C >> 5;
+  const int cb = (int)(blockIdx.x % (unsigned)nb);
+  const long chunk = (long)(blockIdx.x / (unsigned)nb);
+  const int g = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  const int c0 = cb * 32 + g * 8;
+  float mean[8], invstd[8], gam[8], bet[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    mean[j] = mi[c0 + j];
+    invstd[j] = mi[C + c0 + j];
+    gam[j] = gamma[c0 + j];
+    bet[j] = beta[c0 + j];
+  }
+  const long q = chunk * 64 + (threadIdx.x & 63);
+  if (q >= nquads) return;
+  const int qh = (H + 1) >> 1, qw = (W + 1) >> 1, Ho = H >> 1, Wo = W >> 1;
+  const unsigned qrow = (unsigned)q / (unsigned)qw;
+  const int qx = (int)((unsigned)q - qrow * (unsigned)qw);
+  const unsigned b = qrow / (unsigned)qh;
+  const int qy = (int)(qrow - b * (unsigned)qh);
+  float m[8];
+  unsigned over = 0u;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int yy = 2 * qy + (k >> 1), xx = 2 * qx + (k & 1);
+    if (yy >= H || xx >= W) continue;
+    const long row = (long)b * H + yy;
+    const long o = (row * W + xx) * C + c0;
+    float v[8];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const f32x4 zz = *reinterpret_cast<const f32x4*>(z + o + 4 * h);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        v[4 * h + j] = sfh_relu((zz[j] - mean[4 * h + j]) * invstd[4 * h + j] * gam[4 * h + j] + bet[4 * h + j]);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) m[j] = k == 0 ? v[j] : sfh_max_nan(m[j], v[j]);
+    if constexpr (NP == 3) tr_split8(v, y_s3, tr_s3_elem(row, xx, c0, W, C), 4L * W * 8);
+    else tr_split8_h2(v, y_s3, tr_s3_elem(row, xx, c0, W, C, 2), 4L * W * 8, over);
+  }
+  if (qy < Ho && qx < Wo) {
+    const long prow = (long)b * Ho + qy;
+    if constexpr (NP == 3) tr_split8(m, p_s3, tr_s3_elem(prow, qx, c0, Wo, C), 4L * Wo * 8);
+    else tr_split8_h2(m, p_s3, tr_s3_elem(prow, qx, c0, Wo, C, 2), 4L * Wo * 8, over);
+  }
+  if constexpr (NP == 2)
+    if (overflow && sfh_h2_out_of_range(over)) atomicOr(overflow, 1u);
+}
+
+// Backward of the same pair, up to the BatchNorm sums: dx (B,H,W,C; the gradient y already has from its other consumer
+// when accumulate != 0) += the max-pool routing of dp (first maximum of each window in scan order, as maxpool2_bwd; the
+// window values y = relu(bn(z)) are recomputed from z with bn_apply's arithmetic instead of read), and, since dx is then
+// the layer's total gradient, acc[0][c] += sum g, acc[1][c] += sum g * xhat with g = dx * (y > 0): what bn_bwd_reduce would
+// find in a second pass over dx and z.  Mapping of the reductions above; one thread-iteration = a 2x2 window x 4 channels.
+__global__ __launch_bounds__(256) void pool2_bwd_bn_reduce_kernel(const float* __restrict__ z, const float* __restrict__ mi,
+                                                                  const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                  const float* __restrict__ dp, int H, int W, int C,
+                                                                  long nquads, int accumulate, float* __restrict__ dx,
+                                                                  double* __restrict__ acc) {
+  __shared__ double sh[256];
+  const int qh = (H + 1) >> 1, qw = (W + 1) >> 1, Ho = H >> 1, Wo = W >> 1;
+  for (int c0 = 0; c0 < C; c0 += 1024) {
+    const int cq = min(1024, C - c0) >> 2;
+    const int lanes = 256 / cq;
+    const int cqi = threadIdx.x % cq, pl = threadIdx.x / cq;
+    double s0[4] = {0, 0, 0, 0}, s1[4] = {0, 0, 0, 0};
+    if (pl < lanes) {
+      const int cc = c0 + 4 * cqi;
+      float mean[4], invstd[4], gam[4], bet[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        mean[j] = mi[cc + j];
+        invstd[j] = mi[C + cc + j];
+        gam[j] = gamma[cc + j];
+        bet[j] = beta[cc + j];
+      }
+      for (long q = (long)blockIdx.x * lanes + pl; q < nquads; q += (long)gridDim.x * lanes) {
+        const unsigned qrow = (unsigned)q / (unsigned)qw;
+        const int qx = (int)((unsigned)q - qrow * (unsigned)qw);
+        const unsigned b = qrow / (unsigned)qh;
+        const int qy = (int)(qrow - b * (unsigned)qh);
+        const bool window = qy < Ho && qx < Wo;
+        const long base = (((long)b * H + 2 * qy) * W + 2 * qx) * C + cc;
+        const long off[4] = {0, C, (long)W * C, (long)W * C + C};
+        const bool valid[4] = {true, 2 * qx + 1 < W, 2 * qy + 1 < H, 2 * qx + 1 < W && 2 * qy + 1 < H};
+        f32x4 yv[4], xh[4], t[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          f32x4 zz = {0.f, 0.f, 0.f, 0.f};
+          t[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+          if (valid[k]) {
+            zz = *reinterpret_cast<const f32x4*>(z + base + off[k]);
+            if (accumulate) t[k] = *reinterpret_cast<const f32x4*>(dx + base + off[k]);
+          }
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            yv[k][j] = (zz[j] - mean[j]) * invstd[j] * gam[j] + bet[j];
+            xh[k][j] = (zz[j] - mean[j]) * invstd[j];
+          }
+        }
+        if (window) {
+          const f32x4 gq = *reinterpret_cast<const f32x4*>(dp + (((long)b * Ho + qy) * Wo + qx) * C + cc);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            int best = 0;
+            float bv = sfh_relu(yv[0][j]);
+#pragma unroll
+            for (int k = 1; k < 4; ++k) {
+              const float v = sfh_relu(yv[k][j]);
+              if (v > bv) { bv = v; best = k; }
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) t[k][j] += (k == best) ? gq[j] : 0.f;
+          }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          if (!valid[k]) continue;
+          if (window || !accumulate) *reinterpret_cast<f32x4*>(dx + base + off[k]) = t[k];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float gj = yv[k][j] > 0.f ? t[k][j] : 0.f;
+            s0[j] += (double)gj;
+            s1[j] += (double)gj * (double)xh[k][j];
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      __syncthreads();
+      sh[threadIdx.x] = (pl < lanes) ? (j < 4 ? s0[j] : s1[j - 4]) : 0.0;
+      __syncthreads();
+      if (threadIdx.x < cq) {
+        double tt = 0.0;
+        for (int l = 0; l < lanes; ++l) tt += sh[l * cq + threadIdx.x];
+        unsafeAtomicAdd(&acc[(long)(j >> 2) * C + c0 + 4 * threadIdx.x + (j & 3)], tt);
+      }
     }
   }
 }
@@ -1296,6 +1495,61 @@ extern "C" int sfh_colsum(const float* x, int64_t npix, int C, int cs, double* a
   const unsigned nb = red_grid((long)npix);
   hipLaunchKernelGGL(colsum_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, x, (long)npix, C, cs, acc);
   return sfh_check_launch("colsum_kernel");
+}
+
+extern "C" int sfh_s2d_split_colsum(const float* du, int batch, int h, int w, int cout, void* s_split, int split_fmt,
+                                    double* acc, uint32_t* overflow, void* stream) {
+  SFH_REQUIRE(du && s_split && acc && batch > 0 && h > 0 && w > 0 && cout > 0 && cout % 8 == 0,
+              "s2d_split_colsum: bad argument (cout %% 8 == 0)");
+  SFH_REQUIRE(split_fmt == SFH_FMT_S3 || split_fmt == SFH_FMT_H2, "s2d_split_colsum: split_fmt=%d (S3 or H2)", split_fmt);
+  const long npix = (long)batch * h * w;
+  SFH_REQUIRE(npix < (1L << 31) - 64 && (long)batch * 2 * h < (1L << 31), "s2d_split_colsum: tensor too large for one launch");
+  const int nb = 4 * cout / 32;
+  const long nchunks = (npix + 63) / 64;
+  long per = 4096 / nb;                       // about 4096 blocks: 16 per CU, each striding over its share of the chunks
+  if (per < 1) per = 1;
+  if (per > nchunks) per = nchunks;
+  const dim3 grid((unsigned)(per * nb));
+  if (split_fmt == SFH_FMT_H2)
+    hipLaunchKernelGGL(s2d_split_colsum_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, du, h, w, cout, npix, nchunks,
+                       (int)per, (unsigned short*)s_split, acc, overflow);
+  else
+    hipLaunchKernelGGL(s2d_split_colsum_kernel<3>, grid, dim3(256), 0, (hipStream_t)stream, du, h, w, cout, npix, nchunks,
+                       (int)per, (unsigned short*)s_split, acc, overflow);
+  return sfh_check_launch("s2d_split_colsum_kernel");
+}
+
+extern "C" int sfh_bn_apply_pool(const float* z, const float* mean_invstd, const float* gamma, const float* beta, int batch,
+                                 int H, int W, int C, void* y_s3, void* pool_s3, int split_fmt, uint32_t* overflow,
+                                 void* stream) {
+  SFH_REQUIRE(z && mean_invstd && gamma && beta && y_s3 && pool_s3 && batch > 0 && H >= 2 && W >= 2 && C > 0 && C % 32 == 0,
+              "bn_apply_pool: bad argument (C %% 32 == 0, H and W >= 2)");
+  SFH_REQUIRE(split_fmt == SFH_FMT_S3 || split_fmt == SFH_FMT_H2, "bn_apply_pool: split_fmt=%d (S3 or H2)", split_fmt);
+  const long nquads = (long)batch * ((H + 1) / 2) * ((W + 1) / 2);
+  const long nblk = (nquads + 63) / 64 * (C / 32);
+  SFH_REQUIRE(nblk < (1L << 31) && nquads < (1L << 31) - 64 && (long)batch * H * W < (1L << 31),
+              "bn_apply_pool: tensor too large for one launch");
+  if (split_fmt == SFH_FMT_H2)
+    hipLaunchKernelGGL(bn_apply_pool_s3_kernel<2>, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, z, mean_invstd,
+                       gamma, beta, H, W, C, nquads, (unsigned short*)y_s3, (unsigned short*)pool_s3, overflow);
+  else
+    hipLaunchKernelGGL(bn_apply_pool_s3_kernel<3>, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, z, mean_invstd,
+                       gamma, beta, H, W, C, nquads, (unsigned short*)y_s3, (unsigned short*)pool_s3, overflow);
+  return sfh_check_launch("bn_apply_pool_s3_kernel");
+}
+
+extern "C" int sfh_pool2_bwd_bn_reduce(const float* z, const float* mean_invstd, const float* gamma, const float* beta,
+                                       const float* dpool, int batch, int H, int W, int C, int accumulate, float* dx,
+                                       double* acc, void* stream) {
+  SFH_REQUIRE(z && mean_invstd && gamma && beta && dpool && dx && acc && batch > 0 && H >= 2 && W >= 2 && C > 0 && C % 4 == 0,
+              "pool2_bwd_bn_reduce: bad argument");
+  SFH_REQUIRE(C <= 1024 || C % 1024 == 0 || (C % 1024) % 4 == 0, "pool2_bwd_bn_reduce: C=%d", C);
+  const long nquads = (long)batch * ((H + 1) / 2) * ((W + 1) / 2);
+  SFH_REQUIRE(nquads < (1L << 31) && (long)batch * H * W < (1L << 31), "pool2_bwd_bn_reduce: tensor too large for one launch");
+  const unsigned nb = red_grid(nquads);
+  hipLaunchKernelGGL(pool2_bwd_bn_reduce_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, z, mean_invstd, gamma, beta,
+                     dpool, H, W, C, nquads, accumulate, dx, acc);
+  return sfh_check_launch("pool2_bwd_bn_reduce_kernel");
 }
 
 extern "C" int sfh_maxpool2_fwd(const float* x, float* y, int batch, int H, int W, int C, void* stream) {

@@ -166,6 +166,9 @@ class Tape:
         # BatchNorm + ReLU layers whose output has ONE consumer (the next conv): id(y) -> {z, mi, bn}; that conv's
         # backward-data launch leaves the layer's backward sums in entry["table"] (sfh_conv_desc.bwd_z)
         self.single_consumer = {}
+        # id(y) -> fp64 [sum g | sum g * xhat] of a BatchNorm + ReLU layer whose total gradient is complete and whose sums
+        # were taken by the pass that completed it (pool_backward_fused); a later add_grad to y is an ordering bug
+        self.bwd_sums = {}
         # f16x3 (H2 copies of activations and gradients): fp16's exponent range has to hold them.
         #   overflow - device word the kernels raise when a value does not fit (checked at the end of the backward pass);
         #   gscale   - power of two all gradients are carried with (the losses are means over B*H*W pixels, their
@@ -224,6 +227,8 @@ class Tape:
 
     def add_grad(self, t, g):
         """grad[t] += g (g has t's shape; ownership of g passes to the tape)."""
+        if id(t) in self.bwd_sums:
+            raise RuntimeError("Tape.add_grad: a gradient arrived after the layer's BatchNorm sums were taken")
         cur = self.grads.get(id(t))
         if cur is None:
             self.grads[id(t)] = g
@@ -249,10 +254,15 @@ class Tape:
 # --------------------------------------------------------------------------------------- layers
 STATS_IN_EPILOGUE = os.environ.get("SFH_TRAIN_STATS_EPILOGUE", "1") != "0"
 BWD_SUMS_IN_EPILOGUE = os.environ.get("SFH_TRAIN_BWD_SUMS_EPILOGUE", "1") != "0"
+# ConvTranspose2d backward: bias gradient + space-to-depth + split copy in one pass (sfh_s2d_split_colsum)
+S2D_FUSED = os.environ.get("SFH_TRAIN_S2D_FUSED", "1") != "0"
+# encoder skip tensors: BatchNorm + ReLU + MaxPool2d(2) in one forward pass (split copies only), max-pool backward +
+# the BatchNorm backward sums in one backward pass (sfh_bn_apply_pool / sfh_pool2_bwd_bn_reduce)
+POOL_FUSED = os.environ.get("SFH_TRAIN_POOL_FUSED", "1") != "0"
 STATS_ROWS = 2048   # most rows of the table a conv epilogue adds its per-wave BatchNorm sums into (sfh_conv_desc.stats_partial)
 
 
-def _bn_forward(lib, z, bn, relu, residual, tape, want_s3=True, want_f32=True, stats=None):
+def _bn_forward(lib, z, bn, relu, residual, tape, want_s3=True, want_f32=True, stats=None, pool=False):
     """Batch-statistics BatchNorm (+residual) (+ReLU); updates the running stats in place.  In split-operand mode
     (and want_s3) the split copy the next convolution needs is written by the same kernel.  want_f32=False (with a
     split copy): nobody reads the fp32 values - the returned tensor is a handle (shape + identity for the tape,
@@ -271,6 +281,21 @@ def _bn_forward(lib, z, bn, relu, residual, tape, want_s3=True, want_f32=True, s
     # (the kernel also advances nn.BatchNorm2d's step counter: one launch per layer less)
     _lib.check(lib.sfh_bn_finalize(_ptr(acc), npix, C, float(bn.eps), BN_MOMENTUM, _ptr(bn.running_mean),
                                    _ptr(bn.running_var), _ptr(mi), _ptr(nbt), _stream()), "bn_finalize")
+    if pool:
+        # y and maxpool2(y) in the split format only, from one pass over z (both come back as handles without fp32 storage)
+        if not (relu and residual is None and tape.use_s3 and C % 32 == 0 and H >= 2 and W >= 2):
+            raise RuntimeError("_bn_forward(pool=True): needs ReLU, no residual, a split format and C % 32 == 0")
+        y_s3 = E.split_empty(tape.fmt, B, H, W, C, z.device)
+        p_s3 = E.split_empty(tape.fmt, B, H // 2, W // 2, C, z.device)
+        _lib.check(lib.sfh_bn_apply_pool(_ptr(z), _ptr(mi), _ptr(bn.weight.detach()), _ptr(bn.bias.detach()), B, H, W, C,
+                                         _ptr(y_s3), _ptr(p_s3), tape.fmt_code, _ptr(tape.overflow), _stream()),
+                   "bn_apply_pool")
+        y = z.new_empty((1,)).expand(z.shape)
+        pl = z.new_empty((1,)).expand(B, H // 2, W // 2, C)
+        for t, ts in ((y, y_s3), (pl, p_s3)):
+            tape.no_f32.add(id(t))
+            tape._s3[id(t)] = (t, ts)
+        return y, mi, pl
     y_s3 = E.split_empty(tape.fmt, B, H, W, C, z.device) if (want_s3 and tape.use_s3 and C % 32 == 0) else None
     handle_only = y_s3 is not None and not want_f32
     y = z.new_empty((1,)).expand(z.shape) if handle_only else _empty(z.shape, z)
@@ -284,18 +309,20 @@ def _bn_forward(lib, z, bn, relu, residual, tape, want_s3=True, want_f32=True, s
     return y, mi
 
 
-def _bn_backward(lib, tape, dy, y, z, mi, bn, relu, want_dres, want_s3=False, want_f32=True, sums_table=None):
+def _bn_backward(lib, tape, dy, y, z, mi, bn, relu, want_dres, want_s3=False, want_f32=True, sums_table=None, sums=None):
     """want_dres: the layer added a residual before its ReLU (its gradient is returned as dres).
     want_f32=False (with want_s3): only the split copy of dz is written (its consumers are the split-operand
     backward-data and backward-filter kernels); the returned dz is None."""
     B, H, W, C = z.shape
     npix = B * H * W
-    acc = tape.zeros((2 * C,), z, torch.float64)
+    acc = sums if sums is not None else tape.zeros((2 * C,), z, torch.float64)
     # without a residual the ReLU decision y > 0 is a function of z alone: the kernels recompute it (same arithmetic as
     # bn_apply) instead of reading y - 8 instead of 12 bytes per element in the reduction, 16 instead of 20 in the apply
     ysign = y if (relu and want_dres) else None
     gam, bet = bn.weight.detach(), bn.bias.detach()
-    if sums_table is not None:   # the backward-data launch that produced dy left the sums (conv_bn_act)
+    if sums is not None:         # the pass that completed dy took them (pool_backward_fused)
+        pass
+    elif sums_table is not None:   # the backward-data launch that produced dy left the sums (conv_bn_act)
         _lib.check(lib.sfh_bn_stats_partials(_ptr(sums_table), sums_table.shape[0], C, _ptr(acc), _stream()),
                    "bn_stats_partials")
     else:
@@ -361,10 +388,13 @@ class _Names:
 
 
 def conv_bn_act(tape, names, conv, bn, srcs, B, H, W, relu=True, residual=None, need_dx=True, s3_out=True,
-                f32_out=True):
+                f32_out=True, pool=False):
     """z = conv(cat(srcs)) + bias; y = [relu](bn_train(z) [+ residual]).
     f32_out=False: the only consumer of y is a split-operand conv (forward and backward-filter read the split
     copy): y comes back as a handle without fp32 storage (see _bn_forward).
+    pool=True (split formats, ReLU, no residual): returns (y, maxpool2(y)), both as handles with split copies only,
+    written by one pass; the max-pool's backward (pushed here, so that it runs right before this layer's) completes
+    y's gradient and takes the BatchNorm backward sums in the same pass.
 
     srcs: [(tensor NHWC, channels used, pad_top, pad_left)], one or two (skip first, like torch.cat
     in unet/unet_parts.py:67).  Stride-1 3x3 / 1x1 convs, and stride-2 ones via zero-stuffing in the
@@ -393,9 +423,13 @@ def conv_bn_act(tape, names, conv, bn, srcs, B, H, W, relu=True, residual=None, 
            pad1=(srcs[1][2], srcs[1][3]) if t1 is not None else (0, 0), stats=stats)
     if any(id(t) in tape.no_f32 for t in (t0, t1) if t is not None) and not s3:
         raise RuntimeError("conv_bn_act: a source has no fp32 storage (f32_out=False) but this conv reads fp32")
-    y, mi = _bn_forward(lib, z, bn, relu, residual, tape, want_s3=s3_out,   # s3_out: a conv consumes y
-                        want_f32=f32_out or residual is not None, stats=stats)
-    if not f32_out and residual is None and relu and BWD_SUMS_IN_EPILOGUE:
+    pooled = None
+    if pool:
+        y, mi, pooled = _bn_forward(lib, z, bn, relu, residual, tape, stats=stats, pool=True)
+    else:
+        y, mi = _bn_forward(lib, z, bn, relu, residual, tape, want_s3=s3_out,   # s3_out: a conv consumes y
+                            want_f32=f32_out or residual is not None, stats=stats)
+    if not pool and not f32_out and residual is None and relu and BWD_SUMS_IN_EPILOGUE:
         tape.single_consumer[id(y)] = {"z": z, "mi": mi, "bn": bn}
 
     def backward():
@@ -413,7 +447,8 @@ def conv_bn_act(tape, names, conv, bn, srcs, B, H, W, relu=True, residual=None, 
         dz, dgamma, dbeta, dres, dz_s3 = _bn_backward(lib, tape, dy, y, z, mi, bn, relu, residual is not None,
                                                       want_s3=s3 and stride == 1 and (need_dx or wg_s3),
                                                       want_f32=not (s3 and stride == 1 and wg_s3),
-                                                      sums_table=ent.get("table") if ent is not None else None)
+                                                      sums_table=ent.get("table") if ent is not None else None,
+                                                      sums=tape.bwd_sums.pop(id(y), None))
         g = tape.param_grads
         g[names(bn.weight)], g[names(bn.bias)] = dgamma, dbeta
         if conv.bias is not None:
@@ -476,7 +511,27 @@ def conv_bn_act(tape, names, conv, bn, srcs, B, H, W, relu=True, residual=None, 
         tape.add_grad(t1, d1)
 
     tape.push(backward)
-    return y
+    if not pool:
+        return y
+
+    def pool_backward_fused():
+        dp = tape.pop_grad(pooled)
+        if dp is None:
+            raise RuntimeError("conv_bn_act(pool=True): no gradient reached the pooled tensor")
+        cur = tape.peek_grad(y)
+        acc = tape.zeros((2 * cout,), z, torch.float64)
+        fresh = cur is None
+        if fresh:
+            cur = _empty(z.shape, z)
+        _lib.check(lib.sfh_pool2_bwd_bn_reduce(_ptr(z), _ptr(mi), _ptr(bn.weight.detach()), _ptr(bn.bias.detach()), _ptr(dp),
+                                               B, ho, wo, cout, 0 if fresh else 1, _ptr(cur), _ptr(acc), _stream()),
+                   "pool2_bwd_bn_reduce")
+        if fresh:
+            tape.add_grad(y, cur)
+        tape.bwd_sums[id(y)] = acc
+
+    tape.push(pool_backward_fused)
+    return y, pooled
 
 
 def maxpool2(tape, x):
@@ -528,12 +583,23 @@ def conv_transpose2x2(tape, names, up, x):
     def backward():
         du = tape.pop_grad(u)
         g = tape.param_grads
-        g[names(up.bias)] = _colsum(lib, du)
-        s = _empty((B, h, w, 4 * cout), x)  # s[(py*2+px)*cout + co] = du[2y+py][2x+px][co]
-        _lib.check(lib.sfh_space_to_depth2(_ptr(du), _ptr(s), B, 2 * h, 2 * w, cout, _stream()), "space_to_depth2")
-        s_split = E.f32_to_split(s, tape.fmt, tape.overflow) if s3 else None
         wsrc = [(x, cin, 0, 0, 0)]
-        if s3 and wgrad_s3_ok(1, 1, 4 * cout, wsrc):   # one split copy of s feeds backward-filter and backward-data
+        wg_s3 = s3 and wgrad_s3_ok(1, 1, 4 * cout, wsrc)
+        if wg_s3 and cout % 8 == 0 and S2D_FUSED:
+            # one pass over du: bias gradient + the split copy of s (nobody reads s itself: backward-filter and
+            # backward-data take the split copy)
+            acc = tape.zeros((cout,), x, torch.float64)
+            s_split = E.split_empty(tape.fmt, B, h, w, 4 * cout, x.device)
+            _lib.check(lib.sfh_s2d_split_colsum(_ptr(du), B, h, w, cout, _ptr(s_split), tape.fmt_code, _ptr(acc),
+                                                _ptr(tape.overflow), _stream()), "s2d_split_colsum")
+            g[names(up.bias)] = acc.to(torch.float32)
+            s = None
+        else:
+            g[names(up.bias)] = _colsum(lib, du)
+            s = _empty((B, h, w, 4 * cout), x)  # s[(py*2+px)*cout + co] = du[2y+py][2x+px][co]
+            _lib.check(lib.sfh_space_to_depth2(_ptr(du), _ptr(s), B, 2 * h, 2 * w, cout, _stream()), "space_to_depth2")
+            s_split = E.f32_to_split(s, tape.fmt, tape.overflow) if s3 else None
+        if wg_s3:   # one split copy of s feeds backward-filter and backward-data
             raw = _wgrad_s3(lib, tape, s_split, 4 * cout, wsrc, B, h, w, cin, 1)
         else:
             raw = _wgrad(lib, s, wsrc, B, h, w, 1, cin, tape)      # (4*cout, 1, cin)
@@ -605,20 +671,27 @@ class UNetTrainer:
         B, _, H, W = x_nchw.shape
         x = E.nchw_to_nhwc(x_nchw, 4)
 
-        def dconv(block, srcs, h, w, need_dx=True, s3_out=True):
+        def dconv(block, srcs, h, w, need_dx=True, s3_out=True, pool=False):
             (cv1, bn1), (cv2, bn2) = block.convs()
             # y1 feeds cv2 only: forward, backward-data and backward-filter of cv2 read its split copy
             mid_f32 = not (tape.use_s3 and cv1.out_channels % 32 == 0 and cv2.out_channels % 64 == 0 and CAPTURE is None)
             y1 = conv_bn_act(tape, names, cv1, bn1, srcs, B, h, w, need_dx=need_dx, f32_out=mid_f32)
-            return conv_bn_act(tape, names, cv2, bn2, [(y1, y1.shape[3], 0, 0)], B, h, w, s3_out=s3_out)
+            # pool: this block's output is a skip tensor (consumers: MaxPool2d(2), and an Up block's conv with all its
+            # channels - conv and backward-filter read the split copy) - BatchNorm, ReLU and pooling in one pass
+            pool = (pool and POOL_FUSED and tape.use_s3 and cv2.out_channels % 64 == 0 and CAPTURE is None
+                    and not net.unet_bilinear and h >= 2 and w >= 2)
+            out = conv_bn_act(tape, names, cv2, bn2, [(y1, y1.shape[3], 0, 0)], B, h, w, s3_out=s3_out, pool=pool)
+            return out if pool else (out, None)
 
-        x1 = dconv(net.inc, [(x, 3, 0, 0)], H, W, need_dx=False)
+        x1, p = dconv(net.inc, [(x, 3, 0, 0)], H, W, need_dx=False, pool=True)
         feats = [x1]
         h, w = H, W
         for i in range(1, 5):
-            p = maxpool2(tape, feats[-1])
+            if p is None:
+                p = maxpool2(tape, feats[-1])
             h, w = h // 2, w // 2
-            feats.append(dconv(getattr(net, f"down{i}").block, [(p, p.shape[3], 0, 0)], h, w))
+            f, p = dconv(getattr(net, f"down{i}").block, [(p, p.shape[3], 0, 0)], h, w, pool=i < 4)
+            feats.append(f)
         y = feats[4]
         for i in range(1, 5):
             up = getattr(net, f"up{i}")
@@ -627,7 +700,7 @@ class UNetTrainer:
             hs, ws = skip.shape[1], skip.shape[2]
             dy_, dx_ = hs - u.shape[1], ws - u.shape[2]
             # the last block feeds the 1x1 heads (fp32) only: no S3 copy of it
-            y = dconv(up.conv, [(skip, skip.shape[3], 0, 0), (u, u.shape[3], dy_ // 2, dx_ // 2)], hs, ws, s3_out=i < 4)
+            y, _ = dconv(up.conv, [(skip, skip.shape[3], 0, 0), (u, u.shape[3], dy_ // 2, dx_ // 2)], hs, ws, s3_out=i < 4)
         frame = x if want_stn_in else None
         logits, stn_in, oc_bwd = out_conv(tape, names, net.outc, y, B, H, W, frame, stn_cs)
         heads = [(logits, oc_bwd)]

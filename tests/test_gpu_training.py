@@ -1019,3 +1019,133 @@ def test_backward_data_epilogue_leaves_the_batchnorm_backward_sums(T, shape, cin
     dy2 = torch.empty_like(dy)
     bd.run(E.f32_to_split(dz2, "h2"), B, H, W, dy2)
     assert torch.equal(dy, dy2)
+
+
+@pytest.mark.parametrize("fmt", ["h2", "s3"])
+@pytest.mark.parametrize("shape,cout", [((2, 11, 20), 64), ((1, 5, 70), 32), ((3, 7, 9), 8), ((16, 22, 40), 256)])
+def test_conv_transpose_backward_first_pass_in_one_kernel(T, shape, cout, fmt):
+    """sfh_s2d_split_colsum: bias gradient, space-to-depth and the split copy of ConvTranspose2d's output gradient in one
+    pass - the split planes bit for bit those of sfh_space_to_depth2 + sfh_f32_to_h2 / _s3, the column sums those of
+    sfh_colsum (fp64, different order of additions)."""
+    from sfh_amd import _lib, engine as E
+    from sfh_amd.engine import _ptr, _stream
+    lib = _lib.load()
+    B, h, w = shape
+    g = torch.Generator().manual_seed(5 + h + cout)
+    du = (torch.randn(B, 2 * h, 2 * w, cout, generator=g) * torch.rand(1, 1, 1, cout, generator=g) * 3).cuda()
+    s = torch.empty(B, h, w, 4 * cout, device="cuda")
+    _lib.check(lib.sfh_space_to_depth2(_ptr(du), _ptr(s), B, 2 * h, 2 * w, cout, _stream()), "space_to_depth2")
+    want = E.f32_to_split(s, fmt)
+    ref = T._colsum(lib, du).double()
+    got = E.split_empty(fmt, B, h, w, 4 * cout, "cuda")
+    acc = torch.zeros(cout, dtype=torch.float64, device="cuda")
+    over = torch.zeros(1, dtype=torch.int32, device="cuda")
+    _lib.check(lib.sfh_s2d_split_colsum(_ptr(du), B, h, w, cout, _ptr(got), {"s3": _lib.FMT_S3, "h2": _lib.FMT_H2}[fmt], _ptr(acc), _ptr(over), _stream()),
+               "s2d_split_colsum")
+    torch.cuda.synchronize()
+    assert torch.equal(got.view(torch.int16), want.view(torch.int16))
+    assert int(over) == 0
+    assert float((acc - ref).abs().max()) <= 1e-6 * float(du.abs().double().sum(dim=(0, 1, 2)).max())
+    assert float((acc - du.double().sum(dim=(0, 1, 2))).abs().max()) <= 1e-9 * float(du.abs().double().sum(dim=(0, 1, 2)).max())
+    # a value outside the H2 range raises the overflow word, as the separate conversion does
+    if fmt == "h2":
+        du[0, 1, 1, 3] = 1e6
+        _lib.check(lib.sfh_s2d_split_colsum(_ptr(du), B, h, w, cout, _ptr(got), _lib.FMT_H2, _ptr(acc), _ptr(over), _stream()),
+                   "s2d_split_colsum")
+        torch.cuda.synchronize()
+        assert int(over) == 1
+
+
+@pytest.mark.parametrize("fmt", ["h2", "s3"])
+@pytest.mark.parametrize("shape,C", [((2, 12, 20), 64), ((1, 45, 81), 32), ((3, 7, 9), 128), ((16, 45, 80), 512), ((1, 2, 2), 64)])
+def test_skip_tensor_batchnorm_relu_maxpool_in_one_pass(T, shape, C, fmt):
+    """sfh_bn_apply_pool / sfh_pool2_bwd_bn_reduce (odd sizes: the cropped row / column still gets its y and its gradient):
+    forward planes bit for bit those of sfh_bn_apply -> sfh_maxpool2_fwd -> sfh_f32_to_h2 / _s3; backward dx bit for bit
+    that of sfh_maxpool2_bwd (fresh and accumulating), sums those of sfh_bn_bwd_reduce over the finished dx."""
+    from sfh_amd import _lib, engine as E
+    from sfh_amd.engine import _ptr, _stream
+    lib = _lib.load()
+    B, H, W = shape
+    code = {"s3": _lib.FMT_S3, "h2": _lib.FMT_H2}[fmt]
+    g = torch.Generator().manual_seed(31 + H + C)
+    z = torch.randn(B, H, W, C, generator=g).cuda()
+    z = torch.where(torch.rand(B, H, W, 1, generator=g).cuda() < 0.5, torch.round(z * 2) / 2, z)   # exact ties in half the windows
+    mi = torch.cat([torch.randn(C, generator=g) * 0.2, torch.rand(C, generator=g) + 0.5]).cuda()
+    gam, bet = (torch.rand(C, generator=g) + 0.5).cuda(), (torch.randn(C, generator=g) * 0.3).cuda()
+    npix = B * H * W
+    # reference: three passes
+    y = torch.empty_like(z)
+    ys_ref = E.split_empty(fmt, B, H, W, C, "cuda")
+    _lib.check(lib.sfh_bn_apply(_ptr(z), _ptr(mi), _ptr(gam), _ptr(bet), None, 1, npix, C, _ptr(y), _ptr(ys_ref), W, code, None,
+                                _stream()), "bn_apply")
+    p = torch.empty(B, H // 2, W // 2, C, device="cuda")
+    _lib.check(lib.sfh_maxpool2_fwd(_ptr(y), _ptr(p), B, H, W, C, _stream()), "maxpool2_fwd")
+    ps_ref = E.f32_to_split(p, fmt)
+    ys, ps = E.split_empty(fmt, B, H, W, C, "cuda"), E.split_empty(fmt, B, H // 2, W // 2, C, "cuda")
+    over = torch.zeros(1, dtype=torch.int32, device="cuda")
+    _lib.check(lib.sfh_bn_apply_pool(_ptr(z), _ptr(mi), _ptr(gam), _ptr(bet), B, H, W, C, _ptr(ys), _ptr(ps), code, _ptr(over),
+                                     _stream()), "bn_apply_pool")
+    torch.cuda.synchronize()
+    assert torch.equal(ys.view(torch.int16), ys_ref.view(torch.int16))
+    assert torch.equal(ps.view(torch.int16), ps_ref.view(torch.int16))
+    assert int(over) == 0
+    if fmt == "s3":
+        return
+    dp = torch.randn(B, H // 2, W // 2, C, generator=g).cuda()
+    other = torch.randn(B, H, W, C, generator=g).cuda()       # the gradient from y's other consumer
+    for accumulate in (1, 0):
+        want = other.clone() if accumulate else (torch.empty_like(other) if H % 2 == 0 and W % 2 == 0 else torch.zeros_like(other))
+        _lib.check(lib.sfh_maxpool2_bwd(_ptr(y), _ptr(dp), _ptr(want), B, H, W, C,
+                                        1 if (accumulate or H % 2 or W % 2) else 0, _stream()), "maxpool2_bwd")
+        ref = torch.zeros(2 * C, dtype=torch.float64, device="cuda")
+        _lib.check(lib.sfh_bn_bwd_reduce(_ptr(want), None, _ptr(z), _ptr(mi), _ptr(gam), _ptr(bet), 1, npix, C, _ptr(ref),
+                                         _stream()), "bn_bwd_reduce")
+        got = other.clone() if accumulate else torch.full_like(other, float("nan"))
+        acc = torch.zeros(2 * C, dtype=torch.float64, device="cuda")
+        _lib.check(lib.sfh_pool2_bwd_bn_reduce(_ptr(z), _ptr(mi), _ptr(gam), _ptr(bet), _ptr(dp), B, H, W, C, accumulate, _ptr(got),
+                                               _ptr(acc), _stream()), "pool2_bwd_bn_reduce")
+        torch.cuda.synchronize()
+        assert torch.equal(got, want)
+        scale = torch.cat([want.abs().double().reshape(-1, C).sum(0)] * 2) * 8 + 1e-9
+        assert float(((acc - ref).abs() / scale).max()) < 1e-12
+
+
+@pytest.mark.parametrize("prec", ["bf16x6", "f16x3"])
+def test_fused_training_passes_give_the_gradients_of_the_separate_ones(T, prec, monkeypatch):
+    """Round 5: the one-pass forms (BatchNorm + ReLU + max-pool of the skip tensors; max-pool backward + BatchNorm sums;
+    ConvTranspose2d backward's bias gradient + space-to-depth + split copy) are what a training step runs, and they
+    give the gradients of the separate passes (same values per element; fp64 sums in another order), also at odd sizes."""
+    from sfh_amd.reconstructor import Reconstructor
+    monkeypatch.setenv("SFH_TRAIN_PRECISION", prec)
+    B, H, W = 2, 90, 136                      # 45 x 68 -> 22 x 34 -> 11 x 17: cropped rows / columns at two levels
+    court = synth.load_court_template("ncaa_nc4_640x360", 4, B)[:, :, :H, :W].contiguous().cuda()
+    poi = synth.load_court_poi("pitch", B).cuda()
+    x = synth.frames_to_float(synth.synth_frames_u8(B, H, W, seed=7)).cuda()
+    batch = {k: v.cuda() for k, v in _batch(B, H, W, poi.shape[1], 8).items()}
+    tags = []
+    real = T._lib.check
+    monkeypatch.setattr(T._lib, "check", lambda rc, tag="": (tags.append(tag), real(rc, tag))[1])
+
+    def grads(fused):
+        monkeypatch.setattr(T, "POOL_FUSED", fused)
+        monkeypatch.setattr(T, "S2D_FUSED", fused)
+        net = Reconstructor(court, poi, target_size=(W, H), unet_size=(W, H), warp_size=(W, H))
+        net.load_state_dict(synth.synth_state_dict(net.state_dict(), 3))
+        net.cuda().train()
+        ts = T.TrainStep(net, lr=1e-4)
+        del tags[:]
+        losses = ts.loss_and_grads(x, batch).cpu()
+        torch.cuda.synchronize()
+        return losses, {k: g.clone() for (k, _), g in zip(net.named_parameters(), ts.grads)}, list(tags)
+
+    l1, g1, t1 = grads(True)
+    l0, g0, t0 = grads(False)
+    assert t1.count("bn_apply_pool") == 4 and t1.count("pool2_bwd_bn_reduce") == 4 and t1.count("s2d_split_colsum") == 4
+    assert "maxpool2_fwd" not in t1 and "maxpool2_bwd" not in t1 and "colsum" not in t1
+    assert t0.count("maxpool2_fwd") == 4 and "bn_apply_pool" not in t0 and "s2d_split_colsum" not in t0
+    assert t1.count("bn_bwd_reduce") == t0.count("bn_bwd_reduce") - 4
+    # (the forward values are the same per element; the batch statistics come from fp64 atomics whose order varies run to run)
+    assert float((l1 - l0).abs().max()) < 1e-5 * float(l0.abs().max())
+    for k in g0:
+        d = float((g1[k].double() - g0[k].double()).norm()) / (float(g0[k].double().norm()) + 1e-30)
+        assert d < 1e-5 or float(g0[k].abs().max()) < 1e-12, (k, d)
