@@ -487,6 +487,13 @@ int sfh_zero_stuff2(const float* src, float* dst, int batch, int ho, int wo, int
 int sfh_conv_wgrad(const float* dz, int dz_cs, int M, const float* x, int x_cs, int xh, int xw, int N,
                    int pad_top, int pad_left, int batch, int H, int W, int ksize, float* raw, int raw_n,
                    int n_off, void* stream);
+/* The UNet's first layer (3 input channels stored as 4; unet/unet_parts.py:15-17) with its BatchNorm backward applied while
+ * the gradient tiles are loaded: dy = gradient of the BatchNorm + ReLU output, z = the conv output, acc = the finished sums
+ * [sum g | sum g * xhat] (sfh_bn_bwd_reduce, or the consumer's backward-data epilogue); raw as sfh_conv_wgrad (M, 9, raw_n).
+ * Same values as sfh_bn_bwd_apply followed by sfh_conv_wgrad, without writing and re-reading dz.                        */
+int sfh_conv_wgrad_c4_bn(const float* dy, const float* z, const float* mean_invstd, const float* gamma, const float* beta,
+                         const double* acc, int M, const float* x, int N, int batch, int H, int W, float* raw, int raw_n,
+                         void* stream);
 
 /* The same weight gradient for 3x3 (pad 1) and 1x1 stride-1 convs on the 16-bit matrix cores, fp32-equivalent ("bf16x6",
  * six bf16 MFMA products per fp32 product, as sfh_conv_s3_fwd): dz and the layer input are S3 (split-bf16)

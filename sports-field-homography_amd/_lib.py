@@ -112,6 +112,7 @@ SIGNATURES = {
     "sfh_slice_add": (C.c_int, [_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _p,
                                 C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _p]),
     "sfh_zero_stuff2": (C.c_int, [_p, _p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _p]),
+    "sfh_conv_wgrad_c4_bn": (C.c_int, [_p, _p, _p, _p, _p, _p, C.c_int, _p, C.c_int, C.c_int, C.c_int, C.c_int, _p, C.c_int, _p]),
     "sfh_conv_wgrad": (C.c_int, [_p, C.c_int, C.c_int, _p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                  C.c_int, C.c_int, C.c_int, C.c_int, _p, C.c_int, C.c_int, _p]),
     "sfh_conv_wgrad_s3": (C.c_int, [_p, C.c_int, _p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,

@@ -1138,6 +1138,10 @@ struct WgradArgs {
   int batch, H, W;
   float* raw; int raw_n, n_off;
   int ntx, nty, ntiles, nsplit, mt, mn;
+  // wgrad_c4_kernel only (sfh_conv_wgrad_c4_bn): dz points at dy, the gradient of the BatchNorm + ReLU OUTPUT, and the
+  // BatchNorm backward is applied while a tile is loaded (bn_z != nullptr): z, mean | invstd, gamma, beta, the finished
+  // backward sums [sum g | sum g * xhat] and 1 / (pixels per channel)
+  const float* bn_z; const float* bn_mi; const float* bn_gamma; const float* bn_beta; const double* bn_acc; float bn_inv_n;
 };
 
 template <int KS, int NSUB, int TH, int TW>
@@ -1283,7 +1287,10 @@ int launch_wgrad(WgradArgs a, hipStream_t stream) {
 // blocks of 16 - three MFMAs per four pixels instead of nine - and the halo is 16 bytes per pixel (2 KB instead of 35 KB of
 // LDS: four workgroups per CU).  B fragment: lane (j = n in the block, k = pixel) reads x[pixel + tap(n)][c(n)], one
 // ds_read_b32 at a per-lane constant offset; columns 36 .. 47 read a slot that stays zero.
-template <int TH, int TW>
+// BN: the layer's BatchNorm backward rides in the tile load (bn_bwd_apply_kernel's arithmetic, same operation order): the
+// kernel reads dy and z (8 B per element) instead of a dz tensor that a separate pass would first write and this one read
+// back (12 + 4 B per element moved by the pair).
+template <int TH, int TW, bool BN>
 __global__ __launch_bounds__(256, 4) void wgrad_c4_kernel(const WgradArgs a) {
   static_assert(TH * TW == 64 && TW % 4 == 0, "64-pixel tiles");
   constexpr int HR = TH + 2, HW = TW + 2, HPX = HR * HW;
@@ -1307,6 +1314,20 @@ __global__ __launch_bounds__(256, 4) void wgrad_c4_kernel(const WgradArgs a) {
   for (int nb = 0; nb < 3; ++nb) acc[nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
   if (tid == 0) xL[HPX] = (f32x4){0.f, 0.f, 0.f, 0.f};
   f32x4 hv, zv[4];
+  // (BN) the four channels m0 + 4 * (tid & 15) .. + 3 of every value this thread loads: 256 % 16 == 0
+  float bmean[4], binv[4], bgam[4], bbet[4], bmg[4], bmgx[4];
+  if constexpr (BN) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int m = min(m0 + 4 * (tid & 15) + j, a.M - 1);
+      bmean[j] = a.bn_mi[m];
+      binv[j] = a.bn_mi[a.M + m];
+      bgam[j] = a.bn_gamma[m];
+      bbet[j] = a.bn_beta[m];
+      bmg[j] = (float)a.bn_acc[m] * a.bn_inv_n;
+      bmgx[j] = (float)a.bn_acc[a.M + m] * a.bn_inv_n;
+    }
+  }
   auto load_tile = [&](int tile) {
     const int tx = tile % a.ntx;
     const int ty = (tile / a.ntx) % a.nty;
@@ -1326,8 +1347,20 @@ __global__ __launch_bounds__(256, 4) void wgrad_c4_kernel(const WgradArgs a) {
       const int r = p / TW, c = p - r * TW;
       const int y = y0 + r, x = x0 + c, m = m0 + 4 * q;
       zv[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      if (y < a.H && x < a.W && m < a.M)
-        zv[k] = *reinterpret_cast<const f32x4*>(a.dz + (((long)b * a.H + y) * a.W + x) * a.dz_cs + m);
+      if (y < a.H && x < a.W && m < a.M) {
+        const long o = (((long)b * a.H + y) * a.W + x) * a.dz_cs + m;
+        zv[k] = *reinterpret_cast<const f32x4*>(a.dz + o);
+        if constexpr (BN) {
+          const f32x4 zz = *reinterpret_cast<const f32x4*>(a.bn_z + o);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float yv = (zz[j] - bmean[j]) * binv[j] * bgam[j] + bbet[j];
+            const float g = yv > 0.f ? zv[k][j] : 0.f;
+            const float xh = (zz[j] - bmean[j]) * binv[j];
+            zv[k][j] = bgam[j] * binv[j] * (g - bmg[j] - xh * bmgx[j]);
+          }
+        }
+      }
     }
   };
   if (split < a.ntiles) load_tile(split);
@@ -1370,7 +1403,7 @@ __global__ __launch_bounds__(256, 4) void wgrad_c4_kernel(const WgradArgs a) {
   }
 }
 
-template <int TH, int TW>
+template <int TH, int TW, bool BN = false>
 int launch_wgrad_c4(WgradArgs a, hipStream_t stream) {
   a.ntx = sfh_cdiv(a.W, TW);
   a.nty = sfh_cdiv(a.H, TH);
@@ -1384,7 +1417,7 @@ int launch_wgrad_c4(WgradArgs a, hipStream_t stream) {
   a.mt = mn;
   a.mn = mn;
   const dim3 grid((unsigned)(sfh_cdiv(ns, 8) * 8 * mn));
-  hipLaunchKernelGGL((wgrad_c4_kernel<TH, TW>), grid, dim3(256), 0, stream, a);
+  hipLaunchKernelGGL((wgrad_c4_kernel<TH, TW, BN>), grid, dim3(256), 0, stream, a);
   return sfh_check_launch("wgrad_c4_kernel");
 }
 
@@ -1610,6 +1643,7 @@ extern "C" int sfh_conv_wgrad(const float* dz, int dz_cs, int M, const float* x,
   a.batch = batch; a.H = H; a.W = W;
   a.raw = raw; a.raw_n = raw_n; a.n_off = n_off;
   a.ntx = a.nty = a.ntiles = a.nsplit = a.mt = a.mn = 0;
+  a.bn_z = a.bn_mi = a.bn_gamma = a.bn_beta = nullptr; a.bn_acc = nullptr; a.bn_inv_n = 0.f;
   hipStream_t st = (hipStream_t)stream;
   const int t = wgrad_tile(H, W);
 #define SFH_WG(KS_, NS_)                                         \
@@ -1623,6 +1657,26 @@ extern "C" int sfh_conv_wgrad(const float* dz, int dz_cs, int M, const float* x,
   if (ksize == 1) return SFH_WG(1, 4);
   return SFH_WG(4, 2);
 #undef SFH_WG
+}
+
+extern "C" int sfh_conv_wgrad_c4_bn(const float* dy, const float* z, const float* mean_invstd, const float* gamma,
+                                    const float* beta, const double* acc, int M, const float* x, int N, int batch, int H,
+                                    int W, float* raw, int raw_n, void* stream) {
+  SFH_REQUIRE(dy && z && mean_invstd && gamma && beta && acc && x && raw, "conv_wgrad_c4_bn: null pointer");
+  SFH_REQUIRE(batch > 0 && H > 0 && W > 0 && M > 0 && M % 4 == 0 && N > 0 && N <= 4 && raw_n >= N,
+              "conv_wgrad_c4_bn: M=%d N=%d raw_n=%d", M, N, raw_n);
+  WgradArgs a;
+  a.dz = dy; a.dz_cs = M; a.M = M;
+  a.x = x; a.x_cs = 4; a.xh = H; a.xw = W; a.N = N; a.pad_top = 0; a.pad_left = 0;
+  a.batch = batch; a.H = H; a.W = W;
+  a.raw = raw; a.raw_n = raw_n; a.n_off = 0;
+  a.ntx = a.nty = a.ntiles = a.nsplit = a.mt = a.mn = 0;
+  a.bn_z = z; a.bn_mi = mean_invstd; a.bn_gamma = gamma; a.bn_beta = beta; a.bn_acc = acc;
+  a.bn_inv_n = 1.0f / (float)((long)batch * H * W);
+  hipStream_t st = (hipStream_t)stream;
+  const int t = wgrad_tile(H, W);
+  return t == 0 ? launch_wgrad_c4<2, 32, true>(a, st)
+                : (t == 1 ? launch_wgrad_c4<4, 16, true>(a, st) : launch_wgrad_c4<8, 8, true>(a, st));
 }
 
 extern "C" int sfh_outconv_bwd(const float* x, int cin, const float* w, const float* dlogits_nchw, int nc,

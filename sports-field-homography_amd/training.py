@@ -259,6 +259,8 @@ S2D_FUSED = os.environ.get("SFH_TRAIN_S2D_FUSED", "1") != "0"
 # encoder skip tensors: BatchNorm + ReLU + MaxPool2d(2) in one forward pass (split copies only), max-pool backward +
 # the BatchNorm backward sums in one backward pass (sfh_bn_apply_pool / sfh_pool2_bwd_bn_reduce)
 POOL_FUSED = os.environ.get("SFH_TRAIN_POOL_FUSED", "1") != "0"
+# first layer: BatchNorm backward applied inside the backward-filter kernel (sfh_conv_wgrad_c4_bn)
+C4_BN_FUSED = os.environ.get("SFH_TRAIN_C4_BN_FUSED", "1") != "0"
 STATS_ROWS = 2048   # most rows of the table a conv epilogue adds its per-wave BatchNorm sums into (sfh_conv_desc.stats_partial)
 
 
@@ -309,7 +311,8 @@ def _bn_forward(lib, z, bn, relu, residual, tape, want_s3=True, want_f32=True, s
     return y, mi
 
 
-def _bn_backward(lib, tape, dy, y, z, mi, bn, relu, want_dres, want_s3=False, want_f32=True, sums_table=None, sums=None):
+def _bn_backward(lib, tape, dy, y, z, mi, bn, relu, want_dres, want_s3=False, want_f32=True, sums_table=None, sums=None,
+                 apply=True):
     """want_dres: the layer added a residual before its ReLU (its gradient is returned as dres).
     want_f32=False (with want_s3): only the split copy of dz is written (its consumers are the split-operand
     backward-data and backward-filter kernels); the returned dz is None."""
@@ -328,6 +331,9 @@ def _bn_backward(lib, tape, dy, y, z, mi, bn, relu, want_dres, want_s3=False, wa
     else:
         _lib.check(lib.sfh_bn_bwd_reduce(_ptr(dy), _ptr(ysign), _ptr(z), _ptr(mi), _ptr(gam), _ptr(bet), 1 if relu else 0,
                                          npix, C, _ptr(acc), _stream()), "bn_bwd_reduce")
+    if not apply:   # the caller's next kernel applies it while loading (sfh_conv_wgrad_c4_bn): sums only
+        a = acc.to(torch.float32)
+        return None, a[C:], a[:C], None, acc
     dres = _empty(z.shape, z) if want_dres else None
     dz_s3 = E.split_empty(tape.fmt, B, H, W, C, z.device) if (want_s3 and C % 32 == 0) else None
     dz = _empty(z.shape, z) if (want_f32 or dz_s3 is None) else None
@@ -444,6 +450,24 @@ def conv_bn_act(tape, names, conv, bn, srcs, B, H, W, relu=True, residual=None, 
             raise RuntimeError("conv_bn_act: a source has no fp32 storage (f32_out=False) but its backward-filter reads fp32")
         # fp32 dz is read by the fp32 backward-filter kernel and by the zero-stuffing of stride-2 layers only
         ent = tape.single_consumer.pop(id(y), None)
+        # the first layer (three channels stored as four, nothing upstream): its BatchNorm backward rides in the
+        # backward-filter kernel's tile load - no dz tensor
+        c4_bn = (C4_BN_FUSED and not need_dx and not s3 and relu and residual is None and t1 is None and ks == 3
+                 and stride == 1 and c0 <= 4 and t0.shape[3] == 4 and cout % 4 == 0)
+        if c4_bn:
+            _, dgamma, dbeta, _, acc = _bn_backward(lib, tape, dy, y, z, mi, bn, relu, False, apply=False,
+                                                    sums_table=ent.get("table") if ent is not None else None,
+                                                    sums=tape.bwd_sums.pop(id(y), None))
+            g = tape.param_grads
+            g[names(bn.weight)], g[names(bn.bias)] = dgamma, dbeta
+            if conv.bias is not None:
+                g[names(conv.bias)] = tape.zeros((cout,), z)
+            raw = tape.zeros((cout, 9, 4), z)
+            _lib.check(lib.sfh_conv_wgrad_c4_bn(_ptr(dy), _ptr(z), _ptr(mi), _ptr(bn.weight.detach()), _ptr(bn.bias.detach()),
+                                                _ptr(acc), cout, _ptr(t0), c0, B, H, W, _ptr(raw), 4, _stream()),
+                       "conv_wgrad_c4_bn")
+            g[names(conv.weight)] = raw.view(cout, 3, 3, 4)[..., :c0].permute(0, 3, 1, 2)
+            return
         dz, dgamma, dbeta, dres, dz_s3 = _bn_backward(lib, tape, dy, y, z, mi, bn, relu, residual is not None,
                                                       want_s3=s3 and stride == 1 and (need_dx or wg_s3),
                                                       want_f32=not (s3 and stride == 1 and wg_s3),

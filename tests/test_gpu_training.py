@@ -1113,7 +1113,8 @@ def test_skip_tensor_batchnorm_relu_maxpool_in_one_pass(T, shape, C, fmt):
 @pytest.mark.parametrize("prec", ["bf16x6", "f16x3"])
 def test_fused_training_passes_give_the_gradients_of_the_separate_ones(T, prec, monkeypatch):
     """Round 5: the one-pass forms (BatchNorm + ReLU + max-pool of the skip tensors; max-pool backward + BatchNorm sums;
-    ConvTranspose2d backward's bias gradient + space-to-depth + split copy) are what a training step runs, and they
+    ConvTranspose2d backward's bias gradient + space-to-depth + split copy; the first layer's BatchNorm backward inside its
+    backward-filter kernel) are what a training step runs, and they
     give the gradients of the separate passes (same values per element; fp64 sums in another order), also at odd sizes."""
     from sfh_amd.reconstructor import Reconstructor
     monkeypatch.setenv("SFH_TRAIN_PRECISION", prec)
@@ -1129,6 +1130,7 @@ def test_fused_training_passes_give_the_gradients_of_the_separate_ones(T, prec, 
     def grads(fused):
         monkeypatch.setattr(T, "POOL_FUSED", fused)
         monkeypatch.setattr(T, "S2D_FUSED", fused)
+        monkeypatch.setattr(T, "C4_BN_FUSED", fused)
         net = Reconstructor(court, poi, target_size=(W, H), unet_size=(W, H), warp_size=(W, H))
         net.load_state_dict(synth.synth_state_dict(net.state_dict(), 3))
         net.cuda().train()
@@ -1144,6 +1146,7 @@ def test_fused_training_passes_give_the_gradients_of_the_separate_ones(T, prec, 
     assert "maxpool2_fwd" not in t1 and "maxpool2_bwd" not in t1 and "colsum" not in t1
     assert t0.count("maxpool2_fwd") == 4 and "bn_apply_pool" not in t0 and "s2d_split_colsum" not in t0
     assert t1.count("bn_bwd_reduce") == t0.count("bn_bwd_reduce") - 4
+    assert t1.count("conv_wgrad_c4_bn") == 1 and "conv_wgrad_c4_bn" not in t0 and t1.count("bn_bwd_apply") == t0.count("bn_bwd_apply") - 1
     # (the forward values are the same per element; the batch statistics come from fp64 atomics whose order varies run to run)
     assert float((l1 - l0).abs().max()) < 1e-5 * float(l0.abs().max())
     for k in g0:
