@@ -157,7 +157,7 @@ typedef struct sfh_conv_desc {
    * tensor (the fused Up block: the composed 2x2 conv writes its partial divided by the skip-half conv's scale).  Loaded
    * in the prologue instead of sixteen dependent reads in the epilogue. */
   const float* acc_init;
-  /* sfh_conv_s3_fwd, H2 sources, 3x3 stride 1, plain fp32 destination without ReLU / residual (the raw z = conv + bias of
+  /* sfh_conv_s3_fwd, H2 sources, 3x3 or 1x1 stride 1, plain fp32 destination without ReLU / residual (the raw z = conv + bias of
    * a training-mode layer; optional): batch-statistics BatchNorm sums from the epilogue.  stats_partial = float64 table
    * [stats_rows][2][cout], zero before the launch; every wave ADDS (fp64 sums, fp64 atomics) the sums of z and of z * z
    * over its in-frame pixels into row (wave's tile slot) % stats_rows.  sfh_bn_stats_partials then adds the rows up

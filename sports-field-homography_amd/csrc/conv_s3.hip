@@ -1252,10 +1252,10 @@ extern "C" int sfh_conv_s3_fwd(const sfh_conv_desc* dp, void* stream_) {
   SFH_REQUIRE(d.wg_couts == 0 || d.wg_couts == 64 || (d.wg_couts == 128 && (w8_ok || w8h_ok)),
               "conv_s3_fwd: wg_couts=%d is not available for this launch (see sfh_conv_desc.wg_couts)", d.wg_couts);
   if (d.stats_partial) {
-    SFH_REQUIRE(d.src_fmt == SFH_FMT_H2 && d.dst_fmt == SFH_FMT_F32 && d.ksize == 3 && d.stride == 1 && !d.relu && !d.residual &&
+    SFH_REQUIRE(d.src_fmt == SFH_FMT_H2 && d.dst_fmt == SFH_FMT_F32 && (d.ksize == 3 || d.ksize == 1) && d.stride == 1 && !d.relu && !d.residual &&
                     !d.dst_pool && !d.head_w && !(d.ksplit > 1) && d.out_mode == SFH_OUT_NHWC && d.stats_rows >= 64 &&
                     d.stats_rows <= 65536 && (d.stats_rows & (d.stats_rows - 1)) == 0,
-                "conv_s3_fwd: stats_partial needs H2 sources, a 3x3 stride-1 conv with a plain fp32 destination (no ReLU / "
+                "conv_s3_fwd: stats_partial needs H2 sources, a 3x3 or 1x1 stride-1 conv with a plain fp32 destination (no ReLU / "
                 "residual / pooled output / head / split-K) and stats_rows a power of two in 64 .. 65536");
     SFH_REQUIRE(!d.bwd_z || (d.bwd_mi && d.dst_cs == d.cout && (!d.bwd_gamma == !d.bwd_beta) &&
                              (unsigned long long)d.batch * d.H * d.W * d.cout * 4ULL < 0xFFFFFFF0ULL),
@@ -1300,7 +1300,7 @@ extern "C" int sfh_conv_s3_fwd(const sfh_conv_desc* dp, void* stream_) {
   if (d.ksize == KS && d.stride == ST && d.tile == TILE) {             \
     if (d.src_fmt == SFH_FMT_H2) {                                     \
       using CFG = S3Cfg<KS, ST, SH, SW, TH, TW, 2>;                    \
-      if constexpr (KS == 3 && ST == 1) {                              \
+      if constexpr ((KS == 3 || KS == 1) && ST == 1) {                 \
         using CFGS = S3Cfg<KS, ST, SH, SW, TH, TW, 2, 2, 2, true>;     \
         if (d.stats_partial) return launch_s3<CFGS, false>(d, stream); \
       }                                                                \

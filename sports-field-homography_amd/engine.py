@@ -541,7 +541,7 @@ class PackedConv:
     @property
     def stats_ok(self):
         """this layer's launch can leave BatchNorm batch statistics from its epilogue (run(stats=...))"""
-        return (self.fmt == "h2" and self.ksize == 3 and self.stride == 1 and not self.relu and not self.transposed
+        return (self.fmt == "h2" and self.ksize in (1, 3) and self.stride == 1 and not self.relu and not self.transposed
                 and not self.stem_cin and not self.c4)
 
     def _pack_split(self, w, ksize, c0, c1, mode, aux, wexp=None):

@@ -205,6 +205,10 @@ class Tape:
             v = self._s3[id(t)] = (t, E.f32_to_split(t, self.fmt, self.overflow))
         return v[1]
 
+    def f32(self, t):
+        """fp32 NHWC values of an activation of this pass, also when only its split copy was written (a handle)"""
+        return E.s3_to_f32(self._s3[id(t)][1]) if id(t) in self.no_f32 else t
+
     def prepare_h2(self, net, n_pixels):
         """H2 mode: gradient scale for n_pixels = B*H*W and the weight exponents of all conv weights (one sync)."""
         if self.fmt != "h2":
@@ -261,6 +265,8 @@ S2D_FUSED = os.environ.get("SFH_TRAIN_S2D_FUSED", "1") != "0"
 POOL_FUSED = os.environ.get("SFH_TRAIN_POOL_FUSED", "1") != "0"
 # first layer: BatchNorm backward applied inside the backward-filter kernel (sfh_conv_wgrad_c4_bn)
 C4_BN_FUSED = os.environ.get("SFH_TRAIN_C4_BN_FUSED", "1") != "0"
+# layers whose only consumer is an Up block's ConvTranspose2d: split copy only, backward sums from that conv's backward-data launch
+UP_SUMS_FUSED = os.environ.get("SFH_TRAIN_UP_SUMS_FUSED", "1") != "0"
 STATS_ROWS = 2048   # most rows of the table a conv epilogue adds its per-wave BatchNorm sums into (sfh_conv_desc.stats_partial)
 
 
@@ -625,12 +631,27 @@ def conv_transpose2x2(tape, names, up, x):
             s_split = E.f32_to_split(s, tape.fmt, tape.overflow) if s3 else None
         if wg_s3:   # one split copy of s feeds backward-filter and backward-data
             raw = _wgrad_s3(lib, tape, s_split, 4 * cout, wsrc, B, h, w, cin, 1)
+        elif id(x) in tape.no_f32:
+            raise RuntimeError("conv_transpose2x2: the input has no fp32 storage but its backward-filter reads fp32")
         else:
             raw = _wgrad(lib, s, wsrc, B, h, w, 1, cin, tape)      # (4*cout, 1, cin)
         g[names(up.weight)] = raw.view(2, 2, cout, cin).permute(3, 2, 0, 1)
         bd = PackedConv.backward_data(wt, 1, transposed=True, fmt=tape.fmt if s3 else None, wexp=tape.wexp_of(up.weight))
+        bd.order = tape.order
         dx = _empty((B, h, w, bd.cout), x)
-        bd.run(s_split if s3 else s, B, h, w, dx)
+        src_ent = tape.single_consumer.get(id(x))
+        if src_ent is not None and s3 and bd.stats_ok and bd.cout == cin and tape.peek_grad(x) is None:
+            # x is a BatchNorm + ReLU output that only this transposed conv consumed: the layer's backward sums ride in this
+            # launch (as in conv_bn_act)
+            rows = 64
+            while rows < STATS_ROWS and rows * 1024 < B * h * w:
+                rows *= 2
+            table = tape.zeros((rows, 2, bd.cout), x, torch.float64)
+            sb = src_ent["bn"]
+            bd.run(s_split, B, h, w, dx, stats=table, bwd=(src_ent["z"], src_ent["mi"], sb.weight.detach(), sb.bias.detach()))
+            src_ent["table"] = table
+        else:
+            bd.run(s_split if s3 else s, B, h, w, dx)
         tape.add_grad(x, dx)
 
     tape.push(backward)
@@ -695,7 +716,7 @@ class UNetTrainer:
         B, _, H, W = x_nchw.shape
         x = E.nchw_to_nhwc(x_nchw, 4)
 
-        def dconv(block, srcs, h, w, need_dx=True, s3_out=True, pool=False):
+        def dconv(block, srcs, h, w, need_dx=True, s3_out=True, pool=False, to_up=False):
             (cv1, bn1), (cv2, bn2) = block.convs()
             # y1 feeds cv2 only: forward, backward-data and backward-filter of cv2 read its split copy
             mid_f32 = not (tape.use_s3 and cv1.out_channels % 32 == 0 and cv2.out_channels % 64 == 0 and CAPTURE is None)
@@ -704,7 +725,12 @@ class UNetTrainer:
             # channels - conv and backward-filter read the split copy) - BatchNorm, ReLU and pooling in one pass
             pool = (pool and POOL_FUSED and tape.use_s3 and cv2.out_channels % 64 == 0 and CAPTURE is None
                     and not net.unet_bilinear and h >= 2 and w >= 2)
-            out = conv_bn_act(tape, names, cv2, bn2, [(y1, y1.shape[3], 0, 0)], B, h, w, s3_out=s3_out, pool=pool)
+            # to_up: the only consumer is an Up block's ConvTranspose2d (forward, backward-filter and backward-data read
+            # the split copy; its backward-data launch leaves this layer's BatchNorm backward sums)
+            to_up = (to_up and UP_SUMS_FUSED and tape.use_s3 and cv2.out_channels % 64 == 0 and CAPTURE is None and not net.unet_bilinear
+                     and not pool)
+            out = conv_bn_act(tape, names, cv2, bn2, [(y1, y1.shape[3], 0, 0)], B, h, w, s3_out=s3_out, pool=pool,
+                              f32_out=not to_up)
             return out if pool else (out, None)
 
         x1, p = dconv(net.inc, [(x, 3, 0, 0)], H, W, need_dx=False, pool=True)
@@ -714,7 +740,7 @@ class UNetTrainer:
             if p is None:
                 p = maxpool2(tape, feats[-1])
             h, w = h // 2, w // 2
-            f, p = dconv(getattr(net, f"down{i}").block, [(p, p.shape[3], 0, 0)], h, w, pool=i < 4)
+            f, p = dconv(getattr(net, f"down{i}").block, [(p, p.shape[3], 0, 0)], h, w, pool=i < 4, to_up=i == 4)
             feats.append(f)
         y = feats[4]
         for i in range(1, 5):
@@ -724,7 +750,8 @@ class UNetTrainer:
             hs, ws = skip.shape[1], skip.shape[2]
             dy_, dx_ = hs - u.shape[1], ws - u.shape[2]
             # the last block feeds the 1x1 heads (fp32) only: no S3 copy of it
-            y, _ = dconv(up.conv, [(skip, skip.shape[3], 0, 0), (u, u.shape[3], dy_ // 2, dx_ // 2)], hs, ws, s3_out=i < 4)
+            y, _ = dconv(up.conv, [(skip, skip.shape[3], 0, 0), (u, u.shape[3], dy_ // 2, dx_ // 2)], hs, ws, s3_out=i < 4,
+                         to_up=i < 4)
         frame = x if want_stn_in else None
         logits, stn_in, oc_bwd = out_conv(tape, names, net.outc, y, B, H, W, frame, stn_cs)
         heads = [(logits, oc_bwd)]
