@@ -465,19 +465,36 @@ __global__ __launch_bounds__(256) void s2d_split_colsum_kernel(const float* __re
   const int par = c0 / cout, co = c0 - par * cout, py = par >> 1, px = par & 1;
   double s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   unsigned over = 0u;
-  for (long chunk = (long)(blockIdx.x / (unsigned)nb); chunk < nchunks; chunk += chunk_stride) {
-    const long p = chunk * 64 + (threadIdx.x & 63);
-    if (p >= npix) break;
-    const unsigned row = (unsigned)p / (unsigned)w;          // b * h + y   (npix < 2^31: checked by the launcher)
-    const int x = (int)((unsigned)p - row * (unsigned)w);
-    const unsigned b = row / (unsigned)h, y = row - b * (unsigned)h;
-    const float* sp = du + (((long)b * 2 * h + 2 * y + py) * (2L * w) + 2 * x + px) * cout + co;
-    const f32x4 a = *reinterpret_cast<const f32x4*>(sp), bq = *reinterpret_cast<const f32x4*>(sp + 4);
-    const float v[8] = {a[0], a[1], a[2], a[3], bq[0], bq[1], bq[2], bq[3]};
+  // four chunks per iteration, all eight 16-byte loads of a lane issued before the first value is used
+  for (long chunk = (long)(blockIdx.x / (unsigned)nb); chunk < nchunks; chunk += 4L * chunk_stride) {
+    f32x4 a[4], bq[4];
+    unsigned rowu[4];
+    int xu[4];
+    bool ok[4];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) s[j] += (double)v[j];
-    if constexpr (NP == 3) tr_split8(v, s_split, tr_s3_elem((long)row, x, c0, w, C4), 4L * w * 8);
-    else tr_split8_h2(v, s_split, tr_s3_elem((long)row, x, c0, w, C4, 2), 4L * w * 8, over);
+    for (int u = 0; u < 4; ++u) {
+      const long p = (chunk + (long)u * chunk_stride) * 64 + (threadIdx.x & 63);
+      ok[u] = chunk + (long)u * chunk_stride < nchunks && p < npix;
+      const unsigned pu = ok[u] ? (unsigned)p : 0u;             // (npix < 2^31: checked by the launcher)
+      rowu[u] = pu / (unsigned)w;                               // b * h + y
+      xu[u] = (int)(pu - rowu[u] * (unsigned)w);
+      const unsigned b = rowu[u] / (unsigned)h, y = rowu[u] - b * (unsigned)h;
+      const float* sp = du + (((long)b * 2 * h + 2 * y + py) * (2L * w) + 2 * xu[u] + px) * cout + co;
+      a[u] = bq[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (ok[u]) {
+        a[u] = *reinterpret_cast<const f32x4*>(sp);
+        bq[u] = *reinterpret_cast<const f32x4*>(sp + 4);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (!ok[u]) continue;
+      const float v[8] = {a[u][0], a[u][1], a[u][2], a[u][3], bq[u][0], bq[u][1], bq[u][2], bq[u][3]};
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s[j] += (double)v[j];
+      if constexpr (NP == 3) tr_split8(v, s_split, tr_s3_elem((long)rowu[u], xu[u], c0, w, C4), 4L * w * 8);
+      else tr_split8_h2(v, s_split, tr_s3_elem((long)rowu[u], xu[u], c0, w, C4, 2), 4L * w * 8, over);
+    }
   }
   if constexpr (NP == 2)
     if (overflow && sfh_h2_out_of_range(over)) atomicOr(overflow, 1u);
@@ -564,9 +581,12 @@ __global__ __launch_bounds__(256) void maxpool2_bwd_kernel(const float* __restri
 template <int NP>
 __global__ __launch_bounds__(256) void bn_apply_pool_s3_kernel(const float* __restrict__ z, const float* __restrict__ mi,
                                                                const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                               int H, int W, int C, long nquads,
+                                                               int H, int W, int C, long ncols,
                                                                unsigned short* __restrict__ y_s3, unsigned short* __restrict__ p_s3,
                                                                unsigned* __restrict__ overflow) {
+  // one thread = the two rows of a window row x ONE column x 8 channels; lanes run along x (every store of a wave is one
+  // contiguous run), the horizontal half of the maximum comes from the neighbouring lane.  Columns are counted over a width
+  // rounded up to even, so that lanes 2i / 2i + 1 always hold the two columns of one window.
   const int nb = C >> 5;
   const int cb = (int)(blockIdx.x % (unsigned)nb);
   const long chunk = (long)(blockIdx.x / (unsigned)nb);
@@ -580,38 +600,44 @@ __global__ __launch_bounds__(256) void bn_apply_pool_s3_kernel(const float* __re
     gam[j] = gamma[c0 + j];
     bet[j] = beta[c0 + j];
   }
+  const int qh = (H + 1) >> 1, Wp = (W + 1) & ~1, Ho = H >> 1, Wo = W >> 1;
   const long q = chunk * 64 + (threadIdx.x & 63);
-  if (q >= nquads) return;
-  const int qh = (H + 1) >> 1, qw = (W + 1) >> 1, Ho = H >> 1, Wo = W >> 1;
-  const unsigned qrow = (unsigned)q / (unsigned)qw;
-  const int qx = (int)((unsigned)q - qrow * (unsigned)qw);
-  const unsigned b = qrow / (unsigned)qh;
-  const int qy = (int)(qrow - b * (unsigned)qh);
-  float m[8];
+  const unsigned qu = q < ncols ? (unsigned)q : 0u;
+  const unsigned prow = qu / (unsigned)Wp;                 // b * qh + qy
+  const int x = (int)(qu - prow * (unsigned)Wp);
+  const unsigned b = prow / (unsigned)qh;
+  const int qy = (int)(prow - b * (unsigned)qh);
+  const bool live = q < ncols && x < W;
+  float vr[2][8] = {{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}};
   unsigned over = 0u;
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const int yy = 2 * qy + (k >> 1), xx = 2 * qx + (k & 1);
-    if (yy >= H || xx >= W) continue;
+  for (int k = 0; k < 2; ++k) {
+    const int yy = 2 * qy + k;
+    if (!live || yy >= H) continue;
     const long row = (long)b * H + yy;
-    const long o = (row * W + xx) * C + c0;
-    float v[8];
+    const long o = (row * W + x) * C + c0;
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       const f32x4 zz = *reinterpret_cast<const f32x4*>(z + o + 4 * h);
 #pragma unroll
       for (int j = 0; j < 4; ++j)
-        v[4 * h + j] = sfh_relu((zz[j] - mean[4 * h + j]) * invstd[4 * h + j] * gam[4 * h + j] + bet[4 * h + j]);
+        vr[k][4 * h + j] = sfh_relu((zz[j] - mean[4 * h + j]) * invstd[4 * h + j] * gam[4 * h + j] + bet[4 * h + j]);
     }
-#pragma unroll
-    for (int j = 0; j < 8; ++j) m[j] = k == 0 ? v[j] : sfh_max_nan(m[j], v[j]);
-    if constexpr (NP == 3) tr_split8(v, y_s3, tr_s3_elem(row, xx, c0, W, C), 4L * W * 8);
-    else tr_split8_h2(v, y_s3, tr_s3_elem(row, xx, c0, W, C, 2), 4L * W * 8, over);
+    if constexpr (NP == 3) tr_split8(vr[k], y_s3, tr_s3_elem(row, x, c0, W, C), 4L * W * 8);
+    else tr_split8_h2(vr[k], y_s3, tr_s3_elem(row, x, c0, W, C, 2), 4L * W * 8, over);
   }
-  if (qy < Ho && qx < Wo) {
-    const long prow = (long)b * Ho + qy;
-    if constexpr (NP == 3) tr_split8(m, p_s3, tr_s3_elem(prow, qx, c0, Wo, C), 4L * Wo * 8);
-    else tr_split8_h2(m, p_s3, tr_s3_elem(prow, qx, c0, Wo, C, 2), 4L * Wo * 8, over);
+  // the window's maximum with maxpool2_fwd's nesting, max(max(a, b), max(c, d)) over (row 0: a b, row 1: c d) - sfh_max_nan
+  // picks its second argument on ties, so the nesting decides the sign of a zero; used on the even lane (a, c are its own)
+  float m[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const float r0 = __shfl_xor(vr[0][j], 1, 64), r1 = __shfl_xor(vr[1][j], 1, 64);
+    m[j] = sfh_max_nan(sfh_max_nan(vr[0][j], r0), sfh_max_nan(vr[1][j], r1));
+  }
+  if (live && !(x & 1) && qy < Ho && (x >> 1) < Wo) {
+    const long pr = (long)b * Ho + qy;
+    if constexpr (NP == 3) tr_split8(m, p_s3, tr_s3_elem(pr, x >> 1, c0, Wo, C), 4L * Wo * 8);
+    else tr_split8_h2(m, p_s3, tr_s3_elem(pr, x >> 1, c0, Wo, C, 2), 4L * Wo * 8, over);
   }
   if constexpr (NP == 2)
     if (overflow && sfh_h2_out_of_range(over)) atomicOr(overflow, 1u);
@@ -1558,7 +1584,7 @@ extern "C" int sfh_bn_apply_pool(const float* z, const float* mean_invstd, const
   SFH_REQUIRE(z && mean_invstd && gamma && beta && y_s3 && pool_s3 && batch > 0 && H >= 2 && W >= 2 && C > 0 && C % 32 == 0,
               "bn_apply_pool: bad argument (C %% 32 == 0, H and W >= 2)");
   SFH_REQUIRE(split_fmt == SFH_FMT_S3 || split_fmt == SFH_FMT_H2, "bn_apply_pool: split_fmt=%d (S3 or H2)", split_fmt);
-  const long nquads = (long)batch * ((H + 1) / 2) * ((W + 1) / 2);
+  const long nquads = (long)batch * ((H + 1) / 2) * ((W + 1) & ~1);   // (row pair, column) slots, width rounded up to even
   const long nblk = (nquads + 63) / 64 * (C / 32);
   SFH_REQUIRE(nblk < (1L << 31) && nquads < (1L << 31) - 64 && (long)batch * H * W < (1L << 31),
               "bn_apply_pool: tensor too large for one launch");
