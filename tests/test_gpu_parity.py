@@ -697,7 +697,7 @@ def test_warp_consistency_fused_kernel_with_a_warp_twice_the_logits_size(E, size
 
 @pytest.mark.parametrize("wh", [(112, 90), (640, 360), (160, 96)])
 def test_single_kernel_up_block_gives_the_two_launch_bits(E, wh):
-    """Round 5 experiment (csrc/conv_upfused.hip, engine knob SFH_UP_SINGLE): the first conv of a fused Up block as ONE kernel -
+    """Round 5 (csrc/conv_upfused.hip; the engine's default for levels 3 and 4, SFH_UP_SINGLE): the first conv of a fused Up block as ONE kernel -
     the composed 2x2 conv over the low-resolution tensor and the skip-half 3x3 conv accumulate into the same registers, a wave per
     output-parity class - against the two-launch form (fp32 partial + acc_init): same products in the same order per output =>
     identical logits and theta, at every level, incl. the level whose skip tensor is one row larger than twice the low-resolution
