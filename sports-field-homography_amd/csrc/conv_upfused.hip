@@ -1,4 +1,4 @@
-// conv_upfused.hip - the first conv of a fused Up block as ONE kernel (round 5 experiment, engine knob SFH_UP_SINGLE):
+// conv_upfused.hip - the first conv of a fused Up block as ONE kernel (round 5; the engine's default for up3 / up4, SFH_UP_SINGLE):
 //   conv3x3(cat([skip, ConvTranspose2d(x)])) + BatchNorm + ReLU  (unet/unet_parts.py:52-68)
 // Today (engine.UNetEngine, "swap + seed" path): the composed 2x2 conv over the low-resolution x (conv_s3_kernel<KS = 2>,
 // up-scatter) writes an fp32 partial in the skip-half conv's accumulator units, and the skip-half 3x3 conv STARTS from it
@@ -15,7 +15,9 @@
 // registers).  Its operand reads of the low-resolution halo (10 x 18 pixels) are unit-stride, those of the skip halo (18 x 34)
 // have a stride of two pixels.  Weights come from the two packed buffers the two-launch path already has (the four quadrant blocks
 // of the composed conv, the skip-half's block), per wave from L2, one tap ahead.  One LDS buffer of 78 KB (the skip halo of a
-// 32-channel stage), two workgroups per CU.
+// 32-channel stage), two workgroups per CU.  (Measured and not kept: the skip halo stored with every row's even columns first,
+// so that the stride-2 reads become unit-stride - SQ_LDS_BANK_CONFLICT says a third of this kernel's LDS cycles are conflicts -
+// bit-identical, same 2.37 ms per step for the two launches: the LDS pipe is not what they wait for.)
 #include "common.h"
 #include "conv_epilogue.h"
 
