@@ -449,10 +449,12 @@ int sfh_colsum(const float* x, int64_t npix, int C, int cs, double* acc, void* s
 /* First pass of nn.ConvTranspose2d(c, c/2, 2, stride=2).backward (unet/unet_parts.py:52, called from train.py:233):
  * du (B, 2h, 2w, cout) fp32 -> the space-to-depth tensor s (B, h, w, 4*cout), s[(py*2+px)*cout + co] at (y, x) =
  * du[2y+py][2x+px][co], written in the split format only (split_fmt SFH_FMT_S3 / SFH_FMT_H2 at the default exponent;
- * overflow as sfh_bn_apply), and acc[co] += sum of du[..., co] (fp64, the bias gradient) - one pass instead of
- * sfh_colsum + sfh_space_to_depth2 + sfh_f32_to_h2.  cout % 8 == 0.                                          */
+ * overflow as sfh_bn_apply), and the column sums of du (fp64, the bias gradient) - one pass instead of
+ * sfh_colsum + sfh_space_to_depth2 + sfh_f32_to_h2.  acc = [acc_rows][cout] doubles, zeroed by the caller: a workgroup adds
+ * its sums into row (its index) % acc_rows - same-address fp64 atomics are slow, 32 rows take them out of the way - and the
+ * caller adds the rows up (sfh_bn_stats_partials with C = cout / 2; acc_rows = 1: acc is the result).  cout % 8 == 0.   */
 int sfh_s2d_split_colsum(const float* du, int batch, int h, int w, int cout, void* s_split, int split_fmt,
-                         double* acc, uint32_t* overflow, void* stream);
+                         double* acc, int acc_rows, uint32_t* overflow, void* stream);
 /* nn.MaxPool2d(2) (unet/unet_parts.py:33) on NHWC, forward (floor) and backward: the gradient goes to
  * the first maximum of each window in scan order, like ATen; accumulate != 0 adds into dx.          */
 int sfh_maxpool2_fwd(const float* x, float* y, int batch, int H, int W, int C, void* stream);

@@ -104,7 +104,7 @@ SIGNATURES = {
     "sfh_bn_bwd_apply": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, C.c_int, C.c_int64, C.c_int, _p, _p, _p, C.c_int, C.c_int,
                                    _p, _p, _p]),
     "sfh_colsum": (C.c_int, [_p, C.c_int64, C.c_int, C.c_int, _p, _p]),
-    "sfh_s2d_split_colsum": (C.c_int, [_p, C.c_int, C.c_int, C.c_int, C.c_int, _p, C.c_int, _p, _p, _p]),
+    "sfh_s2d_split_colsum": (C.c_int, [_p, C.c_int, C.c_int, C.c_int, C.c_int, _p, C.c_int, _p, C.c_int, _p, _p]),
     "sfh_maxpool2_fwd": (C.c_int, [_p, _p, C.c_int, C.c_int, C.c_int, C.c_int, _p]),
     "sfh_bn_apply_pool": (C.c_int, [_p, _p, _p, _p, C.c_int, C.c_int, C.c_int, C.c_int, _p, _p, C.c_int, _p, _p]),
     "sfh_pool2_bwd_bn_reduce": (C.c_int, [_p, _p, _p, _p, _p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _p, _p, _p]),

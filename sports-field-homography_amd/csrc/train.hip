@@ -457,7 +457,8 @@ template <int NP>
 __global__ __launch_bounds__(256) void s2d_split_colsum_kernel(const float* __restrict__ du, int h, int w, int cout,
                                                                long npix, long nchunks, int chunk_stride,
                                                                unsigned short* __restrict__ s_split,
-                                                               double* __restrict__ acc, unsigned* __restrict__ overflow) {
+                                                               double* __restrict__ acc, int acc_rows,
+                                                               unsigned* __restrict__ overflow) {
   const int C4 = 4 * cout, nb = C4 >> 5;
   const int cb = (int)(blockIdx.x % (unsigned)nb);
   const int g = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
@@ -490,8 +491,10 @@ __global__ __launch_bounds__(256) void s2d_split_colsum_kernel(const float* __re
     for (int u = 0; u < 4; ++u) {
       if (!ok[u]) continue;
       const float v[8] = {a[u][0], a[u][1], a[u][2], a[u][3], bq[u][0], bq[u][1], bq[u][2], bq[u][3]};
+#ifndef SFH_S2D_NOSUM   // (experiment build: without the column sums)
 #pragma unroll
       for (int j = 0; j < 8; ++j) s[j] += (double)v[j];
+#endif
       if constexpr (NP == 3) tr_split8(v, s_split, tr_s3_elem((long)rowu[u], xu[u], c0, w, C4), 4L * w * 8);
       else tr_split8_h2(v, s_split, tr_s3_elem((long)rowu[u], xu[u], c0, w, C4, 2), 4L * w * 8, over);
     }
@@ -503,7 +506,10 @@ __global__ __launch_bounds__(256) void s2d_split_colsum_kernel(const float* __re
     double t = s[j];
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) t += __shfl_xor(t, m, 64);
-    if ((threadIdx.x & 63) == 0) unsafeAtomicAdd(&acc[co + j], t);
+    // (same-address fp64 atomics are what this kernel would otherwise wait for: 4096 blocks on ONE row of 64 addresses ran
+    // at 3.5 TB/s, on 32 rows at the 5 TB/s of the plain BatchNorm pass - profiles/r05_s2d_atomics.txt)
+    if ((threadIdx.x & 63) == 0)
+      unsafeAtomicAdd(&acc[(size_t)((blockIdx.x / (unsigned)nb) % (unsigned)acc_rows) * (size_t)cout + co + j], t);
   }
 }
 
@@ -1557,24 +1563,28 @@ extern "C" int sfh_colsum(const float* x, int64_t npix, int C, int cs, double* a
 }
 
 extern "C" int sfh_s2d_split_colsum(const float* du, int batch, int h, int w, int cout, void* s_split, int split_fmt,
-                                    double* acc, uint32_t* overflow, void* stream) {
-  SFH_REQUIRE(du && s_split && acc && batch > 0 && h > 0 && w > 0 && cout > 0 && cout % 8 == 0,
-              "s2d_split_colsum: bad argument (cout %% 8 == 0)");
+                                    double* acc, int acc_rows, uint32_t* overflow, void* stream) {
+  SFH_REQUIRE(du && s_split && acc && batch > 0 && h > 0 && w > 0 && cout > 0 && cout % 8 == 0 && acc_rows >= 1 && acc_rows <= 4096,
+              "s2d_split_colsum: bad argument (cout %% 8 == 0, 1 <= acc_rows <= 4096)");
   SFH_REQUIRE(split_fmt == SFH_FMT_S3 || split_fmt == SFH_FMT_H2, "s2d_split_colsum: split_fmt=%d (S3 or H2)", split_fmt);
   const long npix = (long)batch * h * w;
   SFH_REQUIRE(npix < (1L << 31) - 64 && (long)batch * 2 * h < (1L << 31), "s2d_split_colsum: tensor too large for one launch");
   const int nb = 4 * cout / 32;
   const long nchunks = (npix + 63) / 64;
+#ifdef SFH_S2D_BLOCKS                          // (experiment build: another number of blocks)
+  long per = SFH_S2D_BLOCKS / nb;
+#else
   long per = 4096 / nb;                       // about 4096 blocks: 16 per CU, each striding over its share of the chunks
+#endif
   if (per < 1) per = 1;
   if (per > nchunks) per = nchunks;
   const dim3 grid((unsigned)(per * nb));
   if (split_fmt == SFH_FMT_H2)
     hipLaunchKernelGGL(s2d_split_colsum_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, du, h, w, cout, npix, nchunks,
-                       (int)per, (unsigned short*)s_split, acc, overflow);
+                       (int)per, (unsigned short*)s_split, acc, acc_rows, overflow);
   else
     hipLaunchKernelGGL(s2d_split_colsum_kernel<3>, grid, dim3(256), 0, (hipStream_t)stream, du, h, w, cout, npix, nchunks,
-                       (int)per, (unsigned short*)s_split, acc, overflow);
+                       (int)per, (unsigned short*)s_split, acc, acc_rows, overflow);
   return sfh_check_launch("s2d_split_colsum_kernel");
 }
 

@@ -260,6 +260,7 @@ STATS_IN_EPILOGUE = os.environ.get("SFH_TRAIN_STATS_EPILOGUE", "1") != "0"
 BWD_SUMS_IN_EPILOGUE = os.environ.get("SFH_TRAIN_BWD_SUMS_EPILOGUE", "1") != "0"
 # ConvTranspose2d backward: bias gradient + space-to-depth + split copy in one pass (sfh_s2d_split_colsum)
 S2D_FUSED = os.environ.get("SFH_TRAIN_S2D_FUSED", "1") != "0"
+S2D_ROWS = 32
 # encoder skip tensors: BatchNorm + ReLU + MaxPool2d(2) in one forward pass (split copies only), max-pool backward +
 # the BatchNorm backward sums in one backward pass (sfh_bn_apply_pool / sfh_pool2_bwd_bn_reduce)
 POOL_FUSED = os.environ.get("SFH_TRAIN_POOL_FUSED", "1") != "0"
@@ -618,10 +619,12 @@ def conv_transpose2x2(tape, names, up, x):
         if wg_s3 and cout % 8 == 0 and S2D_FUSED:
             # one pass over du: bias gradient + the split copy of s (nobody reads s itself: backward-filter and
             # backward-data take the split copy)
+            table = tape.zeros((S2D_ROWS, cout), x, torch.float64)     # (rows: see sfh_s2d_split_colsum)
             acc = tape.zeros((cout,), x, torch.float64)
             s_split = E.split_empty(tape.fmt, B, h, w, 4 * cout, x.device)
-            _lib.check(lib.sfh_s2d_split_colsum(_ptr(du), B, h, w, cout, _ptr(s_split), tape.fmt_code, _ptr(acc),
+            _lib.check(lib.sfh_s2d_split_colsum(_ptr(du), B, h, w, cout, _ptr(s_split), tape.fmt_code, _ptr(table), S2D_ROWS,
                                                 _ptr(tape.overflow), _stream()), "s2d_split_colsum")
+            _lib.check(lib.sfh_bn_stats_partials(_ptr(table), S2D_ROWS, cout // 2, _ptr(acc), _stream()), "bn_stats_partials")
             g[names(up.bias)] = acc.to(torch.float32)
             s = None
         else:

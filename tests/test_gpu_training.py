@@ -1040,17 +1040,23 @@ def test_conv_transpose_backward_first_pass_in_one_kernel(T, shape, cout, fmt):
     got = E.split_empty(fmt, B, h, w, 4 * cout, "cuda")
     acc = torch.zeros(cout, dtype=torch.float64, device="cuda")
     over = torch.zeros(1, dtype=torch.int32, device="cuda")
-    _lib.check(lib.sfh_s2d_split_colsum(_ptr(du), B, h, w, cout, _ptr(got), {"s3": _lib.FMT_S3, "h2": _lib.FMT_H2}[fmt], _ptr(acc), _ptr(over), _stream()),
+    _lib.check(lib.sfh_s2d_split_colsum(_ptr(du), B, h, w, cout, _ptr(got), {"s3": _lib.FMT_S3, "h2": _lib.FMT_H2}[fmt], _ptr(acc), 1, _ptr(over), _stream()),
                "s2d_split_colsum")
     torch.cuda.synchronize()
     assert torch.equal(got.view(torch.int16), want.view(torch.int16))
     assert int(over) == 0
     assert float((acc - ref).abs().max()) <= 1e-6 * float(du.abs().double().sum(dim=(0, 1, 2)).max())
     assert float((acc - du.double().sum(dim=(0, 1, 2))).abs().max()) <= 1e-9 * float(du.abs().double().sum(dim=(0, 1, 2)).max())
+    # the sums spread over the rows of a table (what the training step passes: same-address fp64 atomics are slow)
+    table = torch.zeros(32, cout, dtype=torch.float64, device="cuda")
+    _lib.check(lib.sfh_s2d_split_colsum(_ptr(du), B, h, w, cout, _ptr(got), {"s3": _lib.FMT_S3, "h2": _lib.FMT_H2}[fmt], _ptr(table), 32,
+                                        _ptr(over), _stream()), "s2d_split_colsum")
+    torch.cuda.synchronize()
+    assert float((table.sum(0) - acc).abs().max()) <= 1e-9 * float(du.abs().double().sum(dim=(0, 1, 2)).max())
     # a value outside the H2 range raises the overflow word, as the separate conversion does
     if fmt == "h2":
         du[0, 1, 1, 3] = 1e6
-        _lib.check(lib.sfh_s2d_split_colsum(_ptr(du), B, h, w, cout, _ptr(got), _lib.FMT_H2, _ptr(acc), _ptr(over), _stream()),
+        _lib.check(lib.sfh_s2d_split_colsum(_ptr(du), B, h, w, cout, _ptr(got), _lib.FMT_H2, _ptr(acc), 1, _ptr(over), _stream()),
                    "s2d_split_colsum")
         torch.cuda.synchronize()
         assert int(over) == 1
