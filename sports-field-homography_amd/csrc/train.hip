@@ -794,7 +794,8 @@ template <int NC>
 __global__ __launch_bounds__(256) void outconv_bwd_kernel(const float* __restrict__ x, int cin,
                                                           const float* __restrict__ w, const float* __restrict__ dl,
                                                           long npix, int HW, float* __restrict__ dx,
-                                                          double* __restrict__ acc_w, double* __restrict__ acc_b) {
+                                                          double* __restrict__ acc_w, double* __restrict__ acc_b,
+                                                          int pix_per_block) {
   __shared__ double sh[256];
   const int cq = cin >> 2;  // <= 64
   const int lanes = 256 / cq;
@@ -809,7 +810,7 @@ __global__ __launch_bounds__(256) void outconv_bwd_kernel(const float* __restric
 #pragma unroll
     for (int j = 0; j < 4; ++j) sw[k][j] = 0.f;
   }
-  const long p0 = (long)blockIdx.x * 1024, p1 = min(p0 + 1024, npix);
+  const long p0 = (long)blockIdx.x * pix_per_block, p1 = min(p0 + (long)pix_per_block, npix);
   if (pl < lanes)
     for (long p = p0 + pl; p < p1; p += lanes) {
       const long b = p / HW, i = p - b * HW;
@@ -1721,11 +1722,15 @@ extern "C" int sfh_outconv_bwd(const float* x, int cin, const float* w, const fl
   SFH_REQUIRE(cin % 4 == 0 && cin >= 4 && cin <= 256, "outconv_bwd: cin=%d (multiple of 4, <= 256)", cin);
   SFH_REQUIRE(nc >= 1 && nc <= 8, "outconv_bwd: nc=%d unsupported (1..8)", nc);
   const long npix = (long)batch * H * W;
-  const unsigned grid = (unsigned)((npix + 1023) / 1024);
+  // every workgroup ends with nc * (cin + 1) fp64 atomics on the same addresses: about 1024 workgroups (at 640x360 x 16:
+  // 3840 pixels each, 0.49 ms; 1024 pixels each = 3600 workgroups: 0.56 ms; 8192: 0.63 - profiles/r05_s2d_atomics.txt)
+  long ppb = (npix / 1024 + 255) / 256 * 256;
+  if (ppb < 1024) ppb = 1024;
+  const unsigned grid = (unsigned)((npix + ppb - 1) / ppb);
 #define SFH_OB(N)                                                                                      \
   case N:                                                                                              \
     hipLaunchKernelGGL(outconv_bwd_kernel<N>, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, cin, w, \
-                       dlogits_nchw, npix, H * W, dx, acc_w, acc_b);                                   \
+                       dlogits_nchw, npix, H * W, dx, acc_w, acc_b, (int)ppb);                         \
     break;
   switch (nc) { SFH_OB(1) SFH_OB(2) SFH_OB(3) SFH_OB(4) SFH_OB(5) SFH_OB(6) SFH_OB(7) SFH_OB(8) }
 #undef SFH_OB
