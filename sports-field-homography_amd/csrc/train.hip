@@ -1613,7 +1613,6 @@ extern "C" int sfh_pool2_bwd_bn_reduce(const float* z, const float* mean_invstd,
                                        double* acc, void* stream) {
   SFH_REQUIRE(z && mean_invstd && gamma && beta && dpool && dx && acc && batch > 0 && H >= 2 && W >= 2 && C > 0 && C % 4 == 0,
               "pool2_bwd_bn_reduce: bad argument");
-  SFH_REQUIRE(C <= 1024 || C % 1024 == 0 || (C % 1024) % 4 == 0, "pool2_bwd_bn_reduce: C=%d", C);
   const long nquads = (long)batch * ((H + 1) / 2) * ((W + 1) / 2);
   SFH_REQUIRE(nquads < (1L << 31) && (long)batch * H * W < (1L << 31), "pool2_bwd_bn_reduce: tensor too large for one launch");
   const unsigned nb = red_grid(nquads);
