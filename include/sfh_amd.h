@@ -510,6 +510,13 @@ int sfh_conv_wgrad_s3(const void* dz_s3, int M, const void* x_s3, int x_channels
  * dx NHWC (optional), acc_w (nc*cin doubles) += dW, acc_b (nc doubles) += db (caller-zeroed).        */
 int sfh_outconv_bwd(const float* x, int cin, const float* w, const float* dlogits_nchw, int nc, int batch,
                     int H, int W, float* dx, double* acc_w, double* acc_b, void* stream);
+/* The same pass when x is the BatchNorm + ReLU output of the layer in front and the head is its only consumer (up4.conv.3 ->
+ * OutConv, unet/unet_model.py): x is recomputed from that layer's conv output z (mean_invstd, gamma, beta: sfh_bn_apply's
+ * arithmetic, same bits) instead of read, and acc_bn (2 * cin doubles, zeroed by the caller) += [sum g | sum g * xhat] with
+ * g = dx * (x > 0) - the layer's BatchNorm backward sums, without sfh_bn_bwd_reduce's pass over dx and z.                  */
+int sfh_outconv_bwd_bn(const float* z, const float* mean_invstd, const float* gamma, const float* beta, int cin,
+                       const float* w, const float* dlogits_nchw, int nc, int batch, int H, int W, float* dx,
+                       double* acc_w, double* acc_b, double* acc_bn, void* stream);
 
 /* ResNetSTN backward pieces (models/resnet.py:235-254).
  * MaxPool2d(3, stride 2, padding 1) on NHWC: dx (B,H,W,C) from dy (B,Ho,Wo,C), first maximum wins. */

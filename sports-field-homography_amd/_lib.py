@@ -118,6 +118,7 @@ SIGNATURES = {
     "sfh_conv_wgrad_s3": (C.c_int, [_p, C.c_int, _p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                     C.c_int, C.c_int, C.c_int, _p, C.c_int, C.c_int, C.c_int, _p]),
     "sfh_outconv_bwd": (C.c_int, [_p, C.c_int, _p, _p, C.c_int, C.c_int, C.c_int, C.c_int, _p, _p, _p, _p]),
+    "sfh_outconv_bwd_bn": (C.c_int, [_p, _p, _p, _p, C.c_int, _p, _p, C.c_int, C.c_int, C.c_int, C.c_int, _p, _p, _p, _p, _p]),
     "sfh_maxpool3x3s2_bwd": (C.c_int, [_p, _p, _p, C.c_int, C.c_int, C.c_int, C.c_int, _p]),
     "sfh_avgpool_linear_bwd": (C.c_int, [_p, _p, _p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _p, _p, _p, _p]),
     "sfh_stem_bwd_data": (C.c_int, [_p, _p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _p, _p]),

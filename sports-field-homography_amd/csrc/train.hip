@@ -790,12 +790,17 @@ __global__ __launch_bounds__(256) void zero_stuff2_kernel(const float* __restric
 // ------------------------------------------------------------------ OutConv backward
 // logits = w x + b (1x1, cin -> NC): dx[p][ci] = sum_k dl[k][p] w[k][ci];
 // acc_w[k][ci] += sum_p dl[k][p] x[p][ci]; acc_b[k] += sum_p dl[k][p].   dl is NCHW, x / dx NHWC.
-template <int NC>
+// BN (sfh_outconv_bwd_bn): x is not read - it is the BatchNorm + ReLU output of the layer in front, recomputed from that
+// layer's conv output z with bn_apply's arithmetic (same bits) - and, dx being that layer's whole gradient, the pass also leaves
+// its backward sums [sum g | sum g * xhat], g = dx * (x > 0): sfh_bn_bwd_reduce's second pass over dx and z is not needed.
+template <int NC, bool BN>
 __global__ __launch_bounds__(256) void outconv_bwd_kernel(const float* __restrict__ x, int cin,
                                                           const float* __restrict__ w, const float* __restrict__ dl,
                                                           long npix, int HW, float* __restrict__ dx,
                                                           double* __restrict__ acc_w, double* __restrict__ acc_b,
-                                                          int pix_per_block) {
+                                                          int pix_per_block, const float* __restrict__ bn_mi,
+                                                          const float* __restrict__ bn_gamma, const float* __restrict__ bn_beta,
+                                                          double* __restrict__ acc_bn) {
   __shared__ double sh[256];
   const int cq = cin >> 2;  // <= 64
   const int lanes = 256 / cq;
@@ -803,6 +808,17 @@ __global__ __launch_bounds__(256) void outconv_bwd_kernel(const float* __restric
   f32x4 wk[NC];
 #pragma unroll
   for (int k = 0; k < NC; ++k) wk[k] = *reinterpret_cast<const f32x4*>(w + k * cin + 4 * q);
+  float bmean[4], binv[4], bgam[4], bbet[4];
+  double s0[4] = {0, 0, 0, 0}, s1[4] = {0, 0, 0, 0};
+  if constexpr (BN) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      bmean[j] = bn_mi[4 * q + j];
+      binv[j] = bn_mi[cin + 4 * q + j];
+      bgam[j] = bn_gamma[4 * q + j];
+      bbet[j] = bn_beta[4 * q + j];
+    }
+  }
   float sw[NC][4], sb[NC];
 #pragma unroll
   for (int k = 0; k < NC; ++k) {
@@ -814,7 +830,15 @@ __global__ __launch_bounds__(256) void outconv_bwd_kernel(const float* __restric
   if (pl < lanes)
     for (long p = p0 + pl; p < p1; p += lanes) {
       const long b = p / HW, i = p - b * HW;
-      const f32x4 xv = *reinterpret_cast<const f32x4*>(x + p * cin + 4 * q);
+      f32x4 xv = *reinterpret_cast<const f32x4*>(x + p * cin + 4 * q);
+      f32x4 xh = {0.f, 0.f, 0.f, 0.f};
+      if constexpr (BN) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          xh[j] = (xv[j] - bmean[j]) * binv[j];
+          xv[j] = sfh_relu((xv[j] - bmean[j]) * binv[j] * bgam[j] + bbet[j]);
+        }
+      }
       f32x4 o = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int k = 0; k < NC; ++k) {
@@ -827,7 +851,28 @@ __global__ __launch_bounds__(256) void outconv_bwd_kernel(const float* __restric
         }
       }
       if (dx) *reinterpret_cast<f32x4*>(dx + p * cin + 4 * q) = o;
+      if constexpr (BN) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float gj = xv[j] > 0.f ? o[j] : 0.f;     // (x > 0 exactly where bn_apply's pre-ReLU value is > 0)
+          s0[j] += (double)gj;
+          s1[j] += (double)gj * (double)xh[j];
+        }
+      }
     }
+  if constexpr (BN) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      __syncthreads();
+      sh[threadIdx.x] = (pl < lanes) ? (j < 4 ? s0[j] : s1[j - 4]) : 0.0;
+      __syncthreads();
+      if (threadIdx.x < cq) {
+        double t = 0.0;
+        for (int l = 0; l < lanes; ++l) t += sh[l * cq + threadIdx.x];
+        unsafeAtomicAdd(&acc_bn[(long)(j >> 2) * cin + 4 * threadIdx.x + (j & 3)], t);
+      }
+    }
+  }
 #pragma unroll
   for (int k = 0; k < NC; ++k) {
 #pragma unroll
@@ -1715,8 +1760,9 @@ extern "C" int sfh_conv_wgrad_c4_bn(const float* dy, const float* z, const float
                 : (t == 1 ? launch_wgrad_c4<4, 16, true>(a, st) : launch_wgrad_c4<8, 8, true>(a, st));
 }
 
-extern "C" int sfh_outconv_bwd(const float* x, int cin, const float* w, const float* dlogits_nchw, int nc,
-                               int batch, int H, int W, float* dx, double* acc_w, double* acc_b, void* stream) {
+static int launch_outconv_bwd(const float* x, int cin, const float* w, const float* dlogits_nchw, int nc, int batch, int H,
+                              int W, float* dx, double* acc_w, double* acc_b, const float* bn_mi, const float* bn_gamma,
+                              const float* bn_beta, double* acc_bn, void* stream) {
   SFH_REQUIRE(x && w && dlogits_nchw && acc_w && acc_b && batch > 0 && H > 0 && W > 0, "outconv_bwd: bad argument");
   SFH_REQUIRE(cin % 4 == 0 && cin >= 4 && cin <= 256, "outconv_bwd: cin=%d (multiple of 4, <= 256)", cin);
   SFH_REQUIRE(nc >= 1 && nc <= 8, "outconv_bwd: nc=%d unsupported (1..8)", nc);
@@ -1726,14 +1772,30 @@ extern "C" int sfh_outconv_bwd(const float* x, int cin, const float* w, const fl
   long ppb = (npix / 1024 + 255) / 256 * 256;
   if (ppb < 1024) ppb = 1024;
   const unsigned grid = (unsigned)((npix + ppb - 1) / ppb);
-#define SFH_OB(N)                                                                                      \
-  case N:                                                                                              \
-    hipLaunchKernelGGL(outconv_bwd_kernel<N>, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, cin, w, \
-                       dlogits_nchw, npix, H * W, dx, acc_w, acc_b, (int)ppb);                         \
+#define SFH_OB(N)                                                                                                  \
+  case N:                                                                                                          \
+    if (acc_bn)                                                                                                    \
+      hipLaunchKernelGGL((outconv_bwd_kernel<N, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, x, cin, w,   \
+                         dlogits_nchw, npix, H * W, dx, acc_w, acc_b, (int)ppb, bn_mi, bn_gamma, bn_beta, acc_bn); \
+    else                                                                                                           \
+      hipLaunchKernelGGL((outconv_bwd_kernel<N, false>), dim3(grid), dim3(256), 0, (hipStream_t)stream, x, cin, w,  \
+                         dlogits_nchw, npix, H * W, dx, acc_w, acc_b, (int)ppb, bn_mi, bn_gamma, bn_beta, acc_bn); \
     break;
   switch (nc) { SFH_OB(1) SFH_OB(2) SFH_OB(3) SFH_OB(4) SFH_OB(5) SFH_OB(6) SFH_OB(7) SFH_OB(8) }
 #undef SFH_OB
   return sfh_check_launch("outconv_bwd_kernel");
+}
+
+extern "C" int sfh_outconv_bwd(const float* x, int cin, const float* w, const float* dlogits_nchw, int nc,
+                               int batch, int H, int W, float* dx, double* acc_w, double* acc_b, void* stream) {
+  return launch_outconv_bwd(x, cin, w, dlogits_nchw, nc, batch, H, W, dx, acc_w, acc_b, nullptr, nullptr, nullptr, nullptr, stream);
+}
+
+extern "C" int sfh_outconv_bwd_bn(const float* z, const float* mean_invstd, const float* gamma, const float* beta, int cin,
+                                  const float* w, const float* dlogits_nchw, int nc, int batch, int H, int W, float* dx,
+                                  double* acc_w, double* acc_b, double* acc_bn, void* stream) {
+  SFH_REQUIRE(mean_invstd && gamma && beta && acc_bn && dx, "outconv_bwd_bn: null pointer");
+  return launch_outconv_bwd(z, cin, w, dlogits_nchw, nc, batch, H, W, dx, acc_w, acc_b, mean_invstd, gamma, beta, acc_bn, stream);
 }
 
 extern "C" int sfh_maxpool3x3s2_bwd(const float* x, const float* dy, float* dx, int batch, int H, int W, int C,

@@ -169,6 +169,9 @@ class Tape:
         # id(y) -> fp64 [sum g | sum g * xhat] of a BatchNorm + ReLU layer whose total gradient is complete and whose sums
         # were taken by the pass that completed it (pool_backward_fused); a later add_grad to y is an ordering bug
         self.bwd_sums = {}
+        # id(y) -> {z, mi, bn} of every BatchNorm + ReLU layer without a residual (consumers that complete y's gradient use it to
+        # take the backward sums on the way: out_conv)
+        self.bn_layers = {}
         # f16x3 (H2 copies of activations and gradients): fp16's exponent range has to hold them.
         #   overflow - device word the kernels raise when a value does not fit (checked at the end of the backward pass);
         #   gscale   - power of two all gradients are carried with (the losses are means over B*H*W pixels, their
@@ -268,6 +271,8 @@ POOL_FUSED = os.environ.get("SFH_TRAIN_POOL_FUSED", "1") != "0"
 C4_BN_FUSED = os.environ.get("SFH_TRAIN_C4_BN_FUSED", "1") != "0"
 # layers whose only consumer is an Up block's ConvTranspose2d: split copy only, backward sums from that conv's backward-data launch
 UP_SUMS_FUSED = os.environ.get("SFH_TRAIN_UP_SUMS_FUSED", "1") != "0"
+# the last DoubleConv's BatchNorm backward sums from the OutConv backward pass (sfh_outconv_bwd_bn)
+OUTCONV_SUMS_FUSED = os.environ.get("SFH_TRAIN_OUTCONV_SUMS_FUSED", "1") != "0"
 STATS_ROWS = 2048   # most rows of the table a conv epilogue adds its per-wave BatchNorm sums into (sfh_conv_desc.stats_partial)
 
 
@@ -442,6 +447,8 @@ def conv_bn_act(tape, names, conv, bn, srcs, B, H, W, relu=True, residual=None, 
     else:
         y, mi = _bn_forward(lib, z, bn, relu, residual, tape, want_s3=s3_out,   # s3_out: a conv consumes y
                             want_f32=f32_out or residual is not None, stats=stats)
+    if relu and residual is None:
+        tape.bn_layers[id(y)] = {"z": z, "mi": mi, "bn": bn}
     if not pool and not f32_out and residual is None and relu and BWD_SUMS_IN_EPILOGUE:
         tape.single_consumer[id(y)] = {"z": z, "mi": mi, "bn": bn}
 
@@ -678,8 +685,10 @@ def upsample2x(tape, x):
     return u
 
 
-def out_conv(tape, names, oc, y, B, H, W, frame_nhwc=None, stn_cs=0):
-    """OutConv (unet/unet_parts.py:74-77) -> logits NCHW (+ the STN input cat((logits, x), 1) in NHWC)."""
+def out_conv(tape, names, oc, y, B, H, W, frame_nhwc=None, stn_cs=0, sole_consumer=False):
+    """OutConv (unet/unet_parts.py:74-77) -> logits NCHW (+ the STN input cat((logits, x), 1) in NHWC).
+    sole_consumer: y feeds nothing but this head - when y is a BatchNorm + ReLU output, the backward pass takes that layer's
+    backward sums while it writes y's gradient (sfh_outconv_bwd_bn), and reads the layer's conv output instead of y."""
     lib = tape.lib
     wt, bias = oc.conv.weight.detach(), oc.conv.bias.detach()
     nc, cin = wt.shape[0], wt.shape[1]
@@ -694,12 +703,22 @@ def out_conv(tape, names, oc, y, B, H, W, frame_nhwc=None, stn_cs=0):
         acc_w = tape.zeros((nc * cin,), y, torch.float64)
         acc_b = tape.zeros((nc,), y, torch.float64)
         dy = _empty(y.shape, y)
-        _lib.check(lib.sfh_outconv_bwd(_ptr(y), cin, _ptr(wt), _ptr(dlogits), nc, B, H, W, _ptr(dy), _ptr(acc_w),
-                                       _ptr(acc_b), _stream()), "outconv_bwd")
+        ent = tape.bn_layers.get(id(y)) if (sole_consumer and OUTCONV_SUMS_FUSED and tape.peek_grad(y) is None) else None
+        if ent is not None:
+            sb = ent["bn"]
+            acc_bn = tape.zeros((2 * cin,), y, torch.float64)
+            _lib.check(lib.sfh_outconv_bwd_bn(_ptr(ent["z"]), _ptr(ent["mi"]), _ptr(sb.weight.detach()), _ptr(sb.bias.detach()),
+                                              cin, _ptr(wt), _ptr(dlogits), nc, B, H, W, _ptr(dy), _ptr(acc_w), _ptr(acc_b),
+                                              _ptr(acc_bn), _stream()), "outconv_bwd_bn")
+        else:
+            _lib.check(lib.sfh_outconv_bwd(_ptr(y), cin, _ptr(wt), _ptr(dlogits), nc, B, H, W, _ptr(dy), _ptr(acc_w),
+                                           _ptr(acc_b), _stream()), "outconv_bwd")
         g = tape.param_grads
         g[names(oc.conv.weight)] = acc_w.to(torch.float32).view(nc, cin, 1, 1)
         g[names(oc.conv.bias)] = acc_b.to(torch.float32)
         tape.add_grad(y, dy)
+        if ent is not None:
+            tape.bwd_sums[id(y)] = acc_bn     # (after add_grad: a later gradient for y would be an ordering bug and raises)
 
     return logits, stn_in, backward
 
@@ -756,7 +775,7 @@ class UNetTrainer:
             y, _ = dconv(up.conv, [(skip, skip.shape[3], 0, 0), (u, u.shape[3], dy_ // 2, dx_ // 2)], hs, ws, s3_out=i < 4,
                          to_up=i < 4)
         frame = x if want_stn_in else None
-        logits, stn_in, oc_bwd = out_conv(tape, names, net.outc, y, B, H, W, frame, stn_cs)
+        logits, stn_in, oc_bwd = out_conv(tape, names, net.outc, y, B, H, W, frame, stn_cs, sole_consumer=not net.unet_uv)
         heads = [(logits, oc_bwd)]
         uv = None
         if net.unet_uv:  # second 1x1 head on the same features (models/reconstructor.py:79,148)

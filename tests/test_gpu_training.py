@@ -1138,6 +1138,7 @@ def test_fused_training_passes_give_the_gradients_of_the_separate_ones(T, prec, 
         monkeypatch.setattr(T, "S2D_FUSED", fused)
         monkeypatch.setattr(T, "C4_BN_FUSED", fused)
         monkeypatch.setattr(T, "UP_SUMS_FUSED", fused)
+        monkeypatch.setattr(T, "OUTCONV_SUMS_FUSED", fused)
         net = Reconstructor(court, poi, target_size=(W, H), unet_size=(W, H), warp_size=(W, H))
         net.load_state_dict(synth.synth_state_dict(net.state_dict(), 3))
         net.cuda().train()
@@ -1153,7 +1154,9 @@ def test_fused_training_passes_give_the_gradients_of_the_separate_ones(T, prec, 
     assert "maxpool2_fwd" not in t1 and "maxpool2_bwd" not in t1 and "colsum" not in t1
     assert t0.count("maxpool2_fwd") == 4 and "bn_apply_pool" not in t0 and "s2d_split_colsum" not in t0
     # four skip tensors; in f16x3 also the four inputs of transposed convs (the sums ride in a conv epilogue of the H2 kernel)
-    assert t1.count("bn_bwd_reduce") == t0.count("bn_bwd_reduce") - (8 if prec == "f16x3" else 4)
+    # and the last DoubleConv's from the OutConv backward
+    assert t1.count("bn_bwd_reduce") == t0.count("bn_bwd_reduce") - (9 if prec == "f16x3" else 5)
+    assert t1.count("outconv_bwd_bn") == 1 and "outconv_bwd" not in t1 and t0.count("outconv_bwd") == 1
     assert t1.count("conv_wgrad_c4_bn") == 1 and "conv_wgrad_c4_bn" not in t0 and t1.count("bn_bwd_apply") == t0.count("bn_bwd_apply") - 1
     # (the forward values are the same per element; the batch statistics come from fp64 atomics whose order varies run to run)
     assert float((l1 - l0).abs().max()) < 1e-5 * float(l0.abs().max())
