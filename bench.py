@@ -448,6 +448,18 @@ def extra_configs(args):
 
 
 def main():
+    """_run() with the process group torn down on EVERY exit path (an exception or SystemExit after
+    init_process_group must not leave RCCL's communicator and its proxy thread behind)"""
+    try:
+        _run()
+    finally:
+        if "torch.distributed" in sys.modules:
+            import torch.distributed as dist
+            if dist.is_available() and dist.is_initialized():
+                dist.destroy_process_group()
+
+
+def _run():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
@@ -468,6 +480,10 @@ def main():
                          "autograd node (the reference's train.py structure) instead of the all-HIP TrainStep")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend (nccl = RCCL over xGMI; gloo only to rehearse the multi-rank path)")
+    ap.add_argument("--force-collective", action="store_true",
+                    help="run the exchange step's collective even with ONE rank: `--gpus 1 --force-collective` initialises a "
+                         "one-rank process group on --dist-backend (nccl = RCCL) and gathers theta + consist_score through the "
+                         "real all_gather_into_tensor on the side stream, exactly as N > 1 does; gather_check is then non-null")
     ap.add_argument("--share-gpu", action="store_true",
                     help="rehearsal on a one-GPU box: every rank uses cuda:0 (needs --dist-backend gloo; the value "
                          "then measures nothing)")
@@ -510,8 +526,17 @@ def main():
         torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank) if on_gpu else torch.device("cpu")
     sync = torch.cuda.synchronize if on_gpu else (lambda: None)
-    if world > 1:
+    use_pg = world > 1 or args.force_collective
+    if use_pg:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:        # `--gpus 1 --force-collective` without a launcher: a one-rank world of our own
+            import socket
+            with socket.socket() as so:
+                so.bind(("127.0.0.1", 0))
+                os.environ.setdefault("MASTER_PORT", str(so.getsockname()[1]))
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
+            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if args.dist_backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=dev)
         else:
@@ -519,7 +544,7 @@ def main():
 
     B, W, H = args.batch, args.width, args.height
     # BASELINE config 4 (N > 1) names theta + consistency: the sharded run computes the score that its gather carries
-    cons = bool(args.consistency or world > 1)
+    cons = bool(args.consistency or use_pg)
     tmpl_name = "ncaa_nc4_640x360" if (W, H) == (640, 360) else "pitch_v3_nc4_1280x720"
     court = synth.load_court_template(tmpl_name, 4, B).to(dev)
     if tuple(court.shape[2:]) != (H, W):
@@ -537,7 +562,7 @@ def main():
               for k in range(nbatches)]
     # the one exchange step of the sharded path: theta (+score) rows to every rank, all-gathered on a side stream
     # while the next batch's kernels run (sharding.ResultGather; the final device synchronize covers it)
-    gather = sharding.ResultGather(world, B, dev, depth=2) if world > 1 else None
+    gather = sharding.ResultGather(world, B, dev, depth=2, force_collective=args.force_collective) if use_pg else None
 
     pending = []    # predict_async handles: at most two batches in flight
     last = {}       # slot + theta of the newest gathered step (checked after the timed region)
@@ -571,7 +596,7 @@ def main():
         for k in range(args.warmup):
             step(k, last=(k == args.warmup - 1))
         sync()
-        if world > 1:
+        if use_pg:
             dist.barrier()
         # live HIP events around the launches of the dominant kernel (roofline); the other kernel groups are timed in the
         # unpipelined pass behind the region when there is one (two event records per launch are not free: all 59 timed
@@ -587,7 +612,7 @@ def main():
             out = step(k, last=(k == args.steps - 1))      # the K-th call drains the pipeline: exactly K batches are timed
         sync()
         own_elapsed = time.perf_counter() - t0             # this rank's own K steps (before it waits for the others)
-        if world > 1:
+        if use_pg:
             dist.barrier()
         elapsed = time.perf_counter() - t0
         if power is not None:
@@ -603,7 +628,10 @@ def main():
                                and torch.equal(th_all[rank * B:(rank + 1) * B], last["theta"]))], device=dev)
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)
         gather_check = {"rows_per_rank": int(th_all.shape[0]), "own_rows_equal_own_theta_on_every_rank": bool(ok.item()),
-                        "bytes_per_step_per_rank": 40 * B}
+                        "bytes_per_step_per_rank": 40 * B, "backend": dist.get_backend(),
+                        "collective": "all_gather_into_tensor on a side stream, one per step",
+                        "collectives_run": int(gather.collectives_run),
+                        "forced_on_one_rank": bool(world == 1)}
 
     # the same K steps once more WITHOUT the pipeline: per-kernel durations of launches that run alone on the chip (under
     # the pipeline the ResNet-STN launches of batch k share the CUs with the UNet launches of batch k + 1, so every launch
@@ -626,7 +654,7 @@ def main():
             engine.PackedConv.timer = None
         alone = (tm2.summary(), el2)
     el = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-    if world > 1:
+    if use_pg:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
     elapsed = el.item()
     # per-rank figures: each rank's own step time and what its device sustains - a 4 % spread between the pool's devices
@@ -655,22 +683,29 @@ def main():
     x6 = nprod is not None
     half = "fp16" if prec == "f16x3" else "bf16"
     traffic, traffic_src = pmc_traffic("doubleconv3x3") if (W, H, B) == (640, 360, 16) else (None, None)
-    roofline = {"bound": "mfma", "achieved": round(achieved, 2), "peak": round(peak, 1),
-                "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
+    # frac = ALGORITHMIC FLOPs / launch time / the dense MFMA peak of the dtype the launches execute in.  The
+    # split-operand modes execute nprod MFMA products per algorithmic product: that executed-work share of the matrix
+    # pipe is `mfma_utilisation` (north_star's "MFMA util"), never `frac`.
+    mfma_peak = BF16_MFMA_PEAK_TFLOPS if x6 else FP32_MFMA_PEAK_TFLOPS
+    talg = timer.traffic().get("doubleconv3x3")
+    talg = talg / max(n, 1) if talg else None
+    roofline = {"bound": "mfma", "achieved": round(achieved, 2), "peak": round(mfma_peak, 1),
+                "unit": "TFLOP/s", "frac": round(achieved / mfma_peak, 4),
                 "traffic": traffic, "traffic_source": traffic_src,
-                "peak_basis": (f"2500 TFLOP/s dense {half} MFMA / {nprod} {half} products per fp32-grade product; the "
-                               f"launches execute {nprod}x the algorithmic FLOPs on the {half} matrix cores "
-                               f"(= {achieved * (nprod or 1):.0f} TFLOP/s of {half} MFMA work, "
-                               f"{achieved * (nprod or 1) / BF16_MFMA_PEAK_TFLOPS:.1%} of 2.5 PFLOP/s)"
+                "traffic_algorithmic": round(talg) if talg else None,
+                "traffic_ratio": round(traffic / talg, 3) if (traffic and talg) else None,
+                "traffic_algorithmic_basis": "per launch: source tensor(s) read once at 4 B per element (two fp16 planes), result (+ "
+                                             "pooled copy) written once, packed weights read once; averaged over the timed launches",
+                "mfma_utilisation": round(achieved * (nprod or 1) / mfma_peak, 4),
+                "fp32_grade_peak": round(peak, 1), "frac_of_fp32_grade_peak": round(achieved / peak, 4),
+                "peak_basis": (f"2500 TFLOP/s dense {half} MFMA (MI355X_MICROARCH.md).  Every fp32-grade product is {nprod} {half} MFMA "
+                               f"products, so the launches execute {nprod}x the algorithmic FLOPs: {achieved * (nprod or 1):.0f} TFLOP/s of "
+                               f"{half} MFMA work = mfma_utilisation; the most algorithmic work this arithmetic could reach is "
+                               f"2500 / {nprod} = fp32_grade_peak"
                                if x6 else "157.3 TFLOP/s dense fp32 MFMA (v_mfma_f32_16x16x4_f32)"),
                 "kernel": ((f"conv_s3_kernel<3x3, {'2 fp16' if prec == 'f16x3' else '3 bf16'} planes> (DoubleConv, split operands)")
                            if x6 else "conv_mfma_kernel<3x3,s1> (DoubleConv)"),
-                # algorithmic FLOPs / time against the dense MFMA peak of the dtype the launches execute in (no
-                # division by the products per element): `frac` is the executed-work figure (matrix-pipe utilisation)
-                "frac_algorithmic": round(achieved / (BF16_MFMA_PEAK_TFLOPS if x6 else FP32_MFMA_PEAK_TFLOPS), 4),
-                "frac_meaning": ("frac = executed %s MFMA work / 2500 TFLOP/s (= achieved x %d / 2500: what north_star calls MFMA "
-                                 "utilisation); frac_algorithmic = achieved / 2500 (SURVEY 8d's definition)" % (half, nprod)) if x6 else
-                                "fp32 MFMA: executed = algorithmic work",
+                "frac_meaning": "frac = achieved (algorithmic 2 x MAC of the reference conv / launch time) / peak: SURVEY 8(d)",
                 "launches": n,
                 "avg_launch_ms": round(ms / max(n, 1), 4),
                 "algorithmic_gflop_per_launch": round(fl / max(n, 1) / 1e9, 2),
@@ -681,7 +716,8 @@ def main():
         roofline["note"] = ("timed region = predict_async(): launches of two batches share the chip, so a launch's duration here "
                             "includes what it gives to the other batch's launches; `unpipelined` = the same kernel timed over "
                             "the same number of predict() steps right after, alone on the chip")
-        roofline["unpipelined"] = {"achieved": round(a2, 2), "frac": round(a2 / peak, 4), "avg_launch_ms": round(ms2 / max(n2, 1), 4),
+        roofline["unpipelined"] = {"achieved": round(a2, 2), "frac": round(a2 / mfma_peak, 4),
+                                   "mfma_utilisation": round(a2 * (nprod or 1) / mfma_peak, 4), "avg_launch_ms": round(ms2 / max(n2, 1), 4),
                                    "ms_per_step": round(alone[1] / args.steps * 1e3, 3),
                                    "frames_per_s": round(B * args.steps / alone[1], 2)}
     # every timed kernel group against the roofline that bounds it: conv groups against the matrix peak of the mode
@@ -706,8 +742,8 @@ def main():
                                      "final launch (profiles/r05_warpce_pmc.txt); live figure of this run: other_configs.C5...['warp+ce']"})
         else:
             tf = v[1] / (v[2] * 1e-3) / 1e12
-            other[t] = {"launches": v[0], "bound": "mfma", "tflops": round(tf, 2), "frac": round(tf / peak, 4),
-                        "ms_per_step": round(v[2] / args.steps, 3)}
+            other[t] = {"launches": v[0], "bound": "mfma", "tflops": round(tf, 2), "frac": round(tf / mfma_peak, 4),
+                        "mfma_utilisation": round(tf * (nprod or 1) / mfma_peak, 4), "ms_per_step": round(v[2] / args.steps, 3)}
             if t in executed:      # credited with the reference's work, executes less (composed 2x2 Up conv: 8/9)
                 ex = executed[t] / (v[2] * 1e-3) / 1e12
                 basis = ("credited = the u-half of the reference's 3x3 conv (9 taps x C; the ConvTranspose2d it also replaces is not "
@@ -716,7 +752,7 @@ def main():
                          "up-sampled channels (9 taps x 2C; its ConvTranspose2d is not credited); executed = 9 taps x C on the skip "
                          "tensor + 4 taps x 2C on the low-resolution tensor; these launches are not in `doubleconv3x3` / `fusedup2x2`")
                 other[t].update({"frac_basis": basis,
-                                 "executed_tflops": round(ex, 2), "executed_frac": round(ex / peak, 4)})
+                                 "executed_tflops": round(ex, 2), "mfma_utilisation": round(ex * (nprod or 1) / mfma_peak, 4)})
     step_gflop = STEP_GFLOP_PER_FRAME_640x360 * (W * H) / (640.0 * 360.0) * B
     whole_tf = step_gflop * 1e9 * args.steps / elapsed / 1e12    # per GPU: every rank runs its own batch per step
 
@@ -749,6 +785,8 @@ def main():
         except OSError:
             pass
         cpu_baseline = {"value": round(nf * len(samples) / sum(samples), 4), "unit": "frames/s", "cores": ncpu, "kind": "port",
+                        "cores_note": f"{ncpu} = every core this process may use (affinity mask capped by the cgroup CPU quota) of the "
+                                      f"host's {os.cpu_count()} logical CPUs: the one-GPU lease exposes that share, not the socket",
                         "sample": f"{len(samples)} batches of {nf} frames of the same {W}x{H} workload, 1 warm-up frame, "
                                   f"torch {torch.__version__} CPU fp32, {ncpu} threads, {model}",
                         "per_batch_frames_per_s": [round(nf / t, 4) for t in samples],
@@ -773,6 +811,13 @@ def main():
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "value_predict_sync": (round(B * args.steps / alone[1], 2) if alone is not None else round(fps, 2)) if world == 1 else None,
+            "value_exact_operands": ((other_configs or {}).get("C2_640x360_batch16_bf16x6") or {}).get("value"),
+            "value_exact_operands_note": "the same workload with every fp32 operand carried EXACTLY (bf16x6: three bf16 planes, six MFMA "
+                                         "products); `value` is the default two-plane fp16 emulation (22 significand bits, DESIGN.md section 2)",
+            "value_per_calibrated_pflop": (round(fps / world / (calib["mfma_f16_tflops"] / 1000.0), 2)
+                                           if calib and calib.get("mfma_f16_tflops") else None),
+            "value_per_calibrated_pflop_note": "frames/s per GPU / (device_calibration.mfma_f16_tflops / 1000): comparable across the "
+                                               "pool's devices, which hold different clocks under an MFMA-dense load",
             "value_predict_sync_note": "frames/s of the drop-in predict() called per batch (no predict_async pipelining), "
                                        "same kernels, timed right after the headline region; N = 1 only",
             "dtype": {"bf16x6": "bf16x6->f32 (3-way bf16 split operands, 6 bf16 MFMA products, fp32 accumulate; fp32-equivalent)",
@@ -790,11 +835,15 @@ def main():
                        "range_raises": int(getattr(net, "range_raises", 0)),
                        "parallelism": (f"frame-sharded x{world}, all_gather_into_tensor(theta + consist_score) over "
                                        + ("RCCL" if args.dist_backend == "nccl" else "gloo (REHEARSAL, ranks share a GPU)" if args.share_gpu else "gloo")
-                                       if world > 1 else "single GPU")},
+                                       if world > 1 else
+                                       ("single GPU; exchange step forced through a one-rank " +
+                                        ("RCCL" if args.dist_backend == "nccl" else "gloo") + " process group (--force-collective)")
+                                       if use_pg else "single GPU")},
             "roofline": roofline,
             "whole_step": {"algorithmic_gflop_per_step_per_gpu": round(step_gflop, 1), "tflops_per_gpu": round(whole_tf, 2),
-                           "frac": round(whole_tf / peak, 4),
-                           "note": "UNet + ResNet34-STN algorithmic FLOPs of a batch / ms_per_step, against the matrix peak of the mode"},
+                           "frac": round(whole_tf / mfma_peak, 4), "mfma_utilisation": round(whole_tf * (nprod or 1) / mfma_peak, 4),
+                           "note": "UNet + ResNet34-STN algorithmic FLOPs of a batch / ms_per_step; frac against the dense MFMA peak of the "
+                                   "dtype executed (2500), mfma_utilisation = executed MFMA work (x products per element) / that peak"},
             "cpu_baseline": cpu_baseline,
             "parity": parity,
             "device_calibration": dict(calib, power_timed_region=(power.summary() if power is not None else None)) if calib else None,
@@ -806,8 +855,6 @@ def main():
             "other_configs": other_configs,
         }
         print(json.dumps(line), flush=True)
-    if world > 1:
-        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -392,6 +392,16 @@ class ConvTimer:
             out[tag] = (n + 1, f + flops, t + e0.elapsed_time(e1))
         return out
 
+    def traffic(self):
+        """-> {tag: ALGORITHMIC HBM bytes of the launches}: every operand tensor read once, every result written once
+        (sources at their stored width, packed weights, fp32 seed / residual where a launch has one) - the figure the
+        counters' FETCH_SIZE + WRITE_SIZE are compared with (bench.py roofline.traffic_algorithmic)."""
+        out = {}
+        for rec in self.records:
+            if len(rec) > 5 and rec[5] is not None:
+                out[rec[0]] = out.get(rec[0], 0.0) + rec[5]
+        return out
+
     def executed(self):
         """-> {tag: FLOPs the launches EXECUTED} where that differs from the algorithmic work they are credited with
         (the composed 2x2 Up conv runs 4 taps x 2C channels for the reference's 9 taps x C)."""
@@ -848,7 +858,21 @@ class PackedConv:
                 # what the composed conv really multiplies: 4 quadrants x 4 taps x all low-resolution channels (8/9 of the credit)
                 executed = 2.0 * batch * ho * wo * self.cout * 4 * self.c0
                 flops = fpp * batch * (2 * ho) * (2 * wo)
-            tm.records.append((self.tag, flops, e0, e1, executed))
+            bpe = {"h2": 4, "s3": 6}.get(self.fmt, 4)          # stored bytes per activation element
+            nbytes = batch * d.h0 * d.w0 * self.c0 * bpe + self.wpacked.numel() * self.wpacked.element_size()
+            if src1 is not None:
+                nbytes += batch * d.h1 * d.w1 * self.c1 * bpe
+            obpe = {"h2": 4, "s3": 6}.get(_fmt_of(dst), 4)
+            if not (head is not None and head.get("skip_dst")):
+                nbytes += exp[0] * exp[1] * exp[2] * self.cout_real * (4 if (ksplit and ksplit > 1) else obpe)
+            if dst_pool is not None:
+                nbytes += batch * (ho // 2) * (wo // 2) * self.cout_real * obpe
+            if head is not None:
+                nbytes += batch * ho * wo * head["nc"] * 4
+            for t in (residual, acc_init):
+                if t is not None:
+                    nbytes += t.numel() * t.element_size()
+            tm.records.append((self.tag, flops, e0, e1, executed, float(nbytes)))
         return dst
 
 
@@ -890,8 +914,10 @@ def run_upfused(fu, sk, skip, ylow, dst, batch, H, W, exp_dst=None, range_word=N
         # credited like the two launches it replaces: the whole reference conv over cat([skip, up]) (9 taps x (c_skip + c_up))
         c_up = fu.flops_per_out_pixel / (2.0 * sk.cout * 9)
         # executed: 9 taps x the skip channels + 4 taps x all low-resolution channels (= 8/9 of the u-half's credit)
+        nbytes = (batch * H * W * (sk.c0 + sk.cout) + batch * d.h1 * d.w1 * fu.c0) * 4 \
+            + (sk.wpacked.numel() * sk.wpacked.element_size() + fu.wpacked.numel() * fu.wpacked.element_size())
         tm.records.append(("upfused", 2.0 * batch * H * W * sk.cout * 9 * (sk.c0 + c_up), e0, e1,
-                           2.0 * batch * H * W * sk.cout * (9 * sk.c0 + 4 * fu.c0)))
+                           2.0 * batch * H * W * sk.cout * (9 * sk.c0 + 4 * fu.c0), float(nbytes)))
     return dst
 
 

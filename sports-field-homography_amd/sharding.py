@@ -9,9 +9,37 @@ tests.  The payload is latency-bound (5 KB for 128 frames), so a single all_gath
 is used - ``all_gather_into_tensor`` on ONE (world * n, 10) receive buffer: with the list form RCCL gathers into a
 flat staging buffer and then copies every rank's rows out with a launch per rank; on the fully connected xGMI
 mesh the collective itself resolves in one hop.
+
+``force_collective`` (every exchange entry point): a world of ONE rank normally takes a local copy instead of the
+collective; with the switch the real ``all_gather_into_tensor`` / ``all_reduce`` runs anyway.  That is how the N > 1 code
+is put on RCCL on a one-GPU box (``tests/test_gpu_rccl.py``, ``bench.py --gpus 1 --force-collective``): same calls, same
+side stream, same events as at N = 8 - only the peer count differs.
 """
+import os
+
 import torch
 import torch.distributed as dist
+
+FORCE_COLLECTIVE = os.environ.get("SFH_FORCE_COLLECTIVE", "") not in ("", "0")
+
+
+def _use_collective(world, force):
+    """the collective runs when there is a peer, or when a one-rank world was told to exercise it anyway"""
+    if world > 1 and not dist.is_initialized():
+        raise RuntimeError(f"{world} ranks but torch.distributed is not initialised: call dist.init_process_group "
+                           "(backend 'nccl' = RCCL on GPUs) before the sharded entry points")
+    return dist.is_initialized() and (world > 1 or force or FORCE_COLLECTIVE)
+
+
+def _all_gather_flat(buf, rows, group=None):
+    """one all_gather_into_tensor on the flat receive buffer; list form where a backend lacks the flat one"""
+    try:
+        dist.all_gather_into_tensor(buf, rows, group=group)
+    except (RuntimeError, NotImplementedError) as e:
+        if "allgather_base" not in str(e) and "all_gather_into_tensor" not in str(e) and "not support" not in str(e):
+            raise
+        n = rows.shape[0]
+        dist.all_gather([buf[r * n:(r + 1) * n] for r in range(buf.shape[0] // max(n, 1))], rows, group=group)
 
 
 def shard_range(n_frames, rank, world):
@@ -31,7 +59,7 @@ def pack_results(theta, consist_score=None):
     return out
 
 
-def gather_results(theta, consist_score=None, group=None, n_max=None):
+def gather_results(theta, consist_score=None, group=None, n_max=None, force_collective=False):
     """All ranks receive (theta_all (N,1,3,3), score_all (N,)) in frame order.
 
     Ragged shards (n differs across ranks) are padded to ``n_max`` rows; pass the per-rank
@@ -39,7 +67,7 @@ def gather_results(theta, consist_score=None, group=None, n_max=None):
     exchanged first (one tiny all_gather of an int)."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rows = pack_results(theta, consist_score)
-    if world == 1:
+    if not _use_collective(world, force_collective):
         return theta, rows[:, 9].clone()
     n = rows.shape[0]
     cnt = torch.tensor([n], dtype=torch.int64, device=rows.device)
@@ -50,7 +78,7 @@ def gather_results(theta, consist_score=None, group=None, n_max=None):
     if n < n_max:
         rows = torch.cat([rows, rows.new_zeros((n_max - n, 10))], 0)
     buf = rows.new_empty((world * n_max, 10))
-    dist.all_gather_into_tensor(buf, rows.contiguous(), group=group)
+    _all_gather_flat(buf, rows.contiguous(), group=group)
     if all(c == n_max for c in counts):
         allrows = buf
     else:
@@ -70,9 +98,11 @@ class ResultGather:
         theta_all, score_all = g.result(slot)                        # orders the caller's stream behind the gather
     """
 
-    def __init__(self, world, n, device, depth=2, group=None):
+    def __init__(self, world, n, device, depth=2, group=None, force_collective=False):
         device = torch.device(device)
         self.world, self.n, self.group = world, n, group
+        self.collective = _use_collective(world, force_collective)
+        self.collectives_run = 0      # all_gather_into_tensor calls issued (0 on the one-rank shortcut)
         self.cuda = device.type == "cuda"
         self.side = torch.cuda.Stream(device) if self.cuda else None
         # one flat receive buffer per slot: rank r's rows land at [r * n, (r + 1) * n) - a single collective, no copy-out
@@ -92,17 +122,18 @@ class ResultGather:
         slot["rows"][:, :9] = theta.reshape(n, 9)
         if consist_score is not None:
             slot["rows"][:, 9] = consist_score
-        if self.world == 1 or not dist.is_initialized():
+        if not self.collective:       # one rank, nothing to exchange (world > 1 without a process group raised in __init__)
             slot["buf"].copy_(slot["rows"])
             return slot
+        self.collectives_run += 1
         if not self.cuda:
-            dist.all_gather_into_tensor(slot["buf"], slot["rows"], group=self.group)
+            _all_gather_flat(slot["buf"], slot["rows"], group=self.group)
             return slot
         ready = torch.cuda.Event()
         ready.record()
         with torch.cuda.stream(self.side):
             self.side.wait_event(ready)
-            dist.all_gather_into_tensor(slot["buf"], slot["rows"], group=self.group)
+            _all_gather_flat(slot["buf"], slot["rows"], group=self.group)
             slot["done"] = torch.cuda.Event()
             slot["done"].record()
         return slot
@@ -115,7 +146,7 @@ class ResultGather:
         return rows[:, :9].reshape(-1, 1, 3, 3).clone(), rows[:, 9].clone()    # (copies: the slot is reused two steps later)
 
 
-def predict_sharded(net, frames, consistency=True, group=None):
+def predict_sharded(net, frames, consistency=True, group=None, force_collective=False):
     """Run ``net.predict`` on this rank's shard of ``frames`` (a tensor holding the WHOLE batch
     or a callable rank_range -> shard tensor) and gather theta/consist_score from all ranks.
     Per-frame masks (logits, warp_mask) stay on the rank that computed them."""
@@ -134,7 +165,7 @@ def predict_sharded(net, frames, consistency=True, group=None):
         dev = frames.device if not callable(frames) else x.device
         theta = torch.zeros((0, 1, 3, 3), device=dev)
         score = torch.zeros((0,), device=dev) if consistency else None
-    theta_all, score_all = gather_results(theta, score, group=group)
+    theta_all, score_all = gather_results(theta, score, group=group, force_collective=force_collective)
     out["theta_all"], out["consist_score_all"] = theta_all, score_all
     out["shard"] = (s, e)
     return out
@@ -160,7 +191,7 @@ def world_size(group=None):
     return dist.get_world_size(group) if dist.is_initialized() else 1
 
 
-def allreduce_gradients(flat, group=None):
+def allreduce_gradients(flat, group=None, force_collective=False):
     """Sum the flat gradient buffer over the ranks (RCCL all-reduce over xGMI on GPUs, gloo in the CPU
     tests); returns the factor 1/world that turns the sum into the data-parallel mean - the optimizer
     kernel applies it while reading the gradient (before clip_grad_value_, like DistributedDataParallel's
@@ -168,7 +199,7 @@ def allreduce_gradients(flat, group=None):
     if not dist.is_initialized():
         return 1.0
     world = dist.get_world_size(group)
-    if world == 1:
+    if not _use_collective(world, force_collective):
         return 1.0
     dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
     return 1.0 / world

@@ -59,6 +59,89 @@ def _fill(seed, name, shape):
     raise ValueError(f"no synthetic rule for {name} {shape}")
 
 
+def _conv_bn_pairs(names):
+    """[(conv weight key, conv bias key or None, BatchNorm prefix)] for every conv that a BatchNorm follows, found by
+    the checkpoint's own naming (unet/unet_parts.py:14-21: double_conv.{0,3} -> .{1,4}; models/resnet.py: convN -> bnN,
+    conv0 -> bn1, downsample.0 -> downsample.1)"""
+    have = set(names)
+    pairs = []
+    for k in names:
+        if not k.endswith(".weight"):
+            continue
+        stem = k[:-len(".weight")]
+        head, _, leaf = stem.rpartition(".")
+        cand = None
+        if leaf.isdigit():                       # Sequential index: BatchNorm is the next module
+            cand = f"{head}.{int(leaf) + 1}"
+        elif leaf == "conv0":
+            cand = f"{head}.bn1"
+        elif leaf.startswith("conv") and leaf[4:].isdigit():
+            cand = f"{head}.bn{leaf[4:]}"
+        if cand and f"{cand}.running_var" in have:
+            pairs.append((k, f"{stem}.bias" if f"{stem}.bias" in have else None, cand))
+    return pairs
+
+
+def trained_like_state_dict(template_sd, seed=0, scaled_layer_exp=None, return_info=False):
+    """A second weight family with the statistics of a TRAINED checkpoint, where `synth_state_dict` has those of a fresh
+    one: the fp16 per-tensor-exponent arithmetic is exactly what such statistics stress.
+
+    * every BatchNorm: running_var log-uniform over 1e-3 .. 1e3 (six decades across the channels of one layer), gamma ~
+      N(0, 1) - so negative - with 5 % of the channels EXACTLY zero (dead), beta ~ N(0, 0.3);
+    * every conv in front of one: Gaussian bulk + 1 % outliers at 30 - 50 sigma with random signs (heavy tail), then
+      each output channel rescaled so that the conv's output has about the variance its BatchNorm recorded - what
+      training makes true (running_var IS the conv output's variance; without this coupling the activations would
+      grow by E[gamma^2 / var]^(1/2) = 8.5x per layer, which no checkpoint that was ever evaluated does) - and
+      running_mean ~ N(0, 0.3 sqrt(var));
+    * ONE UNet layer (picked by the seed) with its conv weights and bias scaled by 2^scaled_layer_exp (default: +12 for
+      even seeds, -12 for odd ones) and its BatchNorm statistics scaled to match: computed through a tensor 4096x larger /
+      smaller than its neighbours (+12: the same function; -12: the variances fall to 6e-11 .. 6e-5, BatchNorm's eps = 1e-5
+      takes over and most of the layer's channels go quiet - a collapsed layer, as checkpoints have them);
+    * residual-branch BatchNorms of the ResNet (bn2 / bn3 / downsample) keep a gain of N(0, 0.3) so that the 16
+      un-normalised residual adds stay bounded; the regression head as in `synth_state_dict`.
+
+    unet/unet_parts.py:14-21 (BatchNorm after every conv), models/resnet.py:64-82."""
+    names = list(template_sd.keys())
+    out = {n: torch.from_numpy(np.ascontiguousarray(_fill(seed, n, tuple(t.shape)))).to(t.dtype).reshape(t.shape)
+           for n, t in template_sd.items()}
+    pairs = _conv_bn_pairs(names)
+    unet_pairs = [p for p in pairs if not p[0].startswith("resnet_reg")]
+    pick = unet_pairs[_rng(seed, "scaled-layer").integers(0, len(unet_pairs))][0] if unet_pairs else None
+    if scaled_layer_exp is None:
+        scaled_layer_exp = 12 if seed % 2 == 0 else -12
+    for wk, bk, bn in pairs:
+        g = _rng(seed, "trained:" + wk)
+        w = out[wk].numpy().astype(np.float64)
+        cout = w.shape[0]
+        sigma = w.std()
+        hot = g.random(w.shape) < 0.01
+        w = np.where(hot, g.uniform(30.0, 50.0, w.shape) * sigma * g.choice([-1.0, 1.0], w.shape), w)
+        var = np.exp(g.uniform(np.log(1e-3), np.log(1e3), cout))
+        # conv output variance for inputs of power 1/2 per channel (ReLU of a unit Gaussian; frames: 1/3): sum of w^2 / 2
+        pred = 0.5 * (w.reshape(cout, -1) ** 2).sum(1)
+        w *= np.sqrt(var / np.maximum(pred, 1e-30)).reshape((cout,) + (1,) * (w.ndim - 1))
+        mean = g.normal(0.0, 0.3, cout) * np.sqrt(var)
+        residual = wk.startswith("resnet_reg") and (".bn2" in bn or ".bn3" in bn or "downsample" in bn)
+        gamma = g.normal(0.0, 0.3 if residual else 1.0, cout)
+        gamma[g.random(cout) < 0.05] = 0.0
+        beta = g.normal(0.0, 0.3, cout)
+        bias = g.normal(0.0, 0.1, cout) * np.sqrt(var) if bk else None
+        if wk == pick:
+            f = 2.0 ** scaled_layer_exp
+            w, var, mean = w * f, var * f * f, mean * f
+            bias = bias * f if bias is not None else None
+        out[wk] = torch.from_numpy(w.astype(np.float32))
+        if bk:
+            out[bk] = torch.from_numpy(bias.astype(np.float32))
+        out[bn + ".running_var"] = torch.from_numpy(var.astype(np.float32))
+        out[bn + ".running_mean"] = torch.from_numpy(mean.astype(np.float32))
+        out[bn + ".weight"] = torch.from_numpy(gamma.astype(np.float32))
+        out[bn + ".bias"] = torch.from_numpy(beta.astype(np.float32))
+    if return_info:
+        return out, {"scaled_layer": pick, "scaled_layer_exp": scaled_layer_exp, "conv_bn_pairs": len(pairs)}
+    return out
+
+
 def synth_state_dict(template_sd, seed=0):
     """Return a state_dict with the keys/shapes of ``template_sd`` filled deterministically."""
     out = {}

@@ -1181,6 +1181,7 @@ class TrainStep:
         self._bn_snapshot = None     # f16x3 only: copies of the BatchNorm statistics for a repeated step
         self._assemble = None        # _MultiCopy into self.grads
         self.range_fallbacks = 0     # steps repeated with bf16x6 because a value left the fp16 range
+        self.force_collective = False  # one-rank world: run the gradient all-reduce anyway (sharding.py, RCCL rehearsal)
         self._init_optimizer([p for p in net.parameters()])
 
     def _init_optimizer(self, params):
@@ -1337,7 +1338,7 @@ class TrainStep:
         from . import sharding
         # one process per GPU: frames shard by batch, gradients are summed over RCCL and averaged in the
         # optimizer kernel (BatchNorm statistics stay per rank, like DistributedDataParallel's default)
-        gscale = sharding.allreduce_gradients(self.gflat)
+        gscale = sharding.allreduce_gradients(self.gflat, force_collective=self.force_collective)
         _lib.check(lib.sfh_rmsprop_step(_ptr(self.table), _ptr(self.chunks), self.nchunks, hp["lr"], hp["alpha"],
                                         hp["eps"], hp["wd"], hp["mu"], hp["clip"], gscale, _stream()), "rmsprop_step")
         self.global_step += 1

@@ -402,3 +402,30 @@ def test_small_map_kernel_rule():
     assert E.choose_small_map(4, 12, 20, 2, 64, E._lib.TILE_16x16) is False
     # the threshold is a parameter (experiments): with 224, layer3's 240 standard workgroups stay on the standard kernel
     assert E.choose_small_map(16, 23, 40, 1, 256, E._lib.TILE_32x8, max_wgs=224) is False
+
+
+def _trained_like_template():
+    from sfh_amd import synth
+    from sfh_amd.reconstructor import Reconstructor
+    court = synth.load_court_template("ncaa_nc4_640x360", 4, 1)
+    poi = synth.load_court_poi("pitch", 1)
+    return Reconstructor(court, poi, target_size=(640, 360), unet_size=(640, 360), warp_size=(640, 360), warp_with_nearest=True)
+
+
+def test_trained_like_family_has_the_stated_statistics():
+    """(CPU part of the GPU file: cheap) the family is what its docstring says"""
+    from sfh_amd import synth
+    net = _trained_like_template()
+    sd, info = synth.trained_like_state_dict(net.state_dict(), 0, return_info=True)
+    assert info["conv_bn_pairs"] == 54 and info["scaled_layer_exp"] == 12
+    rv = sd["down2.maxpool_conv.1.double_conv.4.running_var"]
+    assert float(rv.min()) < 1e-2 and float(rv.max()) > 1e2
+    g = torch.cat([sd[k].flatten() for k in sd if k.endswith("double_conv.1.weight") or k.endswith("double_conv.4.weight")])
+    assert 0.02 < float((g == 0).float().mean()) < 0.09 and float((g < 0).float().mean()) > 0.4
+    w = sd["down3.maxpool_conv.1.double_conv.0.weight"]
+    per_ch = w.flatten(1)
+    z = (per_ch.abs() / per_ch.std(1, keepdim=True))
+    assert float((z > 10).float().mean()) > 0.003          # the outliers survive the per-channel rescale
+    net.load_state_dict(sd)                                 # and the layout is the checkpoint's (strict)
+
+

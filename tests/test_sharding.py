@@ -226,12 +226,13 @@ def _bench_main_worker(rank, world, port, q):
     bench = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(bench)
     sys.argv = ["bench.py", "--gpus", str(world), "--steps", "3", "--warmup", "1", "--device", "cpu", "--dist-backend", "gloo",
-                "--no-cpu-baseline", "--no-extra-configs"]
+                "--no-cpu-baseline", "--no-extra-configs"] + (["--force-collective"] if world == 1 else [])
     buf = io.StringIO()
     with contextlib.redirect_stdout(buf):
         bench.main()
     lines = [ln for ln in buf.getvalue().splitlines() if ln.startswith("{")]
-    q.put((rank, json.loads(lines[-1]) if lines else None))
+    import torch.distributed as dist
+    q.put((rank, json.loads(lines[-1]) if lines else None, dist.is_initialized()))
 
 
 def test_bench_main_two_ranks_gloo_reports_the_whole_job():
@@ -244,10 +245,12 @@ def test_bench_main_two_ranks_gloo_reports_the_whole_job():
     procs = [ctx.Process(target=_bench_main_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    res = dict(q.get(timeout=240) for _ in range(2))
+    got = [q.get(timeout=240) for _ in range(2)]
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
+    assert not any(g[2] for g in got)              # main() tore the process group down
+    res = {g[0]: g[1] for g in got}
     assert res[1] is None                          # only rank 0 prints
     line = res[0]
     assert line["n_gpus"] == 2 and line["steps"] == 3 and line["warmup"] == 1 and line["scaling"] == "weak"
@@ -257,7 +260,9 @@ def test_bench_main_two_ranks_gloo_reports_the_whole_job():
     # whole-job throughput: 2 ranks x 16 frames x 3 steps over the (max over ranks) elapsed time
     assert abs(line["value"] - 2 * 16 * 3 / (line["ms_per_step"] * 3e-3)) < 0.02 * line["value"]
     assert line["gather_check"] == {"rows_per_rank": 32, "own_rows_equal_own_theta_on_every_rank": True,
-                                    "bytes_per_step_per_rank": 640}
+                                    "bytes_per_step_per_rank": 640, "backend": "gloo",
+                                    "collective": "all_gather_into_tensor on a side stream, one per step",
+                                    "collectives_run": 4, "forced_on_one_rank": False}
     assert line["cpu_baseline"] is None and line["other_configs"] is None and line["vs_baseline"] is None
     # round 5: BASELINE config 4 gathers theta + consistency - with N > 1 the score is computed without --consistency
     assert "consistency" in line["config"]["workload"] and "all_gather_into_tensor" in line["config"]["parallelism"]
@@ -266,5 +271,135 @@ def test_bench_main_two_ranks_gloo_reports_the_whole_job():
     assert [r["rank"] for r in pr["ranks"]] == [0, 1]
     assert pr["ms_per_step_min"] <= pr["ms_per_step_median"] <= pr["ms_per_step_max"] <= line["ms_per_step"] * 1.001
     assert all(set(r) >= {"ms_per_step", "device", "mfma_f16_tflops", "in_kernel_clock_ghz", "power_w_timed_region"} for r in pr["ranks"])
-    assert "frac_algorithmic" in line["roofline"] and "device_calibration" in line and "parity" in line
+    assert {"frac", "mfma_utilisation", "traffic_algorithmic", "traffic_ratio"} <= set(line["roofline"])
+    assert "device_calibration" in line and "parity" in line
+    assert {"value_predict_sync", "value_exact_operands", "value_per_calibrated_pflop"} <= set(line)
     assert line["config"]["range_raises"] == 0
+
+
+
+def test_bench_main_one_rank_force_collective_gloo():
+    """`bench.py --gpus 1 --force-collective`: a one-rank process group of its own (no launcher), the exchange step
+    through the real collective, a non-null gather_check, and the group destroyed when main() returns."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        os.environ.pop(k, None)
+    p = ctx.Process(target=_bench_main_one_rank_worker, args=(q,))
+    p.start()
+    rank, line, still_up = q.get(timeout=240)
+    p.join(timeout=60)
+    assert p.exitcode == 0 and not still_up
+    assert line["n_gpus"] == 1 and line["config"]["global_batch"] == 16
+    gc = line["gather_check"]
+    assert gc is not None and gc["forced_on_one_rank"] and gc["own_rows_equal_own_theta_on_every_rank"]
+    assert gc["rows_per_rank"] == 16 and gc["collectives_run"] == 4 and gc["backend"] == "gloo"
+    assert "--force-collective" in line["config"]["parallelism"] and "consistency" in line["config"]["workload"]
+
+
+def _bench_main_one_rank_worker(q):
+    import contextlib
+    import importlib.util
+    import io
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        os.environ.pop(k, None)
+    import sfh_amd.reconstructor as R
+    from sfh_amd import synth
+    R.Reconstructor = _StandInReconstructor
+    real = synth.synth_frames_u8
+    synth.synth_frames_u8 = lambda B, H, W, seed=0: real(B, 36, 64, seed=seed)
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    sys.argv = ["bench.py", "--gpus", "1", "--steps", "3", "--warmup", "1", "--device", "cpu", "--dist-backend", "gloo",
+                "--no-cpu-baseline", "--no-extra-configs", "--force-collective"]
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        bench.main()
+    lines = [ln for ln in buf.getvalue().splitlines() if ln.startswith("{")]
+    import torch.distributed as dist
+    q.put((0, json.loads(lines[-1]) if lines else None, dist.is_initialized()))
+
+
+def _bench_main_raises_worker(q):
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        os.environ.pop(k, None)
+    import sfh_amd.reconstructor as R
+
+    class _Boom(_StandInReconstructor):
+        def predict_async(self, *a, **k):
+            raise RuntimeError("boom inside the timed region")
+    R.Reconstructor = _Boom
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    sys.argv = ["bench.py", "--gpus", "1", "--steps", "2", "--warmup", "1", "--device", "cpu", "--dist-backend", "gloo",
+                "--no-cpu-baseline", "--no-extra-configs", "--force-collective"]
+    import torch.distributed as dist
+    try:
+        bench.main()
+        q.put(("no error", dist.is_initialized()))
+    except RuntimeError as e:
+        q.put((str(e), dist.is_initialized()))
+
+
+def test_bench_main_destroys_the_process_group_when_a_step_raises():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_bench_main_raises_worker, args=(q,))
+    p.start()
+    msg, still_up = q.get(timeout=240)
+    p.join(timeout=60)
+    assert "boom" in msg and not still_up
+
+
+def _force_worker(q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29500 + (os.getpid() % 2000) + 211), RANK="0", WORLD_SIZE="1")
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        theta = torch.arange(36.0).reshape(4, 1, 3, 3)
+        score = torch.arange(4.0)
+        a = sharding.gather_results(theta, score)                              # one rank: the local shortcut
+        b = sharding.gather_results(theta, score, force_collective=True)       # the collective anyway
+        g0 = sharding.ResultGather(1, 4, "cpu")
+        g1 = sharding.ResultGather(1, 4, "cpu", force_collective=True)
+        r0 = g0.result(g0.submit(theta, score))
+        r1 = g1.result(g1.submit(theta, score))
+        flat, _ = sharding.flat_views([(3, 3), (5,)], "cpu")
+        flat.fill_(2.0)
+        s0 = sharding.allreduce_gradients(flat)
+        s1 = sharding.allreduce_gradients(flat, force_collective=True)
+        q.put((a[0].data_ptr() == theta.data_ptr(), b[0].data_ptr() != theta.data_ptr(),
+               torch.equal(b[0], theta) and torch.equal(b[1], score),
+               g0.collectives_run, g1.collectives_run, torch.equal(r0[0], r1[0]) and torch.equal(r1[0], theta)
+               and torch.equal(r1[1], score), s0, s1, float(flat.sum())))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_force_collective_takes_a_one_rank_world_through_the_collectives():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_force_worker, args=(q,))
+    p.start()
+    res = q.get(timeout=120)
+    p.join(timeout=60)
+    assert p.exitcode == 0
+    assert res == (True, True, True, 0, 1, True, 1.0, 1.0, 28.0)
+
+
+def test_more_than_one_rank_without_a_process_group_raises():
+    """world > 1 with torch.distributed uninitialised used to copy (n, 10) rows into a (world * n, 10)
+    buffer (a broadcast shape error); it is a clear error now"""
+    assert not dist.is_initialized()
+    with pytest.raises(RuntimeError, match="not initialised"):
+        sharding.ResultGather(2, 4, "cpu")
+    g = sharding.ResultGather(1, 4, "cpu")                 # one rank needs no group
+    th, sc = g.result(g.submit(torch.ones(4, 1, 3, 3), torch.ones(4)))
+    assert tuple(th.shape) == (4, 1, 3, 3) and float(sc.sum()) == 4.0
