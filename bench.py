@@ -196,6 +196,7 @@ def c2_parity(net, dev):
     return {"against": "tests/golden/c2_640x360_b16.npz (the reference's own UNet / ResNetSTN classes on torch CPU fp32, 16 frames)",
             "argmax_pixels": int(B * H * W), "argmax_differ": int(len(diff)),
             "largest_golden_top2_margin_among_differing": float(dm.max()) if len(diff) else 0.0,
+            "golden_pixels_inside_softmax_tie_margin_1.2e-7": int((g["low_margin_value"] < 1.2e-7).sum()),
             "max_abs_dtheta": float((out["theta"].cpu() - torch.from_numpy(g["theta"])).abs().max()),
             "max_abs_dlogits_every_16th_pixel": float((logits[:, :, 4::16, 4::16] - torch.from_numpy(g["logits_sub"])).abs().max()),
             "max_abs_dpoi": float((out["poi"].cpu() - torch.from_numpy(g["poi"])).abs().max()),

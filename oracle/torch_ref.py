@@ -27,6 +27,26 @@ import torch.nn.functional as F
 
 from . import warp_ref
 
+# utils/postprocess.py:10-11 labels a pixel with argmax(softmax(logits)), not argmax(logits).  fp32 softmax is only weakly
+# monotone: exp(b - a) rounds to 1.0 when the top-2 margin a - b is at most 2^-25 = 3.0e-8 (measured on torch 2.10 CPU:
+# every such pair ties, no pair at 6e-8 or beyond does), the two probabilities are then EQUAL and argmax returns the lower
+# index.  Distinct fp32 logits can be that close only below magnitude 0.5 (ulp(0.5) = 6e-8).  1.2e-7 = 2^-23 is the
+# conservative band (one ulp of 1.0) inside which an argmax(logits) implementation may differ from the reference's rule.
+SOFTMAX_TIE_MARGIN = 1.2e-7
+
+
+def preds_to_masks(logits):
+    """utils/postprocess.py:7-18 for n_classes > 1: argmax over softmax probabilities."""
+    return torch.argmax(F.softmax(logits, dim=1), dim=1)
+
+
+def softmax_argmax_may_differ(logits):
+    """bool (B,H,W): pixels whose top-2 logit margin is inside SOFTMAX_TIE_MARGIN - the only ones where
+    argmax(softmax(logits)) (the reference) and argmax(logits) (the HIP epilogue) can disagree"""
+    top2 = logits.topk(2, dim=1).values
+    return (top2[:, 0] - top2[:, 1]) < SOFTMAX_TIE_MARGIN
+
+
 BN_EPS = 1e-5  # nn.BatchNorm2d default, used unchanged by unet/unet_parts.py:16,19
 
 
