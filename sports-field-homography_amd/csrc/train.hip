@@ -819,16 +819,37 @@ __global__ __launch_bounds__(256) void outconv_bwd_kernel(const float* __restric
       bbet[j] = bn_beta[4 * q + j];
     }
   }
+  // dW / db partial sums: fp32 over at most 64 pixels of a thread, then promoted into fp64 - a workgroup covers npix / 1024
+  // pixels, so a thread's chain grows with the image (about 900 terms at 1280x720 x 16) and must not stay in fp32
   float sw[NC][4], sb[NC];
+  double dsw[NC][4], dsb[NC];
 #pragma unroll
   for (int k = 0; k < NC; ++k) {
     sb[k] = 0.f;
+    dsb[k] = 0.0;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) sw[k][j] = 0.f;
+    for (int j = 0; j < 4; ++j) {
+      sw[k][j] = 0.f;
+      dsw[k][j] = 0.0;
+    }
   }
   const long p0 = (long)blockIdx.x * pix_per_block, p1 = min(p0 + (long)pix_per_block, npix);
+  int since_flush = 0;
   if (pl < lanes)
     for (long p = p0 + pl; p < p1; p += lanes) {
+      if (++since_flush > 64) {
+        since_flush = 1;
+#pragma unroll
+        for (int k = 0; k < NC; ++k) {
+          dsb[k] += (double)sb[k];
+          sb[k] = 0.f;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            dsw[k][j] += (double)sw[k][j];
+            sw[k][j] = 0.f;
+          }
+        }
+      }
       const long b = p / HW, i = p - b * HW;
       f32x4 xv = *reinterpret_cast<const f32x4*>(x + p * cin + 4 * q);
       f32x4 xh = {0.f, 0.f, 0.f, 0.f};
@@ -878,7 +899,7 @@ __global__ __launch_bounds__(256) void outconv_bwd_kernel(const float* __restric
 #pragma unroll
     for (int j = 0; j < 5; ++j) {
       __syncthreads();
-      sh[threadIdx.x] = (pl < lanes) ? (double)(j < 4 ? sw[k][j] : sb[k]) : 0.0;
+      sh[threadIdx.x] = (pl < lanes) ? (j < 4 ? dsw[k][j] + (double)sw[k][j] : dsb[k] + (double)sb[k]) : 0.0;
       __syncthreads();
       if (j < 4) {
         if (threadIdx.x < cq) {

@@ -224,21 +224,33 @@ class H2Ranges:
     def quiet(self, bits):
         """The other direction (bits = read()'s dict of a pass WITHOUT saturated tensors): {key: larger exponent} for
         every key whose written tensors all peaked below RAISE_BELOW in stored units - the largest word of the key,
-        converted with the exponent in force, goes to [2^12, 2^13).  Tensors whose word is still zero (not written
-        since the reset, or all zeros) say nothing; a key with no written tensor is left alone.  Never above the
+        converted with the exponent in force, goes to [2^12, 2^13).  A tensor whose word is still zero (a resumed pass
+        starts behind it) is judged by the peak it showed earlier in this weights generation; one that was never seen
+        says nothing, and a key with no seen tensor is left alone.  Never above the
         exponent `lower` gave the key in this weights generation, never above MAX_EXP."""
-        top = {}
+        top, skip = {}, set()
         for n, b in bits.items():
             s = self.slot.get(n)
-            if s is None or b == 0:
+            if s is None:
                 continue
-            top[s[0]] = max(top.get(s[0], 0), b)
-        plan = {}
-        for key, b in top.items():
+            key = s[0]
             if b > self.LIMIT:
-                continue                                   # saturated / non-finite: `lower`'s business
-            stored = _bits_to_float(b)
-            if stored >= self.RAISE_BELOW:
+                skip.add(key)                              # saturated / non-finite: `lower`'s business
+                continue
+            if b:
+                stored = _bits_to_float(b)
+            else:
+                # not written since the words were zeroed (a resumed pass starts behind this tensor): what it showed
+                # BEFORE the reset still counts - its largest |v| of this weights generation, in today's stored units -
+                # so that a key shared by an early and a late tensor is never judged on the late one alone
+                v = self.peak.get(n)
+                if v is None:
+                    continue                               # never seen (or all zeros): says nothing
+                stored = v * 2.0 ** self.exps.get(key, self.DEFAULT)
+            top[key] = max(top.get(key, 0.0), stored)
+        plan = {}
+        for key, stored in top.items():
+            if key in skip or stored >= self.RAISE_BELOW or stored <= 0.0:
                 continue
             e = self.exps.get(key, self.DEFAULT)
             new = 13 - math.frexp(stored * 2.0 ** -e)[1]

@@ -174,10 +174,16 @@ class FramePipeline:
         return {k: v.numpy() for k, v in s["host"].items()}
 
     def run(self, batches):
-        """Generator over host uint8 batches -> result dicts (copies), two batches in flight."""
+        """Generator over host uint8 batches -> result dicts (copies), two batches in flight.  The producer may hand over the
+        SAME pinned buffer every time: the next item is pulled from `batches` only after the upload of the batch just
+        submitted has read its buffer (wait_uploaded) - with the one copy stream per device that upload queues behind the
+        download of the batch two submissions back, so without the wait a producer that refills one buffer would overwrite
+        frames still waiting to be copied."""
         prev = None
         done = None
-        for fr in batches:
+        it = iter(batches)
+        fr = next(it, None)
+        while fr is not None:
             t = self.submit(fr)
             if done is not None:
                 yield {k: np.array(v) for k, v in self.get(done).items()}
@@ -185,6 +191,8 @@ class FramePipeline:
             if prev is not None:
                 done = self.collect(prev)
             prev = t
+            self.wait_uploaded(t)
+            fr = next(it, None)
         if done is not None:
             yield {k: np.array(v) for k, v in self.get(done).items()}
         if prev is not None:

@@ -250,11 +250,29 @@ class Reconstructor(nn.Module):
     def _get_engines(self):
         stamp = self._param_stamp()
         if self._engine_stamp != stamp:
+            if self.__dict__.get("_retiring"):
+                # re-entered from the drain below (a batch in flight failed its range check and is recomputed): the OLD
+                # engines - they hold packed copies of the old weights - finish the old batches
+                eng = self._engines_by_precision.get(self._forced_precision or self.precision)
+                if eng is None:
+                    raise RuntimeError("a predict_async() batch in flight when the weights changed needs an engine of the old "
+                                       "weights that was never built (three-plane fallback); take its result() before "
+                                       "load_state_dict / an optimizer step")
+                self._engines = eng
+                return eng
             old = self._engine_stamp
+            if old is not None:
+                # batches of predict_async() still in flight were computed with the old engines: take their results (and
+                # their range checks) while engines, stamp and range words are still the old ones
+                self.__dict__["_retiring"] = True
+                try:
+                    self._on_new_weights()
+                finally:
+                    self.__dict__["_retiring"] = False
             self._engines_by_precision = {}
             self._engine_stamp = stamp
-            if old is not None:
-                self._on_new_weights()
+            if old is not None and self._h2_ranges is not None:
+                self._h2_ranges.new_generation()
         precision = self._forced_precision or self.precision
         eng = self._engines_by_precision.get(precision)
         if eng is None:
@@ -277,15 +295,14 @@ class Reconstructor(nn.Module):
         return eng
 
     def _on_new_weights(self):
-        """The stamp moved (new weights, another mode or precision): batches of predict_async() still in flight were
-        computed with the old engines - take their results (and their range checks) now - and what the range words and
-        the `lower` ceilings of the "f16x3" mode hold describes the old weights (engine.H2Ranges.new_generation)."""
+        """The stamp is about to move (new weights, another mode): batches of predict_async() still in flight were computed
+        with the old engines - take their results and their range checks now, BEFORE the engines are dropped (a batch whose
+        check fails is recomputed by the old engines, never with the new weights).  Afterwards the caller starts a new
+        generation of the range words (engine.H2Ranges.new_generation)."""
         p = self.__dict__.get("_pipe")
         if p is not None and p["inflight"]:
             for h in list(p["inflight"]):
                 h.result()
-        if self._h2_ranges is not None:
-            self._h2_ranges.new_generation()
 
     @staticmethod
     def _run_phases(phases):

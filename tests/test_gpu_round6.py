@@ -1,0 +1,88 @@
+"""Round-6 GPU tests of the host logic around the kernels (each cites the review item it answers)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from sfh_amd import synth  # noqa: E402
+
+
+def _net(B, w=112, h=90, seed=23, **kw):
+    from sfh_amd.reconstructor import Reconstructor
+    court = synth.load_court_template("ncaa_nc4_640x360", 4, B)[:, :, :h, :w].contiguous()
+    poi = synth.load_court_poi("pitch", B)
+    kw.setdefault("warp_with_nearest", True)
+    net = Reconstructor(court.cuda(), poi.cuda(), target_size=(w, h), unet_size=(w, h), warp_size=(w, h), **kw)
+    sd = synth.synth_state_dict(net.state_dict(), seed)
+    net.load_state_dict(sd)
+    return net.cuda().eval(), sd
+
+
+def _close(a, b, th=1e-4, lg=5e-4):
+    assert float((a["theta"] - b["theta"]).abs().max()) < th
+    assert float((a["logits"] - b["logits"]).abs().max()) < lg
+
+
+def test_new_weights_with_two_batches_in_flight_finish_on_the_old_engines():
+    """ADVICE r05 (reconstructor.py:_on_new_weights): batches of predict_async() in flight when the weights change are
+    resolved BEFORE the engines are dropped; one whose range check fails is recomputed by the old engines (packed copies of
+    the old weights), never with the new weights."""
+    B, w, h = 2, 112, 90
+    net, sd_a = _net(B, seed=23)
+    sd_b = synth.synth_state_dict(net.state_dict(), 24)
+    xs = [synth.smooth_frames(B, h, w, seed=60 + k).cuda() for k in range(3)]
+    with torch.no_grad():
+        ref_a = [{k: v.clone() for k, v in net.predict(x, consistency=True).items()} for x in xs[:2]]
+        # make the batches in flight FAIL their range check: an activation exponent far too high saturates its tensor
+        rg = net._h2_ranges
+        assert rg is not None and "down2.mid" in rg.slot
+        rg.exps[rg.key("down2.mid")] = 30
+        h1 = net.predict_async(xs[0], consistency=True)
+        h2 = net.predict_async(xs[1], consistency=True)
+        net.load_state_dict(sd_b)                         # weights change with both batches in flight
+        out_b = net.predict(xs[2], consistency=True)      # first call with the new stamp: drains, then builds new engines
+        o1, o2 = h1.result(), h2.result()
+    torch.cuda.synchronize()
+    assert net.range_rescales >= 1                        # the planted saturation was seen and fixed
+    _close(o1, ref_a[0])
+    _close(o2, ref_a[1])                                  # old weights, not sd_b's
+    fresh, _ = _net(B, seed=24)
+    with torch.no_grad():
+        want_b = fresh.predict(xs[2], consistency=True)
+    _close(out_b, want_b)
+    assert float((out_b["theta"] - ref_a[0]["theta"]).abs().max()) > 1e-3      # the two checkpoints really differ
+
+
+def test_outconv_backward_filter_at_1280x720_against_fp64():
+    """ADVICE r05 (csrc/train.hip outconv_bwd_kernel): a workgroup covers npix / 1024 pixels, so a thread's dW / db chain
+    grows with the image (about 900 terms at 1280x720 x 16); the partial sums are promoted to fp64 every 64 pixels.  dW
+    and db of sfh_outconv_bwd at 1280x720 against an fp64 contraction of the same tensors (unet/unet_parts.py:71-77)."""
+    import ctypes
+    from sfh_amd import _lib
+    lib = _lib.load()
+    B, H, W, cin, nc = 4, 720, 1280, 64, 4
+    g = torch.Generator(device="cuda").manual_seed(12)
+    # activations with a large common offset: the case an fp32 running sum loses (sum of ~1e3 terms of magnitude 3)
+    y = (torch.rand((B, H, W, cin), device="cuda", generator=g) + 2.5).contiguous()
+    dl = (torch.randn((B, nc, H, W), device="cuda", generator=g) * 1e-3 + 2e-3).contiguous()
+    w = torch.randn((nc, cin), device="cuda", generator=g).contiguous()
+    dy = torch.empty_like(y)
+    acc_w = torch.zeros((nc, cin), dtype=torch.float64, device="cuda")
+    acc_b = torch.zeros((nc,), dtype=torch.float64, device="cuda")
+    p = lambda t: ctypes.c_void_p(t.data_ptr())
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    _lib.check(lib.sfh_outconv_bwd(p(y), cin, p(w), p(dl), nc, B, H, W, p(dy), p(acc_w), p(acc_b), st), "outconv_bwd")
+    torch.cuda.synchronize()
+    want_w = torch.zeros((nc, cin), dtype=torch.float64, device="cuda")
+    for b in range(B):                                   # fp64 contraction frame by frame (memory)
+        want_w += torch.einsum("khw,hwc->kc", dl[b].double(), y[b].double())
+    want_b = dl.double().sum(dim=(0, 2, 3))
+    rel_w = float(((acc_w - want_w).abs() / want_w.abs().clamp(min=1e-30)).max())
+    rel_b = float(((acc_b - want_b).abs() / want_b.abs()).max())
+    # 64-term fp32 chains of products g * x: relative error a few 1e-7 per chain, averaging down over the 57,600 chains
+    assert rel_w < 2e-6 and rel_b < 2e-6, (rel_w, rel_b)
+    want_dy = torch.einsum("bkhw,kc->bhwc", dl, w)
+    assert float((dy - want_dy).abs().max()) < 1e-6

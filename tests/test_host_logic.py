@@ -229,11 +229,45 @@ def test_h2_ranges_raise_quiet_keys():
     rg.new_generation()                 # new weights: the ceiling belongs to the old ones
     assert int(rg.words.abs().sum()) == 0 and rg.exp("inc.out") == 14
     put("inc.out", 2.0 ** -3)
-    assert rg.quiet(rg.read()) == {"inc.out": 14 + 15}
+    plan = rg.quiet(rg.read())
+    assert plan == {"inc.out": 14 + 15}
+    rg.raise_(plan)
     # tiny tensors stop at MAX_EXP; an all-zero tensor (word 0) is left alone
     rg.reset_words()
     put("down1.out", 2.0 ** -120)
     assert rg.quiet(rg.read()) == {"down1.out": rg.MAX_EXP}
+
+
+def test_h2_ranges_quiet_judges_a_key_on_all_of_its_tensors_across_a_resume():
+    """a key shared by an EARLY tensor (a skip tensor) and a LATE one (the decoder's up tensor).  After a
+    decision the words are zeroed and the pass resumes behind the early tensor, so only the late one has a word: the key
+    must not be raised on the late tensor alone - the early tensor's peak of this weights generation still counts."""
+    import numpy as np
+    from sfh_amd import engine as E
+    rg = E.H2Ranges(torch.device("cpu"), capacity=8)
+    rg.register("inc.out")
+    rg.register("up4.up", key="inc.out")
+    rg.register("down4.out")
+    w = rg.words.numpy().view("uint32")
+
+    def put(name, u):
+        w[rg.slot[name][1]] = np.float32(u).view("uint32")
+    # full pass: the skip tensor peaks at |v| = 25 (stored 100), the up tensor is quiet, down4.out is quiet too
+    put("inc.out", 100.0)
+    put("up4.up", 2.0 ** -6)
+    put("down4.out", 2.0 ** -8)
+    plan = rg.quiet(rg.read())
+    assert plan == {"down4.out": 22}                     # inc.out's key is decided by its larger tensor: left alone
+    rg.raise_(plan)
+    # the words are zeroed and the pass resumes from down4 (behind inc.out): only the late tensors are written again
+    rg.reset_words()
+    put("up4.up", 2.0 ** -6)
+    put("down4.out", 2.0 ** 12)
+    assert rg.quiet(rg.read()) == {}                     # NOT {"inc.out": ...}: the un-inspected skip tensor would saturate
+    # the same words without the earlier observation (a new weights generation): the late tensor alone decides
+    rg.new_generation()
+    put("up4.up", 2.0 ** -6)
+    assert rg.quiet(rg.read()) == {"inc.out": 20}
 
 
 def test_range_guard_reruns_a_non_finite_batch_in_bf16x6_and_rechunks():
