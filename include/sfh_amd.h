@@ -616,6 +616,37 @@ int sfh_pack_stem_weights(const float* w, void* packed, int cin, int fmt, int we
  * the chip HELD inside the kernel is 100 MHz * clk[0] / clk[1].  The caller times the launch with events on `stream`. */
 int sfh_probe_mfma_f16(int iters, int workgroups, float* out, uint64_t* clk, void* stream);
 
+/* ---- engine-build helpers (csrc/hostprep.hip, round 6): what an engine needs while it packs a checkpoint, so that no stock
+ * torch kernel runs on the predict path (the reference does this work inside nn.Module construction / cuDNN descriptors).
+ *
+ * sfh_multi_absminmax: ONE launch over `ntensors` float32 tensors - table = device array of {const float* ptr; int64 numel}
+ * pairs - leaves in words[2 t] the bit pattern of max |x| of tensor t and in words[2 t + 1] 0x7FFFFFFF - (bit pattern of min
+ * |x|); `words` must be zero-filled by the caller (zero is the identity of both).  A NaN / Inf element shows as a pattern >=
+ * 0x7F800000.  The exponent of every two-plane fp16 weight tensor of a model comes from one call and one read-back
+ * (replaces a torch abs().max() + host sync per layer); the min leg answers "does any folded BatchNorm scale vanish".      */
+int sfh_multi_absminmax(const void* table, int ntensors, uint32_t* words, void* stream);
+
+/* dst[i] = a[i] * factor (op 0), a[i] / b[i % nb] (op 1; factor applied after the division when != 1) or a[i] * b[i % nb] *
+ * factor (op 2), float32, n elements; dst may alias a.  The folded scale / shift vectors of a layer (<= 16 K floats).    */
+int sfh_vec_op(int op, const float* a, const float* b, int64_t n, int nb, float factor, float* dst, void* stream);
+
+/* Pitched copy of 4-byte words: rows x width, pitches in words (channel slices of OIHW weights: the skip half of an Up
+ * block's first conv, unet/unet_parts.py:67).                                                                           */
+int sfh_copy2d_words(const void* src, int64_t src_pitch, void* dst, int64_t dst_pitch, int width, int64_t rows, void* stream);
+
+/* dst[0 .. n) = value (4-byte words): range words, flags, constant scale / shift vectors.                                 */
+int sfh_fill_words(void* dst, int64_t n, uint32_t value, void* stream);
+
+/* *flag |= 1 (flag zero-filled by the caller) if any of rows 1 .. rows-1 of a (rows, row_words) array of 4-byte words differs
+ * from row 0: "is the court template ONE image replicated over the batch" (utils/dataset.py:59), asked once per template. */
+int sfh_rows_differ(const void* x, int64_t row_words, int rows, uint32_t* flag, void* stream);
+
+/* ResNet-STN input for the modes the fused OutConv epilogue does not assemble (models/reconstructor.py:174-183,214: "img",
+ * "mask", "img+mask+uv", and "img+mask" with resized logits): dst (B,H,W,cs) NHWC = cat((logits (B,nc,H,W), frame (B,cf,H,W),
+ * uv (B,cu,H,W)), channel), zero-padded to cs; a source with 0 channels may be NULL.  Replaces torch.cat + a layout pass. */
+int sfh_stn_input_assemble(const float* logits, int nc, const float* frame, int cf, const float* uv, int cu, int batch, int H,
+                           int W, int cs, float* dst, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

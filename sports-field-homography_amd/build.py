@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB = os.path.join(_HERE, "libsfh_amd.so")
 SOURCES = ["capi.hip", "conv_mfma.hip", "conv_s3.hip", "conv_c4h2.hip", "pointwise.hip", "warp.hip", "train.hip", "stem.hip",
-           "wgrad_s3.hip", "probe.hip", "conv_small.hip", "conv_upfused.hip"]
+           "wgrad_s3.hip", "probe.hip", "conv_small.hip", "conv_upfused.hip", "hostprep.hip"]
 # warp.hip's coordinate arithmetic must not be contracted into FMAs (bit-exact nearest
 # sampling against oracle/warp_ref.py); the flag is harmless elsewhere.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-ffp-contract=off",

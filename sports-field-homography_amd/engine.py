@@ -60,6 +60,112 @@ def _f32c(t, what):
     return t
 
 
+# ---- engine-build helpers (csrc/hostprep.hip): the work around packing a checkpoint on this library's own kernels
+def filled(shape, dtype, device, value=0):
+    """torch.full / torch.zeros for 4-byte element types on this library's fill kernel"""
+    import struct
+    t = torch.empty(shape, dtype=dtype, device=device)
+    if t.element_size() != 4:
+        raise ValueError("filled: 4-byte element types only")
+    if t.numel():
+        word = struct.unpack("<I", struct.pack("<f" if dtype.is_floating_point else "<i", value))[0]
+        with torch.cuda.device(t.device):
+            _lib.check(_lib.load().sfh_fill_words(_ptr(t), t.numel(), word, _stream()), "fill_words")
+    return t
+
+
+def absminmax(tensors):
+    """[(max |x|, min |x|)] of float32 device tensors - ONE launch over all of them (sfh_multi_absminmax) and ONE
+    read-back, where torch would run an abs + a reduction + a host sync per tensor.  A non-finite element gives inf / nan."""
+    import numpy as np
+    if not tensors:
+        return []
+    lib = _lib.load()
+    dev = tensors[0].device
+    tab = np.zeros((len(tensors), 2), dtype=np.int64)
+    for i, t in enumerate(tensors):
+        _f32c(t, "absminmax operand")
+        tab[i] = (t.data_ptr(), t.numel())
+    dtab = torch.from_numpy(tab.view(np.uint8).reshape(-1)).to(dev)          # H2D of the table (runtime copy)
+    words = filled((2 * len(tensors),), torch.int32, dev)
+    _lib.check(lib.sfh_multi_absminmax(_ptr(dtab), len(tensors), _ptr(words), _stream()), "multi_absminmax")
+    w = words.cpu().numpy().view(np.uint32)
+    mx = w[0::2].copy().view(np.float32)
+    mn = (np.uint32(0x7FFFFFFF) - w[1::2]).astype(np.uint32).view(np.float32)
+    return [(float(a), float(b)) for a, b in zip(mx, mn)]
+
+
+def h2_weight_exp(wmax, top=14):
+    """exponent e with max |w| * 2^e in [2^(top-1), 2^top) (include/sfh_amd.h, H2 weights); 0 for an all-zero tensor"""
+    import math
+    if not math.isfinite(wmax):
+        raise ValueError("conv weight holds non-finite values")
+    return max(-100, min(100, top - math.frexp(wmax)[1])) if wmax > 0 else 0
+
+
+def vec_op(a, b=None, op="scale", factor=1.0, out=None):
+    """out = a * factor ("scale"), a / b ("div") or a * b * factor ("mul") on the HIP helper kernel; b is indexed modulo
+    its length (a tiled operand); out may be a itself.  Small float32 vectors: a layer's folded scale / shift."""
+    lib = _lib.load()
+    code = {"scale": 0, "div": 1, "mul": 2}[op]
+    a = _f32c(a, "vec_op operand")
+    if out is None:
+        out = torch.empty_like(a)
+    if b is not None:
+        b = _f32c(b, "vec_op operand")
+    _lib.check(lib.sfh_vec_op(code, _ptr(a), _ptr(b) if b is not None else None, a.numel(), b.numel() if b is not None else 0,
+                              float(factor), _ptr(out), _stream()), "vec_op")
+    return out
+
+
+def snapshot(t):
+    """a private copy of a small float32 tensor (engines keep NO live reference to a parameter: load_state_dict writes
+    parameters in place, and an engine that finishes batches in flight must still see the weights it was built from)"""
+    return vec_op(_f32c(t.detach(), "snapshot operand"))
+
+
+def rows_all_equal(t):
+    """do all t[k] hold the bits of t[0]?  (4-byte elements, contiguous; one launch, one word read back)"""
+    lib = _lib.load()
+    if t.shape[0] <= 1:
+        return True
+    if not t.is_contiguous() or t.element_size() != 4 or not t.is_cuda:
+        raise ValueError("rows_all_equal: expected a contiguous GPU tensor of 4-byte elements")
+    flag = filled((1,), torch.int32, t.device)
+    _lib.check(lib.sfh_rows_differ(_ptr(t), t[0].numel(), t.shape[0], _ptr(flag), _stream()), "rows_differ")
+    return int(flag.cpu()[0]) == 0
+
+
+def stn_input_assemble(logits, frame, uv, cs):
+    """(B,H,W,cs) NHWC = cat((logits, frame, uv), 1) zero-padded (any of the three may be None): the ResNet-STN input of
+    the modes the fused OutConv epilogue does not cover (models/reconstructor.py:174-183,214)"""
+    lib = _lib.load()
+    srcs = [_f32c(t.contiguous(), "stn input source") if t is not None else None for t in (logits, frame, uv)]
+    ref = next(t for t in srcs if t is not None)
+    B, _, H, W = ref.shape
+    for t in srcs:
+        if t is not None and (t.shape[0], t.shape[2], t.shape[3]) != (B, H, W):
+            raise ValueError("stn_input_assemble: sources of different batch / size")
+    out = torch.empty((B, H, W, cs), dtype=torch.float32, device=ref.device)
+    ch = [t.shape[1] if t is not None else 0 for t in srcs]
+    _lib.check(lib.sfh_stn_input_assemble(_ptr(srcs[0]) if srcs[0] is not None else None, ch[0],
+                                          _ptr(srcs[1]) if srcs[1] is not None else None, ch[1],
+                                          _ptr(srcs[2]) if srcs[2] is not None else None, ch[2], B, H, W, cs, _ptr(out),
+                                          _stream()), "stn_input_assemble")
+    return out
+
+
+def slice_in_channels(w, c0, c1):
+    """w[:, c0:c1] of an OIHW weight as a contiguous tensor (sfh_copy2d_words)"""
+    lib = _lib.load()
+    w = _f32c(w.detach(), "conv weight")
+    cout, cin, kh, kw = w.shape
+    out = torch.empty((cout, c1 - c0, kh, kw), dtype=torch.float32, device=w.device)
+    _lib.check(lib.sfh_copy2d_words(ctypes.c_void_p(w.data_ptr() + 4 * c0 * kh * kw), cin * kh * kw, _ptr(out),
+                                    (c1 - c0) * kh * kw, (c1 - c0) * kh * kw, cout, _stream()), "copy2d_words")
+    return out
+
+
 # Split ("plane") activation formats of include/sfh_amd.h, identified by the tensor dtype:
 #   "s3": (B,H,C/32,3,4,W,8) bfloat16 - three bf16 planes, exact fp32 value            (precision "bf16x6")
 #   "h2": (B,H,C/32,2,4,W,8) float16  - two fp16 planes of v * 2^2, 22 significand bits (precision "f16x3")
@@ -137,7 +243,8 @@ class H2Ranges:
 
     def __init__(self, device, capacity=1024):
         self.device = device
-        self.words = torch.zeros(capacity, dtype=torch.int32, device=device)
+        self.words = filled((capacity,), torch.int32, device) if torch.device(device).type == "cuda" else \
+            torch.zeros(capacity, dtype=torch.int32, device=device)        # (CPU: the host-logic tests)
         self.exps = {}     # key -> exponent (absent = DEFAULT)
         self.slot = {}     # tensor name -> (key, word index)
         self.peak = {}     # tensor name -> largest |v| seen so far (host side, from read())
@@ -269,12 +376,19 @@ class H2Ranges:
         """The model's weights changed (or its mode): what the words and the `lower` ceilings say belongs to the old
         weights.  The exponents stay - they are the best guess for the new weights - and are re-examined in both
         directions by the first pass."""
-        self.words.zero_()
+        self._zero_words()
         self.ceiling.clear()
         self.peak.clear()
 
     def reset_words(self):
-        self.words.zero_()
+        self._zero_words()
+
+    def _zero_words(self):
+        if self.words.is_cuda:
+            with torch.cuda.device(self.words.device):
+                _lib.check(_lib.load().sfh_fill_words(_ptr(self.words), self.words.numel(), 0, _stream()), "fill_words")
+        else:
+            self.words.zero_()
 
     def headroom(self):
         """{tensor name: 65504 * 2^-e / largest |v| seen} - how far each tensor is from saturating"""
@@ -460,8 +574,7 @@ def _unit_epilogue(n, dev, scale=1.0):
     key = (n, str(dev), float(scale))
     v = _UNIT.get(key)
     if v is None:
-        v = _UNIT[key] = (torch.full((n,), float(scale), dtype=torch.float32, device=dev),
-                          torch.zeros(n, dtype=torch.float32, device=dev))
+        v = _UNIT[key] = (filled((n,), torch.float32, dev, float(scale)), filled((n,), torch.float32, dev))
     return v
 
 
@@ -517,11 +630,7 @@ class PackedConv:
         if frame_h2 and not self.c4:
             raise ValueError("frame_h2 is the first-layer kernel: a 3x3 stride-1 conv over at most 4 channels, fmt=None")
         if self.c4h2:
-            import math
-            wmax = float(w.abs().max())
-            if not math.isfinite(wmax):
-                raise ValueError("conv weight holds non-finite values")
-            wx = max(-100, min(100, 14 - math.frexp(wmax)[1])) if wmax > 0 else 0    # max |w| * 2^wx in [2^13, 2^14)
+            wx = int(wexp) if wexp is not None else h2_weight_exp(absminmax([w])[0][0])    # max |w| * 2^wx in [2^13, 2^14)
             self.escale = 2.0 ** -(wx + _lib.H2_ACT_EXP)
             self.wpacked = torch.empty(lib.sfh_packed_c4h2_weight_bytes(self.cout), dtype=torch.uint8, device=dev)
             _lib.check(lib.sfh_pack_c4h2_weights(_ptr(w), _ptr(self.wpacked), c0, self.cout, wx, _stream()), "pack_c4h2_weights")
@@ -558,7 +667,7 @@ class PackedConv:
         _lib.check(lib.sfh_fold_bn(_ptr(b), *[_ptr(a) for a in args], eps, self.cout_real, rep,
                                    _ptr(self.scale), _ptr(self.shift), _stream()), "fold_bn")
         if self.escale != 1.0:
-            self.scale.mul_(self.escale)     # a power of two: exact
+            vec_op(self.scale, factor=self.escale, out=self.scale)     # a power of two: exact
 
     @property
     def stats_ok(self):
@@ -580,12 +689,8 @@ class PackedConv:
             raise ValueError(f"unsupported split-kernel conv geometry ksize={ksize} c0={c0} c1={c1} cout={self.cout}")
         self.wpacked = torch.empty(n, dtype=torch.uint8, device=w.device)
         if self.fmt == "h2":
-            import math
             if wexp is None:
-                wmax = float(w.abs().max())
-                if not math.isfinite(wmax):
-                    raise ValueError("conv weight holds non-finite values")
-                wexp = 13 - math.frexp(wmax)[1] + 1 if wmax > 0 else 0    # frexp: wmax = m * 2^e, 0.5 <= m < 1
+                wexp = h2_weight_exp(absminmax([w])[0][0])     # (callers that pack many layers pass it: one batched read-back)
             wexp = max(-100, min(100, int(wexp)))
             self.escale = 2.0 ** -(wexp + _lib.H2_ACT_EXP)
             _lib.check(lib.sfh_pack_h2_weights(_ptr(w), _ptr(self.wpacked), ksize, c0, c1, self.cout, mode, aux, wexp,
@@ -595,7 +700,7 @@ class PackedConv:
                                                _stream()), "pack_s3_weights")
 
     @classmethod
-    def fused_up(cls, conv, bn, up, c0, tag="fusedup2x2", fmt="s3"):
+    def fused_up(cls, conv, bn, up, c0, tag="fusedup2x2", fmt="s3", defer_pack=False):
         """The u-half of conv3x3(cat([skip, ConvTranspose2d(x)])) (+bias, BN, ReLU) as ONE 2x2 conv over the
         low-resolution x with quadrant scatter (sfh_compose_up_weights): takes x (S3), adds the fp32
         partial of the skip-half conv as residual and writes the activated S3 output.  Split-bf16 kernel only."""
@@ -626,12 +731,19 @@ class PackedConv:
         _lib.check(lib.sfh_compose_up_weights(_ptr(wc), cout, c0, c1, _ptr(wt), cx, _ptr(bt), _ptr(self.scale),
                                               _ptr(self.shift), _ptr(w2), _ptr(self.shift_border), _stream()),
                    "compose_up_weights")
-        self._pack_split(w2, 2, cx, 0, 0, 0)
         # the skip-half conv of the block applies the same BatchNorm scale to ITS accumulator (UNetEngine)
-        self.scale_bn = self.scale.clone()
-        if self.escale != 1.0:
-            self.scale.mul_(self.escale)
+        self.scale_bn = snapshot(self.scale)
+        self._w2 = w2
+        if not defer_pack:          # defer_pack: the engine packs all composed weights behind ONE batched |w| read-back
+            self.finish_pack()
         return self
+
+    def finish_pack(self, wexp=None):
+        """second half of fused_up(): pack the composed weights (H2: with exponent wexp, else from a read-back here)"""
+        self._pack_split(self._w2, 2, self.c0, 0, 0, 0, wexp)
+        self._w2 = None
+        if self.escale != 1.0:
+            vec_op(self.scale, factor=self.escale, out=self.scale)
 
     @classmethod
     def backward_data(cls, weight, ksize, transposed=False, tag="bwd_data", s3=False, fmt=None, wexp=None):
@@ -679,7 +791,7 @@ class PackedConv:
         if self._shared_scale:
             raise ValueError("this layer's epilogue scale is shared with other layers: its source exponent is fixed")
         f = 2.0 ** (self.exp_src - e)
-        self.scale.mul_(f)
+        vec_op(self.scale, factor=f, out=self.scale)
         self.escale *= f
         self.exp_src = e
 
@@ -946,7 +1058,8 @@ class _Workspace:
         cur = self.bufs.get(name)
         if cur is None or cur[0] != key:
             self.bufs.pop(name, None)      # release the old block to the allocator before asking for the new one
-            t = (torch.zeros if zero else torch.empty)(shape, dtype=dtype, device=self.device)
+            t = (filled(shape, dtype, self.device) if (zero and torch.empty((), dtype=dtype).element_size() == 4)
+                 else (torch.zeros if zero else torch.empty)(shape, dtype=dtype, device=self.device))
             self.bufs[name] = (key, t)
             return t
         return cur[1]
@@ -992,47 +1105,71 @@ class UNetEngine:
         # "f16x3": the 3-channel first layer too runs on the fp16 matrix cores, from a frame tensor split once (FH2)
         self.frame_h2 = fmt == "h2" and os.environ.get("SFH_INC0_H2", "1") != "0"
 
+        fuse_up = not self.bilinear and s3 and os.environ.get("SFH_FUSE_UP", "1") != "0"
+        ups = [(i, cin, getattr(net, f"up{i}")) for i, cin in enumerate((1024, 512, 256, 128), start=1)]
+        # the skip halves of the Up blocks' first convs (unet/unet_parts.py:67: cat([skip, up])) as tensors of their own
+        skip_w = {i: slice_in_channels(up.conv.convs()[0][0].weight, 0, cin // 2) for i, cin, up in ups} if fuse_up else {}
+        # "f16x3": the exponent of every weight tensor from ONE batched |w| reduction and one read-back
+        wx = {}
+        if fmt == "h2":
+            ws_ = [p.detach() for n, p in net.named_parameters()
+                   if p.dim() == 4 and not n.startswith("resnet_reg.") and p.is_contiguous()] + list(skip_w.values())
+            for w, (mx, _) in zip(ws_, absminmax(ws_)):
+                wx[w.data_ptr()] = h2_weight_exp(mx)
+
+        def wexp(w):
+            return wx.get(w.data_ptr())
+
         def dc(name, block, c0, c1=0, first_fmt=fmt):
             (cv1, bn1), (cv2, bn2) = block.convs()
             L[name + ".0"] = PackedConv(cv1.weight, cv1.bias, bn1, 3, c0, c1, tag="doubleconv3x3", fmt=first_fmt,
-                                        frame_h2=(self.frame_h2 and first_fmt is None and c0 <= 4))
-            L[name + ".3"] = PackedConv(cv2.weight, cv2.bias, bn2, 3, cv1.out_channels, tag="doubleconv3x3", fmt=fmt)
+                                        frame_h2=(self.frame_h2 and first_fmt is None and c0 <= 4), wexp=wexp(cv1.weight))
+            L[name + ".3"] = PackedConv(cv2.weight, cv2.bias, bn2, 3, cv1.out_channels, tag="doubleconv3x3", fmt=fmt,
+                                        wexp=wexp(cv2.weight))
 
         dc("inc", net.inc, 3, first_fmt=None)  # 3-channel input: fp32 kernel (writes the split format itself)
         for i, cin in enumerate((64, 128, 256, 512), start=1):
             dc(f"down{i}", getattr(net, f"down{i}").block, cin)
-        for i, cin in enumerate((1024, 512, 256, 128), start=1):
-            up = getattr(net, f"up{i}")
-            if not self.bilinear and s3 and os.environ.get("SFH_FUSE_UP", "1") != "0":
+        for i, cin, up in ups:
+            if fuse_up:
                 # ConvTranspose2d folded into the consumer conv (used when no F.pad is needed): the
                 # skip-half 3x3 conv leaves an fp32 partial, the composed 2x2 conv over the low-resolution
                 # tensor finishes it - the up-sampled tensor is never written
                 (cv1, bn1), _ = up.conv.convs()
                 c0s = cin // 2
-                L[f"up{i}.skip"] = PackedConv(cv1.weight.detach()[:, :c0s].contiguous(), None, None, 3, c0s, relu=False,
-                                              tag="doubleconv3x3", fmt=fmt)
-                L[f"up{i}.fused"] = PackedConv.fused_up(cv1, bn1, up.up, c0s, fmt=fmt)
-                # the partial enters the fused conv's epilogue as a residual, i.e. after the BatchNorm scale:
-                # the skip-half carries that scale itself (shift stays 0), times its own operand scaling
-                L[f"up{i}.skip"].scale.copy_(L[f"up{i}.fused"].scale_bn[:cv1.out_channels] * L[f"up{i}.skip"].escale)
-                # accumulator seeding (run()) divides by this scale: only where no channel's BatchNorm scale vanishes
-                smin = float(L[f"up{i}.skip"].scale.abs().min())
-                self.up_seed[i] = (os.environ.get("SFH_UP_SEED", "1") != "0") and 1e-30 < smin < float("inf")
+                L[f"up{i}.skip"] = PackedConv(skip_w[i], None, None, 3, c0s, relu=False, tag="doubleconv3x3", fmt=fmt,
+                                              wexp=wexp(skip_w[i]))
+                L[f"up{i}.fused"] = PackedConv.fused_up(cv1, bn1, up.up, c0s, fmt=fmt, defer_pack=True)
             if not self.bilinear:  # bilinear variant (A3b): parameter-free 2x upsampling kernel instead
                 L[f"up{i}.up"] = PackedConv(up.up.weight, up.up.bias, None, 1, cin, relu=False, transposed=True,
-                                            tag="convT2x2", fmt=fmt)
+                                            tag="convT2x2", fmt=fmt, wexp=wexp(up.up.weight))
             dc(f"up{i}.conv", up.conv, cin // 2, cin // 2)  # cat([skip, up]): cin/2 channels each in both variants
+        if fuse_up:
+            # second batched read-back: the composed 2x2 weights (they exist only now) and the smallest |BatchNorm scale| of
+            # each level (accumulator seeding divides by it)
+            fus = [L[f"up{i}.fused"] for i, _, _ in ups]
+            mm = absminmax([f._w2 for f in fus] + [f.scale_bn for f in fus])
+            for k, (i, cin, up) in enumerate(ups):
+                fu, sk = fus[k], L[f"up{i}.skip"]
+                fu.finish_pack(h2_weight_exp(mm[k][0]) if fmt == "h2" else None)
+                cout = up.conv.convs()[0][0].out_channels
+                # the partial enters the fused conv's epilogue as a residual, i.e. after the BatchNorm scale:
+                # the skip-half carries that scale itself (shift stays 0), times its own operand scaling
+                vec_op(fu.scale_bn[:cout], factor=sk.escale, out=sk.scale)
+                # accumulator seeding (run()) divides by this scale: only where no channel's BatchNorm scale vanishes
+                smin = mm[len(fus) + k][1] * sk.escale
+                self.up_seed[i] = (os.environ.get("SFH_UP_SEED", "1") != "0") and 1e-30 < smin < float("inf")
         self.L = L
         self.order = LaunchOrder()
         for layer in L.values():
             layer.order = self.order
             layer.overflow = self.overflow
-        self.outc_w = _f32c(net.outc.conv.weight.detach(), "outc.weight")
-        self.outc_b = _f32c(net.outc.conv.bias.detach(), "outc.bias")
+        # private copies: an engine holds NO live reference to a parameter (see snapshot())
+        self.outc_w = snapshot(net.outc.conv.weight)
+        self.outc_b = snapshot(net.outc.conv.bias)
         self.outuv = None
         if net.outuv is not None:
-            self.outuv = (_f32c(net.outuv.conv.weight.detach(), "outuv.weight"),
-                          _f32c(net.outuv.conv.bias.detach(), "outuv.bias"))
+            self.outuv = (snapshot(net.outuv.conv.weight), snapshot(net.outuv.conv.bias))
 
     def run(self, x, want_stn_in=False, want_argmax=False, want_uv=False, stn_slot=0):
         """x: (B,3,H,W) float32 NCHW on the GPU.  Returns dict with logits (NCHW, fresh),
@@ -1162,8 +1299,9 @@ class UNetEngine:
                             sk._fold_exp_src(a_sk["exp_src"])
                         key = (fu.exp_src, sk.exp_src)
                         if getattr(fu, "_seed_key", None) != key:
-                            div = sk.scale.repeat(4)
-                            fu._seed_scale, fu._seed_border, fu._seed_key = fu.scale / div, fu.shift_border / div, key
+                            # (sk.scale is indexed modulo its length: the four sub-positions share it)
+                            fu._seed_scale, fu._seed_border, fu._seed_key = (vec_op(fu.scale, sk.scale, "div"),
+                                                                             vec_op(fu.shift_border, sk.scale, "div"), key)
                         # frame bands (experiment, SFH_UP_BANDS="4:4" = level 4 in bands of 4 frames): the two launches of a
                         # band run back to back, so that the band's fp32 partial is read back from the Infinity Cache
                         if single and fu.fmt == "h2" and not bands:
@@ -1263,10 +1401,7 @@ class StemConv:
         wexp_given, wexp = wexp, 0
         if fmt == "h2":
             if wexp_given is None:
-                wmax = float(w.abs().max())
-                if not math.isfinite(wmax):
-                    raise ValueError("stem weight holds non-finite values")
-                wexp_given = 14 - math.frexp(wmax)[1] if wmax > 0 else 0
+                wexp_given = h2_weight_exp(absminmax([w])[0][0])
             wexp = max(-100, min(100, int(wexp_given)))
             self.escale = 2.0 ** -(wexp + _lib.H2_ACT_EXP)
         _lib.check(lib.sfh_pack_stem_weights(_ptr(w), _ptr(self.wpacked), cin, _SPLIT[fmt][2], wexp, _stream()),
@@ -1282,7 +1417,7 @@ class StemConv:
         _lib.check(lib.sfh_fold_bn(None, *[_ptr(a) for a in args], float(bn.eps), 64, 1, _ptr(self.scale),
                                    _ptr(self.shift), _stream()), "fold_bn")
         if self.escale != 1.0:
-            self.scale.mul_(self.escale)
+            vec_op(self.scale, factor=self.escale, out=self.scale)
 
     def run(self, x_nhwc8, B, H, W, dst, exp_src=None, range_word=None):
         """exp_src / range_word (h2 arithmetic): exponent of the split the kernel makes of its fp32 input, and the
@@ -1292,7 +1427,7 @@ class StemConv:
         d = ConvDesc()
         if self.fmt == "h2" and exp_src is not None and int(exp_src) != self.exp_src:
             f = 2.0 ** (self.exp_src - int(exp_src))
-            self.scale.mul_(f)
+            vec_op(self.scale, factor=f, out=self.scale)
             self.escale *= f
             self.exp_src = int(exp_src)
         d.h2_exp_src = self.exp_src
@@ -1345,11 +1480,18 @@ class ResNetEngine:
         if (4 * self.cs_in) % 16:
             self.cs_in = -(-in_channels // 8) * 8
         L = {}
+        wx = {}
+        if fmt == "h2":       # every weight exponent from ONE batched |w| reduction and one read-back
+            ws_ = [p.detach() for p in rn.parameters() if p.dim() == 4 and p.is_contiguous()]
+            for w, (mx, _) in zip(ws_, absminmax(ws_)):
+                wx[w.data_ptr()] = h2_weight_exp(mx)
+        def PC(w, *a, **k):      # (PackedConv with this engine's exponent table behind it)
+            return PackedConv(w, *a, wexp=wx.get(w.data_ptr()), **k)
         # the stem stays on the fp32 kernel: the 16-tap split-bf16 instance spills registers and
         # measured 1.59 ms against 0.55 ms
-        L["stem"] = PackedConv(rn.conv0.weight, None, rn.bn1, 4, 4 * self.cs_in, stem_cin=in_channels, tag="resnet")
+        L["stem"] = PC(rn.conv0.weight, None, rn.bn1, 4, 4 * self.cs_in, stem_cin=in_channels, tag="resnet")
         # bf16x6 mode with <= 8 input channels (every resnet_input mode but img+mask+uv): the tap-packed stem kernel
-        self.stem7 = (StemConv(rn.conv0, rn.bn1, in_channels, fmt=fmt, overflow=self.overflow)
+        self.stem7 = (StemConv(rn.conv0, rn.bn1, in_channels, fmt=fmt, overflow=self.overflow, wexp=wx.get(rn.conv0.weight.data_ptr()))
                       if (s3 and self.cs_in == 8 and rn.conv0.out_channels == 64
                                                                   and os.environ.get("SFH_STEM7", "1") != "0") else None)
         self.blocks = []
@@ -1359,20 +1501,20 @@ class ResNetEngine:
                 cin = blk.conv1.in_channels
                 if hasattr(blk, "conv3"):  # Bottleneck (models/resnet.py:120-140): 1x1, 3x3 (stride), 1x1
                     width, cout = blk.conv1.out_channels, blk.conv3.out_channels
-                    L[name + ".conv1"] = PackedConv(blk.conv1.weight, None, blk.bn1, 1, cin, tag="resnet", fmt=fmt)
-                    L[name + ".conv2"] = PackedConv(blk.conv2.weight, None, blk.bn2, 3, width, stride=blk.stride,
+                    L[name + ".conv1"] = PC(blk.conv1.weight, None, blk.bn1, 1, cin, tag="resnet", fmt=fmt)
+                    L[name + ".conv2"] = PC(blk.conv2.weight, None, blk.bn2, 3, width, stride=blk.stride,
                                                     tag="resnet", fmt=fmt)
-                    L[name + ".conv3"] = PackedConv(blk.conv3.weight, None, blk.bn3, 1, width, tag="resnet",
+                    L[name + ".conv3"] = PC(blk.conv3.weight, None, blk.bn3, 1, width, tag="resnet",
                                                     fmt=fmt)  # ReLU after the residual add
                 else:  # BasicBlock (models/resnet.py:64-82)
                     width = cout = blk.conv1.out_channels
-                    L[name + ".conv1"] = PackedConv(blk.conv1.weight, None, blk.bn1, 3, cin, stride=blk.stride,
+                    L[name + ".conv1"] = PC(blk.conv1.weight, None, blk.bn1, 3, cin, stride=blk.stride,
                                                     tag="resnet", fmt=fmt)
-                    L[name + ".conv2"] = PackedConv(blk.conv2.weight, None, blk.bn2, 3, width, tag="resnet",
+                    L[name + ".conv2"] = PC(blk.conv2.weight, None, blk.bn2, 3, width, tag="resnet",
                                                     fmt=fmt)  # ReLU after the residual add
                 if blk.downsample is not None:
                     ds = blk.downsample
-                    L[name + ".down"] = PackedConv(ds[0].weight, None, ds[1], 1, cin, relu=False, stride=blk.stride,
+                    L[name + ".down"] = PC(ds[0].weight, None, ds[1], 1, cin, relu=False, stride=blk.stride,
                                                    tag="resnet", fmt=fmt)
                 self.blocks.append((name, width, cout, blk.stride, blk.downsample is not None, hasattr(blk, "conv3")))
         self.L = L
@@ -1380,8 +1522,8 @@ class ResNetEngine:
         for layer in L.values():
             layer.order = self.order
             layer.overflow = self.overflow
-        self.reg_w = _f32c(rn.reg.weight.detach(), "reg.weight")
-        self.reg_b = _f32c(rn.reg.bias.detach(), "reg.bias")
+        self.reg_w = snapshot(rn.reg.weight)
+        self.reg_b = snapshot(rn.reg.bias)
 
     def run(self, y_nhwc, B, H, W):
         """y_nhwc: (B,H,W,cs_in) float32 with channels >= cin zero.  Returns theta (B,1,3,3)."""

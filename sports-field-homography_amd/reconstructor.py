@@ -458,7 +458,7 @@ class Reconstructor(nn.Module):
         that once per template tensor so the warp reads a single (cache-resident) image."""
         key = (court_img.data_ptr(), tuple(court_img.shape), court_img._version)
         if self._tmpl_shared is None or self._tmpl_shared[0] != key:
-            same = bool(court_img.shape[0] == 1 or (court_img[1:] == court_img[:1]).all().item())
+            same = bool(court_img.shape[0] == 1 or E.rows_all_equal(court_img))
             self._tmpl_shared = (key, same)
         return self._tmpl_shared[1]
 
@@ -532,13 +532,13 @@ class Reconstructor(nn.Module):
         if self.resnet_input == Input.IMG_AND_MASK and "stn_in" in r:
             y = r["stn_in"]
         elif self.resnet_input == Input.IMG_AND_MASK:  # resized logits: assemble like the reference (:179,214)
-            y = E.nchw_to_nhwc(torch.cat((r["logits"], x), 1).contiguous(), rn.cs_in)
+            y = E.stn_input_assemble(r["logits"], x, None, rn.cs_in)
         elif self.resnet_input == Input.IMG:
-            y = E.nchw_to_nhwc(x.contiguous(), rn.cs_in)
+            y = E.stn_input_assemble(None, x, None, rn.cs_in)
         elif self.resnet_input == Input.MASK:
-            y = E.nchw_to_nhwc(r["logits"], rn.cs_in)
+            y = E.stn_input_assemble(r["logits"], None, None, rn.cs_in)
         elif self.resnet_input == Input.IMG_AND_MASK_AND_UV:
-            y = E.nchw_to_nhwc(torch.cat((r["logits"], x, r["uv"]), 1).contiguous(), rn.cs_in)
+            y = E.stn_input_assemble(r["logits"], x, r["uv"], rn.cs_in)
         else:
             raise NotImplementedError
         with torch.cuda.device(x.device):
