@@ -561,6 +561,23 @@ int sfh_rmsprop_step(const void* tensor_table, const void* chunk_table, int nchu
                      float eps, float weight_decay, float momentum, float clip_value, float grad_scale,
                      void* stream);
 
+/* The reference's other two optimizers (train.py:89-92) behind clip_grad_value_(clip), same tables as sfh_rmsprop_step:
+ * sfh_sgd_step  = torch.optim.SGD(lr, momentum, weight_decay): buf (4th table pointer) = momentum buffer, zero-filled at first;
+ * sfh_adam_step = torch.optim.Adam(lr, (beta1, beta2), eps, weight_decay): buf = exp_avg, sq (3rd pointer) = exp_avg_sq, both
+ *                 zero-filled at first; `step` counts from 1 (bias corrections 1 - beta^step, evaluated in double on the host). */
+int sfh_sgd_step(const void* tensor_table, const void* chunk_table, int nchunks, float lr, float weight_decay, float momentum,
+                 float clip_value, float grad_scale, void* stream);
+int sfh_adam_step(const void* tensor_table, const void* chunk_table, int nchunks, float lr, float beta1, float beta2, float eps,
+                  float weight_decay, float clip_value, float grad_scale, int step, void* stream);
+
+/* UV-head loss (train.py:136-144,203-208): loss[0] += lambda * per_sample_weighted_criterion(MSELoss | SmoothL1Loss, uv, gt_uv,
+ * weight) on (B,C,H,W) tensors and duv = its gradient.  models/losses.py:38-39 reduces a 4-D loss map with
+ * torch.mean(loss, dim=(1, 2)) - over channel and row, leaving (B, W) - and multiplies by the weights, which broadcasts along
+ * the LAST axis: nweights must be 1 (weight[0] everywhere; the B == 1 case) or W (column w takes weight[w]; the B == W case);
+ * anything else is the reference's shape error and returns SFH_E_ARG.  mse: 1 = MSELoss, 0 = SmoothL1Loss(beta 1).          */
+int sfh_uv_loss(const float* uv, const float* gt_uv, const float* weight, int nweights, int batch, int C, int H, int W,
+                float lambda, int mse, float* duv, double* loss, void* stream);
+
 /* Many small copies in one launch (training: the assembly of all parameter gradients into the flat gradient buffer -
  * weight gradients are permuted views of the backward-filter buffers - and the copy of the BatchNorm statistics a repeated
  * step starts from; torch issues one copy per tensor).  tensor_table: device array of {void* dst (contiguous); const

@@ -28,4 +28,4 @@ with torch.no_grad():
         out = net.predict(x, consistency=True, project_poi=True)
         torch.cuda.synchronize()
         print("MARK predict", k, "done", flush=True)
-print(float(out["theta"].abs().sum()))
+print(float(abs(out["theta"].cpu().numpy()).sum()))      # (host arithmetic: no torch kernel of the probe's own in the trace)

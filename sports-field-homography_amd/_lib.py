@@ -127,6 +127,10 @@ SIGNATURES = {
     "sfh_poi_project_bwd_theta": (C.c_int, [_p, _p, C.c_int, C.c_int, C.c_int, _p, _p, _p]),
     "sfh_train_losses": (C.c_int, [_p, _p, _p, _p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float,
                                    C.c_int, C.c_float, C.c_int, _p, _p, _p, _p]),
+    "sfh_sgd_step": (C.c_int, [_p, _p, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _p]),
+    "sfh_adam_step": (C.c_int, [_p, _p, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
+                                C.c_int, _p]),
+    "sfh_uv_loss": (C.c_int, [_p, _p, _p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, _p, _p, _p]),
     "sfh_multi_absminmax": (C.c_int, [_p, C.c_int, _p, _p]),
     "sfh_vec_op": (C.c_int, [C.c_int, _p, _p, C.c_int64, C.c_int, C.c_float, _p, _p]),
     "sfh_copy2d_words": (C.c_int, [_p, C.c_int64, _p, C.c_int64, C.c_int, C.c_int64, _p]),

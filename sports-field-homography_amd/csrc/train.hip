@@ -1194,6 +1194,84 @@ __global__ __launch_bounds__(256) void rmsprop_kernel(const OptTensor* __restric
   }
 }
 
+// train.py:90: torch.optim.SGD(lr, momentum, weight_decay) (dampening 0, no Nesterov) behind clip_grad_value_:
+// g = clamp(grad); g += wd * p; buf = mu * buf + g (a zero-filled buffer gives torch's first step, buf = g); p -= lr * buf.
+__global__ __launch_bounds__(256) void sgd_kernel(const OptTensor* __restrict__ table, const OptChunk* __restrict__ chunks,
+                                                  float lr, float wd, float mu, float clip, float gscale) {
+  const OptChunk c = chunks[blockIdx.x];
+  const OptTensor t = table[c.tensor];
+  for (int i = threadIdx.x; i < c.count; i += 256) {
+    const long o = c.offset + i;
+    float g = t.g[o] * gscale;
+    if (clip > 0.f) g = fminf(fmaxf(g, -clip), clip);
+    const float p = t.p[o];
+    g = g + wd * p;
+    if (mu > 0.f) {
+      g = mu * t.buf[o] + g;
+      t.buf[o] = g;
+    }
+    t.p[o] = p - lr * g;
+  }
+}
+
+// train.py:92: torch.optim.Adam(lr, betas, weight_decay) (L2 form, no amsgrad) behind clip_grad_value_, in torch's own
+// operation order: m = lerp(m, g, 1 - b1); v = b2 * v + (1 - b2) * g * g; denom = sqrt(v) / sqrt(1 - b2^t) + eps;
+// p -= (lr / (1 - b1^t)) * m / denom.  `buf` holds exp_avg, `sq` exp_avg_sq; the two bias corrections come from the host.
+__global__ __launch_bounds__(256) void adam_kernel(const OptTensor* __restrict__ table, const OptChunk* __restrict__ chunks,
+                                                   float step_size, float b1, float b2, float eps, float wd, float clip,
+                                                   float gscale, float bias2_sqrt) {
+  const OptChunk c = chunks[blockIdx.x];
+  const OptTensor t = table[c.tensor];
+  for (int i = threadIdx.x; i < c.count; i += 256) {
+    const long o = c.offset + i;
+    float g = t.g[o] * gscale;
+    if (clip > 0.f) g = fminf(fmaxf(g, -clip), clip);
+    const float p = t.p[o];
+    g = g + wd * p;
+    float m = t.buf[o];
+    m = m + (1.0f - b1) * (g - m);
+    t.buf[o] = m;
+    const float v = b2 * t.sq[o] + (1.0f - b2) * g * g;
+    t.sq[o] = v;
+    const float denom = sqrtf(v) / bias2_sqrt + eps;
+    t.p[o] = p - step_size * (m / denom);
+  }
+}
+
+// train.py:136-144,203-208: per_sample_weighted_criterion(MSELoss / SmoothL1Loss(reduction='none'), uv, gt_uv, weights) *
+// lambda on (B,2,H,W) tensors.  models/losses.py:33-41 takes torch.mean(loss, dim=(1, 2)) - on a 4-D map that is the mean
+// over CHANNEL and ROW, leaving (B, W) - and multiplies by the (B,) weights, which broadcasts along the LAST axis: the
+// weight of column w is weights[w] (legal only for B == W) or weights[0] (B == 1).  Restated as written: `wcol` = 1 picks
+// weights[w], 0 weights[0].  loss += lambda * mean_{b,w}(weight * mean_{c,h} l); duv = its gradient.
+__global__ __launch_bounds__(256) void uv_loss_kernel(const float* __restrict__ uv, const float* __restrict__ gt,
+                                                      const float* __restrict__ weight, int wcol, int C, int H, int W,
+                                                      long total, float lambda, int mse, float* __restrict__ duv,
+                                                      double* __restrict__ loss, float inv) {
+  __shared__ double sh[256];
+  double s = 0.0;
+  for (long p = (long)blockIdx.x * 256 + threadIdx.x; p < total; p += (long)gridDim.x * 256) {
+    const int w = (int)(p % W);
+    const float wb = weight[wcol ? w : 0];
+    const float d = uv[p] - gt[p];
+    const float ad = fabsf(d);
+    if (mse) {
+      s += (double)(wb * d * d);
+      duv[p] = lambda * wb * inv * 2.f * d;
+    } else {
+      s += (double)(wb * (ad < 1.f ? 0.5f * d * d : ad - 0.5f));
+      duv[p] = lambda * wb * inv * (ad < 1.f ? d : (d > 0.f ? 1.f : -1.f));
+    }
+  }
+  __syncthreads();
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if (threadIdx.x < off) sh[threadIdx.x] += sh[threadIdx.x + off];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) unsafeAtomicAdd(loss, sh[0] * (double)lambda * (double)inv);
+}
+
 // ------------------------------------------------------------------ multi-tensor copy
 // dst_t (contiguous) = src_t (up to 4-D, any strides) [* scale] for many tensors in ONE launch: the gradient assembly of a
 // training step (182 tensors, the weight gradients as permuted views of the backward-filter buffers, times 1 / the
@@ -1899,6 +1977,40 @@ extern "C" int sfh_multi_copy(const void* tensor_table, const void* chunk_table,
     hipLaunchKernelGGL(multi_copy_kernel<true>, dim3((unsigned)nchunks), dim3(256), 0, (hipStream_t)stream,
                        (const CopyTensor*)tensor_table, (const OptChunk*)chunk_table, scale);
   return sfh_check_launch("multi_copy_kernel");
+}
+
+extern "C" int sfh_sgd_step(const void* tensor_table, const void* chunk_table, int nchunks, float lr, float weight_decay,
+                            float momentum, float clip_value, float grad_scale, void* stream) {
+  SFH_REQUIRE(tensor_table && chunk_table && nchunks > 0, "sgd_step: bad argument");
+  hipLaunchKernelGGL(sgd_kernel, dim3((unsigned)nchunks), dim3(256), 0, (hipStream_t)stream, (const OptTensor*)tensor_table,
+                     (const OptChunk*)chunk_table, lr, weight_decay, momentum, clip_value, grad_scale);
+  return sfh_check_launch("sgd_kernel");
+}
+
+extern "C" int sfh_adam_step(const void* tensor_table, const void* chunk_table, int nchunks, float lr, float beta1, float beta2,
+                             float eps, float weight_decay, float clip_value, float grad_scale, int step, void* stream) {
+  SFH_REQUIRE(tensor_table && chunk_table && nchunks > 0 && step >= 1, "adam_step: bad argument (step counts from 1)");
+  SFH_REQUIRE(beta1 >= 0.f && beta1 < 1.f && beta2 >= 0.f && beta2 < 1.f, "adam_step: betas must lie in [0, 1)");
+  const double bias1 = 1.0 - pow((double)beta1, (double)step), bias2 = 1.0 - pow((double)beta2, (double)step);
+  hipLaunchKernelGGL(adam_kernel, dim3((unsigned)nchunks), dim3(256), 0, (hipStream_t)stream, (const OptTensor*)tensor_table,
+                     (const OptChunk*)chunk_table, (float)((double)lr / bias1), beta1, beta2, eps, weight_decay, clip_value,
+                     grad_scale, (float)sqrt(bias2));
+  return sfh_check_launch("adam_kernel");
+}
+
+extern "C" int sfh_uv_loss(const float* uv, const float* gt_uv, const float* weight, int nweights, int batch, int C, int H,
+                           int W, float lambda, int mse, float* duv, double* loss, void* stream) {
+  SFH_REQUIRE(uv && gt_uv && weight && duv && loss && batch > 0 && C > 0 && H > 0 && W > 0, "uv_loss: bad argument");
+  SFH_REQUIRE(nweights == 1 || nweights == W,
+              "uv_loss: %d per-sample weights cannot be broadcast along the last axis of the (B, W) = (%d, %d) loss map "
+              "(models/losses.py:38-39 multiplies torch.mean(loss, dim=(1, 2)) of a 4-D map by the weights)", nweights, batch, W);
+  const long total = (long)batch * C * H * W;
+  long nb = (total + 255) / 256;
+  if (nb > 1024) nb = 1024;
+  hipLaunchKernelGGL(uv_loss_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, uv, gt_uv, weight,
+                     nweights == W && nweights != 1 ? 1 : 0, C, H, W, total, lambda, mse, duv, loss,
+                     1.0f / ((float)batch * (float)C * (float)H * (float)W));
+  return sfh_check_launch("uv_loss_kernel");
 }
 
 extern "C" int sfh_rmsprop_step(const void* tensor_table, const void* chunk_table, int nchunks, float lr,

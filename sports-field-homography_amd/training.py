@@ -1166,7 +1166,19 @@ class TrainStep:
 
     def __init__(self, net, lr=1e-4, weight_decay=1e-8, momentum=0.9, alpha=0.99, eps=1e-8, clip_value=0.1,
                  seg_lambda=2.0, rec_lambda=2.0, reproj_lambda=8.0, consist_lambda=1.0, rec_loss="SmoothL1",
-                 seg_loss="CE", consist_loss="CE", consist_start_iter=0):
+                 seg_loss="CE", consist_loss="CE", consist_start_iter=0, optimizer="RMSprop", betas=(0.9, 0.999),
+                 uv_loss="MSE", uv_lambda=2.0):
+        """optimizer: "RMSprop" (momentum, alpha, eps), "SGD" (momentum) or "Adam" (betas, eps) - train.py:87-95, each behind
+        clip_grad_value_(clip_value) with L2 weight_decay; uv_loss / uv_lambda: the UV head's criterion ("MSE" | "SmoothL1" |
+        None) for models built with unet_uv=True (train.py:136-144,203-208; defaults utils/config.py:120,134)."""
+        if optimizer not in ("RMSprop", "SGD", "Adam"):
+            print(f"optimizer {optimizer} does not support yet")        # (train.py:94)
+            raise NotImplementedError(f"optimizer={optimizer!r}")
+        if uv_loss not in (None, "MSE", "SmoothL1"):
+            raise NotImplementedError(f"uv_loss={uv_loss!r}")
+        self.optimizer = optimizer
+        self.betas = (float(betas[0]), float(betas[1]))
+        self.uv_loss, self.uv_lambda = uv_loss, float(uv_lambda)
         if rec_loss not in ("SmoothL1", "MSE"):
             raise NotImplementedError(f"rec_loss={rec_loss!r}")
         if seg_loss not in ("CE", "focal") or consist_loss not in ("CE", "focal"):
@@ -1238,7 +1250,7 @@ class TrainStep:
         """Optimizer state for checkpoint / resume, keyed like ``net.state_dict()`` (train.py:321-322 saves
         the model only; resuming RMSprop needs its running averages too)."""
         names = [self.names(p) for p in self.params]
-        return {"global_step": self.global_step,
+        return {"global_step": self.global_step, "optimizer": self.optimizer, "betas": self.betas,
                 "hyper_parameters": dict(self.hp), "lambdas": dict(self.lam), "rec_mse": self.rec_mse,
                 "focal_flags": self.focal_flags, "consist_start_iter": self.consist_start_iter,
                 "square_avg": {n: t.detach().clone() for n, t in zip(names, self.sq)},
@@ -1246,6 +1258,9 @@ class TrainStep:
 
     def load_state_dict(self, state):
         names = [self.names(p) for p in self.params]
+        if state.get("optimizer", "RMSprop") != self.optimizer:
+            raise RuntimeError(f"TrainStep.load_state_dict: the state belongs to {state.get('optimizer', 'RMSprop')}, this "
+                               f"TrainStep runs {self.optimizer} (square_avg / momentum_buffer hold that optimizer's moments)")
         if set(state["square_avg"]) != set(names) or set(state["momentum_buffer"]) != set(names):
             raise RuntimeError("TrainStep.load_state_dict: parameter names do not match this model")
         for n, sq, buf in zip(names, self.sq, self.buf):
@@ -1287,9 +1302,10 @@ class TrainStep:
         net, lib = self.net, _lib.load()
         if not net.training:
             raise RuntimeError("TrainStep: call net.train() first")
-        if net.unet_uv or net.resnet_input.name != "IMG_AND_MASK" or not (net.use_unet and net.use_resnet and net.warper):
-            raise NotImplementedError("TrainStep covers the reference's training configuration "
-                                      "(UNet + ResNetSTN + warper, resnet_input='img+mask', no uv head)")
+        mode = net.resnet_input.name
+        if not (net.use_unet and net.use_resnet and net.warper) or mode not in ("IMG_AND_MASK", "IMG_AND_MASK_AND_UV"):
+            raise NotImplementedError("TrainStep covers the reference's training configurations: UNet + ResNetSTN + warper "
+                                      "with resnet_input 'img+mask', or 'img+mask+uv' with the uv head")
         tape = Tape(fmt=fmt)
         B, _, H, W = x.shape
         x = E._f32c(x, "input frames")
@@ -1300,7 +1316,8 @@ class TrainStep:
         if (wh, ww) != (H, W):
             raise NotImplementedError("TrainStep needs warp_size == frame size (the losses compare per pixel)")
         st = _stream()
-        losses = _zeros((4,), x, torch.float64)   # seg, rec, consist, reproj
+        has_uv = bool(net.unet_uv and self.uv_loss is not None)
+        losses = _zeros((5 if has_uv else 4,), x, torch.float64)   # seg, rec, consist, reproj[, uv]
         mask = batch["mask"]
         if mask.dtype != torch.int64 or not mask.is_contiguous():
             raise ValueError("batch['mask'] must be a contiguous int64 tensor (B,H,W)")
@@ -1318,7 +1335,23 @@ class TrainStep:
                                        _ptr(E._f32c(batch["num_nonzero"], "num_nonzero")), B, poi.shape[1],
                                        self.lam["reproj"], _ptr(dpoi), ctypes.c_void_p(losses.data_ptr() + 24), st),
                    "reproj_loss")
-        g = run_backward(net, tape, f, [dlogits], theta_gradient(net, f, None, dpoi, dwarp), unscale=False)
+        dheads = [dlogits]
+        if net.unet_uv:
+            duv = None
+            if has_uv:
+                uv = f["uv"]
+                gt_uv = E._f32c(batch["uv"], "gt uv")
+                if tuple(gt_uv.shape) != tuple(uv.shape):
+                    raise ValueError(f"batch['uv'] must have the uv head's shape {tuple(uv.shape)}")
+                wgt = E._f32c(batch["weight"], "weight")
+                duv = _empty(uv.shape, x)
+                # models/losses.py:38-39 on a 4-D map: mean over (channel, row) -> (B, W), times the (B,) weights along the
+                # LAST axis - the reference's own broadcasting rule (B == 1 or B == W), its shape error otherwise
+                _lib.check(lib.sfh_uv_loss(_ptr(uv), _ptr(gt_uv), _ptr(wgt), wgt.numel(), B, uv.shape[1], H, W, self.uv_lambda,
+                                           1 if self.uv_loss == "MSE" else 0, _ptr(duv),
+                                           ctypes.c_void_p(losses.data_ptr() + 32), st), "uv_loss")
+            dheads.append(duv)
+        g = run_backward(net, tape, f, dheads, theta_gradient(net, f, None, dpoi, dwarp), unscale=False)
         srcs = []
         for p, dst in zip(self.params, self.grads):
             src = g[self.names(p)]
@@ -1331,7 +1364,7 @@ class TrainStep:
         return losses
 
     def step(self, x, batch):
-        """-> float64 device tensor [seg, rec, consist, reproj] (each already times its lambda)."""
+        """-> float64 device tensor [seg, rec, consist, reproj(, uv)] (each already times its lambda)."""
         self._check_parameter_storage()
         losses = self.loss_and_grads(x, batch)
         lib, hp = _lib.load(), self.hp
@@ -1339,8 +1372,16 @@ class TrainStep:
         # one process per GPU: frames shard by batch, gradients are summed over RCCL and averaged in the
         # optimizer kernel (BatchNorm statistics stay per rank, like DistributedDataParallel's default)
         gscale = sharding.allreduce_gradients(self.gflat, force_collective=self.force_collective)
-        _lib.check(lib.sfh_rmsprop_step(_ptr(self.table), _ptr(self.chunks), self.nchunks, hp["lr"], hp["alpha"],
-                                        hp["eps"], hp["wd"], hp["mu"], hp["clip"], gscale, _stream()), "rmsprop_step")
+        if self.optimizer == "RMSprop":
+            _lib.check(lib.sfh_rmsprop_step(_ptr(self.table), _ptr(self.chunks), self.nchunks, hp["lr"], hp["alpha"],
+                                            hp["eps"], hp["wd"], hp["mu"], hp["clip"], gscale, _stream()), "rmsprop_step")
+        elif self.optimizer == "SGD":
+            _lib.check(lib.sfh_sgd_step(_ptr(self.table), _ptr(self.chunks), self.nchunks, hp["lr"], hp["wd"], hp["mu"],
+                                        hp["clip"], gscale, _stream()), "sgd_step")
+        else:
+            _lib.check(lib.sfh_adam_step(_ptr(self.table), _ptr(self.chunks), self.nchunks, hp["lr"], self.betas[0],
+                                         self.betas[1], hp["eps"], hp["wd"], hp["clip"], gscale, self.global_step + 1,
+                                         _stream()), "adam_step")
         self.global_step += 1
         self.net.invalidate_engines()   # weights changed through raw device pointers: predict() must re-pack
         return losses

@@ -1163,3 +1163,141 @@ def test_fused_training_passes_give_the_gradients_of_the_separate_ones(T, prec, 
     for k in g0:
         d = float((g1[k].double() - g0[k].double()).norm()) / (float(g0[k].double().norm()) + 1e-30)
         assert d < 1e-5 or float(g0[k].abs().max()) < 1e-12, (k, d)
+
+
+# ------------------------------------------------------------------ round 6: the reference's other optimizers and the UV loss
+@pytest.mark.parametrize("name", ["SGD", "Adam"])
+def test_sgd_and_adam_kernels_vs_torch(T, name):
+    """train.py:89-92: clip_grad_value_(0.1) + torch.optim.SGD(lr, momentum 0.9, weight_decay) / torch.optim.Adam(lr,
+    betas (0.9, 0.999), weight_decay) over three steps on odd tensor sizes, like test_rmsprop_kernel_vs_torch."""
+    g = torch.Generator().manual_seed(6)
+    shapes = [(64, 3, 3, 3), (64,), (9, 512), (70001,), (1,)]
+    net = torch.nn.ParameterList([torch.nn.Parameter(torch.randn(s, generator=g)) for s in shapes])
+    ref = [p.detach().clone().requires_grad_(True) for p in net]
+    if name == "SGD":
+        opt = torch.optim.SGD(ref, lr=1e-2, weight_decay=1e-4, momentum=0.9)
+    else:
+        opt = torch.optim.Adam(ref, lr=1e-3, betas=(0.9, 0.999), weight_decay=1e-4)
+    net.cuda()
+    holder = torch.nn.Module()
+    holder.ps = net
+    ts = T.TrainStep.__new__(T.TrainStep)
+    ts.net, ts.hp = holder, dict(lr=1e-2 if name == "SGD" else 1e-3, wd=1e-4, mu=0.9, alpha=0.99, eps=1e-8, clip=0.1)
+    T.TrainStep._init_optimizer(ts, list(net))
+    from sfh_amd import _lib
+    from sfh_amd.engine import _ptr, _stream
+    lib = _lib.load()
+    for it in range(3):
+        grads = [torch.randn(s, generator=g) * (0.3 if it else 0.05) for s in shapes]
+        for p, gr in zip(ref, grads):
+            p.grad = gr.clone()
+        torch.nn.utils.clip_grad_value_(ref, 0.1)
+        opt.step()
+        for dst, gr in zip(ts.grads, grads):
+            dst.copy_(gr)
+        hp = ts.hp
+        if name == "SGD":
+            _lib.check(lib.sfh_sgd_step(_ptr(ts.table), _ptr(ts.chunks), ts.nchunks, hp["lr"], hp["wd"], hp["mu"], hp["clip"],
+                                        1.0, _stream()), "sgd")
+        else:
+            _lib.check(lib.sfh_adam_step(_ptr(ts.table), _ptr(ts.chunks), ts.nchunks, hp["lr"], 0.9, 0.999, hp["eps"],
+                                         hp["wd"], hp["clip"], 1.0, it + 1, _stream()), "adam")
+    torch.cuda.synchronize()
+    for p, r in zip(net, ref):
+        assert (p.detach().cpu() - r.detach()).abs().max().item() < 2e-6
+    # Adam's step counter starts at 1
+    assert lib.sfh_adam_step(_ptr(ts.table), _ptr(ts.chunks), ts.nchunks, 1e-3, 0.9, 0.999, 1e-8, 0.0, 0.1, 1.0, 0, _stream()) != 0
+
+
+@pytest.mark.parametrize("crit", ["MSE", "SmoothL1"])
+@pytest.mark.parametrize("shape", [(1, 2, 21, 34), (12, 2, 9, 12)])
+def test_uv_loss_kernel_vs_the_reference_rule(T, crit, shape):
+    """train.py:136-144,203-208 with models/losses.py:33-41 AS WRITTEN: on the (B,2,H,W) uv maps torch.mean(loss, dim=(1, 2))
+    leaves (B, W) and the (B,) weights broadcast along the LAST axis - legal for B == 1 and for B == W only."""
+    import torch.nn.functional as F
+    from sfh_amd import _lib
+    from sfh_amd.engine import _ptr, _stream
+    lib = _lib.load()
+    B, C, H, W = shape
+    g = torch.Generator().manual_seed(21)
+    uv = (torch.rand(shape, generator=g) * 3 - 1).requires_grad_(True)      # differences beyond 1: both SmoothL1 branches
+    gt = torch.rand(shape, generator=g)
+    wgt = torch.rand(B, generator=g) + 0.5
+    lam = 2.0
+    fn = F.mse_loss if crit == "MSE" else F.smooth_l1_loss
+    want = train_ref.per_sample_weighted(fn(uv, gt, reduction="none"), wgt) * lam
+    want.backward()
+    duv = torch.empty(shape, device="cuda")
+    loss = torch.zeros(1, dtype=torch.float64, device="cuda")
+    uvc, gtc, wc = uv.detach().cuda(), gt.cuda(), wgt.cuda()
+    _lib.check(lib.sfh_uv_loss(_ptr(uvc), _ptr(gtc), _ptr(wc), B, B, C, H, W, lam, 1 if crit == "MSE" else 0, _ptr(duv),
+                               _ptr(loss), _stream()), "uv_loss")
+    torch.cuda.synchronize()
+    assert abs(float(loss) - float(want)) < 1e-6 * max(1.0, abs(float(want)))
+    assert _relerr(duv, uv.grad) < 1e-6
+    # any other batch size is the reference's broadcasting error, not a silently different loss
+    bad = torch.ones(5, device="cuda")
+    assert lib.sfh_uv_loss(_ptr(uvc), _ptr(gtc), _ptr(bad), 5, B, C, H, W, lam, 1, _ptr(duv), _ptr(loss), _stream()) != 0
+    if W != 5:
+        with pytest.raises(RuntimeError):     # torch's own broadcasting error for the same call
+            train_ref.per_sample_weighted(torch.zeros(5, C, H, W), torch.ones(5))
+
+
+@pytest.mark.parametrize("optimizer,mode", [("SGD", "img+mask+uv"), ("Adam", "img+mask"), ("RMSprop", "img+mask+uv")])
+def test_train_step_with_uv_head_and_the_other_optimizers(T, optimizer, mode):
+    """TrainStep on a unet_uv model (train.py:136-144,203-208) with each optimizer of train.py:87-95, one frame per step (the
+    reference's uv loss broadcasts only for B == 1 or B == W): the five losses against the CPU restatement, and the
+    post-step weights against torch's optimizer fed with the CPU restatement's clipped gradients."""
+    import torch.nn.functional as F
+    from sfh_amd.reconstructor import Reconstructor
+    B, H, W = 1, 64, 96
+    court = synth.load_court_template("ncaa_nc4_640x360", 4, B)[:, :, :H, :W].contiguous()
+    poi = synth.load_court_poi("pitch", B)
+    net = Reconstructor(court, poi, target_size=(W, H), unet_size=(W, H), warp_size=(W, H), unet_uv=True, resnet_input=mode)
+    sd = synth.synth_state_dict(net.state_dict(), 57)
+    net.load_state_dict(sd)
+    x = synth.frames_to_float(synth.synth_frames_u8(B, H, W, seed=57))
+    batch = _batch(B, H, W, poi.shape[1], 58)
+    g = torch.Generator().manual_seed(59)
+    batch["uv"] = torch.rand(B, 2, H, W, generator=g)
+    lam = (2.0, 2.0, 8.0, 1.0)
+    lr = 1e-3
+
+    ref = train_ref.leaf_state(sd)
+    params = [v for v in ref.values() if v.requires_grad]
+    opt = {"SGD": lambda: torch.optim.SGD(params, lr=lr, weight_decay=1e-8, momentum=0.9),
+           "Adam": lambda: torch.optim.Adam(params, lr=lr, betas=(0.9, 0.999), weight_decay=1e-8),
+           "RMSprop": lambda: torch.optim.RMSprop(params, lr=lr, weight_decay=1e-8, momentum=0.9)}[optimizer]()
+    pr = train_ref.forward_train(x, ref, court, poi, warp_size=(W, H), unet_size=(W, H), target_size=(W, H), resnet_input=mode)
+    lref = train_ref.losses(pr, batch, lambdas=lam)
+    luv = train_ref.per_sample_weighted(F.mse_loss(pr["uv"], batch["uv"], reduction="none"), batch["weight"]) * 2.0
+    (lref["total"] + luv).backward()
+    torch.nn.utils.clip_grad_value_(params, 0.1)
+    opt.step()
+
+    net.court_img, net.court_poi = court.cuda(), poi.cuda()
+    net.cuda().train()
+    ts = T.TrainStep(net, lr=lr, weight_decay=1e-8, optimizer=optimizer, uv_loss="MSE", uv_lambda=2.0)
+    lh = ts.step(x.cuda(), {k: v.cuda() for k, v in batch.items()}).cpu()
+    torch.cuda.synchronize()
+    assert lh.numel() == 5
+    want = torch.tensor([lref["seg"].item(), lref["rec"].item(), lref["consist"].item(), lref["reproj"].item(), luv.item()],
+                        dtype=torch.float64)
+    assert (lh - want).abs().max().item() < 2e-3 * want.abs().max().item(), (lh, want)
+    new = net.state_dict()
+    agree = total = 0
+    step = {"SGD": lr * 0.1, "Adam": lr, "RMSprop": 10 * lr}[optimizer]      # size of a first step on a clipped gradient
+    for k, v in ref.items():
+        if not v.requires_grad:
+            continue
+        d_ref = (v.detach() - sd[k]).double()
+        d_hip = (new[k].cpu() - sd[k]).double()
+        agree += ((d_ref - d_hip).abs() <= 0.05 * step).sum().item()
+        total += d_ref.numel()
+    assert agree / total > 0.9, agree / total
+    # the optimizer state travels under the optimizer's name
+    st = ts.state_dict()
+    assert st["optimizer"] == optimizer and st["global_step"] == 1
+    other = T.TrainStep(net, optimizer="SGD" if optimizer != "SGD" else "Adam")
+    with pytest.raises(RuntimeError, match="belongs to"):
+        other.load_state_dict(st)
