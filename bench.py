@@ -290,6 +290,8 @@ def train_bench(args):
                   "bf16x6": "bf16x6->f32 convs, forward, backward-data and 3x3 backward-filter on the bf16 matrix cores (fp32-equivalent)",
                   "fp32": "f32 (fp32 MFMA)"}[os.environ.get("SFH_TRAIN_PRECISION", "f16x3")],
         "range_fallbacks": int(getattr(ts, "range_fallbacks", 0)) if ts is not None else None,
+        "range_rescales": int(getattr(ts, "range_rescales", 0)) if ts is not None else None,
+        "grad_scale_shift": int(getattr(ts, "grad_scale_shift", 0)) if ts is not None else None,
         "data": "synthetic", "final_loss": float(loss.detach()),
         "losses_and_optimizer": "torch ops (caller side)" if args.train_autograd else "HIP kernels (training.TrainStep)",
         "peak_mem_gib": round(torch.cuda.max_memory_allocated() / 2**30, 2),
@@ -443,7 +445,7 @@ def extra_configs(args):
     t = train_bench(a)
     res["C3_train_step_640x360_batch16"] = {k: t[k] for k in ("value", "unit", "ms_per_step", "steps", "warmup", "dtype",
                                                               "losses_and_optimizer", "peak_mem_gib", "final_loss",
-                                                              "range_fallbacks")}
+                                                              "range_fallbacks", "range_rescales")}
     res["C3_train_step_640x360_batch16"]["workload"] = t["config"]["workload"]
     return res
 

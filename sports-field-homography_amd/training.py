@@ -218,13 +218,21 @@ class Tape:
             return
         import math
         dev = next(net.parameters()).device
-        self.overflow = torch.zeros(1, dtype=torch.int32, device=dev)
+        # two words: [0] raised by the kernels; [1] = a copy of [0] taken behind the forward pass (mark_forward_done), so that
+        # the one read-back at the end of the step can tell a forward overflow from a backward one
+        self.overflow = E.filled((2,), torch.int32, dev)
         ws = [p for p in net.parameters() if p.dim() == 4]
         mx = torch.stack(torch._foreach_norm([w.detach() for w in ws], float("inf"))).cpu().tolist()
         for w, m in zip(ws, mx):
             if not math.isfinite(m):
                 raise ValueError("a conv weight holds non-finite values")
             self.wexp[id(w)] = (14 - math.frexp(m)[1]) if m > 0 else 0
+
+    def mark_forward_done(self):
+        """H2: remember (on the device, no synchronisation) whether anything overflowed up to here"""
+        if self.overflow is not None and self.overflow.numel() > 1:
+            _lib.check(self.lib.sfh_copy2d_words(_ptr(self.overflow), 1, ctypes.c_void_p(self.overflow.data_ptr() + 4), 1, 1, 1,
+                                                 _stream()), "copy2d_words")
 
     def wexp_of(self, param):
         return self.wexp.get(id(param)) if self.fmt == "h2" else None
@@ -1002,6 +1010,7 @@ def run_backward(net, tape, f, dheads, dtheta, unscale=True):
             m, target = mt, 13
         if not (math.isfinite(mh) and math.isfinite(mt)):
             raise FP16RangeError("non-finite gradient at the outputs of the model")
+        target += int(getattr(tape, "gshift", 0))        # TrainStep lowers it for good after a gradient overflow (sticky)
         if m > 0.0:
             S = 2.0 ** (target - math.frexp(m)[1])       # m = f * 2^e, 0.5 <= f < 1  ->  m * S in [2^(target-1), 2^target)
         if heads and 0.0 < mt * S < 2.0 ** -16:
@@ -1035,12 +1044,16 @@ def run_backward(net, tape, f, dheads, dtheta, unscale=True):
     g = tape.param_grads
     if S != 1.0 and unscale:     # (unscale=False: the caller divides tape.gscale out itself, e.g. once over a flat buffer)
         torch._foreach_mul_([t for t in g.values() if t is not None], 1.0 / S)
-    if tape.overflow is not None and int(tape.overflow.item()):
+    ov = tape.overflow.cpu().tolist() if tape.overflow is not None else [0]
+    if ov[0]:
         tape.ops, tape.param_grads = [], {}
         tape.grads.clear()
         tape._s3.clear()
-        raise FP16RangeError("training step with SFH_TRAIN_PRECISION=f16x3: an activation or gradient left the range of "
+        err = FP16RangeError("training step with SFH_TRAIN_PRECISION=f16x3: an activation or gradient left the range of "
                              "the two-plane fp16 format (or was not finite); use SFH_TRAIN_PRECISION=bf16x6 for this model")
+        # the forward pass was clean (its copy of the word is 0): only a GRADIENT overflowed - a lower scale can hold it
+        err.phase = "backward" if (len(ov) > 1 and not ov[1]) else "forward"
+        raise err
     # the closures reference the tape and the tape the closures: break the cycle so the activations
     # are released now rather than at the next garbage collection
     tape.param_grads = {}
@@ -1086,7 +1099,7 @@ class _TrainForward(torch.autograd.Function):
                 snap = net.__dict__["_bn_snapshot"] = _BNSnapshot(net)
             ctx.snap_gen = snap.save()
             f = run_forward(net, tape, x)
-            if int(tape.overflow.item()):
+            if int(tape.overflow[0].item()):
                 snap.restore()
                 _warn_range_fallback()
                 net.__dict__["train_range_fallbacks"] = net.__dict__.get("train_range_fallbacks", 0) + 1
@@ -1193,6 +1206,8 @@ class TrainStep:
         self._bn_snapshot = None     # f16x3 only: copies of the BatchNorm statistics for a repeated step
         self._assemble = None        # _MultiCopy into self.grads
         self.range_fallbacks = 0     # steps repeated with bf16x6 because a value left the fp16 range
+        self.range_rescales = 0      # steps repeated in f16x3 with a lower gradient scale (kept for the steps that follow)
+        self.grad_scale_shift = 0    # power of two the backward pass's scale is lowered by (sticky, <= 0 in normal use)
         self.force_collective = False  # one-rank world: run the gradient all-reduce anyway (sharding.py, RCCL rehearsal)
         self._init_optimizer([p for p in net.parameters()])
 
@@ -1251,6 +1266,7 @@ class TrainStep:
         the model only; resuming RMSprop needs its running averages too)."""
         names = [self.names(p) for p in self.params]
         return {"global_step": self.global_step, "optimizer": self.optimizer, "betas": self.betas,
+                "grad_scale_shift": self.grad_scale_shift,
                 "hyper_parameters": dict(self.hp), "lambdas": dict(self.lam), "rec_mse": self.rec_mse,
                 "focal_flags": self.focal_flags, "consist_start_iter": self.consist_start_iter,
                 "square_avg": {n: t.detach().clone() for n, t in zip(names, self.sq)},
@@ -1272,6 +1288,7 @@ class TrainStep:
             sq.copy_(state["square_avg"][n])
             buf.copy_(state["momentum_buffer"][n])
         self.global_step = int(state["global_step"])
+        self.grad_scale_shift = int(state.get("grad_scale_shift", self.grad_scale_shift))
         # hyper-parameters travel with the state (a learning rate lowered by ReduceLROnPlateau survives a resume)
         if "hyper_parameters" in state:
             self.hp.update(state["hyper_parameters"])
@@ -1283,20 +1300,30 @@ class TrainStep:
     def loss_and_grads(self, x, batch):
         """forward + losses + backward; fills self.grads, returns a float64 device tensor of 4 values in the
         order [seg, rec, consist, reproj] (each already times its lambda).  batch: mask (B,H,W) int64, weight (B), poi (B,N,2),
-        nonzeros (B,N), num_nonzero (B).  With SFH_TRAIN_PRECISION=f16x3 a step whose activations or gradients leave
-        the fp16 range is repeated with bf16x6 operands from the same BatchNorm statistics (range_fallbacks counts)."""
+        nonzeros (B,N), num_nonzero (B)[, uv (B,2,H,W)].  With SFH_TRAIN_PRECISION=f16x3 a step whose GRADIENTS leave the fp16
+        range is repeated in f16x3 with a lower gradient scale that is kept from then on (range_rescales counts); one whose
+        ACTIVATIONS do, or that no scale holds, is repeated with bf16x6 operands (range_fallbacks) - always from the same
+        BatchNorm statistics."""
         if _train_fmt() != "h2":
             return self._loss_and_grads(x, batch, "env")
         if self._bn_snapshot is None:
             self._bn_snapshot = _BNSnapshot(self.net)
         self._bn_snapshot.save()
-        try:
-            return self._loss_and_grads(x, batch, "h2")
-        except FP16RangeError:
-            self._bn_snapshot.restore()
-            self.range_fallbacks += 1
-            _warn_range_fallback()
-            return self._loss_and_grads(x, batch, "s3")
+        for attempt in range(4):
+            try:
+                return self._loss_and_grads(x, batch, "h2")
+            except FP16RangeError as e:
+                self._bn_snapshot.restore()
+                if getattr(e, "phase", None) != "backward" or self.grad_scale_shift <= -24 or attempt == 3:
+                    break
+                # only a gradient left the range (the forward pass was clean): the backward pass is linear in its seeds,
+                # so a lower power-of-two scale holds the spike.  Lowered FOR GOOD - like the inference path's exponents -
+                # and the step repeated on the same two-plane fp16 kernels; bf16x6 only if that does not help either.
+                self.grad_scale_shift -= 6
+                self.range_rescales += 1
+        self.range_fallbacks += 1
+        _warn_range_fallback()
+        return self._loss_and_grads(x, batch, "s3")
 
     def _loss_and_grads(self, x, batch, fmt):
         net, lib = self.net, _lib.load()
@@ -1307,9 +1334,11 @@ class TrainStep:
             raise NotImplementedError("TrainStep covers the reference's training configurations: UNet + ResNetSTN + warper "
                                       "with resnet_input 'img+mask', or 'img+mask+uv' with the uv head")
         tape = Tape(fmt=fmt)
+        tape.gshift = self.grad_scale_shift
         B, _, H, W = x.shape
         x = E._f32c(x, "input frames")
         f = run_forward(net, tape, x)
+        tape.mark_forward_done()
         logits, theta, poi, warp = f["logits"], f["theta"], f["poi"], f["warp_mask"]
         self.last_outputs = {"logits": logits, "theta": theta, "poi": poi, "warp_mask": warp}   # of the step just run
         ww, wh = net.warp_size

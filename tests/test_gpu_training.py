@@ -1301,3 +1301,42 @@ def test_train_step_with_uv_head_and_the_other_optimizers(T, optimizer, mode):
     other = T.TrainStep(net, optimizer="SGD" if optimizer != "SGD" else "Adam")
     with pytest.raises(RuntimeError, match="belongs to"):
         other.load_state_dict(st)
+
+
+def test_train_step_gradient_overflow_lowers_the_scale_for_good(T, monkeypatch):
+    """a step whose GRADIENTS leave the fp16 range (forward clean) is repeated on the same two-plane fp16
+    kernels with a lower power-of-two gradient scale, kept for the steps that follow - not in bf16x6.  Planted by raising
+    the scale 2^10 above where TrainStep puts it: the layer gradients (two to three orders of magnitude above the head
+    gradients) then pass 16376."""
+    from sfh_amd.reconstructor import Reconstructor
+    monkeypatch.setenv("SFH_TRAIN_PRECISION", "f16x3")
+    B, H, W = 2, 64, 96
+    court = synth.load_court_template("ncaa_nc4_640x360", 4, B)[:, :, :H, :W].contiguous().cuda()
+    poi = synth.load_court_poi("pitch", B).cuda()
+    x = synth.frames_to_float(synth.synth_frames_u8(B, H, W, seed=9)).cuda()
+    batch = {k: v.cuda() for k, v in _batch(B, H, W, poi.shape[1], 10).items()}
+
+    def run(shift):
+        net = Reconstructor(court, poi, target_size=(W, H), unet_size=(W, H), warp_size=(W, H))
+        net.load_state_dict(synth.synth_state_dict(net.state_dict(), 9))
+        net.cuda().train()
+        ts = T.TrainStep(net, lr=1e-5)
+        ts.grad_scale_shift = shift
+        losses = ts.loss_and_grads(x, batch)
+        torch.cuda.synchronize()
+        stats = {k: v.clone() for k, v in net.state_dict().items() if "running" in k}
+        return losses.clone(), ts.gflat.clone(), stats, ts, net
+
+    l0, g0, b0, ts0, _ = run(0)
+    assert (ts0.range_rescales, ts0.range_fallbacks, ts0.grad_scale_shift) == (0, 0, 0)
+    l1, g1, b1, ts1, net1 = run(12)
+    assert ts1.range_rescales >= 1 and ts1.range_fallbacks == 0 and ts1.grad_scale_shift <= 6
+    assert torch.allclose(l0, l1, rtol=1e-6, atol=0) and _relerr(g1, g0) < 1e-3
+    for k in b0:      # the repeated step started from the restored BatchNorm statistics (moved once, not twice)
+        assert torch.allclose(b0[k].double(), b1[k].double(), rtol=1e-5, atol=1e-7), k
+    # sticky: the next step repeats nothing, and the shift travels with the optimizer state
+    before = ts1.range_rescales
+    ts1.step(x, batch)
+    torch.cuda.synchronize()
+    assert ts1.range_rescales == before and ts1.range_fallbacks == 0
+    assert ts1.state_dict()["grad_scale_shift"] == ts1.grad_scale_shift
