@@ -397,6 +397,15 @@ def extra_configs(args):
                     "(NCAA template resized NEAREST), consistency through the nearest-resized warp mask, batch 16"}
     del net_d, court_hd
     torch.cuda.empty_cache()
+    # small batches (the reference's default batchsize is 8, utils/config.py:30; one frame = the latency case): predict() per
+    # batch.  These are GPU-bound, not host-bound: at one frame the ~90 dependent launches keep the GPU busy 95 % of the batch
+    # (profiles/r06_batch1_launch_table.txt), so a launch list / HIP graph has at most 0.1-0.2 ms to return
+    for bs in (1, 8):
+        n = 40 if bs == 1 else 12
+        el = _timed_predicts(net, x[:bs].contiguous(), n, 4, False, consistency=False)
+        res[f"C2_640x360_batch{bs}"] = {
+            "value": round(bs * n / el, 2), "unit": "frames/s", "ms_per_step": round(el / n * 1e3, 3), "steps": n, "warmup": 4,
+            "workload": f"the headline workload at batch {bs}: predict() per batch (no pipelining), 640x360, theta + warp_mask"}
     for prec in ("bf16x6", "fp32"):
         net.precision = prec
         n = 4
