@@ -402,9 +402,20 @@ def extra_configs(args):
     # (profiles/r06_batch1_launch_table.txt), so a launch list / HIP graph has at most 0.1-0.2 ms to return
     for bs in (1, 8):
         n = 40 if bs == 1 else 12
-        el = _timed_predicts(net, x[:bs].contiguous(), n, 4, False, consistency=False)
+        xb = x[:bs].contiguous()
+        el = _timed_predicts(net, xb, n, 4, False, consistency=False)
+        with torch.no_grad():
+            for _ in range(4):
+                net.predict_replay(xb, consistency=False)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(n):
+                net.predict_replay(xb, consistency=False)
+            torch.cuda.synchronize()
+            el_g = time.perf_counter() - t0
         res[f"C2_640x360_batch{bs}"] = {
             "value": round(bs * n / el, 2), "unit": "frames/s", "ms_per_step": round(el / n * 1e3, 3), "steps": n, "warmup": 4,
+            "ms_per_step_graph_replay": round(el_g / n * 1e3, 3),
             "workload": f"the headline workload at batch {bs}: predict() per batch (no pipelining), 640x360, theta + warp_mask"}
     for prec in ("bf16x6", "fp32"):
         net.precision = prec

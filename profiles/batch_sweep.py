@@ -22,13 +22,24 @@ net.to(dev).eval()
 for B in sizes:
     x = synth.frames_to_float(synth.synth_frames_u8(B, H, W, seed=0)).to(dev)
     with torch.no_grad():
-        for _ in range(3):
-            net.predict(x, consistency=False)
-        torch.cuda.synchronize()
-        n = max(5, 160 // B)
-        t0 = time.perf_counter()
-        for _ in range(n):
-            net.predict(x, consistency=False)
-        torch.cuda.synchronize()
-        el = (time.perf_counter() - t0) / n
-    print(f"B={B} {B / el:.2f} frames/s {el * 1e3:.3f} ms per batch  (split-K {'off' if os.environ.get('SFH_SPLITK') == '0' else 'on'})", flush=True)
+        res = {}
+        for name, fn in (("predict", net.predict), ("predict_replay", net.predict_replay)):
+            for _ in range(4):
+                fn(x, consistency=False)
+            torch.cuda.synchronize()
+            n = max(5, 160 // B)
+            t0 = time.perf_counter()
+            for _ in range(n):
+                fn(x, consistency=False)
+            torch.cuda.synchronize()
+            res[name] = (time.perf_counter() - t0) / n
+            # host time of a call with the GPU idle at entry: how long the caller's thread is held
+            t0 = time.perf_counter()
+            for _ in range(n):
+                fn(x, consistency=False)
+                held = time.perf_counter()
+                torch.cuda.synchronize()
+            res[name + "_sync_each"] = (time.perf_counter() - t0) / n
+    print(f"B={B:3d}  predict() {B / res['predict']:8.1f} frames/s {res['predict'] * 1e3:7.3f} ms per batch   "
+          f"predict_replay() {B / res['predict_replay']:8.1f} frames/s {res['predict_replay'] * 1e3:7.3f} ms per batch   "
+          f"(one batch at a time, synchronised: {res['predict_sync_each'] * 1e3:.3f} / {res['predict_replay_sync_each'] * 1e3:.3f} ms)", flush=True)

@@ -86,3 +86,67 @@ def test_outconv_backward_filter_at_1280x720_against_fp64():
     assert rel_w < 2e-6 and rel_b < 2e-6, (rel_w, rel_b)
     want_dy = torch.einsum("bkhw,kc->bhwc", dl, w)
     assert float((dy - want_dy).abs().max()) < 1e-6
+
+
+@pytest.mark.parametrize("precision", ["f16x3", "bf16x6"])
+@pytest.mark.parametrize("B", [1, 2, 8])
+def test_graph_replay_gives_predict_s_bits(B, precision):
+    """predict_replay() - one HIP-graph launch per batch - returns predict()'s outputs bit for bit, batch
+    after batch with different frames, as fresh tensors; new weights capture anew; `net.graph_replay = True` routes predict()."""
+    w, h = 160, 96
+    net, sd = _net(B, w=w, h=h, seed=29)
+    net.precision = precision
+    xs = [synth.smooth_frames(B, h, w, seed=80 + k).cuda() for k in range(4)]
+    with torch.no_grad():
+        want = [{k: v.clone() for k, v in net.predict(x, consistency=True, project_poi=True).items()} for x in xs]
+        got = [net.predict_replay(x, consistency=True, project_poi=True) for x in xs]     # first call captures, the rest replay
+        assert len(net.__dict__["_replay"]) == 1
+        for g_, w_ in zip(got, want):
+            assert sorted(g_) == sorted(w_)
+            for k in w_:
+                assert g_[k].dtype == w_[k].dtype and torch.equal(g_[k], w_[k]), k
+        # fresh tensors: a later replay does not overwrite an earlier result
+        assert got[1]["theta"].data_ptr() != got[2]["theta"].data_ptr() and torch.equal(got[1]["logits"], want[1]["logits"])
+        # another output set is another capture; the first one stays valid
+        o2 = net.predict_replay(xs[0], consistency=False)
+        assert "consist_score" not in o2 and torch.equal(o2["theta"], want[0]["theta"])
+        o3 = net.predict_replay(xs[3], consistency=True, project_poi=True)
+        assert torch.equal(o3["warp_mask"], want[3]["warp_mask"])
+        # new weights: the captures of the old engines are dropped, the next call is right for the new checkpoint
+        net.load_state_dict(synth.synth_state_dict(net.state_dict(), 30))
+        fresh = net.predict(xs[0], consistency=True, project_poi=True)
+        fresh = {k: v.clone() for k, v in fresh.items()}
+        again = [net.predict_replay(xs[0], consistency=True, project_poi=True) for _ in range(3)]
+        for a in again:
+            assert all(torch.equal(a[k], fresh[k]) for k in fresh)
+        assert float((fresh["theta"] - want[0]["theta"]).abs().max()) > 1e-4
+        # predict() itself goes through the graph when asked to
+        net.graph_replay = True
+        via = net.predict(xs[0], consistency=True, project_poi=True)
+        assert all(torch.equal(via[k], fresh[k]) for k in fresh)
+    torch.cuda.synchronize()
+
+
+def test_graph_replay_range_event_recomputes_and_recaptures():
+    """a replayed batch whose activations leave the fp16 range of the captured exponents is never returned: predict()
+    recomputes it (lowering the exponent), and the next call captures under the new exponents"""
+    B, w, h = 2, 160, 96
+    net, sd = _net(B, w=w, h=h, seed=29)
+    x = synth.smooth_frames(B, h, w, seed=90).cuda()
+    with torch.no_grad():
+        net.predict_replay(x)
+        net.predict_replay(x)
+        big = x * 40000.0                                   # the frame tensor itself leaves +-16376
+        want = net.predict(big)
+        want = {k: v.clone() for k, v in want.items()}
+        assert net.range_rescales >= 1
+        # back to ordinary frames: exponents moved -> the old capture's key no longer matches
+        a = net.predict_replay(x)
+        b = net.predict_replay(x)
+        ref = net.predict(x)
+        assert all(torch.equal(a[k], ref[k]) and torch.equal(b[k], ref[k]) for k in ref)
+        # and a saturating batch through the replay path itself
+        c = net.predict_replay(big * 64.0)
+        d = net.predict(big * 64.0)
+        assert all(torch.equal(c[k], d[k]) or (torch.isnan(c[k]).any() and torch.isnan(d[k]).any()) for k in d)
+    torch.cuda.synchronize()
