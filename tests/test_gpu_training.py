@@ -1340,3 +1340,54 @@ def test_train_step_gradient_overflow_lowers_the_scale_for_good(T, monkeypatch):
     torch.cuda.synchronize()
     assert ts1.range_rescales == before and ts1.range_fallbacks == 0
     assert ts1.state_dict()["grad_scale_shift"] == ts1.grad_scale_shift
+
+
+@pytest.mark.parametrize("seed", [0, 1])
+def test_train_step_on_trained_like_checkpoints(T, seed, monkeypatch):
+    """One TrainStep iteration from a checkpoint with TRAINED statistics (synth.trained_like_state_dict: conv rows over three
+    decades of scale, negative / dead gammas, 1 % weight outliers, one layer scaled by 2^+12 (seed 0) / 2^-12 (seed 1)) against
+    the CPU restatement.  Under batch-statistics BatchNorm the 2^-12 layer's pre-activation gradient is 4096x its
+    neighbours': the f16x3 backward pass must hold it by lowering its gradient scale (range_rescales), not by leaving the
+    two-plane fp16 kernels (range_fallbacks == 0)."""
+    from sfh_amd.reconstructor import Reconstructor
+    monkeypatch.setenv("SFH_TRAIN_PRECISION", "f16x3")
+    B, H, W = 4, 96, 128
+    lr, lam = 1e-4, (2.0, 2.0, 8.0, 1.0)
+    court = synth.load_court_template("ncaa_nc4_640x360", 4, B)[:, :, :H, :W].contiguous()
+    poi = synth.load_court_poi("pitch", B)
+    net = Reconstructor(court, poi, target_size=(W, H), unet_size=(W, H), warp_size=(W, H))
+    sd, info = synth.trained_like_state_dict(net.state_dict(), seed, return_info=True)
+    net.load_state_dict(sd)
+    x = synth.frames_to_float(synth.synth_frames_u8(B, H, W, seed=61 + seed))
+    batch = _batch(B, H, W, poi.shape[1], 62 + seed)
+
+    ref = train_ref.leaf_state(sd)
+    params = [v for v in ref.values() if v.requires_grad]
+    opt = torch.optim.RMSprop(params, lr=lr, weight_decay=1e-8, momentum=0.9)
+    pr = train_ref.forward_train(x, ref, court, poi, warp_size=(W, H), unet_size=(W, H), target_size=(W, H))
+    lref = train_ref.losses(pr, batch, lambdas=lam)
+    lref["total"].backward()
+    torch.nn.utils.clip_grad_value_(params, 0.1)
+    opt.step()
+
+    net.court_img, net.court_poi = court.cuda(), poi.cuda()
+    net.cuda().train()
+    ts = T.TrainStep(net, lr=lr, weight_decay=1e-8)
+    lh = ts.step(x.cuda(), {k: v.cuda() for k, v in batch.items()}).cpu()
+    torch.cuda.synchronize()
+    want = torch.tensor([lref["seg"].item(), lref["rec"].item(), lref["consist"].item(), lref["reproj"].item()], dtype=torch.float64)
+    new = net.state_dict()
+    agree = total = 0
+    for k, v in ref.items():
+        if not v.requires_grad:
+            continue
+        d_ref = (v.detach() - sd[k]).double()
+        d_hip = (new[k].cpu() - sd[k]).double()
+        agree += ((d_ref - d_hip).abs() <= 0.05 * (10 * lr)).sum().item()
+        total += v.numel()
+    print(f"trained-like seed {seed} ({info['scaled_layer']} x 2^{info['scaled_layer_exp']}): losses hip {lh.tolist()} cpu {want.tolist()}; "
+          f"updates agreeing {agree / total:.4f}; range_rescales {ts.range_rescales} range_fallbacks {ts.range_fallbacks} "
+          f"grad_scale_shift {ts.grad_scale_shift}")
+    assert ts.range_fallbacks == 0
+    assert (lh - want).abs().max().item() < 2e-3 * want.abs().max().item(), (lh, want)
+    assert agree / total > 0.9, agree / total
