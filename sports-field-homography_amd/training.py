@@ -222,8 +222,8 @@ class Tape:
         # the one read-back at the end of the step can tell a forward overflow from a backward one
         self.overflow = E.filled((2,), torch.int32, dev)
         ws = [p for p in net.parameters() if p.dim() == 4]
-        mx = torch.stack(torch._foreach_norm([w.detach() for w in ws], float("inf"))).cpu().tolist()
-        for w, m in zip(ws, mx):
+        # one launch over all conv weights + one read-back (sfh_multi_absminmax)
+        for w, (m, _) in zip(ws, E.absminmax([w.detach() for w in ws])):
             if not math.isfinite(m):
                 raise ValueError("a conv weight holds non-finite values")
             self.wexp[id(w)] = (14 - math.frexp(m)[1]) if m > 0 else 0
@@ -1001,7 +1001,8 @@ def run_backward(net, tape, f, dheads, dtheta, unscale=True):
         import math
         heads = [d for d in dheads if d is not None]
         # one read-back for both seeds: the largest head gradient and the largest theta gradient
-        mx = torch.stack([d.abs().max() for d in heads] + ([dtheta.abs().max()] if dtheta is not None else [])).cpu().tolist()
+        mx = [m for m, _ in E.absminmax([d if d.is_contiguous() else d.contiguous() for d in heads]
+                                        + ([dtheta.contiguous()] if dtheta is not None else []))]
         mh = max(mx[:len(heads)]) if heads else 0.0
         mt = mx[-1] if dtheta is not None else 0.0
         if heads:
