@@ -40,6 +40,22 @@ for B in sizes:
                 held = time.perf_counter()
                 torch.cuda.synchronize()
             res[name + "_sync_each"] = (time.perf_counter() - t0) / n
-    print(f"B={B:3d}  predict() {B / res['predict']:8.1f} frames/s {res['predict'] * 1e3:7.3f} ms per batch   "
+        # two batches in flight (predict_async): the ResNet-STN / warp of batch k under the UNet of batch k + 1
+        def piped(m):
+            prev = None
+            for _ in range(m):
+                h = net.predict_async(x, consistency=False)
+                if prev is not None:
+                    prev.result()
+                prev = h
+            prev.result()
+        piped(4)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        piped(n)
+        torch.cuda.synchronize()
+        res["async"] = (time.perf_counter() - t0) / n
+    print(f"B={B:3d}  predict_async() {B / res['async']:8.1f} frames/s {res['async'] * 1e3:7.3f} ms per batch   "
+          f"predict() {B / res['predict']:8.1f} frames/s {res['predict'] * 1e3:7.3f} ms per batch   "
           f"predict_replay() {B / res['predict_replay']:8.1f} frames/s {res['predict_replay'] * 1e3:7.3f} ms per batch   "
           f"(one batch at a time, synchronised: {res['predict_sync_each'] * 1e3:.3f} / {res['predict_replay_sync_each'] * 1e3:.3f} ms)", flush=True)
