@@ -7,16 +7,31 @@
 
 namespace {
 
-// one workgroup per (slice of a tensor): |x| bit patterns are ordered like unsigned integers, NaN above Inf
+// grid = (slices, tensors): slice s of tensor t covers elements [s, s + 1) * ceil(n / slices) rounded to 16-byte quads; |x| bit
+// patterns are ordered like unsigned integers, NaN above Inf.  16-byte loads where the tensor's address allows.
 __global__ __launch_bounds__(256) void multi_absminmax_kernel(const long* __restrict__ table, uint32_t* __restrict__ words) {
   const int t = blockIdx.y;
   const float* p = reinterpret_cast<const float*>(table[2 * t]);
   const long n = table[2 * t + 1];
   uint32_t mx = 0u, mn = 0x7FFFFFFFu;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
-    const uint32_t b = __float_as_uint(p[i]) & 0x7FFFFFFFu;
+  auto take = [&](float v) {
+    const uint32_t b = __float_as_uint(v) & 0x7FFFFFFFu;
     mx = b > mx ? b : mx;
     mn = b < mn ? b : mn;
+  };
+  // small tensors are finished by the first few workgroups of their row; the others have no element and leave at once
+  const bool quads = (reinterpret_cast<uintptr_t>(p) & 15) == 0;
+  if (blockIdx.x != 0 && (long)blockIdx.x * 256 >= (quads ? (n >> 2) : n)) return;
+  if (quads) {
+    const long nq = n >> 2;
+    const f32x4* q = reinterpret_cast<const f32x4*>(p);
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nq; i += (long)gridDim.x * 256) {
+      const f32x4 v = q[i];
+      take(v[0]); take(v[1]); take(v[2]); take(v[3]);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) take(p[(nq << 2) + threadIdx.x]);
+  } else {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) take(p[i]);
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
@@ -24,7 +39,7 @@ __global__ __launch_bounds__(256) void multi_absminmax_kernel(const long* __rest
     mx = a > mx ? a : mx;
     mn = c < mn ? c : mn;
   }
-  if ((threadIdx.x & 63) == 0 && (long)blockIdx.x * 256 < n) {
+  if ((threadIdx.x & 63) == 0) {
     atomicMax(&words[2 * t], mx);
     atomicMax(&words[2 * t + 1], 0x7FFFFFFFu - mn);      // stored inverted: a zero-filled table is the identity of both
   }
@@ -101,7 +116,7 @@ extern "C" int sfh_rows_differ(const void* x, int64_t row_words, int rows, uint3
 
 extern "C" int sfh_multi_absminmax(const void* table, int ntensors, uint32_t* words, void* stream) {
   SFH_REQUIRE(table && words && ntensors > 0 && ntensors <= 65535, "multi_absminmax: bad argument");
-  hipLaunchKernelGGL(multi_absminmax_kernel, dim3(64, (unsigned)ntensors), dim3(256), 0, (hipStream_t)stream,
+  hipLaunchKernelGGL(multi_absminmax_kernel, dim3(512, (unsigned)ntensors), dim3(256), 0, (hipStream_t)stream,
                      reinterpret_cast<const long*>(table), words);
   return sfh_check_launch("multi_absminmax_kernel");
 }

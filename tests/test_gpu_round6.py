@@ -150,3 +150,28 @@ def test_graph_replay_range_event_recomputes_and_recaptures():
         d = net.predict(big * 64.0)
         assert all(torch.equal(c[k], d[k]) or (torch.isnan(c[k]).any() and torch.isnan(d[k]).any()) for k in d)
     torch.cuda.synchronize()
+
+
+def test_multi_absminmax_against_torch():
+    """sfh_multi_absminmax (one launch for all weight exponents of an engine / a training step): max |x| and min |x| of
+    tensors of awkward sizes and alignments, NaN / Inf visible as non-finite"""
+    from sfh_amd import engine as E
+    g = torch.Generator(device="cuda").manual_seed(3)
+    base = torch.randn(3_000_000, device="cuda", generator=g)
+    sizes = [1, 2, 3, 5, 255, 256, 257, 1023, 4096, 4097, 70001, 1_000_003, 9 * 512 * 512]
+    ts, off = [], 0
+    for k, n in enumerate(sizes):
+        if off + n + 1 > base.numel():
+            off = 0
+        ts.append(base[off + (k % 2):off + (k % 2) + n])          # every second one starts 4 bytes off a 16-byte boundary
+        off += n + 1
+    got = E.absminmax(ts)
+    for t, (mx, mn) in zip(ts, got):
+        assert mx == float(t.abs().max()) and mn == float(t.abs().min()), t.numel()
+    bad = torch.ones(1000, device="cuda")
+    bad[777] = float("nan")
+    inf = torch.ones(1000, device="cuda")
+    inf[3] = float("-inf")
+    (m1, _), (m2, _) = E.absminmax([bad, inf])
+    assert m1 != m1 and m2 == float("inf")
+    assert E.absminmax([torch.zeros(17, device="cuda")]) == [(0.0, 0.0)]
