@@ -1140,7 +1140,7 @@ def test_f16x3_quiet_layers_get_larger_exponents(E, factor):
            "two_sided_dtheta": err2[0], "two_sided_dlogits": err2[1], "raises": n1, "exps": {k: ex.get(k, 2) for k in scaled}}
     print(json.dumps(rec))
     if os.path.isdir(out):
-        with open(os.path.join(out, "parity_r05.jsonl"), "a") as f:
+        with open(os.path.join(out, "r06_parity_full_size.jsonl"), "a") as f:
             f.write(json.dumps(rec) + "\n")
 
 
