@@ -35,11 +35,6 @@ from . import warp_ref
 SOFTMAX_TIE_MARGIN = 1.2e-7
 
 
-def preds_to_masks(logits):
-    """utils/postprocess.py:7-18 for n_classes > 1: argmax over softmax probabilities."""
-    return torch.argmax(F.softmax(logits, dim=1), dim=1)
-
-
 def softmax_argmax_may_differ(logits):
     """bool (B,H,W): pixels whose top-2 logit margin is inside SOFTMAX_TIE_MARGIN - the only ones where
     argmax(softmax(logits)) (the reference) and argmax(logits) (the HIP epilogue) can disagree"""

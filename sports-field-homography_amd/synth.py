@@ -82,7 +82,7 @@ def _conv_bn_pairs(names):
     return pairs
 
 
-def trained_like_state_dict(template_sd, seed=0, scaled_layer_exp=None, return_info=False):
+def trained_like_state_dict(template_sd, seed=0, scaled_layer_exp=None, return_info=False, head_sigma=0.02):
     """A second weight family with the statistics of a TRAINED checkpoint, where `synth_state_dict` has those of a fresh
     one: the fp16 per-tensor-exponent arithmetic is exactly what such statistics stress.
 
@@ -98,7 +98,11 @@ def trained_like_state_dict(template_sd, seed=0, scaled_layer_exp=None, return_i
       smaller than its neighbours (+12: the same function; -12: the variances fall to 6e-11 .. 6e-5, BatchNorm's eps = 1e-5
       takes over and most of the layer's channels go quiet - a collapsed layer, as checkpoints have them);
     * residual-branch BatchNorms of the ResNet (bn2 / bn3 / downsample) keep a gain of N(0, 0.3) so that the 16
-      un-normalised residual adds stay bounded; the regression head as in `synth_state_dict`.
+      un-normalised residual adds stay bounded;
+    * the regression head (`resnet_reg.reg.weight`) ~ N(0, head_sigma = 0.02) instead of `synth_state_dict`'s N(0, 1e-4): theta
+      then depends on the 512 pooled features at full strength (entries move by O(0.1 .. 1) between frames, like the trained
+      homographies of utils/mapping_example.py), so an error in the ResNet-STN's features shows in theta instead of being
+      scaled away by a near-zero head.
 
     unet/unet_parts.py:14-21 (BatchNorm after every conv), models/resnet.py:64-82."""
     names = list(template_sd.keys())
@@ -137,6 +141,9 @@ def trained_like_state_dict(template_sd, seed=0, scaled_layer_exp=None, return_i
         out[bn + ".running_mean"] = torch.from_numpy(mean.astype(np.float32))
         out[bn + ".weight"] = torch.from_numpy(gamma.astype(np.float32))
         out[bn + ".bias"] = torch.from_numpy(beta.astype(np.float32))
+    for k in names:
+        if k.endswith("reg.weight") and out[k].dim() == 2:
+            out[k] = torch.from_numpy(_rng(seed, "trained:" + k).normal(0.0, head_sigma, tuple(out[k].shape)).astype(np.float32))
     if return_info:
         return out, {"scaled_layer": pick, "scaled_layer_exp": scaled_layer_exp, "conv_bn_pairs": len(pairs)}
     return out
