@@ -422,7 +422,14 @@ int sfh_bn_stats_partials(const double* partial, int rows, int C, double* acc, v
 /* mean_invstd[0][c] = mean, [1][c] = 1/sqrt(biased var + eps); running stats (optional pair) updated
  * with `momentum` and the unbiased variance like torch.                                           */
 int sfh_bn_finalize(const double* acc, int64_t npix, int C, float eps, float momentum, float* running_mean,
-                    float* running_var, float* mean_invstd, int64_t* num_batches_tracked, void* stream);   /* num_batches_tracked
+                    float* running_var, float* mean_invstd, int64_t* num_batches_tracked, void* stream);
+
+/* sfh_bn_stats_partials + sfh_bn_finalize in one launch (round 6): `partial` = the (rows, 2, C) float64 table of per-wave sums of
+ * z and z^2 that a conv epilogue left (sfh_conv_desc.stats_partial); summed in a fixed order (no atomics), then finished exactly
+ * as sfh_bn_finalize does.                                                                                              */
+int sfh_bn_finalize_partials(const double* partial, int rows, int64_t npix, int C, float eps, float momentum,
+                             float* running_mean, float* running_var, float* mean_invstd, int64_t* num_batches_tracked,
+                             void* stream);   /* num_batches_tracked
                     (optional): nn.BatchNorm2d's int64 step counter, incremented by one */
 /* y = [relu]((z - mean) * invstd * gamma + beta [+ residual]); y_s3 (optional, C % 32 == 0, W = row
  * length of the (rows, W, C) tensor): the same values again in the split layout split_fmt (SFH_FMT_S3 or

@@ -99,6 +99,7 @@ SIGNATURES = {
     "sfh_bn_stats": (C.c_int, [_p, C.c_int64, C.c_int, _p, _p]),
     "sfh_bn_stats_partials": (C.c_int, [_p, C.c_int, C.c_int, _p, _p]),
     "sfh_bn_finalize": (C.c_int, [_p, C.c_int64, C.c_int, C.c_float, C.c_float, _p, _p, _p, _p, _p]),
+    "sfh_bn_finalize_partials": (C.c_int, [_p, C.c_int, C.c_int64, C.c_int, C.c_float, C.c_float, _p, _p, _p, _p, _p]),
     "sfh_bn_apply": (C.c_int, [_p, _p, _p, _p, _p, C.c_int, C.c_int64, C.c_int, _p, _p, C.c_int, C.c_int, _p, _p]),
     "sfh_bn_bwd_reduce": (C.c_int, [_p, _p, _p, _p, _p, _p, C.c_int, C.c_int64, C.c_int, _p, _p]),
     "sfh_bn_bwd_apply": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, C.c_int, C.c_int64, C.c_int, _p, _p, _p, C.c_int, C.c_int,

@@ -147,6 +147,47 @@ __global__ void bn_finalize_kernel(const double* __restrict__ acc, long npix, in
   }
 }
 
+// bn_stats_partials + bn_finalize in ONE launch (round 6: a training step had 54 such pairs): a workgroup of 16 row lanes x 64
+// channels sums the (rows, 2, C) table of per-wave sums a conv epilogue left - in a fixed order, no atomics - and finishes
+// mean / invstd / running statistics for its 64 channels.
+__global__ __launch_bounds__(1024) void bn_finalize_partials_kernel(const double* __restrict__ partial, int rows, long npix,
+                                                                    int C, float eps, float momentum,
+                                                                    float* __restrict__ running_mean,
+                                                                    float* __restrict__ running_var,
+                                                                    float* __restrict__ mean_invstd,
+                                                                    long* __restrict__ num_batches_tracked) {
+  __shared__ double sh[2][16][64];
+  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
+  double s0 = 0.0, s1 = 0.0;
+  if (c < C)
+    for (int r = rl; r < rows; r += 16) {
+      s0 += partial[(long)r * 2 * C + c];
+      s1 += partial[(long)r * 2 * C + C + c];
+    }
+  sh[0][rl][cl] = s0;
+  sh[1][rl][cl] = s1;
+  __syncthreads();
+  if (blockIdx.x == 0 && threadIdx.x == 0 && num_batches_tracked) *num_batches_tracked += 1;
+  if (rl != 0 || c >= C) return;
+#pragma unroll
+  for (int k = 1; k < 16; ++k) {
+    s0 += sh[0][k][cl];
+    s1 += sh[1][k][cl];
+  }
+  const double n = (double)npix;
+  const double mean = s0 / n;
+  double var = s1 / n - mean * mean;
+  var = var > 0.0 ? var : 0.0;
+  mean_invstd[c] = (float)mean;
+  mean_invstd[C + c] = (float)(1.0 / sqrt(var + (double)eps));
+  if (running_mean) {
+    const double unbiased = npix > 1 ? var * n / (n - 1.0) : var;
+    running_mean[c] = (float)((1.0 - (double)momentum) * (double)running_mean[c] + (double)momentum * mean);
+    running_var[c] = (float)((1.0 - (double)momentum) * (double)running_var[c] + (double)momentum * unbiased);
+  }
+}
+
 // y = [relu]( (z - mean) * invstd * gamma + beta [+ residual] )
 __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ z, const float* __restrict__ mi,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -1636,6 +1677,16 @@ extern "C" int sfh_bn_finalize(const double* acc, int64_t npix, int C, float eps
   hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, (hipStream_t)stream, acc,
                      (long)npix, C, eps, momentum, running_mean, running_var, mean_invstd, (long*)num_batches_tracked);
   return sfh_check_launch("bn_finalize_kernel");
+}
+
+extern "C" int sfh_bn_finalize_partials(const double* partial, int rows, int64_t npix, int C, float eps, float momentum,
+                                        float* running_mean, float* running_var, float* mean_invstd,
+                                        int64_t* num_batches_tracked, void* stream) {
+  SFH_REQUIRE(partial && mean_invstd && rows > 0 && npix > 0 && C > 0, "bn_finalize_partials: bad argument");
+  SFH_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "bn_finalize_partials: running stats must come in pairs");
+  hipLaunchKernelGGL(bn_finalize_partials_kernel, dim3((unsigned)((C + 63) / 64)), dim3(1024), 0, (hipStream_t)stream, partial,
+                     rows, (long)npix, C, eps, momentum, running_mean, running_var, mean_invstd, (long*)num_batches_tracked);
+  return sfh_check_launch("bn_finalize_partials_kernel");
 }
 
 extern "C" int sfh_bn_apply(const float* z, const float* mean_invstd, const float* gamma, const float* beta,

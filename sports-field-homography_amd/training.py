@@ -281,6 +281,8 @@ C4_BN_FUSED = os.environ.get("SFH_TRAIN_C4_BN_FUSED", "1") != "0"
 UP_SUMS_FUSED = os.environ.get("SFH_TRAIN_UP_SUMS_FUSED", "1") != "0"
 # the last DoubleConv's BatchNorm backward sums from the OutConv backward pass (sfh_outconv_bwd_bn)
 OUTCONV_SUMS_FUSED = os.environ.get("SFH_TRAIN_OUTCONV_SUMS_FUSED", "1") != "0"
+# BatchNorm forward: the sum of a conv epilogue's table and the finalize step in one launch (sfh_bn_finalize_partials)
+FINALIZE_FUSED = os.environ.get("SFH_TRAIN_FINALIZE_FUSED", "1") != "0"
 STATS_ROWS = 2048   # most rows of the table a conv epilogue adds its per-wave BatchNorm sums into (sfh_conv_desc.stats_partial)
 
 
@@ -291,18 +293,24 @@ def _bn_forward(lib, z, bn, relu, residual, tape, want_s3=True, want_f32=True, s
     no storage behind it) and the kernel writes a third less."""
     B, H, W, C = z.shape
     npix = B * H * W
-    acc = tape.zeros((2 * C,), z, torch.float64)
-    if stats is not None:   # the conv that wrote z left the per-wave sums: no pass over z
-        _lib.check(lib.sfh_bn_stats_partials(_ptr(stats), stats.shape[0], C, _ptr(acc), _stream()), "bn_stats_partials")
-    else:
-        _lib.check(lib.sfh_bn_stats(_ptr(z), npix, C, _ptr(acc), _stream()), "bn_stats")
     mi = _empty((2 * C,), z)
     nbt = bn.num_batches_tracked
     if nbt is not None and (nbt.dtype != torch.int64 or not nbt.is_cuda):
         raise ValueError("BatchNorm num_batches_tracked must be an int64 tensor on the GPU")
-    # (the kernel also advances nn.BatchNorm2d's step counter: one launch per layer less)
-    _lib.check(lib.sfh_bn_finalize(_ptr(acc), npix, C, float(bn.eps), BN_MOMENTUM, _ptr(bn.running_mean),
-                                   _ptr(bn.running_var), _ptr(mi), _ptr(nbt), _stream()), "bn_finalize")
+    # (the kernels also advance nn.BatchNorm2d's step counter: one launch per layer less)
+    if stats is not None and FINALIZE_FUSED:
+        # the conv that wrote z left the per-wave sums: no pass over z, and table sum + finalize are one launch
+        _lib.check(lib.sfh_bn_finalize_partials(_ptr(stats), stats.shape[0], npix, C, float(bn.eps), BN_MOMENTUM,
+                                                _ptr(bn.running_mean), _ptr(bn.running_var), _ptr(mi), _ptr(nbt), _stream()),
+                   "bn_finalize_partials")
+    else:
+        acc = tape.zeros((2 * C,), z, torch.float64)
+        if stats is not None:
+            _lib.check(lib.sfh_bn_stats_partials(_ptr(stats), stats.shape[0], C, _ptr(acc), _stream()), "bn_stats_partials")
+        else:
+            _lib.check(lib.sfh_bn_stats(_ptr(z), npix, C, _ptr(acc), _stream()), "bn_stats")
+        _lib.check(lib.sfh_bn_finalize(_ptr(acc), npix, C, float(bn.eps), BN_MOMENTUM, _ptr(bn.running_mean),
+                                       _ptr(bn.running_var), _ptr(mi), _ptr(nbt), _stream()), "bn_finalize")
     if pool:
         # y and maxpool2(y) in the split format only, from one pass over z (both come back as handles without fp32 storage)
         if not (relu and residual is None and tape.use_s3 and C % 32 == 0 and H >= 2 and W >= 2):
