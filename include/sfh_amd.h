@@ -593,6 +593,17 @@ int sfh_uv_loss(const float* uv, const float* gt_uv, const float* weight, int nw
  * dst).  scale != 1: dst = src * scale (float32); scale == 1: the words are moved untouched.                     */
 int sfh_multi_copy(const void* tensor_table, const void* chunk_table, int nchunks, float scale, void* stream);
 
+/* sfh_multi_copy with the factor read from device memory (*scale_dev), float32 tensors.                                    */
+int sfh_multi_copy_dscale(const void* tensor_table, const void* chunk_table, int nchunks, const float* scale_dev, void* stream);
+
+/* The power-of-two scale of a training step's backward pass (two-plane fp16 gradients), chosen on the device: words = the output
+ * of sfh_multi_absminmax over the nheads head-gradient tensors followed by the theta gradient (if has_theta); the largest head
+ * gradient goes to [2^(1+shift), 2^(2+shift)) (no heads: theta's to [2^(12+shift), 2^(13+shift))), raised if theta's gradient
+ * would sit below 2^-16 while the heads stay below 2^6.  scale2[0] = S, scale2[1] = 1 / S.  *overflow |= 2 for a non-finite
+ * seed, |= 4 if no scale fits both (train.py:233: loss.backward() has no such limit - the caller then repeats the step with
+ * three-plane bf16 operands).  No host read-back: the following launches take S through the pointer.                      */
+int sfh_grad_scale(const uint32_t* words, int nheads, int has_theta, int shift, float* scale2, uint32_t* overflow, void* stream);
+
 /* Backward of sfh_upsample2x_bilinear_nhwc (the bilinear Up variant, unet/unet_parts.py:49): dy (B,2H,2W,C)
  * -> dx (B,H,W,C).                                                                                        */
 int sfh_upsample2x_bilinear_nhwc_bwd(const float* dy, float* dx, int batch, int H, int W, int C, void* stream);

@@ -132,6 +132,8 @@ SIGNATURES = {
     "sfh_adam_step": (C.c_int, [_p, _p, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
                                 C.c_int, _p]),
     "sfh_uv_loss": (C.c_int, [_p, _p, _p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, _p, _p, _p]),
+    "sfh_multi_copy_dscale": (C.c_int, [_p, _p, C.c_int, _p, _p]),
+    "sfh_grad_scale": (C.c_int, [_p, C.c_int, C.c_int, C.c_int, _p, _p, _p]),
     "sfh_multi_absminmax": (C.c_int, [_p, C.c_int, _p, _p]),
     "sfh_vec_op": (C.c_int, [C.c_int, _p, _p, C.c_int64, C.c_int, C.c_float, _p, _p]),
     "sfh_copy2d_words": (C.c_int, [_p, C.c_int64, _p, C.c_int64, C.c_int, C.c_int64, _p]),

@@ -1322,7 +1322,8 @@ struct CopyTensor { void* dst; const void* src; int d1, d2, d3, pad; long s0, s1
 
 template <bool SCALE>
 __global__ __launch_bounds__(256) void multi_copy_kernel(const CopyTensor* __restrict__ table, const OptChunk* __restrict__ chunks,
-                                                         float scale) {
+                                                         float scale, const float* __restrict__ scale_dev = nullptr) {
+  if (SCALE && scale_dev) scale = *scale_dev;     // (the factor lives on the device: sfh_multi_copy_dscale)
   const OptChunk c = chunks[blockIdx.x];
   const CopyTensor t = table[c.tensor];
   const bool contiguous = t.s3 == 1 && t.s2 == t.d3 && t.s1 == (long)t.d2 * t.d3 && t.s0 == (long)t.d1 * t.d2 * t.d3;
@@ -2062,6 +2063,65 @@ extern "C" int sfh_uv_loss(const float* uv, const float* gt_uv, const float* wei
                      nweights == W && nweights != 1 ? 1 : 0, C, H, W, total, lambda, mse, duv, loss,
                      1.0f / ((float)batch * (float)C * (float)H * (float)W));
   return sfh_check_launch("uv_loss_kernel");
+}
+
+extern "C" int sfh_multi_copy_dscale(const void* tensor_table, const void* chunk_table, int nchunks, const float* scale_dev,
+                                     void* stream) {
+  SFH_REQUIRE(tensor_table && chunk_table && nchunks > 0 && scale_dev, "multi_copy_dscale: bad argument");
+  hipLaunchKernelGGL(multi_copy_kernel<true>, dim3((unsigned)nchunks), dim3(256), 0, (hipStream_t)stream,
+                     (const CopyTensor*)tensor_table, (const OptChunk*)chunk_table, 1.f, scale_dev);
+  return sfh_check_launch("multi_copy_kernel");
+}
+
+// The power-of-two scale a training step's backward pass is carried with in the two-plane fp16 format, chosen ON THE DEVICE from
+// the largest head / theta gradient (words of sfh_multi_absminmax: nheads head tensors, then theta if has_theta) - what
+// training.run_backward computed on the host behind a read-back until round 6.  Same rule: the largest head gradient goes to
+// [2^(1+shift), 2^(2+shift)) (without heads: theta's to [2^(12+shift), 2^(13+shift))); if theta's gradient would then sit below
+// 2^-16 the scale is raised until it does not, provided the head gradients stay below 2^6.  scale2 = {S, 1 / S}.  Raises bit 1
+// of *overflow for a non-finite seed and bit 2 if no scale fits both (the caller reads the word at the end of the step).
+__global__ void grad_scale_kernel(const uint32_t* __restrict__ words, int nheads, int has_theta, int shift,
+                                  float* __restrict__ scale2, uint32_t* __restrict__ overflow) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  float mh = 0.f, mt = 0.f;
+  bool finite = true;
+  for (int i = 0; i < nheads; ++i) {
+    const uint32_t b = words[2 * i];
+    finite &= b < 0x7F800000u;
+    mh = fmaxf(mh, __uint_as_float(b));
+  }
+  if (has_theta) {
+    const uint32_t b = words[2 * nheads];
+    finite &= b < 0x7F800000u;
+    mt = __uint_as_float(b);
+  }
+  float S = 1.f;
+  if (!finite) {
+    atomicOr(overflow, 2u);
+  } else {
+    const float m = nheads > 0 ? mh : mt;
+    const int target = (nheads > 0 ? 2 : 13) + shift;
+    int e = 0;
+    if (m > 0.f) {
+      (void)frexpf(m, &e);                    // m = f * 2^e, 0.5 <= f < 1  ->  m * S in [2^(target-1), 2^target)
+      S = ldexpf(1.f, target - e);
+    }
+    if (nheads > 0 && mt > 0.f && mt * S < 1.52587890625e-05f) {
+      (void)frexpf(mt, &e);
+      const float S2 = ldexpf(1.f, -16 - e + 1);
+      if (mh * S2 >= 64.f) atomicOr(overflow, 4u);
+      else S = S2;
+    }
+  }
+  scale2[0] = S;
+  scale2[1] = 1.f / S;
+}
+
+extern "C" int sfh_grad_scale(const uint32_t* words, int nheads, int has_theta, int shift, float* scale2, uint32_t* overflow,
+                              void* stream) {
+  SFH_REQUIRE(words && scale2 && overflow && nheads >= 0 && (nheads > 0 || has_theta), "grad_scale: bad argument");
+  hipLaunchKernelGGL(grad_scale_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, words, nheads, has_theta, shift, scale2,
+                     overflow);
+  return sfh_check_launch("grad_scale_kernel");
 }
 
 extern "C" int sfh_rmsprop_step(const void* tensor_table, const void* chunk_table, int nchunks, float lr,

@@ -74,6 +74,22 @@ def filled(shape, dtype, device, value=0):
     return t
 
 
+def absminmax_words(tensors):
+    """device int32 tensor of 2 words per tensor (sfh_multi_absminmax: bits of max |x|, 0x7FFFFFFF - bits of min |x|), no
+    read-back - for consumers that stay on the device (sfh_grad_scale)"""
+    import numpy as np
+    lib = _lib.load()
+    dev = tensors[0].device
+    tab = np.zeros((len(tensors), 2), dtype=np.int64)
+    for i, t in enumerate(tensors):
+        _f32c(t, "absminmax operand")
+        tab[i] = (t.data_ptr(), t.numel())
+    dtab = torch.from_numpy(tab.view(np.uint8).reshape(-1)).to(dev)
+    words = filled((2 * len(tensors),), torch.int32, dev)
+    _lib.check(lib.sfh_multi_absminmax(_ptr(dtab), len(tensors), _ptr(words), _stream()), "multi_absminmax")
+    return words
+
+
 def absminmax(tensors):
     """[(max |x|, min |x|)] of float32 device tensors - ONE launch over all of them (sfh_multi_absminmax) and ONE
     read-back, where torch would run an abs + a reduction + a host sync per tensor.  A non-finite element gives inf / nan."""

@@ -79,7 +79,8 @@ class _MultiCopy:
         self._key = None
         self._dev_tab = None
 
-    def run(self, srcs, scale=1.0):
+    def run(self, srcs, scale=1.0, scale_dev=None):
+        """scale_dev: a one-element float32 device tensor holding the factor (sfh_multi_copy_dscale) instead of `scale`"""
         if not self.dsts:
             return
         tab = self._tab
@@ -103,6 +104,10 @@ class _MultiCopy:
         if self._dev_tab is None or key != self._key:      # static pairs (the BatchNorm snapshot): uploaded once
             self._dev_tab = torch.from_numpy(tab.view("uint8").reshape(-1).copy()).to(self.dev)
             self._key = key
+        if scale_dev is not None:
+            _lib.check(_lib.load().sfh_multi_copy_dscale(_ptr(self._dev_tab), _ptr(self.chunks), self.nchunks, _ptr(scale_dev),
+                                                         _stream()), "multi_copy_dscale")
+            return
         _lib.check(_lib.load().sfh_multi_copy(_ptr(self._dev_tab), _ptr(self.chunks), self.nchunks, float(scale), _stream()),
                    "multi_copy")
 
@@ -281,6 +286,8 @@ C4_BN_FUSED = os.environ.get("SFH_TRAIN_C4_BN_FUSED", "1") != "0"
 UP_SUMS_FUSED = os.environ.get("SFH_TRAIN_UP_SUMS_FUSED", "1") != "0"
 # the last DoubleConv's BatchNorm backward sums from the OutConv backward pass (sfh_outconv_bwd_bn)
 OUTCONV_SUMS_FUSED = os.environ.get("SFH_TRAIN_OUTCONV_SUMS_FUSED", "1") != "0"
+# TrainStep: the backward pass's power-of-two gradient scale chosen on the device (sfh_grad_scale), no read-back mid-step
+DEVICE_GRAD_SCALE = os.environ.get("SFH_TRAIN_DEVICE_GRAD_SCALE", "1") != "0"
 # BatchNorm forward: the sum of a conv epilogue's table and the finalize step in one launch (sfh_bn_finalize_partials)
 FINALIZE_FUSED = os.environ.get("SFH_TRAIN_FINALIZE_FUSED", "1") != "0"
 STATS_ROWS = 2048   # most rows of the table a conv epilogue adds its per-wave BatchNorm sums into (sfh_conv_desc.stats_partial)
@@ -994,12 +1001,35 @@ def run_forward(net, tape, x):
     return f
 
 
-def run_backward(net, tape, f, dheads, dtheta, unscale=True):
+def run_backward(net, tape, f, dheads, dtheta, unscale=True, device_scale=False):
     """dheads: gradients of the head outputs in the order of f['heads'] (None = zero); dtheta (B,9) or None.
     -> {state_dict key: gradient}.  ResNet closures run first (pushed last) and add the stem's gradient
-    into the head gradients; then the heads; then the UNet."""
+    into the head gradients; then the heads; then the UNet.
+    device_scale (with unscale=False, the two-plane fp16 format): the power-of-two scale of the pass is chosen ON THE DEVICE
+    (sfh_grad_scale from sfh_multi_absminmax's words) and applied through a pointer - no host read-back in the middle of the
+    step; the caller divides it out with tape.gscale_dev[1] (= 1 / S) and learns of a seed that fits no scale from the
+    overflow word at the end of the step."""
     S = 1.0
-    if tape.fmt == "h2":
+    tape.gscale_dev = None
+    if tape.fmt == "h2" and device_scale and not unscale:
+        heads = [d for d in dheads if d is not None]
+        if any(not d.is_contiguous() for d in heads) or (dtheta is not None and not dtheta.is_contiguous()):
+            raise ValueError("run_backward(device_scale=True): contiguous gradient tensors expected")
+        seeds = heads + ([dtheta] if dtheta is not None else [])
+        if seeds:
+            lib = _lib.load()
+            words = E.absminmax_words(seeds)
+            sbuf = _empty((2,), seeds[0])
+            _lib.check(lib.sfh_grad_scale(_ptr(words), len(heads), 1 if dtheta is not None else 0,
+                                          int(getattr(tape, "gshift", 0)), _ptr(sbuf), _ptr(tape.overflow), _stream()),
+                       "grad_scale")
+            tape.gscale_dev, tape.gscale = sbuf, None
+            one = sbuf[0:1]
+            if CAPTURE is not None and dtheta is not None:
+                CAPTURE["dtheta"] = dtheta.clone()
+            dtheta = None if dtheta is None else E.vec_op(dtheta, one, "mul")
+            dheads = [None if d is None else E.vec_op(d, one, "mul", out=d) for d in dheads]
+    elif tape.fmt == "h2":
         # the whole backward pass is linear in its seeds: carry it at a scale the H2 copies of the gradients can hold.
         # The dense per-pixel gradient of the heads sets it: its largest element -> [2, 4); the pre-activation
         # gradients of this model then peak at 1e2..1e3 (two to three orders of magnitude above the seeds at the last
@@ -1033,7 +1063,7 @@ def run_backward(net, tape, f, dheads, dtheta, unscale=True):
                                      "fit one power-of-two scale of the two-plane fp16 format")
             S = S2
         tape.gscale = S
-    if CAPTURE is not None and dtheta is not None:
+    if CAPTURE is not None and dtheta is not None and tape.gscale_dev is None:
         CAPTURE["dtheta"] = dtheta.clone()
     if S != 1.0:
         dtheta = None if dtheta is None else dtheta * S
@@ -1060,8 +1090,9 @@ def run_backward(net, tape, f, dheads, dtheta, unscale=True):
         tape._s3.clear()
         err = FP16RangeError("training step with SFH_TRAIN_PRECISION=f16x3: an activation or gradient left the range of "
                              "the two-plane fp16 format (or was not finite); use SFH_TRAIN_PRECISION=bf16x6 for this model")
-        # the forward pass was clean (its copy of the word is 0): only a GRADIENT overflowed - a lower scale can hold it
-        err.phase = "backward" if (len(ov) > 1 and not ov[1]) else "forward"
+        # the forward pass was clean (its copy of the word is 0): only a GRADIENT overflowed - a lower scale can hold it.
+        # Bits 2 / 4 (sfh_grad_scale): a non-finite seed / head and theta gradients that fit no common scale - no scale helps.
+        err.phase = "backward" if (len(ov) > 1 and not ov[1] and not (ov[0] & 6)) else "forward"
         raise err
     # the closures reference the tape and the tape the closures: break the cycle so the activations
     # are released now rather than at the next garbage collection
@@ -1389,7 +1420,8 @@ class TrainStep:
                                            1 if self.uv_loss == "MSE" else 0, _ptr(duv),
                                            ctypes.c_void_p(losses.data_ptr() + 32), st), "uv_loss")
             dheads.append(duv)
-        g = run_backward(net, tape, f, dheads, theta_gradient(net, f, None, dpoi, dwarp), unscale=False)
+        g = run_backward(net, tape, f, dheads, theta_gradient(net, f, None, dpoi, dwarp), unscale=False,
+                         device_scale=DEVICE_GRAD_SCALE)
         srcs = []
         for p, dst in zip(self.params, self.grads):
             src = g[self.names(p)]
@@ -1398,7 +1430,10 @@ class TrainStep:
         # and divides out the power of two the backward pass was carried with (exact)
         if self._assemble is None or any(a is not b for a, b in zip(self._assemble.dsts, self.grads)):
             self._assemble = _MultiCopy(self.grads)
-        self._assemble.run(srcs, 1.0 / tape.gscale)
+        if tape.gscale_dev is not None:
+            self._assemble.run(srcs, scale_dev=tape.gscale_dev[1:2])
+        else:
+            self._assemble.run(srcs, 1.0 / tape.gscale)
         return losses
 
     def step(self, x, batch):
