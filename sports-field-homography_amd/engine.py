@@ -74,17 +74,27 @@ def filled(shape, dtype, device, value=0):
     return t
 
 
+_ABSMAX_TABLES = {}
+
+
 def absminmax_words(tensors):
     """device int32 tensor of 2 words per tensor (sfh_multi_absminmax: bits of max |x|, 0x7FFFFFFF - bits of min |x|), no
     read-back - for consumers that stay on the device (sfh_grad_scale)"""
     import numpy as np
     lib = _lib.load()
     dev = tensors[0].device
-    tab = np.zeros((len(tensors), 2), dtype=np.int64)
-    for i, t in enumerate(tensors):
+    for t in tensors:
         _f32c(t, "absminmax operand")
-        tab[i] = (t.data_ptr(), t.numel())
-    dtab = torch.from_numpy(tab.view(np.uint8).reshape(-1)).to(dev)
+    # the (address, size) table lives on the device; a blocking upload would synchronise the caller's stream, so the table of
+    # a recurring set of tensors (a training step's gradient seeds come back at the same addresses) is uploaded once
+    key = (str(dev),) + tuple((t.data_ptr(), t.numel()) for t in tensors)
+    dtab = _ABSMAX_TABLES.get(key)
+    if dtab is None:
+        tab = np.array([(t.data_ptr(), t.numel()) for t in tensors], dtype=np.int64)
+        dtab = torch.from_numpy(tab.view(np.uint8).reshape(-1)).to(dev)
+        if len(_ABSMAX_TABLES) >= 16:
+            _ABSMAX_TABLES.pop(next(iter(_ABSMAX_TABLES)))
+        _ABSMAX_TABLES[key] = dtab
     words = filled((2 * len(tensors),), torch.int32, dev)
     _lib.check(lib.sfh_multi_absminmax(_ptr(dtab), len(tensors), _ptr(words), _stream()), "multi_absminmax")
     return words
@@ -96,16 +106,7 @@ def absminmax(tensors):
     import numpy as np
     if not tensors:
         return []
-    lib = _lib.load()
-    dev = tensors[0].device
-    tab = np.zeros((len(tensors), 2), dtype=np.int64)
-    for i, t in enumerate(tensors):
-        _f32c(t, "absminmax operand")
-        tab[i] = (t.data_ptr(), t.numel())
-    dtab = torch.from_numpy(tab.view(np.uint8).reshape(-1)).to(dev)          # H2D of the table (runtime copy)
-    words = filled((2 * len(tensors),), torch.int32, dev)
-    _lib.check(lib.sfh_multi_absminmax(_ptr(dtab), len(tensors), _ptr(words), _stream()), "multi_absminmax")
-    w = words.cpu().numpy().view(np.uint32)
+    w = absminmax_words(tensors).cpu().numpy().view(np.uint32)
     mx = w[0::2].copy().view(np.float32)
     mn = (np.uint32(0x7FFFFFFF) - w[1::2]).astype(np.uint32).view(np.float32)
     return [(float(a), float(b)) for a, b in zip(mx, mn)]
