@@ -62,6 +62,14 @@ def test_argument_validation_without_gpu():
         _lib.check(rc, "conv_fwd")
     rc = lib.sfh_homography_warp_fwd(None, None, 0, 360, 640, 16, 360, 640, 0, 4.0, None, None, None)
     assert rc == -1
+    # round 6 entries: argument checks fire before anything touches a device
+    assert lib.sfh_vec_op(1, None, None, 16, 0, 1.0, None, None) == -1
+    assert lib.sfh_multi_absminmax(None, 3, None, None) == -1
+    assert lib.sfh_stn_input_assemble(None, 4, None, 3, None, 0, 2, 8, 8, 4, None, None) == -1      # 7 channels into 4
+    assert b"7" in lib.sfh_last_error() or b"channels" in lib.sfh_last_error()
+    assert lib.sfh_uv_loss(None, None, None, 5, 2, 2, 8, 8, 1.0, 1, None, None, None) == -1
+    assert lib.sfh_adam_step(None, None, 0, 1e-3, 0.9, 0.999, 1e-8, 0.0, 0.1, 1.0, 1, None) == -1
+    assert lib.sfh_grad_scale(None, 1, 1, 0, None, None, None) == -1
 
 
 def test_model_refuses_cpu_execution():

@@ -175,3 +175,42 @@ def test_multi_absminmax_against_torch():
     (m1, _), (m2, _) = E.absminmax([bad, inf])
     assert m1 != m1 and m2 == float("inf")
     assert E.absminmax([torch.zeros(17, device="cuda")]) == [(0.0, 0.0)]
+
+
+def test_engine_build_helpers_against_torch():
+    """csrc/hostprep.hip through the C-ABI: vec_op (scale / div / mul with a tiled operand), pitched weight slices, the
+    ResNet-STN input assembly for every input mode (models/reconstructor.py:174-183,214), the template replication check, fills"""
+    from sfh_amd import engine as E
+    g = torch.Generator(device="cuda").manual_seed(8)
+    a = torch.randn(4 * 96, device="cuda", generator=g)
+    b = torch.rand(96, device="cuda", generator=g) + 0.5
+    assert torch.equal(E.vec_op(a, factor=0.25), a * 0.25)
+    assert torch.equal(E.vec_op(a, b, "div"), a / b.repeat(4))
+    assert torch.equal(E.vec_op(a, b, "mul", factor=2.0), a * b.repeat(4) * 2.0)
+    one = torch.tensor([3.0], device="cuda")
+    c = a.clone()
+    assert E.vec_op(c, one, "mul", out=c) is c and torch.equal(c, a * 3.0)          # in place, one-element operand
+    border = torch.randn(16, 4 * 96, device="cuda", generator=g)
+    assert torch.equal(E.vec_op(border, b, "div"), border / b.repeat(4))
+    snap = E.snapshot(a)
+    assert snap.data_ptr() != a.data_ptr() and torch.equal(snap, a)
+    w = torch.randn(70, 24, 3, 3, device="cuda", generator=g)
+    assert torch.equal(E.slice_in_channels(w, 0, 8), w[:, :8].contiguous())
+    assert torch.equal(E.slice_in_channels(w, 8, 24), w[:, 8:].contiguous())
+    B, H, W = 2, 9, 13
+    lg = torch.randn(B, 4, H, W, device="cuda", generator=g)
+    fr = torch.randn(B, 3, H, W, device="cuda", generator=g)
+    uv = torch.randn(B, 2, H, W, device="cuda", generator=g)
+    for srcs, cs in (((lg, fr, None), 8), ((None, fr, None), 4), ((lg, None, None), 4), ((lg, fr, uv), 12), ((lg, fr, uv), 16)):
+        want = torch.cat([t for t in srcs if t is not None], 1).permute(0, 2, 3, 1)
+        got = E.stn_input_assemble(*srcs, cs)
+        assert tuple(got.shape) == (B, H, W, cs) and torch.equal(got[..., :want.shape[3]], want)
+        assert float(got[..., want.shape[3]:].abs().sum()) == 0.0
+    tmpl = torch.rand(1, 1, 36, 64, device="cuda", generator=g).repeat(5, 1, 1, 1)
+    assert E.rows_all_equal(tmpl)
+    tmpl[3, 0, 35, 63] += 1.0
+    assert not E.rows_all_equal(tmpl)
+    assert E.rows_all_equal(tmpl[:1])
+    z = E.filled((3, 5), torch.float32, "cuda", 1.5)
+    zi = E.filled((7,), torch.int32, "cuda", -3)
+    assert torch.equal(z, torch.full((3, 5), 1.5, device="cuda")) and torch.equal(zi, torch.full((7,), -3, dtype=torch.int32, device="cuda"))
