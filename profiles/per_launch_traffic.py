@@ -27,6 +27,11 @@ def label(r):
         return f"S3Cfg<{m.group(1)}> DB={m.group(2)}", r["Grid_Size"]
     if "conv3x3_c4h2" in r["Kernel_Name"]:
         return "conv3x3_c4h2 (first layer, fp16 cores)", r["Grid_Size"]
+    if "conv_upfused_kernel" in r["Kernel_Name"]:
+        return "conv_upfused_kernel (single-kernel Up block: u3 / u4)", r["Grid_Size"]
+    m = re.search(r"conv_small_kernel<(true|false)>", r["Kernel_Name"])
+    if m:
+        return f"conv_small_kernel<DB={m.group(1)}>", r["Grid_Size"]
     return None
 
 

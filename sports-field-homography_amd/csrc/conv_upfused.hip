@@ -34,6 +34,7 @@ constexpr int LSLOTS = 8 * LPIXP, SSLOTS = 8 * SPIXP;                        // 
 
 struct UpGeom {
   int tiles_y, tiles_x, ntiles, nblk;
+  int xcd_order;   // 1: every XCD owns a contiguous range of pixel tiles and runs a tile's cout blocks back to back (round 6)
   unsigned bytes_skip, bytes_low;
 };
 
@@ -46,7 +47,22 @@ __global__ __launch_bounds__(256, 2) void conv_upfused_kernel(const sfh_conv_des
   const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lq = lane & 15, lg = lane >> 4;
   const int py = wv >> 1, px = wv & 1, qd = wv;          // the wave's output parity = quadrant of the composed conv
-  const int nb = (int)blockIdx.x % g.nblk, tile = (int)blockIdx.x / g.nblk;
+  // Workgroups go round-robin to the 8 XCDs, each with its own 4 MB L2.  Round 6 (profiles/r06_tcc_per_launch.txt): with
+  // tile = blockIdx / nblk the cout blocks of ONE pixel tile landed on different XCDs - its skip / low-resolution halos crossed
+  // the fabric once per cout block (u3: 3.28 GB of L2 misses for 1.18 GB of tensors) - and neighbouring tiles never shared an L2.
+  // Now, as in conv_s3_kernel: XCD x owns the contiguous tile range [x * tpx, (x + 1) * tpx) (whole tile rows next to each
+  // other, so vertically adjacent tiles meet their halo rows in that L2) and runs a tile's cout blocks back to back.
+  int nb, tile;
+  if (g.xcd_order) {
+    const int xcd = (int)blockIdx.x & 7, k = (int)blockIdx.x >> 3;
+    const int tpx = (g.ntiles + 7) >> 3;
+    nb = k % g.nblk;
+    tile = xcd * tpx + k / g.nblk;
+    if (tile >= g.ntiles || k / g.nblk >= tpx) return;      // (the whole workgroup leaves: uniform)
+  } else {
+    nb = (int)blockIdx.x % g.nblk;
+    tile = (int)blockIdx.x / g.nblk;
+  }
   const int tpi = g.tiles_y * g.tiles_x;
   const int b = tile / tpi, tr = tile - b * tpi;
   const int ty = tr / g.tiles_x;
@@ -223,7 +239,8 @@ extern "C" int sfh_conv_upfused_fwd(const sfh_conv_desc* dp, void* stream_) {
               "conv_upfused_fwd: a tensor exceeds the 4 GiB descriptor range");
   g.bytes_skip = (unsigned)bs;
   g.bytes_low = (unsigned)bl;
-  const long nblocks = (long)g.ntiles * g.nblk;
+  g.xcd_order = d.wg_couts == 1 ? 0 : 1;     // (wg_couts = 1: the round-5 order, for same-device A/Bs)
+  const long nblocks = g.xcd_order ? (long)sfh_cdiv(g.ntiles, 8) * 8 * g.nblk : (long)g.ntiles * g.nblk;
   SFH_REQUIRE(nblocks < (1L << 31), "conv_upfused_fwd: grid too large");
   sfh_allow_big_lds((const void*)conv_upfused_kernel);
   hipLaunchKernelGGL(conv_upfused_kernel, dim3((unsigned)nblocks), dim3(256), SSLOTS * 16, (hipStream_t)stream_, d, g);

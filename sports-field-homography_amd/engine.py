@@ -1017,6 +1017,9 @@ class PackedConv:
         return dst
 
 
+_UPFUSED_LEGACY_ORDER = os.environ.get("SFH_UPFUSED_ORDER", "") == "legacy"
+
+
 def run_upfused(fu, sk, skip, ylow, dst, batch, H, W, exp_dst=None, range_word=None):
     """The first conv of a fused Up block as ONE launch (sfh_conv_upfused_fwd): fu / sk = the composed 2x2 conv and the skip-half
     3x3 conv of the level (PackedConv.fused_up / the skip-half PackedConv) with fu._seed_scale / fu._seed_border up to date (the
@@ -1036,6 +1039,7 @@ def run_upfused(fu, sk, skip, ylow, dst, batch, H, W, exp_dst=None, range_word=N
     d.dst, d.dst_cs = dst.data_ptr(), _chan(dst)
     d.src_fmt = d.dst_fmt = _lib.FMT_H2
     d.out_mode = _lib.OUT_NHWC
+    d.wg_couts = 1 if _UPFUSED_LEGACY_ORDER else 0      # experiment knob: 1 = the round-5 block order (no XCD-aware mapping)
     if exp_dst is not None:
         d.h2_exp_dst = int(exp_dst)
     ovf = getattr(sk, "overflow", None)
