@@ -36,6 +36,7 @@ struct SmallGeom {
   int Ho, Wo, rows_total, rows_per_img;   // (rows_* only exist for the epilogue's flattened-row mode, unused here)
   unsigned rows_magic;
   int tiles_y, tiles_x, ntiles, nblk;
+  int tile_stationary;   // 1: an XCD owns a contiguous tile range and walks all cout blocks per tile (weights of the layer fit L2)
   unsigned bytes0;
 };
 
@@ -52,7 +53,16 @@ __global__ __launch_bounds__(256, DB ? 1 : 2) void conv_small_kernel(const sfh_c
   // workgroup -> (32-cout block, tile): an XCD (blockIdx & 7) keeps to nblk / 8 cout blocks, so that their weights stay in its L2
   const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
   int nb, tile;
-  if (g.nblk >= 8 && (g.nblk & 7) == 0) {
+  if (g.tile_stationary) {
+    // round 6 (profiles/r06_tcc_per_launch.txt): with the weight-stationary order below every XCD reads the WHOLE input tensor
+    // (ResNet layer3: 147 MB of L2 misses per launch for 33 MB of tensors).  Where all weights of the layer fit an XCD's L2
+    // (layer3: 2.4 MB) the other order is the cheap one: an XCD owns a contiguous range of tiles, fetches their halos once and
+    // finds every cout block's weights in its L2 after the first tile.
+    const int tpx = (g.ntiles + 7) >> 3;
+    nb = idx % g.nblk;
+    tile = xcd * tpx + idx / g.nblk;
+    if (idx / g.nblk >= tpx) return;
+  } else if (g.nblk >= 8 && (g.nblk & 7) == 0) {
     const int per = g.nblk >> 3;
     nb = xcd * per + idx % per;
     tile = idx / per;
@@ -176,7 +186,7 @@ __global__ __launch_bounds__(256, DB ? 1 : 2) void conv_small_kernel(const sfh_c
 
 extern "C" int sfh_conv_small_fwd(const sfh_conv_desc* dp, void* stream_) {
   SFH_REQUIRE(dp, "conv_small_fwd: null descriptor");
-  const sfh_conv_desc& d = *dp;
+  sfh_conv_desc d = *dp;
   SFH_REQUIRE(d.src0 && d.wpacked && d.scale && d.shift && d.dst, "conv_small_fwd: null pointer");
   SFH_REQUIRE(d.src_fmt == SFH_FMT_H2 && (d.dst_fmt == SFH_FMT_H2 || d.dst_fmt == SFH_FMT_F32),
               "conv_small_fwd: H2 sources, an H2 or fp32 destination (src_fmt=%d, dst_fmt=%d)", d.src_fmt, d.dst_fmt);
@@ -208,7 +218,12 @@ extern "C" int sfh_conv_small_fwd(const sfh_conv_desc* dp, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   // at most one workgroup per CU (256 CUs): two LDS buffers, the DMA of stage s + 1 under the MFMAs of stage s
   // (sfh_conv_desc.wg_couts, which has no other meaning here, overrides: 1 = one buffer, 2 = two buffers)
+  // (+ 16: experiment knob - keep the weight-stationary block order whatever the weights' size)
+  const int force_ws = d.wg_couts >= 16;
+  d.wg_couts &= 15;
   SFH_REQUIRE(d.wg_couts >= 0 && d.wg_couts <= 2, "conv_small_fwd: wg_couts=%d (0 = the launcher decides, 1 = one LDS buffer, 2 = two)", d.wg_couts);
+  // all weights of the layer (two fp16 planes) within 3 MB of an XCD's 4 MB L2 -> tiles stay put, weights are found in L2
+  g.tile_stationary = (!force_ws && (long)d.cout * d.c0 * 9 * 4 <= (3L << 20)) ? 1 : 0;
   if (d.wg_couts == 2 || (d.wg_couts == 0 && (long)g.ntiles * g.nblk <= 256)) {
     sfh_allow_big_lds((const void*)conv_small_kernel<true>);
     hipLaunchKernelGGL(conv_small_kernel<true>, dim3((unsigned)nblocks), dim3(256), 2 * SmallCfg::BUF * 16, stream, d, g);

@@ -562,6 +562,7 @@ class ConvTimer:
 # with the threshold at 224 (layer4 only), 13.09 at 256.  SFH_SMALL_MAP=0 switches it off.
 _SMALL_MAP = os.environ.get("SFH_SMALL_MAP", "1") != "0"
 _SMALL_MAP_MAX = int(os.environ.get("SFH_SMALL_MAP_MAX", "256"))
+_SMALL_MAP_WS_ORDER = os.environ.get("SFH_SMALL_MAP_ORDER", "") == "weights"
 _SMALL_MAP_BUFFERS = int(os.environ.get("SFH_SMALL_MAP_BUFFERS", "0"))   # experiment: 1 / 2 = force one / two LDS buffers
 _W8_HALF = os.environ.get("SFH_W8_HALF", "1") != "0"
 _W8_HALF_ROUNDS = float(os.environ.get("SFH_W8_HALF_ROUNDS", "3"))   # rounds of 512 resident workgroups from which the shape is requested
@@ -971,7 +972,9 @@ class PackedConv:
             small = choose_small_map(batch, ho, wo, zr, self.cout, d.tile)
         if small:
             fwd = lib.sfh_conv_small_fwd
-            d.wg_couts = _SMALL_MAP_BUFFERS      # 0: the launcher decides (two LDS buffers for grids of at most 256 workgroups)
+            # 0: the launcher decides (two LDS buffers for grids of at most 256 workgroups); + 16 (experiment knob): keep the
+            # weight-stationary block order also where the layer's weights fit an XCD's L2
+            d.wg_couts = _SMALL_MAP_BUFFERS + (16 if _SMALL_MAP_WS_ORDER else 0)
         if self.c4:
             if src0.shape[-1] != 4 or pool0 or dst_pool is not None:
                 raise ValueError("the <=4-channel first-layer kernel needs an fp32 NHWC source with 4 stored channels")
