@@ -13,7 +13,16 @@ for f in glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True):
     rows += list(csv.DictReader(open(f)))
 
 
+ALL = "--all" in sys.argv
+
+
 def label(n):
+    if ALL:      # every kernel of the library, by its (shortened) name: training steps
+        if "at::native" in n or "rocclr" in n:
+            return None
+        n = re.sub(r"\(anonymous namespace\)::", "", n)
+        n = re.sub(r"^void ", "", n)
+        return re.split(r"\(", n)[0][:64]
     m = re.search(r"S3Cfg<([^>]*)>, (true|false)", n)
     if m:
         return f"conv_s3 S3Cfg<{m.group(1)}> DB={m.group(2)}"
@@ -39,5 +48,7 @@ for (k, grid), a in agg.items():
     m = a.get("TCC_MISS", a.get("TCC_MISS_sum", [0]))
     H, M = sum(h) / max(len(h), 1), sum(m) / max(len(m), 1)
     if H + M == 0:
+        continue
+    if ALL and M * 128 / 1e6 * len(h) < 50:      # training table: launches that matter
         continue
     print("%-64s %10s %4d %14.0f %14.0f %8.1f %10.1f" % (k[:64], grid, len(h), H, M, 100 * H / (H + M), M * 128 / 1e6))

@@ -1033,7 +1033,7 @@ __global__ __launch_bounds__(256) void avgpool_linear_bwd_kernel(const float* __
 template <int NC4>
 __global__ __launch_bounds__(256) void stem_bwd_data_kernel(const float* __restrict__ dz, const float* __restrict__ w,
                                                             int cin, int c_off, int nc, int H, int W, int Ho, int Wo,
-                                                            float* __restrict__ dlogits) {
+                                                            float* __restrict__ dlogits, int batch) {
   extern __shared__ __attribute__((aligned(16))) float wl[];  // [49][64][4*NC4]
   for (int i = threadIdx.x; i < 49 * 64 * 4 * NC4; i += 256) {
     const int c = i % (4 * NC4), co = (i / (4 * NC4)) % 64, t = i / (4 * NC4 * 64);
@@ -1045,9 +1045,19 @@ __global__ __launch_bounds__(256) void stem_bwd_data_kernel(const float* __restr
   // (Round 4: FOUR pixels per thread measured slower, 1.28 -> 1.36 ms; waves of ONE column parity - wave-uniform tap loops,
   // broadcast weight reads - slower still, 1.23 -> 1.88 ms: with lane -> every second column each dz load instruction touches
   // 64 cache lines instead of 32; the kernel is bound by that gather, not by the LDS weight reads.)
-  const int x = blockIdx.x * 128 + (threadIdx.x & 63);
-  const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
-  const int b = blockIdx.z;
+  // Workgroups reach the 8 XCDs round-robin in launch order.  Round 6 (profiles/r06_tcc_train_per_launch.txt): with (x tile, 4-row
+  // band, frame) = blockIdx the neighbouring bands - which gather the same dz rows - sat on different XCDs: 1.78 GB of L2 misses for
+  // 0.3 GB of tensors.  XCD x now owns the contiguous range [x * chunk, (x + 1) * chunk) of the (frame, band, x tile) order.
+  // (1-D launch of 8 * chunk workgroups; gx x gy x batch tiles)
+  const int gx = (W + 127) >> 7, gy = (H + 3) >> 2;
+  const long total = (long)gx * gy * batch;
+  const long chunk = (total + 7) >> 3;
+  const long own = (long)(blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
+  if (own >= total) return;                                // (uniform per workgroup; the weights' barrier is behind us)
+  const int bx = (int)(own % gx), by = (int)((own / gx) % gy);
+  const int x = bx * 128 + (threadIdx.x & 63);
+  const int y = by * 4 + (threadIdx.x >> 6);
+  const int b = (int)(own / ((long)gx * gy));
   if (x >= W || y >= H) return;
   const bool two = x + 64 < W;
   float acc[2][4 * NC4];
@@ -1973,14 +1983,17 @@ extern "C" int sfh_stem_bwd_data(const float* dz, const float* w, int cin, int c
   SFH_REQUIRE(dz && w && dlogits_nchw && batch > 0 && batch <= 65535 && H > 0 && W > 0, "stem_bwd_data: bad argument");
   SFH_REQUIRE(nc >= 1 && nc <= 8 && c_off >= 0 && c_off + nc <= cin, "stem_bwd_data: c_off=%d nc=%d cin=%d", c_off, nc, cin);
   const int Ho = (H + 6 - 7) / 2 + 1, Wo = (W + 6 - 7) / 2 + 1;
-  const dim3 grid((unsigned)sfh_cdiv(W, 128), (unsigned)sfh_cdiv(H, 4), (unsigned)batch);
+  // 1-D launch: the kernel maps workgroup -> (frame, 4-row band, 128-column tile) so that an XCD owns a contiguous range
+  const long total = (long)sfh_cdiv(W, 128) * sfh_cdiv(H, 4) * batch;
+  SFH_REQUIRE(total < (1L << 28), "stem_bwd_data: grid too large");
+  const dim3 grid((unsigned)(((total + 7) >> 3) << 3));
   if (nc <= 4) {
     hipLaunchKernelGGL(stem_bwd_data_kernel<1>, grid, dim3(256), 49 * 64 * 4 * sizeof(float), (hipStream_t)stream, dz, w,
-                       cin, c_off, nc, H, W, Ho, Wo, dlogits_nchw);
+                       cin, c_off, nc, H, W, Ho, Wo, dlogits_nchw, batch);
   } else {
     sfh_allow_big_lds(reinterpret_cast<const void*>(&stem_bwd_data_kernel<2>));
     hipLaunchKernelGGL(stem_bwd_data_kernel<2>, grid, dim3(256), 49 * 64 * 8 * sizeof(float), (hipStream_t)stream, dz, w,
-                       cin, c_off, nc, H, W, Ho, Wo, dlogits_nchw);
+                       cin, c_off, nc, H, W, Ho, Wo, dlogits_nchw, batch);
   }
   return sfh_check_launch("stem_bwd_data_kernel");
 }
