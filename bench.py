@@ -413,9 +413,11 @@ def extra_configs(args):
                 net.predict_replay(xb, consistency=False)
             torch.cuda.synchronize()
             el_g = time.perf_counter() - t0
+        el_a = _timed_predicts(net, xb, n, 4, True, consistency=False)
         res[f"C2_640x360_batch{bs}"] = {
             "value": round(bs * n / el, 2), "unit": "frames/s", "ms_per_step": round(el / n * 1e3, 3), "steps": n, "warmup": 4,
             "ms_per_step_graph_replay": round(el_g / n * 1e3, 3),
+            "ms_per_step_async": round(el_a / n * 1e3, 3), "value_async": round(bs * n / el_a, 2),
             "workload": f"the headline workload at batch {bs}: predict() per batch (no pipelining), 640x360, theta + warp_mask"}
     for prec in ("bf16x6", "fp32"):
         net.precision = prec
