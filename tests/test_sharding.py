@@ -403,3 +403,28 @@ def test_more_than_one_rank_without_a_process_group_raises():
     g = sharding.ResultGather(1, 4, "cpu")                 # one rank needs no group
     th, sc = g.result(g.submit(torch.ones(4, 1, 3, 3), torch.ones(4)))
     assert tuple(th.shape) == (4, 1, 3, 3) and float(sc.sum()) == 4.0
+
+
+def test_bench_main_eight_ranks_gloo_is_config_4_s_shape():
+    """BASELINE config 4's shape - 8 ranks x 16 frames = 128 frames per step, theta + consistency gathered - through bench.py's
+    own main() on the CPU (gloo, a stand-in model): the whole-job line, every rank's rows in the gather, all 8 process groups
+    torn down.  (What the driver's N = 8 run exercises around the kernels; the kernels themselves need the GPUs.)"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000) + 177
+    procs = [ctx.Process(target=_bench_main_worker, args=(r, 8, port, q)) for r in range(8)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=400) for _ in range(8)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert not any(g[2] for g in got)
+    lines = [g[1] for g in got if g[1] is not None]
+    assert len(lines) == 1                                   # only rank 0 prints
+    line = lines[0]
+    assert line["n_gpus"] == 8 and line["config"]["global_batch"] == 128 and line["scaling"] == "weak"
+    gc = line["gather_check"]
+    assert gc["rows_per_rank"] == 128 and gc["own_rows_equal_own_theta_on_every_rank"] and not gc["forced_on_one_rank"]
+    assert [r["rank"] for r in line["per_rank"]["ranks"]] == list(range(8))
+    assert abs(line["value"] - 8 * 16 * 3 / (line["ms_per_step"] * 3e-3)) < 0.02 * line["value"]
