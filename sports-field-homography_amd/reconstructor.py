@@ -195,6 +195,10 @@ class Reconstructor(nn.Module):
         # predict(consistency=True) with a nearest warp of the logits' size: warp + consistency CE as one kernel (False: the two
         # separate kernels; env SFH_FUSE_WARP_CE=0)
         self.fuse_warp_ce = os.environ.get("SFH_FUSE_WARP_CE", "1") != "0"
+        # predict() through predict_replay() (one HIP-graph launch per batch, same bits) for batches of at most
+        # graph_replay_max_batch frames; off by default: it returns the caller's thread, not GPU time
+        self.graph_replay = False
+        self.graph_replay_max_batch = 8
         self._engine_stamp = None
         self._weights_generation = 0
         self._tmpl_shared = None   # (data_ptr, shape) -> bool cache
