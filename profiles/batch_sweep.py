@@ -55,7 +55,16 @@ for B in sizes:
         piped(n)
         torch.cuda.synchronize()
         res["async"] = (time.perf_counter() - t0) / n
+        net.pipeline_splitk = False           # the ResNet-STN launches unsplit beside the other batch's UNet (opt-in: other bits)
+        piped(4)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        piped(n)
+        torch.cuda.synchronize()
+        res["async_nosplit"] = (time.perf_counter() - t0) / n
+        net.pipeline_splitk = True
     print(f"B={B:3d}  predict_async() {B / res['async']:8.1f} frames/s {res['async'] * 1e3:7.3f} ms per batch   "
+          f"(pipeline_splitk=False: {B / res['async_nosplit']:8.1f} frames/s {res['async_nosplit'] * 1e3:7.3f} ms)   "
           f"predict() {B / res['predict']:8.1f} frames/s {res['predict'] * 1e3:7.3f} ms per batch   "
           f"predict_replay() {B / res['predict_replay']:8.1f} frames/s {res['predict_replay'] * 1e3:7.3f} ms per batch   "
           f"(one batch at a time, synchronised: {res['predict_sync_each'] * 1e3:.3f} / {res['predict_replay_sync_each'] * 1e3:.3f} ms)", flush=True)

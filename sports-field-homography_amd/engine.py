@@ -1549,17 +1549,20 @@ class ResNetEngine:
         self.reg_w = snapshot(rn.reg.weight)
         self.reg_b = snapshot(rn.reg.bias)
 
-    def run(self, y_nhwc, B, H, W):
-        """y_nhwc: (B,H,W,cs_in) float32 with channels >= cin zero.  Returns theta (B,1,3,3)."""
+    def run(self, y_nhwc, B, H, W, splitk=None):
+        """y_nhwc: (B,H,W,cs_in) float32 with channels >= cin zero.  Returns theta (B,1,3,3).
+        splitk=False: no split-K at small batches for this pass (Reconstructor.predict_async with pipeline_splitk = False:
+        beside another batch's UNet the unsplit launches - fewer, without their finish launches - overlap better)."""
         with _stream_scope():
-            return self._run(y_nhwc, B, H, W)
+            return self._run(y_nhwc, B, H, W, splitk)
 
     first_step = UNetEngine.first_step
     rerun = UNetEngine.rerun
 
-    def _run(self, y_nhwc, B, H, W):
+    def _run(self, y_nhwc, B, H, W, splitk=None):
         lib = _lib.load()
         ws, L, rg = self.ws, self.L, self.ranges
+        use_splitk = self.splitk and (splitk is None or bool(splitk))
         if y_nhwc.shape[3] != self.cs_in:
             raise ValueError(f"STN input has {y_nhwc.shape[3]} stored channels, engine expects {self.cs_in}")
         steps = self.steps = []
@@ -1612,7 +1615,7 @@ class ResNetEngine:
                 pc = L[layer]
                 # layer3 / layer4 at batch 16: 60-170 workgroups for 512 slots - split the K loop to fill the chip
                 ks, slabs = 1, None
-                if s3 and self.splitk:
+                if s3 and use_splitk:
                     oh, ow = (hh - 1) // pc.stride + 1, (ww - 1) // pc.stride + 1
                     ks = choose_ksplit(B, oh, ow, pc.stride, pc.cout, (pc.c0 + pc.c1) // 32, pc.ksize)
                     if ks > 1:

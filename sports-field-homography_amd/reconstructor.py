@@ -199,6 +199,12 @@ class Reconstructor(nn.Module):
         # graph_replay_max_batch frames; off by default: it returns the caller's thread, not GPU time
         self.graph_replay = False
         self.graph_replay_max_batch = 8
+        # predict_async() at small batches: True = the ResNet-STN launches split their K loops exactly as predict() does (same
+        # bits as predict()); False = unsplit on the side stream - beside the other batch's UNet the fewer, finish-free launches
+        # overlap a little better (same-device A/B, profiles/r06_ab_pipeline_splitk.txt: 2 frames per call 2.23 -> 2.13 ms,
+        # 4 frames 3.83 -> 3.72 ms, 1 and >= 8 frames +-0) - at the price of theta differing from predict()'s in the last
+        # bits (another fp32 summation order); batches of 16 never split, so the headline is untouched either way
+        self.pipeline_splitk = True
         self._engine_stamp = None
         self._weights_generation = 0
         self._tmpl_shared = None   # (data_ptr, shape) -> bool cache
@@ -528,7 +534,7 @@ class Reconstructor(nn.Module):
         o = self._chunked(lambda xi, off: self._guarded(phases, xi, off), x)
         return o["logits"], o["x_top"], o.get("uv")
 
-    def _stn(self, x, r, resume=None):
+    def _stn(self, x, r, resume=None, splitk=None):
         """theta = resnet_reg(cat(...)) for the configured input mode (reference: :174-185).  resume: repeat the
         ResNet engine's last run from that launch on (range guard)."""
         _, rn = self._get_engines()
@@ -549,7 +555,7 @@ class Reconstructor(nn.Module):
         else:
             raise NotImplementedError
         with torch.cuda.device(x.device):
-            return rn.run(y, B, H, W)
+            return rn.run(y, B, H, W, splitk=splitk)
 
     # The conv kernels address every activation tensor through 32-bit buffer descriptors (< 4 GiB).  Larger batches
     # are processed in equal sub-batches and concatenated: the 64-channel full-resolution tensor of 16 frames at
@@ -722,7 +728,7 @@ class Reconstructor(nn.Module):
         if p["stem_read"][slot] is not None:          # the batch that used this STN-input buffer last has consumed it
             cur.wait_event(p["stem_read"][slot])
         off = 0
-        run_unet, run_stn, tail = self._predict_phases(x, off, consistency, project_poi, stn_slot=slot)
+        run_unet, run_stn, tail = self._predict_phases(x, off, consistency, project_poi, stn_slot=slot, pipelined=True)
         r = run_unet()
         unet_done = torch.cuda.Event()
         unet_done.record(cur)
@@ -796,7 +802,7 @@ class Reconstructor(nn.Module):
     def _predict_one(self, x, off, consistency, project_poi):
         return self._guarded(lambda xi, o: self._predict_phases(xi, o, consistency, project_poi), x, off)
 
-    def _predict_phases(self, x, off, consistency, project_poi, stn_slot=0):
+    def _predict_phases(self, x, off, consistency, project_poi, stn_slot=0, pipelined=False):
         def run_unet(resume=None):
             if not self.use_unet:
                 return None
@@ -807,7 +813,7 @@ class Reconstructor(nn.Module):
                 return None
             if self.resnet_input == Input.IMG_AND_MASK_AND_UV:
                 raise NotImplementedError  # the reference's predict() has no uv branch either (:216)
-            return self._stn(x, r, resume=resume)
+            return self._stn(x, r, resume=resume, splitk=False if (pipelined and not self.pipeline_splitk) else None)
 
         def tail(r, theta):
             ret = {}

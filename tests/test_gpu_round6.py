@@ -214,3 +214,23 @@ def test_engine_build_helpers_against_torch():
     z = E.filled((3, 5), torch.float32, "cuda", 1.5)
     zi = E.filled((7,), torch.int32, "cuda", -3)
     assert torch.equal(z, torch.full((3, 5), 1.5, device="cuda")) and torch.equal(zi, torch.full((7,), -3, dtype=torch.int32, device="cuda"))
+
+
+def test_pipeline_without_split_k_is_opt_in_and_fp32_close():
+    """`net.pipeline_splitk = False`: predict_async() runs the ResNet-STN launches unsplit on the side stream (one frame per call:
+    +10 % frames/s, profiles/r06_batch_sweep.txt) - another fp32 summation order, so theta moves in its last bits; the logits
+    (UNet) stay bit-identical.  The default keeps predict()'s bits (tests/test_gpu_parity.py, smoke())."""
+    B, w, h = 1, 320, 192
+    net, _ = _net(B, w=w, h=h, seed=33)
+    x = synth.smooth_frames(B, h, w, seed=95).cuda()
+    with torch.no_grad():
+        ref = {k: v.clone() for k, v in net.predict(x, consistency=True).items()}
+        same = net.predict_async(x, consistency=True).result()
+        assert all(torch.equal(same[k], ref[k]) for k in ref)                  # default: the same bits
+        net.pipeline_splitk = False
+        got = net.predict_async(x, consistency=True).result()
+    torch.cuda.synchronize()
+    assert torch.equal(got["logits"], ref["logits"])
+    d = float((got["theta"] - ref["theta"]).abs().max())
+    assert 0.0 < d < 1e-5, d               # differs (split-K was in use at this size) and stays at fp32 rounding level
+    assert float((got["warp_mask"] != ref["warp_mask"]).float().mean()) < 1e-3
